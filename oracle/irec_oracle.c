@@ -1,0 +1,547 @@
+/*
+ * irec_oracle.c -- CPU ORACLE for the iREC beam-search coder.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is a plain-C restatement of the reference algorithm
+ *   /root/reference/rec/coding/beam_search_coder.py   (BeamSearchCoder)
+ *   /root/reference/rec/coding/coder.py               (split/merge, Gaussian partition algebra)
+ * plus the TensorFlow 2.1.0 / TFP 0.9.0 semantics those files rely on.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The product
+ * (relative-entropy-coding_amd/csrc) never links, includes or calls anything in this directory.
+ *
+ * PARITY STATUS: "parity unpinned" against real TensorFlow.  TF 2.1 / TFP 0.9 cannot be installed in
+ * this image and the reference's own tests hold no golden indices (round trip only,
+ * rec/coding/tests/test_coder.py:12-21).  What pins this file instead:
+ *   - Random123 Philox4x32-10 known-answer vectors,
+ *   - scipy.special.ndtri over the 10006 LUT points,
+ *   - CPython's own `random` module for the MT19937 seed plumbing of tf.random.shuffle,
+ *   - the reference's test_beam_search case (round trip),
+ *   - the literal-vs-canonical cross check below.
+ *
+ * Two arithmetic modes:
+ *   IREC_ORACLE_LITERAL   : every TF/TFP op restated one-to-one in float32 in the reference's op order
+ *                           (log_prob with divisions and logs, sequential float32 reduce_sum).
+ *   IREC_ORACLE_CANONICAL : the bit-exact specification the HIP kernels implement:
+ *                           the same sample arithmetic, but the per-candidate score is the algebraically
+ *                           equal quadratic form accumulated with fma in a FIXED reduction tree, so that
+ *                           GPU == oracle holds bit for bit by construction.  TF's own reduce_sum order
+ *                           is not reproducible, so neither mode can claim more than
+ *                           "equal to TF unless a near tie".
+ *
+ * Build: see oracle/Makefile (gcc -O2 -mfma -ffp-contract=off).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define IREC_P 10007 /* big_prime, beam_search_coder.py:30 */
+
+#define IREC_ORACLE_CANONICAL 0
+#define IREC_ORACLE_LITERAL 1
+
+/* ------------------------------------------------------------------------------------------------
+ * Philox4x32-10 as used by tensorflow/core/lib/random/philox_random.h  
+ * ---------------------------------------------------------------------------------------------- */
+void irec_oracle_philox4x32(const uint32_t key_in[2], const uint32_t ctr_in[4], uint32_t out[4]) {
+  uint32_t k0 = key_in[0], k1 = key_in[1];
+  uint32_t c0 = ctr_in[0], c1 = ctr_in[1], c2 = ctr_in[2], c3 = ctr_in[3];
+  for (int round = 0; round < 10; ++round) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* tf.random.set_seed(g) ; tf.random.uniform(..., seed=o)  ->  (seed1, seed2)
+ * python/framework/random_seed.py get_seed(): both truncated mod (2^31-1); (0,0) -> (0, 2^31-1). */
+static void tf_seed_pair(int64_t global_seed, int64_t op_seed, uint64_t *seed1, uint64_t *seed2) {
+  const int64_t M = 2147483647LL;
+  int64_t a = global_seed % M; if (a < 0) a += M; /* python % */
+  int64_t b = op_seed % M;     if (b < 0) b += M;
+  if (a == 0 && b == 0) b = M;
+  *seed1 = (uint64_t)a; *seed2 = (uint64_t)b;
+}
+
+/* One uint32 of the stream PhiloxRandom(seed1, seed2) at flat element index e:
+ * key = (lo32(seed1), hi32(seed1)); counter = (0,0,lo32(seed2),hi32(seed2)) + (e>>2); lane e&3. */
+static uint32_t philox_stream_u32(uint64_t seed1, uint64_t seed2, uint64_t e) {
+  uint32_t key[2] = {(uint32_t)seed1, (uint32_t)(seed1 >> 32)};
+  uint64_t blk = e >> 2;
+  uint32_t ctr[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)seed2, (uint32_t)(seed2 >> 32)};
+  uint32_t out[4];
+  irec_oracle_philox4x32(key, ctr, out);
+  return out[e & 3];
+}
+
+/* beam_search_coder.py:38-43 -- tf.random.set_seed(seed); tf.random.uniform(shape, 1, 10007, seed=seed, int32)
+ * flat row-major element e -> 1 + u32 % 10006. */
+void irec_oracle_uniform_int(int64_t seed, int64_t n, int32_t *out) {
+  uint64_t s1, s2;
+  tf_seed_pair(seed, seed, &s1, &s2);
+  for (int64_t e = 0; e < n; ++e)
+    out[e] = 1 + (int32_t)(philox_stream_u32(s1, s2, (uint64_t)e) % (uint32_t)(IREC_P - 1));
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Deterministic natural log in float64 using only IEEE + - * / (no libm): the GPU implements the
+ * same operation sequence, so both sides agree bit for bit.  |rel err| < 3e-16 (tested against libm).
+ * ---------------------------------------------------------------------------------------------- */
+double irec_oracle_det_log(double x) {
+  uint64_t bits; memcpy(&bits, &x, 8);
+  int64_t e = (int64_t)((bits >> 52) & 0x7FF);
+  if (e == 0) { /* subnormal: scale by 2^54 */
+    x = x * 18014398509481984.0;
+    memcpy(&bits, &x, 8);
+    e = (int64_t)((bits >> 52) & 0x7FF) - 54;
+  }
+  e -= 1023;
+  bits = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+  double m; memcpy(&m, &bits, 8);
+  if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+  double s = (m - 1.0) / (m + 1.0);
+  double s2 = s * s;
+  double q = 1.0 / 25.0;
+  q = q * s2 + 1.0 / 23.0;
+  q = q * s2 + 1.0 / 21.0;
+  q = q * s2 + 1.0 / 19.0;
+  q = q * s2 + 1.0 / 17.0;
+  q = q * s2 + 1.0 / 15.0;
+  q = q * s2 + 1.0 / 13.0;
+  q = q * s2 + 1.0 / 11.0;
+  q = q * s2 + 1.0 / 9.0;
+  q = q * s2 + 1.0 / 7.0;
+  q = q * s2 + 1.0 / 5.0;
+  q = q * s2 + 1.0 / 3.0;
+  double lnm = 2.0 * s + (2.0 * s) * (s2 * q);
+  return (double)e * 0.6931471805599453 + lnm;
+}
+
+static float det_logf(float x) { return (float)irec_oracle_det_log((double)x); }
+
+/* ------------------------------------------------------------------------------------------------
+ * TFP 0.9.0 special_math._ndtri evaluated in float32, op by op.
+ * tf.math.log -> det_logf (correctly rounded up to double rounding; Eigen's plog is ~1 ulp anyway).
+ * ---------------------------------------------------------------------------------------------- */
+static float horner_f32(float v, const double *c, int n) {
+  /* _create_polynomial: coeffs[0] + poly(coeffs[1:]) * var on the REVERSED list ==
+   * Horner from the highest power, "mul then add", each rounded to float32. */
+  float acc = (float)c[0];
+  for (int i = 1; i < n; ++i) acc = acc * v + (float)c[i];
+  return acc;
+}
+
+float irec_oracle_ndtri_f32(float p) {
+  static const double P0[] = {-5.99633501014107895267E1, 9.80010754185999661536E1, -5.66762857469070293439E1,
+                              1.39312609387279679503E1, -1.23916583867381258016E0};
+  static const double Q0[] = {1.0, 1.95448858338141759834E0, 4.67627912898881538453E0, 8.63602421390890590575E1,
+                              -2.25462687854119370527E2, 2.00260212380060660359E2, -8.20372256168333339912E1,
+                              1.59056225126211695515E1, -1.18331621121330003142E0};
+  static const double P1[] = {4.05544892305962419923E0, 3.15251094599893866154E1, 5.71628192246421288162E1,
+                              4.40805073893200834700E1, 1.46849561928858024014E1, 2.18663306850790267539E0,
+                              -1.40256079171354495875E-1, -3.50424626827848203418E-2, -8.57456785154685413611E-4};
+  static const double Q1[] = {1.0, 1.57799883256466749731E1, 4.53907635128879210584E1, 4.13172038254672030440E1,
+                              1.50425385692907503408E1, 2.50464946208309415979E0, -1.42182922854787788574E-1,
+                              -3.80806407691578277194E-2, -9.33259480895457427372E-4};
+  static const double P2[] = {3.23774891776946035970E0, 6.91522889068984211695E0, 3.93881025292474443415E0,
+                              1.33303460815807542389E0, 2.01485389549179081538E-1, 1.23716634817820021358E-2,
+                              3.01581553508235416007E-4, 2.65806974686737550832E-6, 6.23974539184983293730E-9};
+  static const double Q2[] = {1.0, 6.02427039364742014255E0, 3.67983563856160859403E0, 1.37702099489081330271E0,
+                              2.16236993594496635890E-1, 1.34204006088543189037E-2, 3.28014464682127739104E-4,
+                              2.89247864745380683936E-6, 6.79019408009981274425E-9};
+  const float one_minus_em2 = (float)0.8646647167633873;  /* -np.expm1(-2.) */
+  const float em2 = (float)0.1353352832366127;            /* np.exp(-2.)    */
+  if (p <= 0.0f) return -INFINITY;
+  if (p >= 1.0f) return INFINITY;
+  float mcp = (p > one_minus_em2) ? (1.0f - p) : p;
+  float smcp = (mcp <= 0.0f) ? 0.5f : mcp;
+  /* central branch */
+  float w = smcp - 0.5f;
+  float ww = w * w;
+  float ratio0 = horner_f32(ww, P0, 5) / horner_f32(ww, Q0, 9);
+  float x_big = w + (w * ww) * ratio0;
+  x_big = x_big * (float)(-2.5066282746310002);
+  /* tail branches */
+  float z = sqrtf(-2.0f * det_logf(smcp));
+  float first = z - det_logf(z) / z;
+  float rz = 1.0f / z;
+  float second_small = horner_f32(rz, P2, 9) / horner_f32(rz, Q2, 9) / z;
+  float second_other = horner_f32(rz, P1, 9) / horner_f32(rz, Q1, 9) / z;
+  float x_small = first - second_small;
+  float x_other = first - second_other;
+  float x = (smcp > em2) ? x_big : ((z >= 8.0f) ? x_small : x_other);
+  return (p > (float)(1.0 - 0.1353352832366127)) ? x : -x;
+}
+
+/* lut[k] = Normal(0,1).quantile(float32(k)/float32(10007)) for k = 1..10006; lut[0] = 0 (never indexed:
+ * (r*h) mod 10007 != 0 because 10007 is prime and 1 <= r,h <= 10006).  beam_search_coder.py:45-49. */
+void irec_oracle_build_lut(float *lut) {
+  lut[0] = 0.0f;
+  for (int k = 1; k < IREC_P; ++k) lut[k] = irec_oracle_ndtri_f32((float)k / (float)IREC_P);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * tf.random.set_seed(seed); tf.random.shuffle(tf.range(n))   (coder.py:62-64, 111-113)
+ * CPython MT19937 (random.Random(seed).randint(0, 2^31-1)) supplies the op seed.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { uint32_t mt[624]; int idx; } mt_state;
+
+static void mt_init_genrand(mt_state *st, uint32_t s) {
+  st->mt[0] = s;
+  for (int i = 1; i < 624; ++i) st->mt[i] = 1812433253u * (st->mt[i - 1] ^ (st->mt[i - 1] >> 30)) + (uint32_t)i;
+  st->idx = 624;
+}
+
+static void mt_init_by_array(mt_state *st, const uint32_t *key, int klen) {
+  mt_init_genrand(st, 19650218u);
+  int i = 1, j = 0;
+  int k = 624 > klen ? 624 : klen;
+  for (; k; --k) {
+    st->mt[i] = (st->mt[i] ^ ((st->mt[i - 1] ^ (st->mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+    ++i; ++j;
+    if (i >= 624) { st->mt[0] = st->mt[623]; i = 1; }
+    if (j >= klen) j = 0;
+  }
+  for (k = 623; k; --k) {
+    st->mt[i] = (st->mt[i] ^ ((st->mt[i - 1] ^ (st->mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+    ++i;
+    if (i >= 624) { st->mt[0] = st->mt[623]; i = 1; }
+  }
+  st->mt[0] = 0x80000000u;
+}
+
+static uint32_t mt_genrand(mt_state *st) {
+  if (st->idx >= 624) {
+    for (int kk = 0; kk < 624; ++kk) {
+      uint32_t y = (st->mt[kk] & 0x80000000u) | (st->mt[(kk + 1) % 624] & 0x7fffffffu);
+      st->mt[kk] = st->mt[(kk + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    st->idx = 0;
+  }
+  uint32_t y = st->mt[st->idx++];
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+
+/* random.Random(seed).randint(0, 2**31 - 1): seed(int) -> init_by_array(32-bit words of |seed|);
+ * randint -> _randbelow(2**31) -> k = (2**31).bit_length() = 32; r = getrandbits(32) until r < 2**31. */
+int64_t irec_oracle_py_first_randint31(int64_t seed) {
+  uint64_t a = seed < 0 ? (uint64_t)(-(seed + 1)) + 1u : (uint64_t)seed;
+  uint32_t key[2] = {(uint32_t)a, (uint32_t)(a >> 32)};
+  int klen = key[1] ? 2 : 1;
+  mt_state st;
+  mt_init_by_array(&st, key, klen);
+  uint32_t r;
+  do { r = mt_genrand(&st); } while (r >= 0x80000000u);
+  return (int64_t)r;
+}
+
+/* perm[i] = position-i value of tf.random.shuffle(range(n)) after tf.random.set_seed(seed).
+ * random_shuffle_op.cc: Fisher-Yates forward, swap(a[i], a[i + u32 % (n-i)]), u32 taken lane by lane. */
+void irec_oracle_tf_shuffle_perm(int64_t seed, int64_t n, int64_t *perm) {
+  for (int64_t i = 0; i < n; ++i) perm[i] = i;
+  if (n <= 1) return;
+  uint64_t s1, s2;
+  tf_seed_pair(seed, irec_oracle_py_first_randint31(seed), &s1, &s2);
+  for (int64_t i = 0; i < n - 1; ++i) {
+    uint32_t u = philox_stream_u32(s1, s2, (uint64_t)i);
+    int64_t j = i + (int64_t)(u % (uint32_t)(n - i));
+    int64_t t = perm[i]; perm[i] = perm[j]; perm[j] = t;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Small helpers of the beam search
+ * ---------------------------------------------------------------------------------------------- */
+/* simple_hash, beam_search_coder.py:33-35: floormod(int32 sum_j idx[j]*(69+j), 10006) + 1 */
+static int32_t hash_from_sum(int32_t sum) {
+  int32_t m = sum % (IREC_P - 1);
+  if (m < 0) m += IREC_P - 1; /* tf.math.floormod */
+  return m + 1;
+}
+
+int32_t irec_oracle_simple_hash(const int32_t *idx, int n) {
+  uint32_t sum = 0; /* int32 arithmetic wraps in TF */
+  for (int j = 0; j < n; ++j) sum += (uint32_t)idx[j] * (uint32_t)(69 + j);
+  return hash_from_sum((int32_t)sum);
+}
+
+/* get_auxiliary_ratio, coder.py:16,218-220: np.power(i + 1., -0.7864636765648174), then cast to float32 when it
+ * multiplies a float32 tensor (beam_search_coder.py:68). */
+float irec_oracle_aux_ratio(int i) { return (float)pow((double)i + 1.0, -0.7864636765648174); }
+
+/* Canonical reduction tree: dims in groups of 256; inside a group "lane" l (0..63) owns dims
+ * 4l..4l+3 and has already produced part[l]; pair lanes at distance 32,16,8,4,2,1; groups added in order. */
+static float tree64_f32(float *part) {
+  for (int step = 32; step >= 1; step >>= 1)
+    for (int l = 0; l < step; ++l) part[l] = part[l] + part[l + step];
+  return part[0];
+}
+static double tree64_f64(double *part) {
+  for (int step = 32; step >= 1; step >>= 1)
+    for (int l = 0; l < step; ++l) part[l] = part[l] + part[l + step];
+  return part[0];
+}
+
+/* KL(q||p) summed over the block and K = ceil(KL/omega)  (beam_search_coder.py:57-59).
+ * canonical: float64 per dim 0.5*((mq-mp)/sp)^2 + (0.5*(r-1) - ln t), t = sq/sp, r = t*t, canonical tree, -> float32.
+ * literal  : TFP 0.9 kl_normal_normal in float32, sequential sum. */
+float irec_oracle_block_kl(int mode, int D, const float *mq, const float *sq, const float *mp, const float *sp) {
+  if (mode == IREC_ORACLE_LITERAL) {
+    float sum = 0.0f;
+    for (int d = 0; d < D; ++d) {
+      float dls = logf(sq[d]) - logf(sp[d]);
+      float a = mq[d] / sp[d], b = mp[d] / sp[d];
+      float sd = (a - b) * (a - b);
+      float kl = 0.5f * sd + 0.5f * expm1f(2.0f * dls) - dls;
+      sum = sum + kl;
+    }
+    return sum;
+  }
+  double total = 0.0;
+  int ng = (D + 255) / 256;
+  for (int g = 0; g < ng; ++g) {
+    double part[64];
+    for (int l = 0; l < 64; ++l) {
+      double acc = 0.0;
+      for (int i = 0; i < 4; ++i) {
+        int d = g * 256 + l * 4 + i;
+        if (d >= D) continue;
+        double t = (double)sq[d] / (double)sp[d];
+        double r = t * t;
+        double dm = ((double)mq[d] - (double)mp[d]) / (double)sp[d];
+        double kl = 0.5 * (dm * dm) + (0.5 * (r - 1.0) - irec_oracle_det_log(t));
+        acc = acc + kl;
+      }
+      part[l] = acc;
+    }
+    double gs = tree64_f64(part);
+    total = (g == 0) ? gs : total + gs;
+  }
+  return (float)total;
+}
+
+int32_t irec_oracle_num_aux(float kl, float omega) {
+  if (!(kl > 0.0f)) return 0;
+  float k = ceilf(kl / omega);
+  if (!(k < 1.0e9f)) return 1000000000;
+  return (int32_t)k;
+}
+
+/* per-dimension state of the partition algebra (coder.py:141-154, beam_search_coder.py:64-77) */
+typedef struct {
+  float sa;      /* sqrt(a_t): scale of the auxiliary coder            */
+  float v;       /* a_t + c_t                                           */
+  float m, var;  /* auxiliary target mean / variance                    */
+  float A, Bv;   /* canonical quadratic coefficients (centred on m)     */
+  float s_t, s_v;/* literal: sqrt(var), sqrt(v)                          */
+} step_dim;
+
+static void step_constants(float rho, float mq, float sq, float mp, float sp, float c, float *a_out, step_dim *o) {
+  float var_p = sp * sp;                  /* tf.math.pow(coding_dist.scale, 2) */
+  float a = rho * (var_p - c);            /* beam_search_coder.py:68-69        */
+  float v = a + c;                        /* :74,77                             */
+  float var_q = sq * sq;                  /* coder.py:149                       */
+  float m = (mq - mp) * v / var_p;        /* coder.py:150                       */
+  float var = var_q * (v * v) / (var_p * var_p) + v * (var_p - v) / var_p; /* coder.py:151-152 */
+  o->sa = sqrtf(a);
+  o->v = v; o->m = m; o->var = var;
+  o->A = 0.5f * (1.0f / v - 1.0f / var);
+  o->Bv = m / v;
+  o->s_t = sqrtf(var);
+  o->s_v = sqrtf(v);
+  *a_out = a;
+}
+
+/* TFP 0.9 Normal._log_prob, float32 op by op */
+static float normal_log_prob_literal(float x, float loc, float scale) {
+  float a = x / scale, b = loc / scale;
+  float lu = -0.5f * ((a - b) * (a - b));
+  float ln = (float)0.9189385332046727 + logf(scale);
+  return lu - ln;
+}
+
+typedef struct { uint32_t key; int32_t flat; } cand;
+
+/* tf.argsort(DESCENDING) == top_k: value descending, ties by ascending index.  NaN sorts last. */
+static int cand_before(float va, int32_t fa, float vb, int32_t fb) {
+  int na = isnan(va), nb = isnan(vb);
+  if (na || nb) { if (na != nb) return nb; return fa < fb; }
+  if (va != vb) return va > vb;
+  return fa < fb;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * encode_block (beam_search_coder.py:53-122).  All arrays are for ONE block of D dims (already permuted).
+ *   out_indices : [K]  (caller provides max_K slots; if K > max_K nothing is coded, K is still returned)
+ *   out_sample  : [D]  beams[0] + p.loc
+ *   trace_sel   : optional [K][B][2] selected (s', b') per step, -1 padded
+ *   trace_score : optional [K][S*B] scores in flat order f = s*B_cur + b (unused tail = 0)
+ * returns K.
+ * ---------------------------------------------------------------------------------------------- */
+int32_t irec_oracle_encode_block(int mode, float omega, int S, int B, int D, const float *mq, const float *sq,
+                                 const float *mp, const float *sp, int64_t seed, int32_t max_K,
+                                 int32_t *out_indices, float *out_sample, int32_t *trace_sel, float *trace_score) {
+  static float lut[IREC_P];
+  static int lut_ready = 0;
+  if (!lut_ready) { irec_oracle_build_lut(lut); lut_ready = 1; }
+
+  float kl = irec_oracle_block_kl(mode, D, mq, sq, mp, sp);
+  int32_t K = irec_oracle_num_aux(kl, omega);
+  if (K > max_K) return K;
+  if (K == 0) { /* reference: NameError (beams undefined, :118); here: nothing coded, sample = p.loc */
+    for (int d = 0; d < D; ++d) out_sample[d] = 0.0f + mp[d];
+    return 0;
+  }
+
+  float *beams = (float *)calloc((size_t)B * D, sizeof(float));
+  float *nbeams = (float *)calloc((size_t)B * D, sizeof(float));
+  float *c = (float *)calloc((size_t)D, sizeof(float));
+  float *a = (float *)calloc((size_t)D, sizeof(float));
+  step_dim *sd = (step_dim *)calloc((size_t)D, sizeof(step_dim));
+  int32_t *r = (int32_t *)malloc((size_t)S * D * sizeof(int32_t));
+  float *score = (float *)malloc((size_t)S * B * sizeof(float));
+  int32_t *path = (int32_t *)calloc((size_t)B * K, sizeof(int32_t));
+  int32_t *npath = (int32_t *)calloc((size_t)B * K, sizeof(int32_t));
+  int32_t hsum[64 * 16], nhsum[64 * 16]; /* B <= 1024 */
+  unsigned char *taken = (unsigned char *)malloc((size_t)S * B);
+  int Bcur = 1;
+  hsum[0] = 0;
+
+  for (int t = 0; t < K; ++t) {
+    int i = K - 1 - t;
+    float rho = irec_oracle_aux_ratio(i);
+    for (int d = 0; d < D; ++d) step_constants(rho, mq[d], sq[d], mp[d], sp[d], c[d], &a[d], &sd[d]);
+    irec_oracle_uniform_int(seed + t, (int64_t)S * D, r);
+
+    for (int s = 0; s < S; ++s) {
+      for (int b = 0; b < Bcur; ++b) {
+        int32_t h = hash_from_sum(hsum[b]);
+        const float *beam = beams + (size_t)b * D;
+        const int32_t *rs = r + (size_t)s * D;
+        float sc;
+        if (mode == IREC_ORACLE_LITERAL) {
+          sc = 0.0f;
+          for (int d = 0; d < D; ++d) {
+            int32_t k = (int32_t)(((int64_t)rs[d] * h) % IREC_P);
+            float u = (float)k / (float)IREC_P;
+            (void)u; /* quantile(u) == lut[k] by construction of the LUT */
+            float y = lut[k] * sd[d].sa + 0.0f; /* Normal.quantile: ndtri(p) * scale + loc, loc = 0 */
+            float x = (t == 0) ? y : beam[d] + y;
+            float lp = normal_log_prob_literal(x, sd[d].m, sd[d].s_t) - normal_log_prob_literal(x, 0.0f, sd[d].s_v);
+            sc = sc + lp;
+          }
+        } else {
+          int ng = (D + 255) / 256;
+          sc = 0.0f;
+          for (int g = 0; g < ng; ++g) {
+            float part[64];
+            for (int l = 0; l < 64; ++l) {
+              float acc = 0.0f;
+              for (int q = 0; q < 4; ++q) {
+                int d = g * 256 + l * 4 + q;
+                if (d >= D) continue;
+                int32_t k = (int32_t)(((int64_t)rs[d] * h) % IREC_P);
+                float y = sd[d].sa * lut[k];
+                float w = (beam[d] - sd[d].m) + y;      /* x - m, formed without the big-x rounding */
+                float uu = fmaf(sd[d].A, w, sd[d].Bv);
+                acc = fmaf(uu, w, acc);
+              }
+              part[l] = acc;
+            }
+            float gs = tree64_f32(part);
+            sc = (g == 0) ? gs : sc + gs;
+          }
+        }
+        score[s * Bcur + b] = sc;
+      }
+    }
+    int N = S * Bcur;
+    if (trace_score) {
+      for (int f = 0; f < S * B; ++f) trace_score[(size_t)t * S * B + f] = f < N ? score[f] : 0.0f;
+    }
+
+    /* top-B, descending, ties to the lower flat index */
+    int Bnew = B < N ? B : N;
+    memset(taken, 0, (size_t)N);
+    for (int j = 0; j < Bnew; ++j) {
+      int best = -1;
+      for (int f = 0; f < N; ++f) {
+        if (taken[f]) continue;
+        if (best < 0 || cand_before(score[f], f, score[best], best)) best = f;
+      }
+      taken[best] = 1;
+      int bsrc = best % Bcur, ssrc = best / Bcur; /* :88-89 */
+      const float *beam = beams + (size_t)bsrc * D;
+      const int32_t *rs = r + (size_t)ssrc * D;
+      int32_t h = hash_from_sum(hsum[bsrc]);
+      float *nb = nbeams + (size_t)j * D;
+      for (int d = 0; d < D; ++d) {
+        int32_t k = (int32_t)(((int64_t)rs[d] * h) % IREC_P);
+        float y = (mode == IREC_ORACLE_LITERAL) ? (lut[k] * sd[d].sa + 0.0f) : (sd[d].sa * lut[k]);
+        nb[d] = (mode == IREC_ORACLE_LITERAL && t == 0) ? y : beam[d] + y;
+      }
+      memcpy(npath + (size_t)j * K, path + (size_t)bsrc * K, (size_t)t * sizeof(int32_t));
+      npath[(size_t)j * K + t] = ssrc;
+      nhsum[j] = (int32_t)((uint32_t)hsum[bsrc] + (uint32_t)ssrc * (uint32_t)(69 + t));
+      if (trace_sel) {
+        trace_sel[((size_t)t * B + j) * 2 + 0] = ssrc;
+        trace_sel[((size_t)t * B + j) * 2 + 1] = bsrc;
+      }
+    }
+    if (trace_sel)
+      for (int j = Bnew; j < B; ++j) { trace_sel[((size_t)t * B + j) * 2] = -1; trace_sel[((size_t)t * B + j) * 2 + 1] = -1; }
+    { float *tmp = beams; beams = nbeams; nbeams = tmp; }
+    { int32_t *tmp = path; path = npath; npath = tmp; }
+    memcpy(hsum, nhsum, (size_t)Bnew * sizeof(int32_t));
+    Bcur = Bnew;
+    for (int d = 0; d < D; ++d) c[d] = c[d] + a[d]; /* :109 */
+  }
+
+  for (int t = 0; t < K; ++t) out_indices[t] = path[t];
+  for (int d = 0; d < D; ++d) out_sample[d] = beams[d] + mp[d]; /* :122 */
+
+  free(beams); free(nbeams); free(c); free(a); free(sd); free(r); free(score); free(path); free(npath); free(taken);
+  return K;
+}
+
+/* decode_block (beam_search_coder.py:124-148).  indices in ENCODER order (idx[t] = choice at iteration t);
+ * the reference's in-place list reversal (:127) is an implementation detail of its loop direction. */
+void irec_oracle_decode_block(int mode, int S, int D, const float *mp, const float *sp, const int32_t *indices,
+                              int32_t K, int64_t seed, float *out_sample) {
+  static float lut[IREC_P];
+  static int lut_ready = 0;
+  if (!lut_ready) { irec_oracle_build_lut(lut); lut_ready = 1; }
+  float *c = (float *)calloc((size_t)D, sizeof(float));
+  float *sample = (float *)calloc((size_t)D, sizeof(float));
+  int32_t *r = (int32_t *)malloc((size_t)S * D * sizeof(int32_t));
+  for (int t = 0; t < K; ++t) {
+    int i = K - 1 - t;
+    float rho = irec_oracle_aux_ratio(i);
+    irec_oracle_uniform_int(seed + t, (int64_t)S * D, r);
+    int32_t h = irec_oracle_simple_hash(indices, t);
+    const int32_t *rs = r + (size_t)indices[t] * D;
+    for (int d = 0; d < D; ++d) {
+      float var_p = sp[d] * sp[d];
+      float a = rho * (var_p - c[d]);
+      float sa = sqrtf(a);
+      int32_t k = (int32_t)(((int64_t)rs[d] * h) % IREC_P);
+      float y = (mode == IREC_ORACLE_LITERAL) ? (lut[k] * sa + 0.0f) : (sa * lut[k]);
+      sample[d] = sample[d] + y;
+      c[d] = c[d] + a;
+    }
+  }
+  for (int d = 0; d < D; ++d) out_sample[d] = sample[d] + mp[d];
+  free(c); free(sample); free(r);
+}
+
+int irec_oracle_cpu_has_fma(void) { return __builtin_cpu_supports("fma"); }

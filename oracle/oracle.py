@@ -1,0 +1,226 @@
+"""ctypes front end of the CPU oracle (oracle/irec_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+package (relative-entropy-coding_amd/) never does.  Parity status: see the header of irec_oracle.c
+("parity unpinned" against real TensorFlow; pinned by KATs + self-generated golden fixtures).
+
+Reference call stack restated here (host side of the block loop):
+    GaussianCoder.encode   /root/reference/rec/coding/coder.py:412-457
+    GaussianCoder.decode   /root/reference/rec/coding/coder.py:459-491
+    Coder.split / merge    /root/reference/rec/coding/coder.py:38-122
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libirec_oracle.so")
+
+CANONICAL = 0
+LITERAL = 1
+P = 10007
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "irec_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libirec_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        if not L.irec_oracle_cpu_has_fma():
+            raise RuntimeError("oracle was built with -mfma but this CPU has no FMA")
+        f32p = ctypes.POINTER(ctypes.c_float)
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        i64p = ctypes.POINTER(ctypes.c_int64)
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        L.irec_oracle_philox4x32.argtypes = [u32p, u32p, u32p]
+        L.irec_oracle_uniform_int.argtypes = [ctypes.c_int64, ctypes.c_int64, i32p]
+        L.irec_oracle_det_log.argtypes = [ctypes.c_double]
+        L.irec_oracle_det_log.restype = ctypes.c_double
+        L.irec_oracle_ndtri_f32.argtypes = [ctypes.c_float]
+        L.irec_oracle_ndtri_f32.restype = ctypes.c_float
+        L.irec_oracle_build_lut.argtypes = [f32p]
+        L.irec_oracle_py_first_randint31.argtypes = [ctypes.c_int64]
+        L.irec_oracle_py_first_randint31.restype = ctypes.c_int64
+        L.irec_oracle_tf_shuffle_perm.argtypes = [ctypes.c_int64, ctypes.c_int64, i64p]
+        L.irec_oracle_simple_hash.argtypes = [i32p, ctypes.c_int]
+        L.irec_oracle_simple_hash.restype = ctypes.c_int32
+        L.irec_oracle_aux_ratio.argtypes = [ctypes.c_int]
+        L.irec_oracle_aux_ratio.restype = ctypes.c_float
+        L.irec_oracle_block_kl.argtypes = [ctypes.c_int, ctypes.c_int, f32p, f32p, f32p, f32p]
+        L.irec_oracle_block_kl.restype = ctypes.c_float
+        L.irec_oracle_num_aux.argtypes = [ctypes.c_float, ctypes.c_float]
+        L.irec_oracle_num_aux.restype = ctypes.c_int32
+        L.irec_oracle_encode_block.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               f32p, f32p, f32p, f32p, ctypes.c_int64, ctypes.c_int32, i32p, f32p,
+                                               i32p, f32p]
+        L.irec_oracle_encode_block.restype = ctypes.c_int32
+        L.irec_oracle_decode_block.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, f32p, f32p, i32p,
+                                               ctypes.c_int32, ctypes.c_int64, f32p]
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def n_samples(kl_per_partition, extra_samples=1.0):
+    """beam_search_coder.py:29"""
+    return int(np.exp(kl_per_partition * extra_samples))
+
+
+def philox4x32(key, ctr):
+    k = np.asarray(key, dtype=np.uint32)
+    c = np.asarray(ctr, dtype=np.uint32)
+    o = np.zeros(4, dtype=np.uint32)
+    lib().irec_oracle_philox4x32(_p(k, ctypes.c_uint32), _p(c, ctypes.c_uint32), _p(o, ctypes.c_uint32))
+    return o
+
+
+def uniform_int(seed, n):
+    o = np.zeros(n, dtype=np.int32)
+    lib().irec_oracle_uniform_int(int(seed), n, _p(o, ctypes.c_int32))
+    return o
+
+
+def det_log(x):
+    return lib().irec_oracle_det_log(float(x))
+
+
+def build_lut():
+    o = np.zeros(P, dtype=np.float32)
+    lib().irec_oracle_build_lut(_p(o, ctypes.c_float))
+    return o
+
+
+def py_first_randint31(seed):
+    return lib().irec_oracle_py_first_randint31(int(seed))
+
+
+def tf_shuffle_perm(seed, n):
+    o = np.zeros(n, dtype=np.int64)
+    lib().irec_oracle_tf_shuffle_perm(int(seed), n, _p(o, ctypes.c_int64))
+    return o
+
+
+def simple_hash(idx):
+    a = np.ascontiguousarray(idx, dtype=np.int32)
+    return lib().irec_oracle_simple_hash(_p(a, ctypes.c_int32), len(a))
+
+
+def aux_ratio(i):
+    return lib().irec_oracle_aux_ratio(int(i))
+
+
+def block_kl(mq, sq, mp, sp, mode=CANONICAL):
+    mq, sq, mp, sp = map(_f32, (mq, sq, mp, sp))
+    return lib().irec_oracle_block_kl(mode, mq.size, _p(mq, ctypes.c_float), _p(sq, ctypes.c_float),
+                                      _p(mp, ctypes.c_float), _p(sp, ctypes.c_float))
+
+
+def num_aux(kl, omega):
+    return lib().irec_oracle_num_aux(float(kl), float(np.float32(omega)))
+
+
+def encode_block(mq, sq, mp, sp, seed, omega, S, B, mode=CANONICAL, max_K=4096, trace=False):
+    """BeamSearchCoder.encode_block on one already-permuted block.  Returns (indices list, sample[, trace])."""
+    mq, sq, mp, sp = map(lambda a: _f32(a).reshape(-1), (mq, sq, mp, sp))
+    D = mq.size
+    idx = np.zeros(max_K, dtype=np.int32)
+    sample = np.zeros(D, dtype=np.float32)
+    K0 = num_aux(block_kl(mq, sq, mp, sp, mode), omega)
+    sel = np.full((max(K0, 1), B, 2), -1, dtype=np.int32) if trace else None
+    sc = np.zeros((max(K0, 1), S * B), dtype=np.float32) if trace else None
+    K = lib().irec_oracle_encode_block(mode, float(np.float32(omega)), S, B, D, _p(mq, ctypes.c_float),
+                                       _p(sq, ctypes.c_float), _p(mp, ctypes.c_float), _p(sp, ctypes.c_float),
+                                       int(seed), max_K, _p(idx, ctypes.c_int32), _p(sample, ctypes.c_float),
+                                       _p(sel, ctypes.c_int32) if trace else None,
+                                       _p(sc, ctypes.c_float) if trace else None)
+    if K > max_K:
+        raise ValueError(f"K={K} exceeds max_K={max_K}")
+    out = ([int(v) for v in idx[:K]], sample)
+    if trace:
+        out = out + ({"sel": sel[:K], "score": sc[:K], "K": K},)
+    return out
+
+
+def decode_block(mp, sp, indices, seed, S, mode=CANONICAL):
+    mp, sp = map(lambda a: _f32(a).reshape(-1), (mp, sp))
+    D = mp.size
+    idx = np.ascontiguousarray(indices, dtype=np.int32)
+    out = np.zeros(D, dtype=np.float32)
+    lib().irec_oracle_decode_block(mode, S, D, _p(mp, ctypes.c_float), _p(sp, ctypes.c_float),
+                                   _p(idx, ctypes.c_int32), len(idx), int(seed), _p(out, ctypes.c_float))
+    return out
+
+
+def split_blocks(n, block_size):
+    """coder.py:69-83: [start, stop) of each block in the permuted order; the last block may be short."""
+    return [(i, min(i + block_size, n)) for i in range(0, n, block_size)]
+
+
+def encode_tensor(q_loc, q_scale, p_loc, p_scale, seed, omega, S, B, block_size=None, mode=CANONICAL):
+    """GaussianCoder.encode (coder.py:412-457) for ONE latent tensor (leading batch dim of 1 allowed).
+    Returns (indices, sample) -- indices is list[list[int]] per block when block_size is set, else list[int]."""
+    shape = np.shape(q_loc)
+    mq, sq, mp, sp = map(lambda a: _f32(a).reshape(-1), (q_loc, q_scale, p_loc, p_scale))
+    if block_size is None:
+        idx, samp = encode_block(mq, sq, mp, sp, seed, omega, S, B, mode)
+        return idx, samp.reshape(shape)
+    n = mq.size
+    perm = tf_shuffle_perm(seed, n)
+    out = np.zeros(n, dtype=np.float32)
+    indices = []
+    for lo, hi in split_blocks(n, block_size):
+        g = perm[lo:hi]
+        idx, samp = encode_block(mq[g], sq[g], mp[g], sp[g], seed, omega, S, B, mode)
+        indices.append(idx)
+        out[g] = samp  # merge: inverse permutation (coder.py:111-117)
+    return indices, out.reshape(shape)
+
+
+def decode_tensor(p_loc, p_scale, indices, seed, S, block_size=None, mode=CANONICAL):
+    """GaussianCoder.decode (coder.py:459-491)."""
+    shape = np.shape(p_loc)
+    mp, sp = map(lambda a: _f32(a).reshape(-1), (p_loc, p_scale))
+    if block_size is None:
+        return decode_block(mp, sp, indices, seed, S, mode).reshape(shape)
+    n = mp.size
+    perm = tf_shuffle_perm(seed, n)
+    out = np.zeros(n, dtype=np.float32)
+    for (lo, hi), idx in zip(split_blocks(n, block_size), indices):
+        g = perm[lo:hi]
+        out[g] = decode_block(mp[g], sp[g], idx, seed, S, mode)
+    return out.reshape(shape)
+
+
+def codelength(indices, S):
+    """beam_search_coder.py:150-151 (nats)."""
+    return len(indices) * np.log(S)
+
+
+def synthetic_latent(image_id, n, rng_base=1234):
+    """SURVEY.md §8d synthetic posterior/prior statistics for one latent tensor of n dims."""
+    rng = np.random.default_rng(rng_base + image_id)
+    mp = rng.normal(0.0, 1.0, n)
+    lsp = rng.normal(0.0, 0.25, n)
+    sp = np.exp(lsp)
+    mq = mp + sp * rng.normal(0.0, 0.2, n)
+    sq = np.exp(lsp - np.abs(rng.normal(0.0, 0.05, n)))
+    return tuple(a.astype(np.float32) for a in (mq, sq, mp, sp))
