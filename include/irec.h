@@ -1,0 +1,135 @@
+/*
+ * irec.h -- C ABI of libirec_hip.so: the MI355X-native iREC beam-search coder.
+ *
+ * This is the drop-in boundary for the hot path of gergely-flamich/relative-entropy-coding:
+ *   rec/coding/beam_search_coder.py  BeamSearchCoder.encode_block / decode_block
+ *   rec/coding/coder.py              GaussianCoder.encode / decode, Coder.split / merge
+ * Plain pointers and sizes only; no torch / HIP types in the signatures (a HIP stream is passed as void*).
+ *
+ * Conventions
+ *   - "device pointer" arguments must point to memory of the HIP device the context was created on.
+ *   - Device entry points are ASYNCHRONOUS on the given stream; they never allocate, free or synchronise.
+ *   - The library keeps no hidden mutable state besides the read-only constant tables of a context
+ *     (the reference mutates TF's process-global RNG on every call: beam_search_coder.py:38, coder.py:62,111).
+ *   - Every function returns an irec_status (0 = ok, negative = error); irec_last_error() gives the text
+ *     of the calling thread's last error.
+ *
+ * Blocks.  A "block" is one <= block_size slice of a shuffled latent tensor (coder.py:69-83).  For block k:
+ *     element i (0 <= i < block_dim[k]) lives at flat index
+ *         block_base[k] + ( perm ? perm[block_pos[k] + i] : block_pos[k] + i )
+ *     of q_loc / q_scale / p_loc / p_scale / out_sample, where block_base[k] is the offset of the block's tensor
+ *     inside the concatenated arrays, block_pos[k] the block's start inside the shuffled tensor and perm the
+ *     tf.random.shuffle permutation of that tensor size (irec_tf_shuffle_perm), shared by all tensors of the call.
+ *     Reading through perm IS Coder.split; writing out_sample through it IS Coder.merge.
+ */
+#ifndef IREC_H_
+#define IREC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IREC_BIG_PRIME 10007     /* beam_search_coder.py:30 */
+#define IREC_MAX_BEAMS 64        /* hard limit of this build (reference: unbounded python int) */
+#define IREC_MAX_PARTITIONS 65536 /* hard limit on K = ceil(KL / kl_per_partition) */
+
+typedef enum {
+  IREC_OK = 0,
+  IREC_E_INVALID = -1,     /* bad argument (null pointer, non-positive size, B > IREC_MAX_BEAMS ...)            */
+  IREC_E_HIP = -2,         /* a HIP runtime call failed; text in irec_last_error()                             */
+  IREC_E_NO_DEVICE = -3,   /* no usable gfx950 device: the library has NO CPU fallback                         */
+  IREC_E_WORKSPACE = -4    /* workspace smaller than irec_encode_workspace_bytes()                             */
+} irec_status;
+
+/* Constructor arguments of BeamSearchCoder (beam_search_coder.py:15-30) after its own preprocessing. */
+typedef struct {
+  float kl_per_partition; /* Omega, stored as float32 by GaussianCoder.__init__ (coder.py:192)                 */
+  int32_t n_samples;      /* S = int(exp(kl_per_partition * extra_samples)) (beam_search_coder.py:29)          */
+  int32_t n_beams;        /* B (beam_search_coder.py:28)                                                       */
+  int32_t flags;          /* IREC_FLAG_* below; 0 = defaults                                                   */
+} irec_params;
+
+#define IREC_FLAG_FORCE_GENERIC 1 /* use the generic (any D, any B) kernel even where the fast kernel applies  */
+
+typedef struct irec_context irec_context;
+
+/* ---- host-only helpers ---------------------------------------------------------------------------------- */
+const char *irec_last_error(void);
+const char *irec_version(void);
+
+/* int(np.exp(kl_per_partition * extra_samples))  -- beam_search_coder.py:29 */
+int32_t irec_n_samples(double kl_per_partition, double extra_samples);
+
+/* len(indices) * np.log(n_samples)  -- BeamSearchCoder.get_codelength, beam_search_coder.py:150-151 (nats) */
+double irec_codelength(int64_t n_indices, int32_t n_samples);
+
+/* lut[k] = Normal(0,1).quantile(float32(k)/10007) for k = 1..10006, lut[0] = 0
+ * -- the 10006 values dist.quantile can take in get_pseudo_random_sample, beam_search_coder.py:45-49. */
+irec_status irec_build_lut(float *lut10007);
+
+/* perm = tf.random.shuffle(tf.range(n)) after tf.random.set_seed(seed) -- Coder.split/merge, coder.py:62-64,111-113.
+ * Host memory. */
+irec_status irec_tf_shuffle_perm(int64_t seed, int64_t n, int64_t *perm);
+
+/* out[e] = element e of tf.random.uniform([n], 1, 10007, seed=seed, dtype=int32) after tf.random.set_seed(seed)
+ * -- beam_search_coder.py:38-43.  Host memory; test hook for the in-kernel Philox stream. */
+irec_status irec_philox_uniform_int(int64_t seed, int64_t n, int32_t *out);
+
+/* ---- context ---------------------------------------------------------------------------------------------- */
+/* Builds the constant tables (quantile LUT in discrete-log order, discrete-log table of Z_10007^*, power-law ratios
+ * get_auxiliary_ratio, coder.py:16,218-220) and uploads them to HIP device `device`.
+ * Fails with IREC_E_NO_DEVICE when there is no GPU: there is no CPU fallback. */
+irec_status irec_create(int device, irec_context **out);
+void irec_destroy(irec_context *ctx);
+
+/* Bytes of device scratch irec_beam_encode needs for blocks of at most max_dim dims and max_K partitions. */
+size_t irec_encode_workspace_bytes(const irec_context *ctx, const irec_params *p, int32_t max_dim, int32_t max_K);
+
+/* ---- device entry points ---------------------------------------------------------------------------------- */
+
+/* total_kl and num_aux_variables of every block -- beam_search_coder.py:57-59.
+ *   out_kl [n_blocks] float32 (may be NULL), out_K [n_blocks] int32.  Device pointers. */
+irec_status irec_block_kl(irec_context *ctx, const irec_params *p, int64_t n_blocks, const int64_t *block_base,
+                          const int32_t *block_pos, const int32_t *block_dim, const int32_t *perm,
+                          const float *q_loc, const float *q_scale, const float *p_loc, const float *p_scale,
+                          float *out_kl, int32_t *out_K, void *hip_stream);
+
+/* BeamSearchCoder.encode_block on n_blocks independent blocks -- beam_search_coder.py:53-122, driven the way
+ * GaussianCoder.encode drives it (same seed for every block, coder.py:444-449).
+ *   max_block_dim                   upper bound of block_dim[] (host knows it: block_size); a block with more dims
+ *                                   is not coded and gets out_K = -1
+ *   out_K       [n_blocks]          K of each block.  K > max_K means "not coded: retry with a larger max_K".
+ *   out_indices [n_blocks, max_K]   idx[t], t < K: the sample index chosen at iteration t (rest untouched)
+ *   out_sample  flat, same indexing as the inputs: beams[0] + p.loc, merged
+ *   workspace   device scratch of at least irec_encode_workspace_bytes() bytes, 256-byte aligned
+ * All pointers except p are device pointers. */
+irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_blocks, const int64_t *block_base,
+                             const int32_t *block_pos, const int32_t *block_dim, int32_t max_block_dim,
+                             const int32_t *perm, const float *q_loc, const float *q_scale, const float *p_loc,
+                             const float *p_scale, int64_t seed, int32_t max_K, int32_t *out_K, int32_t *out_indices,
+                             float *out_sample, void *workspace, size_t workspace_bytes, void *hip_stream);
+
+/* BeamSearchCoder.decode_block on n_blocks blocks -- beam_search_coder.py:124-148 (GaussianCoder.decode, coder.py:459-491).
+ *   K [n_blocks], indices [n_blocks, max_K] in ENCODER order (idx[t] = choice at iteration t). */
+irec_status irec_beam_decode(irec_context *ctx, const irec_params *p, int64_t n_blocks, const int64_t *block_base,
+                             const int32_t *block_pos, const int32_t *block_dim, const int32_t *perm,
+                             const float *p_loc, const float *p_scale, int64_t seed, int32_t max_K, const int32_t *K,
+                             const int32_t *indices, float *out_sample, void *hip_stream);
+
+/* ---- test hooks (device pointers) ---------------------------------------------------------------------------- */
+/* r[s*D + d] of get_pseudo_random_sample's int32 draw, generated by the in-kernel Philox stream.  out: int32 [n]. */
+irec_status irec_device_uniform_int(irec_context *ctx, int64_t seed, int64_t n, int32_t *out, void *hip_stream);
+/* in: float [64 lanes][width], width in {64, 32}; out[lane] = sum over lanes of in[.][lane*width/64] in the canonical
+ * 64-lane reduction tree of the score kernels. */
+irec_status irec_test_reduce_scatter(irec_context *ctx, const float *in, float *out, int32_t width, void *hip_stream);
+/* device addresses of the context's constant tables (lut [10007], lut2 [10006], dlog4r [10006] u16, rho [65536]). */
+irec_status irec_device_tables(irec_context *ctx, const float **lut, const float **lut2, const uint16_t **dlog4r,
+                               const float **rho);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IREC_H_ */

@@ -1,0 +1,187 @@
+// irec_device.h -- device-side building blocks of the iREC beam-search kernels (gfx950 only).
+//
+// Arithmetic contract: everything below uses only IEEE-754 correctly rounded + - * / sqrt and
+// explicit fma, in float32 unless stated; the translation unit is compiled with -ffp-contract=off, so no
+// other fused operation exists.  That is what makes the kernels reproducible bit for bit on a CPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define IREC_P 10007u   // big_prime            (reference: rec/coding/beam_search_coder.py:30)
+#define IREC_PM1 10006u // big_prime - 1, order of the multiplicative group, modulus of simple_hash (:35)
+#define IREC_LUT2_BYTES (IREC_PM1 * 4u)
+
+namespace irec {
+
+// ---- Philox4x32-10, TensorFlow's stream layout ------------------------------------------
+struct StepSeed { uint32_t k0, k1, c2, c3; };
+
+// tf.random.set_seed(seed + t); tf.random.uniform(..., seed=seed + t): both seeds truncated mod 2^31-1,
+// (0,0) -> (0, 2^31-1); key = seed1 (64 bit), counter words 2,3 = seed2 (reference: beam_search_coder.py:38-42).
+__host__ __device__ inline StepSeed make_step_seed(int64_t seed_plus_t) {
+  const int64_t M = 2147483647LL;
+  int64_t a = seed_plus_t % M;
+  if (a < 0) a += M;
+  int64_t b = a;
+  if (a == 0) b = M;
+  StepSeed s;
+  s.k0 = (uint32_t)a; s.k1 = 0u; s.c2 = (uint32_t)b; s.c3 = 0u;
+  return s;
+}
+
+__device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                               uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0;
+    const uint32_t n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return make_uint4(c0, c1, c2, c3);
+}
+
+// Philox block number `blk` of the step's stream.
+__device__ __forceinline__ uint4 philox_block(const StepSeed &ss, uint64_t blk) {
+  return philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), ss.c2, ss.c3, ss.k0, ss.k1);
+}
+
+// r-1 (in 0..10005) for ONE flat element e of the [S,1,D] int32 draw: 1 + u32 % 10006  (beam_search_coder.py:39-43)
+__device__ __forceinline__ uint32_t draw_rm1(const StepSeed &ss, uint64_t e) {
+  const uint4 o = philox_block(ss, e >> 2);
+  const uint32_t lane = (uint32_t)e & 3u;
+  const uint32_t u = lane == 0 ? o.x : lane == 1 ? o.y : lane == 2 ? o.z : o.w;
+  return u % IREC_PM1;
+}
+
+// r-1 for the FOUR consecutive elements e0..e0+3.  `off = e0 & 3` must be wave-uniform (it is whenever every lane's
+// first dim is a multiple of 4: off = (s*D) & 3).
+__device__ __forceinline__ void draw_rm1_x4(const StepSeed &ss, uint64_t e0, uint32_t rm1[4]) {
+  const uint32_t off = (uint32_t)e0 & 3u;
+  const uint4 a = philox_block(ss, e0 >> 2);
+  uint32_t u0 = a.x, u1 = a.y, u2 = a.z, u3 = a.w;
+  if (off != 0u) { // uniform branch
+    const uint4 b = philox_block(ss, (e0 >> 2) + 1);
+    if (off == 1u) { u0 = a.y; u1 = a.z; u2 = a.w; u3 = b.x; }
+    else if (off == 2u) { u0 = a.z; u1 = a.w; u2 = b.x; u3 = b.y; }
+    else { u0 = a.w; u1 = b.x; u2 = b.y; u3 = b.z; }
+  }
+  rm1[0] = u0 % IREC_PM1; rm1[1] = u1 % IREC_PM1; rm1[2] = u2 % IREC_PM1; rm1[3] = u3 % IREC_PM1;
+}
+
+// simple_hash from the running int32 sum  sum_j idx[j]*(69+j)  (beam_search_coder.py:33-35), tf.math.floormod.
+__device__ __forceinline__ uint32_t hash_from_sum(int32_t sum) {
+  int32_t m = sum % (int32_t)IREC_PM1;
+  if (m < 0) m += (int32_t)IREC_PM1;
+  return (uint32_t)m + 1u;
+}
+
+// ---- deterministic float64 log (same operation sequence as the test oracle's restatement) ------------------
+__device__ __forceinline__ double det_log(double x) {
+  uint64_t bits = (uint64_t)__double_as_longlong(x);
+  int64_t e = (int64_t)((bits >> 52) & 0x7FF);
+  if (e == 0) {
+    x = x * 18014398509481984.0;
+    bits = (uint64_t)__double_as_longlong(x);
+    e = (int64_t)((bits >> 52) & 0x7FF) - 54;
+  }
+  e -= 1023;
+  bits = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+  double m = __longlong_as_double((long long)bits);
+  if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+  const double s = (m - 1.0) / (m + 1.0);
+  const double s2 = s * s;
+  double q = 1.0 / 25.0;
+  q = q * s2 + 1.0 / 23.0;
+  q = q * s2 + 1.0 / 21.0;
+  q = q * s2 + 1.0 / 19.0;
+  q = q * s2 + 1.0 / 17.0;
+  q = q * s2 + 1.0 / 15.0;
+  q = q * s2 + 1.0 / 13.0;
+  q = q * s2 + 1.0 / 11.0;
+  q = q * s2 + 1.0 / 9.0;
+  q = q * s2 + 1.0 / 7.0;
+  q = q * s2 + 1.0 / 5.0;
+  q = q * s2 + 1.0 / 3.0;
+  const double lnm = 2.0 * s + (2.0 * s) * (s2 * q);
+  return (double)e * 0.6931471805599453 + lnm;
+}
+
+// KL(N(mq,sq) || N(mp,sp)) of one dim in float64 (canonical form of tfd.kl_divergence, beam_search_coder.py:57).
+__device__ __forceinline__ double kl_dim(float mq, float sq, float mp, float sp) {
+  const double t = (double)sq / (double)sp;
+  const double r = t * t;
+  const double dm = ((double)mq - (double)mp) / (double)sp;
+  return 0.5 * (dm * dm) + (0.5 * (r - 1.0) - det_log(t));
+}
+
+// num_aux_variables = int32(ceil(total_kl / kl_per_partition))  (beam_search_coder.py:59)
+__device__ __forceinline__ int32_t num_aux(float kl, float omega) {
+  if (!(kl > 0.0f)) return 0;
+  const float k = ceilf(kl / omega);
+  if (!(k < 1.0e9f)) return 1000000000;
+  return (int32_t)k;
+}
+
+// ---- per-dim, per-step constants of the Gaussian partition algebra ------------------------------------------
+// reference: beam_search_coder.py:67-77 with coder.py:141-154 (get_auxiliary_coder / get_auxiliary_target).
+struct StepConst { float a, sa, m, A, Bv; };
+
+__device__ __forceinline__ StepConst step_constants(float rho, float dmu, float var_q, float var_p, float c) {
+  StepConst o;
+  const float a = rho * (var_p - c);                                              // auxiliary_var
+  const float v = a + c;                                                          // + cumulative_auxiliary_variance
+  const float m = dmu * v / var_p;                                                // auxiliary_target_mean
+  const float var = var_q * (v * v) / (var_p * var_p) + v * (var_p - v) / var_p;  // auxiliary_target_var
+  o.a = a;
+  o.sa = sqrtf(a);                        // scale of the auxiliary coder N(0, sqrt(a))
+  o.m = m;
+  o.A = 0.5f * (1.0f / v - 1.0f / var);   // score(x) = const + (A*w + Bv)*w,  w = x - m
+  o.Bv = m / v;
+  return o;
+}
+
+// one proposal's contribution to a candidate's score: log N(x; m, s_t) - log N(x; 0, sqrt(v)) up to a constant
+// that is the same for every candidate of the step (beam_search_coder.py:82-84).
+__device__ __forceinline__ float score_term(float acc, float beam, float y, float m, float A, float Bv) {
+  const float w = (beam - m) + y;
+  const float u = fmaf(A, w, Bv);
+  return fmaf(u, w, acc);
+}
+
+// ---- ordering of candidates: tf.argsort(DESCENDING) == top_k: value desc, ties -> lower flat index ----
+__device__ __forceinline__ uint32_t score_key(float s) {
+  if (s != s) return 1u;          // NaN sorts after every number
+  if (s == 0.0f) return 0x80000000u; // -0 == +0
+  const uint32_t u = __float_as_uint(s);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ unsigned long long cand_pack(uint32_t key, uint32_t flat) {
+  return key ? (((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - flat)) : 0ull;
+}
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned long long o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// canonical 64-lane tree: pair lanes at distance 32,16,8,4,2,1 (all lanes end with the same bits).
+__device__ __forceinline__ float wave_tree_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_tree_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+  return v;
+}
+
+} // namespace irec

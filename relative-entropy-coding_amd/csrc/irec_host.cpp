@@ -1,0 +1,457 @@
+// irec_host.cpp -- host side of libirec_hip.so: C ABI (include/irec.h), constant tables, argument checks, launches.
+//
+// Nothing here computes the hot path on the CPU: the host builds input-independent constant tables
+// (quantile LUT, discrete-log table of Z_10007^*, power-law variance ratios, the tf.random.shuffle permutation)
+// and launches the gfx950 kernels of irec_kernels.hip.  Without a HIP device every device entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "irec.h"
+#include "irec_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+irec_status fail(irec_status code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                           \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return fail(IREC_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+// ---- deterministic log, float64, IEEE basic ops only (same operation sequence as the device code) ----
+double det_log(double x) {
+  uint64_t bits;
+  std::memcpy(&bits, &x, 8);
+  int64_t e = (int64_t)((bits >> 52) & 0x7FF);
+  if (e == 0) {
+    x = x * 18014398509481984.0;
+    std::memcpy(&bits, &x, 8);
+    e = (int64_t)((bits >> 52) & 0x7FF) - 54;
+  }
+  e -= 1023;
+  bits = (bits & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+  double m;
+  std::memcpy(&m, &bits, 8);
+  if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+  const double s = (m - 1.0) / (m + 1.0), s2 = s * s;
+  double q = 1.0 / 25.0;
+  for (int n = 23; n >= 3; n -= 2) q = q * s2 + 1.0 / (double)n;
+  const double lnm = 2.0 * s + (2.0 * s) * (s2 * q);
+  return (double)e * 0.6931471805599453 + lnm;
+}
+inline float logf_det(float x) { return (float)det_log((double)x); }
+
+// ---- Normal(0,1).quantile in float32: TFP 0.9.0 special_math._ndtri, operation by operation ----
+// (called through tfd.Normal.quantile at rec/coding/beam_search_coder.py:49)
+template <size_t N>
+float poly(float v, const double (&c)[N]) { // highest power first; "mul then add", each rounded to float32
+  float acc = (float)c[0];
+  for (size_t i = 1; i < N; ++i) acc = acc * v + (float)c[i];
+  return acc;
+}
+
+float ndtri_f32(float p) {
+  static const double p0[] = {-5.99633501014107895267E1, 9.80010754185999661536E1, -5.66762857469070293439E1,
+                              1.39312609387279679503E1, -1.23916583867381258016E0};
+  static const double q0[] = {1.0, 1.95448858338141759834E0, 4.67627912898881538453E0, 8.63602421390890590575E1,
+                              -2.25462687854119370527E2, 2.00260212380060660359E2, -8.20372256168333339912E1,
+                              1.59056225126211695515E1, -1.18331621121330003142E0};
+  static const double p1[] = {4.05544892305962419923E0, 3.15251094599893866154E1, 5.71628192246421288162E1,
+                              4.40805073893200834700E1, 1.46849561928858024014E1, 2.18663306850790267539E0,
+                              -1.40256079171354495875E-1, -3.50424626827848203418E-2, -8.57456785154685413611E-4};
+  static const double q1[] = {1.0, 1.57799883256466749731E1, 4.53907635128879210584E1, 4.13172038254672030440E1,
+                              1.50425385692907503408E1, 2.50464946208309415979E0, -1.42182922854787788574E-1,
+                              -3.80806407691578277194E-2, -9.33259480895457427372E-4};
+  static const double p2[] = {3.23774891776946035970E0, 6.91522889068984211695E0, 3.93881025292474443415E0,
+                              1.33303460815807542389E0, 2.01485389549179081538E-1, 1.23716634817820021358E-2,
+                              3.01581553508235416007E-4, 2.65806974686737550832E-6, 6.23974539184983293730E-9};
+  static const double q2[] = {1.0, 6.02427039364742014255E0, 3.67983563856160859403E0, 1.37702099489081330271E0,
+                              2.16236993594496635890E-1, 1.34204006088543189037E-2, 3.28014464682127739104E-4,
+                              2.89247864745380683936E-6, 6.79019408009981274425E-9};
+  const float hi_cut = (float)0.8646647167633873; // 1 - exp(-2)
+  const float lo_cut = (float)0.1353352832366127; // exp(-2)
+  if (p <= 0.0f) return -INFINITY;
+  if (p >= 1.0f) return INFINITY;
+  const float mcp = p > hi_cut ? 1.0f - p : p;
+  const float sp = mcp <= 0.0f ? 0.5f : mcp;
+  const float w = sp - 0.5f, ww = w * w;
+  float x_centre = w + (w * ww) * (poly(ww, p0) / poly(ww, q0));
+  x_centre = x_centre * (float)(-2.5066282746310002);
+  const float z = std::sqrt(-2.0f * logf_det(sp));
+  const float first = z - logf_det(z) / z;
+  const float rz = 1.0f / z;
+  const float x_far = first - poly(rz, p2) / poly(rz, q2) / z;
+  const float x_tail = first - poly(rz, p1) / poly(rz, q1) / z;
+  const float x = sp > lo_cut ? x_centre : (z >= 8.0f ? x_far : x_tail);
+  return p > hi_cut ? x : -x;
+}
+
+// ---- TF seed plumbing (python/framework/random_seed.py) + Philox4x32-10 on the host ----
+void tf_seed_pair(int64_t global_seed, int64_t op_seed, uint64_t &s1, uint64_t &s2) {
+  const int64_t M = 2147483647LL;
+  int64_t a = global_seed % M; if (a < 0) a += M;
+  int64_t b = op_seed % M;     if (b < 0) b += M;
+  if (a == 0 && b == 0) b = M;
+  s1 = (uint64_t)a; s2 = (uint64_t)b;
+}
+
+struct Philox {
+  uint32_t key[2], ctr[4];
+  Philox(uint64_t seed1, uint64_t seed2) {
+    key[0] = (uint32_t)seed1; key[1] = (uint32_t)(seed1 >> 32);
+    ctr[0] = ctr[1] = 0; ctr[2] = (uint32_t)seed2; ctr[3] = (uint32_t)(seed2 >> 32);
+  }
+  void block(uint64_t index, uint32_t out[4]) const {
+    uint32_t c0 = (uint32_t)index, c1 = (uint32_t)(index >> 32), c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+      const uint64_t a = (uint64_t)0xD2511F53u * c0, b = (uint64_t)0xCD9E8D57u * c2;
+      const uint32_t n0 = (uint32_t)(b >> 32) ^ c1 ^ k0, n2 = (uint32_t)(a >> 32) ^ c3 ^ k1;
+      c1 = (uint32_t)b; c3 = (uint32_t)a; c0 = n0; c2 = n2;
+      k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+  }
+  uint32_t element(uint64_t e) const {
+    uint32_t o[4];
+    block(e >> 2, o);
+    return o[e & 3];
+  }
+};
+
+// ---- CPython's random.Random(seed).randint(0, 2**31-1): the op seed TF hands to tf.random.shuffle ----
+struct MT19937 {
+  uint32_t mt[624];
+  int idx;
+  void init_genrand(uint32_t s) {
+    mt[0] = s;
+    for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    idx = 624;
+  }
+  void init_by_array(const std::vector<uint32_t> &key) {
+    init_genrand(19650218u);
+    size_t i = 1, j = 0;
+    for (size_t k = std::max<size_t>(624, key.size()); k; --k) {
+      mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+      if (++i >= 624) { mt[0] = mt[623]; i = 1; }
+      if (++j >= key.size()) j = 0;
+    }
+    for (size_t k = 623; k; --k) {
+      mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+      if (++i >= 624) { mt[0] = mt[623]; i = 1; }
+    }
+    mt[0] = 0x80000000u;
+  }
+  uint32_t next() {
+    if (idx >= 624) {
+      for (int k = 0; k < 624; ++k) {
+        const uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+        mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      idx = 0;
+    }
+    uint32_t y = mt[idx++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+  }
+};
+
+int64_t py_first_randint31(int64_t seed) {
+  const uint64_t a = seed < 0 ? (uint64_t)(-(seed + 1)) + 1u : (uint64_t)seed;
+  std::vector<uint32_t> key{(uint32_t)a};
+  if (a >> 32) key.push_back((uint32_t)(a >> 32));
+  MT19937 g;
+  g.init_by_array(key);
+  uint32_t r;
+  do r = g.next(); while (r >= 0x80000000u); // _randbelow(2**31) with k = 32 bits
+  return (int64_t)r;
+}
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+size_t round_up_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+} // namespace
+
+struct irec_context {
+  int device = -1;
+  int n_cu = 0;
+  float *d_lut = nullptr;
+  float *d_lut2 = nullptr;
+  uint16_t *d_dlog4r = nullptr;
+  float *d_rho = nullptr;
+};
+
+extern "C" {
+
+const char *irec_last_error(void) { return g_last_error.c_str(); }
+const char *irec_version(void) { return "irec-hip 0.1 (gfx950)"; }
+
+int32_t irec_n_samples(double kl_per_partition, double extra_samples) {
+  return (int32_t)std::exp(kl_per_partition * extra_samples);
+}
+
+double irec_codelength(int64_t n_indices, int32_t n_samples) { return (double)n_indices * std::log((double)n_samples); }
+
+irec_status irec_build_lut(float *lut) {
+  if (!lut) return fail(IREC_E_INVALID, "irec_build_lut: null output");
+  lut[0] = 0.0f;
+  for (int k = 1; k < IREC_BIG_PRIME; ++k) lut[k] = ndtri_f32((float)k / (float)IREC_BIG_PRIME);
+  return IREC_OK;
+}
+
+irec_status irec_tf_shuffle_perm(int64_t seed, int64_t n, int64_t *perm) {
+  if (n < 0 || (n > 0 && !perm)) return fail(IREC_E_INVALID, "irec_tf_shuffle_perm: bad arguments");
+  if (n > 0xFFFFFFFFLL) return fail(IREC_E_INVALID, "irec_tf_shuffle_perm: n too large");
+  for (int64_t i = 0; i < n; ++i) perm[i] = i;
+  if (n <= 1) return IREC_OK;
+  uint64_t s1, s2;
+  tf_seed_pair(seed, py_first_randint31(seed), s1, s2);
+  const Philox gen(s1, s2);
+  uint32_t blk[4];
+  for (int64_t i = 0; i < n - 1; ++i) { // random_shuffle_op.cc: forward Fisher-Yates, one uint32 per swap
+    if ((i & 3) == 0) gen.block((uint64_t)i >> 2, blk);
+    const int64_t j = i + (int64_t)(blk[i & 3] % (uint32_t)(n - i));
+    std::swap(perm[i], perm[j]);
+  }
+  return IREC_OK;
+}
+
+irec_status irec_philox_uniform_int(int64_t seed, int64_t n, int32_t *out) {
+  if (n < 0 || (n > 0 && !out)) return fail(IREC_E_INVALID, "irec_philox_uniform_int: bad arguments");
+  uint64_t s1, s2;
+  tf_seed_pair(seed, seed, s1, s2);
+  const Philox gen(s1, s2);
+  for (int64_t e = 0; e < n; ++e) out[e] = 1 + (int32_t)(gen.element((uint64_t)e) % (uint32_t)(IREC_BIG_PRIME - 1));
+  return IREC_OK;
+}
+
+irec_status irec_create(int device, irec_context **out) {
+  if (!out) return fail(IREC_E_INVALID, "irec_create: null output");
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(IREC_E_NO_DEVICE, "irec_create: no HIP device visible (this library has no CPU fallback)");
+  if (device < 0 || device >= count) return fail(IREC_E_INVALID, "irec_create: device %d out of range (%d)", device, count);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(IREC_E_NO_DEVICE, "irec_create: device %d is %s; this build targets gfx950 only", device, prop.gcnArchName);
+  HIP_TRY(hipSetDevice(device));
+
+  const int P = IREC_BIG_PRIME;
+  std::vector<float> lut(P);
+  irec_build_lut(lut.data());
+  // smallest primitive root of 10007 and the discrete-log tables
+  auto mulmod = [&](uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) % P); };
+  uint32_t g = 0;
+  std::vector<uint32_t> powers(P - 1);
+  for (uint32_t cand = 2; cand < (uint32_t)P && !g; ++cand) {
+    uint32_t x = 1;
+    bool ok = true;
+    std::vector<char> seen(P, 0);
+    for (int e = 0; e < P - 1; ++e) {
+      if (seen[x]) { ok = false; break; }
+      seen[x] = 1; powers[e] = x; x = mulmod(x, cand);
+    }
+    if (ok) g = cand;
+  }
+  if (!g) return fail(IREC_E_INVALID, "irec_create: no primitive root found");
+  std::vector<float> lut2(P - 1);
+  std::vector<uint16_t> dlog4r(P - 1);
+  for (int e = 0; e < P - 1; ++e) {
+    lut2[e] = lut[powers[e]];                 // lut2[e] = quantile(g^e / 10007)
+    dlog4r[powers[e] - 1] = (uint16_t)(4 * e); // byte offset of dlog(r) for r - 1 = u32 % 10006
+  }
+  std::vector<float> rho(IREC_MAX_PARTITIONS);
+  for (int i = 0; i < IREC_MAX_PARTITIONS; ++i) // get_auxiliary_ratio, coder.py:16,218-220 (float64 -> float32)
+    rho[i] = (float)std::pow((double)i + 1.0, -0.7864636765648174);
+
+  irec_context *ctx = new irec_context();
+  ctx->device = device;
+  ctx->n_cu = prop.multiProcessorCount;
+  HIP_TRY(hipMalloc(&ctx->d_lut, P * sizeof(float)));
+  HIP_TRY(hipMalloc(&ctx->d_lut2, (P - 1) * sizeof(float)));
+  HIP_TRY(hipMalloc(&ctx->d_dlog4r, (P - 1) * sizeof(uint16_t)));
+  HIP_TRY(hipMalloc(&ctx->d_rho, rho.size() * sizeof(float)));
+  HIP_TRY(hipMemcpy(ctx->d_lut, lut.data(), P * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ctx->d_lut2, lut2.data(), (P - 1) * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ctx->d_dlog4r, dlog4r.data(), (P - 1) * sizeof(uint16_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(ctx->d_rho, rho.data(), rho.size() * sizeof(float), hipMemcpyHostToDevice));
+  *out = ctx;
+  return IREC_OK;
+}
+
+void irec_destroy(irec_context *ctx) {
+  if (!ctx) return;
+  (void)hipFree(ctx->d_lut); (void)hipFree(ctx->d_lut2); (void)hipFree(ctx->d_dlog4r); (void)hipFree(ctx->d_rho);
+  delete ctx;
+}
+
+} // extern "C"
+
+namespace {
+
+struct Plan {
+  bool fast;
+  int grid_cap;      // resident workgroups (persistent kernels pull blocks from an atomic counter)
+  size_t ws_per_wg;
+  int dpad;
+};
+
+irec_status check_params(const irec_params *p) {
+  if (!p) return fail(IREC_E_INVALID, "null irec_params");
+  if (!(p->kl_per_partition > 0.0f)) return fail(IREC_E_INVALID, "kl_per_partition must be > 0");
+  if (p->n_samples < 1 || p->n_samples > (1 << 24)) return fail(IREC_E_INVALID, "n_samples %d out of range", p->n_samples);
+  if (p->n_beams < 1 || p->n_beams > IREC_MAX_BEAMS) return fail(IREC_E_INVALID, "n_beams %d out of range [1,%d]", p->n_beams, IREC_MAX_BEAMS);
+  return IREC_OK;
+}
+
+Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, int32_t max_K) {
+  Plan pl;
+  const int B = p->n_beams, S = p->n_samples;
+  pl.dpad = round_up(max_dim > 0 ? max_dim : 1, 256);
+  pl.fast = !(p->flags & IREC_FLAG_FORCE_GENERIC) && max_dim <= irec::FAST_MAX_DIM && irec::fast_nb_for(B) != 0 &&
+            irec::fast_lds_for(B, S) <= irec::FAST_LDS_LIMIT && (int64_t)S * B < (1 << 24);
+  pl.grid_cap = 2 * (ctx->n_cu > 0 ? ctx->n_cu : 256);
+  if (pl.fast) {
+    pl.ws_per_wg = round_up_sz((size_t)(max_K > 0 ? max_K : 1) * irec::fast_nb_for(B) * 4, 256);
+  } else {
+    pl.ws_per_wg = round_up_sz((size_t)9 * pl.dpad * 4 + (size_t)2 * B * pl.dpad * 4 +
+                                   (size_t)(max_K > 0 ? max_K : 1) * B * 4 + (size_t)S * B * 4, 256);
+  }
+  return pl;
+}
+
+} // namespace
+
+extern "C" {
+
+size_t irec_encode_workspace_bytes(const irec_context *ctx, const irec_params *p, int32_t max_dim, int32_t max_K) {
+  if (!ctx || check_params(p) != IREC_OK || max_dim < 1 || max_K < 0) return 0;
+  const Plan pl = make_plan(ctx, p, max_dim, max_K);
+  return 256 + (size_t)pl.grid_cap * pl.ws_per_wg;
+}
+
+irec_status irec_block_kl(irec_context *ctx, const irec_params *p, int64_t n_blocks, const int64_t *block_base,
+                          const int32_t *block_pos, const int32_t *block_dim, const int32_t *perm, const float *q_loc,
+                          const float *q_scale, const float *p_loc, const float *p_scale, float *out_kl, int32_t *out_K,
+                          void *hip_stream) {
+  if (!ctx) return fail(IREC_E_INVALID, "irec_block_kl: null context");
+  if (irec_status s = check_params(p)) return s;
+  if (n_blocks < 0) return fail(IREC_E_INVALID, "irec_block_kl: n_blocks < 0");
+  if (n_blocks == 0) return IREC_OK;
+  if (!block_base || !block_pos || !block_dim || !q_loc || !q_scale || !p_loc || !p_scale || !out_K)
+    return fail(IREC_E_INVALID, "irec_block_kl: null pointer argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  irec::EncArgs A{};
+  A.block_base = block_base; A.block_pos = block_pos; A.block_dim = block_dim; A.perm = perm;
+  A.q_loc = q_loc; A.q_scale = q_scale; A.p_loc = p_loc; A.p_scale = p_scale;
+  A.n_blocks = n_blocks; A.omega = p->kl_per_partition; A.S = p->n_samples; A.B = p->n_beams; A.out_K = out_K;
+  const int grid = (int)std::min<int64_t>(n_blocks, 8LL * ctx->n_cu);
+  HIP_TRY(irec::launch_block_kl(A, out_kl, grid, (hipStream_t)hip_stream));
+  return IREC_OK;
+}
+
+irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_blocks, const int64_t *block_base,
+                             const int32_t *block_pos, const int32_t *block_dim, int32_t max_block_dim,
+                             const int32_t *perm, const float *q_loc, const float *q_scale, const float *p_loc,
+                             const float *p_scale, int64_t seed, int32_t max_K, int32_t *out_K, int32_t *out_indices,
+                             float *out_sample, void *workspace, size_t workspace_bytes, void *hip_stream) {
+  if (!ctx) return fail(IREC_E_INVALID, "irec_beam_encode: null context");
+  if (irec_status s = check_params(p)) return s;
+  if (n_blocks < 0) return fail(IREC_E_INVALID, "irec_beam_encode: n_blocks < 0");
+  if (n_blocks == 0) return IREC_OK;
+  if (!block_base || !block_pos || !block_dim || !q_loc || !q_scale || !p_loc || !p_scale || !out_K || !out_sample)
+    return fail(IREC_E_INVALID, "irec_beam_encode: null pointer argument");
+  if (max_K < 0 || max_K > IREC_MAX_PARTITIONS) return fail(IREC_E_INVALID, "irec_beam_encode: max_K %d out of range", max_K);
+  if (max_K > 0 && !out_indices) return fail(IREC_E_INVALID, "irec_beam_encode: null out_indices");
+  if (max_block_dim < 1 || max_block_dim > (1 << 22)) return fail(IREC_E_INVALID, "irec_beam_encode: max_block_dim %d out of range", max_block_dim);
+  const Plan pl = make_plan(ctx, p, max_block_dim, max_K);
+  const size_t need = 256 + (size_t)pl.grid_cap * pl.ws_per_wg;
+  if (!workspace || workspace_bytes < need)
+    return fail(IREC_E_WORKSPACE, "irec_beam_encode: workspace %zu bytes < required %zu", workspace_bytes, need);
+  if (((uintptr_t)workspace & 255) != 0) return fail(IREC_E_WORKSPACE, "irec_beam_encode: workspace must be 256-byte aligned");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  irec::EncArgs A{};
+  A.block_base = block_base; A.block_pos = block_pos; A.block_dim = block_dim; A.perm = perm;
+  A.q_loc = q_loc; A.q_scale = q_scale; A.p_loc = p_loc; A.p_scale = p_scale;
+  A.n_blocks = n_blocks; A.seed = seed;
+  A.omega = p->kl_per_partition; A.S = p->n_samples; A.B = p->n_beams; A.max_K = max_K;
+  A.out_K = out_K; A.out_indices = out_indices; A.out_sample = out_sample;
+  A.lut = ctx->d_lut; A.lut2 = ctx->d_lut2; A.dlog4r = ctx->d_dlog4r; A.rho = ctx->d_rho;
+  A.counter = (unsigned int *)workspace;
+  A.ws = (char *)workspace + 256;
+  A.ws_per_wg = pl.ws_per_wg;
+  A.max_dim_pad = pl.dpad;
+  HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));
+  const int grid = (int)std::min<int64_t>(n_blocks, pl.grid_cap);
+  if (pl.fast) HIP_TRY(irec::launch_encode_fast(A, grid, st));
+  else HIP_TRY(irec::launch_encode_generic(A, grid, st));
+  return IREC_OK;
+}
+
+irec_status irec_beam_decode(irec_context *ctx, const irec_params *p, int64_t n_blocks, const int64_t *block_base,
+                             const int32_t *block_pos, const int32_t *block_dim, const int32_t *perm,
+                             const float *p_loc, const float *p_scale, int64_t seed, int32_t max_K, const int32_t *K,
+                             const int32_t *indices, float *out_sample, void *hip_stream) {
+  if (!ctx) return fail(IREC_E_INVALID, "irec_beam_decode: null context");
+  if (irec_status s = check_params(p)) return s;
+  if (n_blocks < 0) return fail(IREC_E_INVALID, "irec_beam_decode: n_blocks < 0");
+  if (n_blocks == 0) return IREC_OK;
+  if (!block_base || !block_pos || !block_dim || !p_loc || !p_scale || !K || !out_sample || (max_K > 0 && !indices))
+    return fail(IREC_E_INVALID, "irec_beam_decode: null pointer argument");
+  if (max_K < 0 || max_K > IREC_MAX_PARTITIONS) return fail(IREC_E_INVALID, "irec_beam_decode: max_K %d out of range", max_K);
+  HIP_TRY(hipSetDevice(ctx->device));
+  irec::DecArgs A{};
+  A.block_base = block_base; A.block_pos = block_pos; A.block_dim = block_dim; A.perm = perm;
+  A.p_loc = p_loc; A.p_scale = p_scale; A.n_blocks = n_blocks; A.seed = seed; A.max_K = max_K; A.K = K;
+  A.indices = indices; A.out_sample = out_sample; A.lut = ctx->d_lut; A.rho = ctx->d_rho;
+  const int grid = (int)std::min<int64_t>(n_blocks, 8LL * ctx->n_cu);
+  HIP_TRY(irec::launch_decode(A, grid, (hipStream_t)hip_stream));
+  return IREC_OK;
+}
+
+irec_status irec_device_uniform_int(irec_context *ctx, int64_t seed, int64_t n, int32_t *out, void *hip_stream) {
+  if (!ctx || n < 0 || (n > 0 && !out)) return fail(IREC_E_INVALID, "irec_device_uniform_int: bad arguments");
+  if (n == 0) return IREC_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(irec::launch_uniform_int(seed, n, out, (hipStream_t)hip_stream));
+  return IREC_OK;
+}
+
+irec_status irec_test_reduce_scatter(irec_context *ctx, const float *in, float *out, int32_t width, void *hip_stream) {
+  if (!ctx || !in || !out || (width != 64 && width != 32)) return fail(IREC_E_INVALID, "irec_test_reduce_scatter: bad arguments");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(irec::launch_reduce_scatter_test(in, out, width, (hipStream_t)hip_stream));
+  return IREC_OK;
+}
+
+irec_status irec_device_tables(irec_context *ctx, const float **lut, const float **lut2, const uint16_t **dlog4r,
+                               const float **rho) {
+  if (!ctx) return fail(IREC_E_INVALID, "irec_device_tables: null context");
+  if (lut) *lut = ctx->d_lut;
+  if (lut2) *lut2 = ctx->d_lut2;
+  if (dlog4r) *dlog4r = ctx->d_dlog4r;
+  if (rho) *rho = ctx->d_rho;
+  return IREC_OK;
+}
+
+} // extern "C"

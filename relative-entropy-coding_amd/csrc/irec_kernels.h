@@ -1,0 +1,50 @@
+// irec_kernels.h -- argument blocks and launchers shared by irec_kernels.hip and irec_host.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define IREC_MAX_PARTITIONS_DEV 65536
+
+namespace irec {
+
+constexpr int FAST_NW = 4;          // waves per workgroup of the fast encoder
+constexpr int FAST_MAX_DIM = 1024;  // 4 dim groups x 64 lanes x 4 dims
+constexpr size_t FAST_LDS_LIMIT = 160 * 1024;
+
+struct EncArgs {
+  // problem
+  const int64_t *block_base; const int32_t *block_pos; const int32_t *block_dim; const int32_t *perm;
+  const float *q_loc, *q_scale, *p_loc, *p_scale;
+  int64_t n_blocks; int64_t seed;
+  float omega; int32_t S, B, max_K;
+  // outputs
+  int32_t *out_K; int32_t *out_indices; float *out_sample;
+  // constant tables of the context
+  const float *lut;        // [10007] natural order: lut[k] = quantile(k/10007)
+  const float *lut2;       // [10006] lut2[e] = lut[g^e mod 10007]
+  const uint16_t *dlog4r;  // [10006] 4 * dlog_g(j + 1)
+  const float *rho;        // [IREC_MAX_PARTITIONS_DEV] rho[i] = float32((i+1)^-0.7864636765648174)
+  // scratch
+  unsigned int *counter; char *ws; size_t ws_per_wg; int32_t max_dim_pad;
+};
+
+struct DecArgs {
+  const int64_t *block_base; const int32_t *block_pos; const int32_t *block_dim; const int32_t *perm;
+  const float *p_loc, *p_scale;
+  int64_t n_blocks; int64_t seed;
+  int32_t max_K; const int32_t *K; const int32_t *indices; float *out_sample;
+  const float *lut; const float *rho;
+};
+
+hipError_t launch_block_kl(const EncArgs &A, float *out_kl, int grid, hipStream_t st);
+size_t generic_lds_bytes();
+hipError_t launch_encode_generic(const EncArgs &A, int grid, hipStream_t st);
+int fast_nb_for(int B);
+size_t fast_lds_for(int B, int S);
+hipError_t launch_encode_fast(const EncArgs &A, int grid, hipStream_t st);
+hipError_t launch_decode(const DecArgs &A, int grid, hipStream_t st);
+hipError_t launch_uniform_int(int64_t seed, int64_t n, int32_t *out, hipStream_t st);
+hipError_t launch_reduce_scatter_test(const float *in, float *out, int width, hipStream_t st);
+
+} // namespace irec

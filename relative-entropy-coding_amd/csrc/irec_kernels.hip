@@ -1,0 +1,720 @@
+// irec_kernels.hip -- hand-written gfx950 (CDNA4, MI355X) kernels of the iREC beam-search coder.
+//
+// Hot path re-implemented here (reference file:line):
+//   BeamSearchCoder.encode_block            rec/coding/beam_search_coder.py:53-122
+//     get_pseudo_random_sample              rec/coding/beam_search_coder.py:37-51
+//     simple_hash                           rec/coding/beam_search_coder.py:33-35
+//     get_auxiliary_coder / _target         rec/coding/coder.py:141-154
+//     get_auxiliary_ratio                   rec/coding/coder.py:16,218-220
+//   BeamSearchCoder.decode_block            rec/coding/beam_search_coder.py:124-148
+//   Coder.split / merge (as gather/scatter) rec/coding/coder.py:38-122
+//
+// Two encoders share one arithmetic specification:
+//   encode_fast_kernel<NB,NW>  D <= 1024, B <= 32: one persistent workgroup per block, beams live in VGPRs
+//                              (lane owns 4 dims), quantile LUT + discrete-log table in LDS, Philox fused in.
+//   encode_generic_kernel      any D, B <= 64: beams in a global scratch slab; correctness fallback.
+//
+// Compiled with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (no implicit fma: see irec_device.h).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "irec_device.h"
+#include "irec_kernels.h"
+
+namespace irec {
+
+// ======================================================================================================
+//  small shared pieces
+// ======================================================================================================
+__device__ __forceinline__ int64_t src_index(const EncArgs &A, int64_t base, int32_t pos, int d) {
+  return base + (A.perm ? (int64_t)A.perm[pos + d] : (int64_t)(pos + d));
+}
+
+// Block-wide top-Bnew selection over key[0..N) (uint32 sort keys; 0 = taken).  NT threads, NT/64 waves.
+// Element f is owned (scanned, cleared) by thread f % NT.  One barrier per selected beam.
+template <int NT>
+__device__ __forceinline__ void select_topB(uint32_t *key, int N, int Bnew, int Bcur, unsigned long long *wb,
+                                            int32_t *sel_s, int32_t *sel_b) {
+  constexpr int NWV = NT / 64;
+  const int tid = threadIdx.x;
+  for (int it = 0; it < Bnew; ++it) {
+    unsigned long long best = 0ull;
+    for (int f = tid; f < N; f += NT) {
+      const unsigned long long c = cand_pack(key[f], (uint32_t)f);
+      best = c > best ? c : best;
+    }
+    best = wave_max_u64(best);
+    if ((tid & 63) == 0) wb[(it & 1) * NWV + (tid >> 6)] = best;
+    __syncthreads();
+    unsigned long long g = 0ull;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) {
+      const unsigned long long o = wb[(it & 1) * NWV + w];
+      g = o > g ? o : g;
+    }
+    const uint32_t fstar = 0xFFFFFFFFu - (uint32_t)g;
+    if ((uint32_t)tid == fstar % (uint32_t)NT) key[fstar] = 0u;
+    if (tid == 0) {
+      sel_s[it] = (int32_t)(fstar / (uint32_t)Bcur); // best_ind_aux  (beam_search_coder.py:89)
+      sel_b[it] = (int32_t)(fstar % (uint32_t)Bcur); // best_ind_beam (beam_search_coder.py:88)
+    }
+  }
+  __syncthreads();
+}
+
+// ======================================================================================================
+//  KL / K kernel  (beam_search_coder.py:57-59)
+// ======================================================================================================
+__global__ __launch_bounds__(256) void block_kl_kernel(EncArgs A, float *out_kl) {
+  __shared__ double gpart[4];
+  __shared__ double total_s;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform by construction: keep it in an SGPR
+  for (int64_t blk = blockIdx.x; blk < A.n_blocks; blk += gridDim.x) {
+    const int D = A.block_dim[blk];
+    const int64_t base = A.block_base[blk];
+    const int32_t pos = A.block_pos[blk];
+    const int NG = (D + 255) >> 8;
+    for (int g0 = 0; g0 < NG; g0 += 4) {
+      const int g = g0 + wave;
+      double acc = 0.0;
+      if (g < NG) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int d = g * 256 + lane * 4 + i;
+          if (d < D) {
+            const int64_t ix = src_index(A, base, pos, d);
+            acc = acc + kl_dim(A.q_loc[ix], A.q_scale[ix], A.p_loc[ix], A.p_scale[ix]);
+          }
+        }
+      }
+      const double gs = wave_tree_sum(acc);
+      if (lane == 0) gpart[wave] = gs;
+      __syncthreads();
+      if (tid == 0) {
+        double t = g0 == 0 ? 0.0 : total_s;
+        for (int w = 0; w < 4 && g0 + w < NG; ++w) t = (g0 + w == 0) ? gpart[w] : t + gpart[w];
+        total_s = t;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const float kl = NG ? (float)total_s : 0.0f;
+      if (out_kl) out_kl[blk] = kl;
+      A.out_K[blk] = num_aux(kl, A.omega);
+    }
+    __syncthreads();
+  }
+}
+
+// ======================================================================================================
+//  generic encoder: any D, B <= 64.  Scratch slab per workgroup:
+//    float dmu,vq,vp,mp,c,sa,m,A,Bv [9][Dpad] | float beams[2][B][Dpad] | int32 bp[max_K][B] | uint32 key[S*B]
+// ======================================================================================================
+constexpr int GEN_NT = 256;
+constexpr int GEN_NSC = 8192; // score/key entries kept in LDS; larger candidate sets go to the scratch slab
+
+__global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *lut_s = reinterpret_cast<float *>(smem);                              // [10008]
+  uint32_t *key_lds = reinterpret_cast<uint32_t *>(smem + 40032);              // [GEN_NSC]
+  unsigned long long *wb = reinterpret_cast<unsigned long long *>(smem + 40032 + GEN_NSC * 4); // [8]
+  double *gpart = reinterpret_cast<double *>(wb + 8);                          // [4]
+  double *total_s = gpart + 4;                                                 // [1]
+  int32_t *sel_s = reinterpret_cast<int32_t *>(total_s + 1);                   // [64]
+  int32_t *sel_b = sel_s + 64;                                                 // [64]
+  int32_t *hsum = sel_b + 64;                                                  // [2][64]
+  int32_t *misc = hsum + 128;                                                  // [4]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform by construction: keep it in an SGPR
+  const int S = A.S, B = A.B;
+  for (int k = tid; k < (int)IREC_P; k += GEN_NT) lut_s[k] = A.lut[k];
+
+  const int Dpad = A.max_dim_pad;
+  char *slab = A.ws + (size_t)blockIdx.x * A.ws_per_wg;
+  float *f_dmu = reinterpret_cast<float *>(slab);
+  float *f_vq = f_dmu + Dpad, *f_vp = f_vq + Dpad, *f_mp = f_vp + Dpad, *f_c = f_mp + Dpad;
+  float *f_sa = f_c + Dpad, *f_m = f_sa + Dpad, *f_A = f_m + Dpad, *f_Bv = f_A + Dpad;
+  float *beams = f_Bv + Dpad;                                                 // [2][B][Dpad]
+  int32_t *bp = reinterpret_cast<int32_t *>(beams + (size_t)2 * B * Dpad);    // [max_K][B]
+  uint32_t *key_glb = reinterpret_cast<uint32_t *>(bp + (size_t)A.max_K * B); // [S*B]
+
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) misc[0] = (int32_t)atomicAdd(A.counter, 1u);
+    __syncthreads();
+    const int64_t blk = misc[0];
+    if (blk >= A.n_blocks) break; // every wave of every workgroup reaches this
+    const int D = A.block_dim[blk];
+    const int64_t base = A.block_base[blk];
+    const int32_t pos = A.block_pos[blk];
+    const int NG = (D + 255) >> 8;
+    if (D < 1 || D > Dpad) { // not codable with this scratch slab: report and skip
+      if (tid == 0) A.out_K[blk] = -1;
+      continue;
+    }
+
+    // ---- load the block (split == gather through perm), KL in the canonical tree ----
+    for (int g0 = 0; g0 < NG; g0 += 4) {
+      const int g = g0 + wave;
+      double acc = 0.0;
+      if (g < NG) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int d = g * 256 + lane * 4 + i;
+          float dmu = 0.f, vq = 1.f, vp = 1.f, mp = 0.f;
+          if (d < D) {
+            const int64_t ix = src_index(A, base, pos, d);
+            const float mq = A.q_loc[ix], sq = A.q_scale[ix], sp = A.p_scale[ix];
+            mp = A.p_loc[ix];
+            acc = acc + kl_dim(mq, sq, mp, sp);
+            dmu = mq - mp; vq = sq * sq; vp = sp * sp;
+          }
+          f_dmu[d] = dmu; f_vq[d] = vq; f_vp[d] = vp; f_mp[d] = mp; f_c[d] = 0.f;
+          f_sa[d] = 0.f; f_m[d] = 0.f; f_A[d] = 0.f; f_Bv[d] = 0.f;
+        }
+      }
+      const double gs = wave_tree_sum(acc);
+      if (lane == 0) gpart[wave] = gs;
+      __syncthreads();
+      if (tid == 0) {
+        double t = g0 == 0 ? 0.0 : *total_s;
+        for (int w = 0; w < 4 && g0 + w < NG; ++w) t = (g0 + w == 0) ? gpart[w] : t + gpart[w];
+        *total_s = t;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const int32_t K = num_aux(NG ? (float)*total_s : 0.0f, A.omega);
+      misc[1] = K;
+      A.out_K[blk] = K;
+      hsum[0] = 0;
+    }
+    __syncthreads();
+    const int K = misc[1];
+    if (K > A.max_K || K > IREC_MAX_PARTITIONS_DEV) continue;
+
+    int cur = 0, Bcur = 1;
+    for (int t = 0; t < K; ++t) {
+      const StepSeed ss = make_step_seed(A.seed + t);
+      const float rho = A.rho[K - 1 - t];
+      // phase 1: per-dim constants; c <- c + a  (beam_search_coder.py:67-77,109)
+      for (int d = tid; d < D; d += GEN_NT) {
+        const StepConst sc = step_constants(rho, f_dmu[d], f_vq[d], f_vp[d], f_c[d]);
+        f_sa[d] = sc.sa; f_m[d] = sc.m; f_A[d] = sc.A; f_Bv[d] = sc.Bv;
+        f_c[d] = f_c[d] + sc.a;
+      }
+      __syncthreads();
+      // phase 2: score every candidate (s, b); one wave per candidate, canonical tree over dims
+      const int N = S * Bcur;
+      uint32_t *key = (N <= GEN_NSC) ? key_lds : key_glb;
+      const float *bcur = beams + (size_t)cur * B * Dpad;
+      for (int f = wave; f < N; f += GEN_NT / 64) {
+        const int s = f / Bcur, b = f - s * Bcur;
+        const uint32_t h = hash_from_sum(hsum[cur * 64 + b]);
+        float sc = 0.f;
+        for (int g = 0; g < NG; ++g) {
+          const int d0 = g * 256 + lane * 4;
+          float acc = 0.f;
+          if (d0 < D) {
+            uint32_t rm1[4];
+            draw_rm1_x4(ss, (uint64_t)s * (uint64_t)D + (uint64_t)d0, rm1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int d = d0 + i;
+              if (d < D) {
+                const uint32_t k = ((rm1[i] + 1u) * h) % IREC_P; // floormod(r * hash, 10007), :45-47
+                const float y = f_sa[d] * lut_s[k];              // dist.quantile(k / 10007), :48-49
+                const float bv = t ? bcur[(size_t)b * Dpad + d] : 0.f;
+                acc = score_term(acc, bv, y, f_m[d], f_A[d], f_Bv[d]);
+              }
+            }
+          }
+          const float gs = wave_tree_sum(acc);
+          sc = g == 0 ? gs : sc + gs;
+        }
+        if (lane == 0) key[f] = __float_as_uint(sc);
+      }
+      __syncthreads();
+      // phase 3: top-B (beam_search_coder.py:85-89 / :104)
+      const int Bnew = B < N ? B : N;
+      for (int f = tid; f < N; f += GEN_NT) key[f] = score_key(__uint_as_float(key[f]));
+      select_topB<GEN_NT>(key, N, Bnew, Bcur, wb, sel_s, sel_b);
+      // phase 4: gather the surviving beams, extend their index paths (:92-95 / :105-106)
+      if (tid < Bnew) {
+        const int32_t sp_ = sel_s[tid], bp_ = sel_b[tid];
+        hsum[(cur ^ 1) * 64 + tid] = (int32_t)((uint32_t)hsum[cur * 64 + bp_] + (uint32_t)sp_ * (uint32_t)(69 + t));
+        bp[(size_t)t * B + tid] = (sp_ << 6) | bp_;
+      }
+      float *bnext = beams + (size_t)(cur ^ 1) * B * Dpad;
+      for (int d = tid; d < D; d += GEN_NT) {
+        const float sa = f_sa[d];
+        for (int j = 0; j < Bnew; ++j) {
+          const int32_t sp_ = sel_s[j], bp_ = sel_b[j];
+          const uint32_t h = hash_from_sum(hsum[cur * 64 + bp_]);
+          const uint32_t rm1 = draw_rm1(ss, (uint64_t)sp_ * (uint64_t)D + (uint64_t)d);
+          const uint32_t k = ((rm1 + 1u) * h) % IREC_P;
+          const float y = sa * lut_s[k];
+          const float ob = t ? bcur[(size_t)bp_ * Dpad + d] : 0.f;
+          bnext[(size_t)j * Dpad + d] = ob + y; // combined_samples = beams + samples, :81
+        }
+      }
+      __syncthreads();
+      cur ^= 1;
+      Bcur = Bnew;
+    }
+    // ---- outputs: beams[0] + p.loc scattered back (merge), index path of beam 0 (:118-122) ----
+    const float *bfin = beams + (size_t)cur * B * Dpad;
+    for (int d = tid; d < D; d += GEN_NT) {
+      const float b0 = K ? bfin[d] : 0.f;
+      A.out_sample[src_index(A, base, pos, d)] = b0 + f_mp[d];
+    }
+    if (tid == 0) {
+      int j = 0;
+      for (int t = K - 1; t >= 0; --t) {
+        const int32_t v = bp[(size_t)t * B + j];
+        A.out_indices[blk * (int64_t)A.max_K + t] = v >> 6;
+        j = v & 63;
+      }
+    }
+  }
+}
+
+// ======================================================================================================
+//  fast encoder: D <= 1024, B <= NB <= 32.
+//  wave w -> (dim group g = w % NG, sample stripe sw = w / NG); lane l owns dims 256 g + 4 l .. +3.
+// ======================================================================================================
+
+// ---- reduce-scatter over the 64 lanes in the canonical tree order (lane bits 5,4,3,2,1,0) -----------------
+__device__ __forceinline__ void swap32(float &a, float &b) { // a[32+i] <-> b[i]
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap16(float &a, float &b) { // a[16+i] <-> b[i], a[48+i] <-> b[32+i]
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+template <int CTRL, int BANK>
+__device__ __forceinline__ float dpp_f(float old, float src) {
+  return __uint_as_float(
+      (uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(old), (int)__float_as_uint(src), CTRL, 0xF, BANK, false));
+}
+// value of the partner lane (lane ^ DIST) for DIST in {8,4,2,1}
+template <int DIST>
+__device__ __forceinline__ float partner(float v) {
+  if constexpr (DIST == 8) return dpp_f<0x128, 0xF>(v, v);             // row_ror:8
+  else if constexpr (DIST == 4) {
+    float r = dpp_f<0x104, 0x5>(v, v);                                 // row_shl:4 -> lanes with bit2 = 0 read lane+4
+    return dpp_f<0x114, 0xA>(r, v);                                    // row_shr:4 -> lanes with bit2 = 1 read lane-4
+  } else if constexpr (DIST == 2) return dpp_f<0x4E, 0xF>(v, v);       // quad_perm [2,3,0,1]
+  else return dpp_f<0xB1, 0xF>(v, v);                                  // quad_perm [1,0,3,2]
+}
+
+// One stage of the reduce-scatter: lanes at distance DIST exchange halves of their N values and add.
+// With N == 1 it degenerates into an all-reduce add (both partners end with the same bits).
+template <int DIST, int N>
+__device__ __forceinline__ void rs_stage(float *v, int lane) {
+  if constexpr (N >= 2) {
+    constexpr int H = N / 2;
+    if constexpr (DIST == 32) {
+#pragma unroll
+      for (int j = 0; j < H; ++j) { swap32(v[j], v[j + H]); v[j] = v[j] + v[j + H]; }
+    } else if constexpr (DIST == 16) {
+#pragma unroll
+      for (int j = 0; j < H; ++j) { swap16(v[j], v[j + H]); v[j] = v[j] + v[j + H]; }
+    } else {
+      const bool hi = (lane & DIST) != 0;
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        const float keep = hi ? v[j + H] : v[j], send = hi ? v[j] : v[j + H];
+        v[j] = keep + partner<DIST>(send);
+      }
+    }
+  } else {
+    static_assert(DIST <= 8, "all-reduce stages only exist inside a row");
+    v[0] = v[0] + partner<DIST>(v[0]);
+  }
+}
+constexpr int rs_half(int n) { return n >= 2 ? n / 2 : 1; }
+
+// v[0..N0) per lane -> every lane l returns the sum over all 64 lanes of v[l * N0 / 64], added in the canonical
+// tree (pairs at lane distance 32, 16, 8, 4, 2, 1).  N0 in {64, 32, 16}.
+template <int N0>
+__device__ __forceinline__ float reduce_scatter(float (&v)[N0], int lane) {
+  static_assert(N0 == 64 || N0 == 32 || N0 == 16, "unsupported width");
+  constexpr int n4 = rs_half(N0), n3 = rs_half(n4), n2 = rs_half(n3), n1 = rs_half(n2), n0 = rs_half(n1);
+  rs_stage<32, N0>(v, lane);
+  rs_stage<16, n4>(v, lane);
+  rs_stage<8, n3>(v, lane);
+  rs_stage<4, n2>(v, lane);
+  rs_stage<2, n1>(v, lane);
+  rs_stage<1, n0>(v, lane);
+  return v[0];
+}
+
+template <int NB>
+struct FastCfg {
+  static constexpr int RW = NB <= 21 ? 64 : 32;   // accumulators reduced together
+  static constexpr int SPC = RW / NB;             // samples per chunk
+  static_assert(SPC >= 1, "NB too large");
+};
+
+// LDS carve (bytes): lut2 40032 | dlog 20016 | region | small 1024.
+// region holds [part | key] during scoring/selection and is re-used as the beam staging area during the update.
+__host__ __device__ inline size_t fast_lds_bytes(int NB, int NW, int S, size_t *off_key, size_t *off_small) {
+  const size_t part = (((size_t)4 * S * NB * 4) + 15) & ~(size_t)15;
+  const size_t key = (((size_t)S * NB * 4) + 15) & ~(size_t)15;
+  const size_t stage = (size_t)NW * NB * 64 * 4;
+  const size_t region = (part + key) > stage ? (part + key) : stage;
+  if (off_key) *off_key = 40032 + 20016 + part;
+  if (off_small) *off_small = 40032 + 20016 + region;
+  return 40032 + 20016 + region + 1024;
+}
+
+template <int NB, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
+  using Cfg = FastCfg<NB>;
+  constexpr int NT = NW * 64;
+  constexpr int RW = Cfg::RW, SPC = Cfg::SPC;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int S = A.S, B = A.B;
+  size_t off_key, off_small;
+  fast_lds_bytes(NB, NW, S, &off_key, &off_small);
+  char *lut2_b = smem;                                                        // float [10006], dlog order
+  const uint16_t *dlog_s = reinterpret_cast<const uint16_t *>(smem + 40032);  // [10006] 4*dlog(j+1)
+  float *part_s = reinterpret_cast<float *>(smem + 40032 + 20016);            // [NG][S][NB]
+  float *stage_s = part_s;                                                    // [NW][NB][64] (aliases part)
+  uint32_t *key_s = reinterpret_cast<uint32_t *>(smem + off_key);             // [S*NB]
+  char *small = smem + off_small;
+  unsigned long long *wb = reinterpret_cast<unsigned long long *>(small);     // [2][NW] (<= 16 entries)
+  double *gpart = reinterpret_cast<double *>(small + 128);                    // [4]
+  int32_t *sel_s = reinterpret_cast<int32_t *>(small + 160);                  // [32]
+  int32_t *sel_b = sel_s + 32;                                                // [32]
+  int32_t *hsum = sel_b + 32;                                                 // [2][32]
+  uint32_t *beta4 = reinterpret_cast<uint32_t *>(hsum + 64);                  // [2][32] 4*dlog(hash(beam))
+  int32_t *misc = reinterpret_cast<int32_t *>(beta4 + 64);                    // [4]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform by construction: keep it in an SGPR
+  {
+    float *l2 = reinterpret_cast<float *>(lut2_b);
+    for (int k = tid; k < (int)IREC_PM1; k += NT) l2[k] = A.lut2[k];
+    uint16_t *dl = reinterpret_cast<uint16_t *>(smem + 40032);
+    for (int k = tid; k < (int)IREC_PM1; k += NT) dl[k] = A.dlog4r[k];
+  }
+  int32_t *bp = reinterpret_cast<int32_t *>(A.ws + (size_t)blockIdx.x * A.ws_per_wg); // [max_K][NB]
+
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) misc[0] = (int32_t)atomicAdd(A.counter, 1u);
+    __syncthreads();
+    const int64_t blk = misc[0];
+    if (blk >= A.n_blocks) break; // every wave of every workgroup reaches this
+    const int D = A.block_dim[blk];
+    const int64_t base = A.block_base[blk];
+    const int32_t pos = A.block_pos[blk];
+    if (D < 1 || D > FAST_MAX_DIM) { // host promised D <= 1024
+      if (tid == 0) A.out_K[blk] = -1;
+      continue;
+    }
+    const int NG = (D + 255) >> 8;          // 1..4
+    const int NSW = NW / NG;                // sample stripes
+    const bool active = wave < NG * NSW;
+    const int g = wave % NG, sw = wave / NG;
+    const int d0 = g * 256 + lane * 4;
+
+    // ---- load my 4 dims (split == gather through perm) and the block's KL ----
+    float dmu[4], vq[4], vp[4], mp[4], c[4];
+    bool valid[4];
+    double klacc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d = d0 + i;
+      valid[i] = d < D;
+      dmu[i] = 0.f; vq[i] = 1.f; vp[i] = 1.f; mp[i] = 0.f; c[i] = 0.f;
+      if (valid[i]) {
+        const int64_t ix = src_index(A, base, pos, d);
+        const float mq = A.q_loc[ix], sq = A.q_scale[ix], sp = A.p_scale[ix];
+        mp[i] = A.p_loc[ix];
+        klacc = klacc + kl_dim(mq, sq, mp[i], sp);
+        dmu[i] = mq - mp[i]; vq[i] = sq * sq; vp[i] = sp * sp;
+      }
+    }
+    {
+      const double gs = wave_tree_sum(klacc);
+      if (sw == 0 && active && lane == 0) gpart[g] = gs;
+      __syncthreads();
+      if (tid == 0) {
+        double tot = gpart[0];
+        for (int gg = 1; gg < NG; ++gg) tot = tot + gpart[gg];
+        const int32_t K = num_aux((float)tot, A.omega);
+        misc[1] = K;
+        A.out_K[blk] = K;
+        hsum[0] = 0;
+        beta4[0] = 0u; // hash of the empty path is 1 = g^0
+      }
+      __syncthreads();
+    }
+    const int K = misc[1];
+    if (K > A.max_K || K > IREC_MAX_PARTITIONS_DEV) continue;
+
+    float beam[NB][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) beam[b][i] = 0.f;
+
+    int cur = 0, Bcur = 1;
+    for (int t = 0; t < K; ++t) {
+      const StepSeed ss = make_step_seed(A.seed + t);
+      const float rho = A.rho[K - 1 - t];
+      float sa[4], m[4], cA[4], cBv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const StepConst sc = step_constants(rho, dmu[i], vq[i], vp[i], c[i]);
+        sa[i] = valid[i] ? sc.sa : 0.f; m[i] = valid[i] ? sc.m : 0.f;
+        cA[i] = valid[i] ? sc.A : 0.f; cBv[i] = valid[i] ? sc.Bv : 0.f;
+        c[i] = c[i] + sc.a; // cumulative_auxiliary_variance += auxiliary_var (:109)
+      }
+      uint32_t bet[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) bet[b] = __builtin_amdgcn_readfirstlane(beta4[cur * 32 + (b < Bcur ? b : 0)]);
+
+      // ---------------- scoring: all S x Bcur candidates (beam_search_coder.py:80-84) ----------------
+      if (active) {
+        const int s_per_stripe = (S + NSW - 1) / NSW;
+        const int nchunks = (s_per_stripe + SPC - 1) / SPC;
+        for (int ch = 0; ch < nchunks; ++ch) {
+          float acc[RW];
+#pragma unroll
+          for (int p = 0; p < RW; ++p) acc[p] = 0.f;
+#pragma unroll
+          for (int cc = 0; cc < SPC; ++cc) {
+            const int s = (ch * SPC + cc) * NSW + sw;
+            if (s < S) { // wave-uniform
+              uint32_t rm1[4];
+              draw_rm1_x4(ss, (uint64_t)s * (uint64_t)D + (uint64_t)d0, rm1);
+              uint32_t al[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) al[i] = dlog_s[rm1[i]];
+#pragma unroll
+              for (int b = 0; b < NB; ++b) {
+                if (b < Bcur) { // wave-uniform
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) {
+                    uint32_t ad = al[i] + bet[b];                       // 4*(dlog r + dlog h)
+                    const uint32_t ad2 = ad - IREC_LUT2_BYTES;
+                    ad = ad2 < ad ? ad2 : ad;                           // mod 10006 (one conditional subtract)
+                    const float z = *reinterpret_cast<const float *>(lut2_b + ad);
+                    const float y = sa[i] * z;
+                    acc[cc * NB + b] = score_term(acc[cc * NB + b], beam[b][i], y, m[i], cA[i], cBv[i]);
+                  }
+                }
+              }
+            }
+          }
+          const float tot = reduce_scatter<RW>(acc, lane);
+          const int p = RW == 64 ? lane : (lane >> 1);
+          const int cc = p / NB, b = p - cc * NB;
+          const int s = (ch * SPC + cc) * NSW + sw;
+          if (cc < SPC && s < S && b < Bcur && (RW == 64 || (lane & 1) == 0)) part_s[((size_t)g * S + s) * NB + b] = tot;
+        }
+      }
+      __syncthreads();
+      // ---------------- combine dim groups in order, build sort keys ----------------
+      const int N = S * Bcur;
+      for (int f = tid; f < N; f += NT) {
+        const int s = f / Bcur, b = f - s * Bcur;
+        float sc = part_s[((size_t)0 * S + s) * NB + b];
+        for (int gg = 1; gg < NG; ++gg) sc = sc + part_s[((size_t)gg * S + s) * NB + b];
+        key_s[f] = score_key(sc);
+      }
+      const int Bnew = B < N ? B : N;
+      select_topB<NT>(key_s, N, Bnew, Bcur, wb, sel_s, sel_b); // first barrier inside orders key_s writes
+      // ---------------- new hashes / back-pointers (beam_search_coder.py:94-95) ----------------
+      if (tid < Bnew) {
+        const int32_t sp_ = sel_s[tid], bp_ = sel_b[tid];
+        const int32_t nh = (int32_t)((uint32_t)hsum[cur * 32 + bp_] + (uint32_t)sp_ * (uint32_t)(69 + t));
+        hsum[(cur ^ 1) * 32 + tid] = nh;
+        beta4[(cur ^ 1) * 32 + tid] = dlog_s[hash_from_sum(nh) - 1u];
+        bp[(size_t)t * NB + tid] = (sp_ << 6) | bp_;
+      }
+      // ---------------- gather the surviving beams in registers (beam_search_coder.py:92-93) ----------------
+      if (active) {
+        uint32_t apk[NB][2];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          apk[j][0] = 0u; apk[j][1] = 0u;
+          if (j < Bnew) {
+            const int32_t sp_ = __builtin_amdgcn_readfirstlane(sel_s[j]);
+            uint32_t rm1[4];
+            draw_rm1_x4(ss, (uint64_t)sp_ * (uint64_t)D + (uint64_t)d0, rm1);
+            apk[j][0] = (uint32_t)dlog_s[rm1[0]] | ((uint32_t)dlog_s[rm1[1]] << 16);
+            apk[j][1] = (uint32_t)dlog_s[rm1[2]] | ((uint32_t)dlog_s[rm1[3]] << 16);
+          }
+        }
+        float *st = stage_s + (size_t)wave * NB * 64 + lane; // lane-private column, dynamic row = old beam id
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) st[b * 64] = beam[b][i];
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            if (j < Bnew) {
+              const int32_t bp_ = __builtin_amdgcn_readfirstlane(sel_b[j]);
+              const uint32_t a16 = (i & 1) ? (apk[j][i >> 1] >> 16) : (apk[j][i >> 1] & 0xFFFFu);
+              uint32_t ad = a16 + beta4[cur * 32 + bp_];
+              const uint32_t ad2 = ad - IREC_LUT2_BYTES;
+              ad = ad2 < ad ? ad2 : ad;
+              const float y = sa[i] * *reinterpret_cast<const float *>(lut2_b + ad);
+              beam[j][i] = st[bp_ * 64] + y; // combined_samples[best_ind_aux, best_ind_beam], :81,92-93
+            }
+          }
+        }
+      }
+      __syncthreads();
+      cur ^= 1;
+      Bcur = Bnew;
+    }
+    // ---- outputs ----
+    if (active && sw == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (valid[i]) A.out_sample[src_index(A, base, pos, d0 + i)] = beam[0][i] + mp[i]; // beams[0] + coding_dist.loc
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int j = 0;
+      for (int t = K - 1; t >= 0; --t) {
+        const int32_t v = __builtin_nontemporal_load(&bp[(size_t)t * NB + j]);
+        A.out_indices[blk * (int64_t)A.max_K + t] = v >> 6;
+        j = v & 63;
+      }
+    }
+  }
+}
+
+// ======================================================================================================
+//  decoder (beam_search_coder.py:124-148): only row indices[t] of each step's draw is needed
+// ======================================================================================================
+__global__ __launch_bounds__(256) void decode_kernel(DecArgs A) {
+  const int tid = threadIdx.x;
+  for (int64_t blk = blockIdx.x; blk < A.n_blocks; blk += gridDim.x) {
+    const int D = A.block_dim[blk];
+    const int64_t base = A.block_base[blk];
+    const int32_t pos = A.block_pos[blk];
+    const int K = A.K[blk];
+    const int32_t *idx = A.indices + blk * (int64_t)A.max_K;
+    if (K > A.max_K || K < 0) continue;
+    for (int d = tid; d < D; d += 256) {
+      const int64_t ix = base + (A.perm ? (int64_t)A.perm[pos + d] : (int64_t)(pos + d));
+      const float sp = A.p_scale[ix];
+      const float var_p = sp * sp;
+      float c = 0.f, sample = 0.f;
+      uint32_t hs = 0u;
+      for (int t = 0; t < K; ++t) {
+        const float rho = A.rho[K - 1 - t];
+        const float a = rho * (var_p - c);
+        const float sa = sqrtf(a);
+        const StepSeed ss = make_step_seed(A.seed + t);
+        const uint32_t it = (uint32_t)idx[t];
+        const uint32_t h = hash_from_sum((int32_t)hs);
+        const uint32_t rm1 = draw_rm1(ss, (uint64_t)it * (uint64_t)D + (uint64_t)d);
+        const uint32_t k = ((rm1 + 1u) * h) % IREC_P;
+        sample = sample + sa * A.lut[k];
+        c = c + a;
+        hs += it * (uint32_t)(69 + t);
+      }
+      A.out_sample[ix] = sample + A.p_loc[ix];
+    }
+  }
+}
+
+// ======================================================================================================
+//  test hooks
+// ======================================================================================================
+__global__ void uniform_int_kernel(int64_t seed, int64_t n, int32_t *out) {
+  const StepSeed ss = make_step_seed(seed);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    out[e] = 1 + (int32_t)draw_rm1(ss, (uint64_t)e);
+}
+
+// in: [64 lanes][width] floats; out[lane] = canonical-tree total of column (lane >> shift)
+__global__ void reduce_scatter_test_kernel(const float *in, float *out, int width) {
+  const int lane = threadIdx.x & 63;
+  if (width == 64) {
+    float v[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) v[j] = in[lane * 64 + j];
+    out[lane] = reduce_scatter<64>(v, lane);
+  } else {
+    float v[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) v[j] = in[lane * 32 + j];
+    out[lane] = reduce_scatter<32>(v, lane);
+  }
+}
+
+// ======================================================================================================
+//  launchers (called from irec_host.cpp)
+// ======================================================================================================
+hipError_t launch_block_kl(const EncArgs &A, float *out_kl, int grid, hipStream_t st) {
+  hipLaunchKernelGGL(block_kl_kernel, dim3(grid), dim3(256), 0, st, A, out_kl);
+  return hipGetLastError();
+}
+
+size_t generic_lds_bytes() { return 40032 + (size_t)GEN_NSC * 4 + 64 + 32 + 8 + 64 * 4 * 2 + 128 * 4 + 16 + 64; }
+
+hipError_t launch_encode_generic(const EncArgs &A, int grid, hipStream_t st) {
+  const size_t lds = generic_lds_bytes();
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_generic_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(encode_generic_kernel, dim3(grid), dim3(GEN_NT), lds, st, A);
+  return hipGetLastError();
+}
+
+template <int NB, int NW>
+static hipError_t launch_fast_t(const EncArgs &A, int grid, hipStream_t st) {
+  const size_t lds = fast_lds_bytes(NB, NW, A.S, nullptr, nullptr);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_fast_kernel<NB, NW>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((encode_fast_kernel<NB, NW>), dim3(grid), dim3(NW * 64), lds, st, A);
+  return hipGetLastError();
+}
+
+int fast_nb_for(int B) { return B <= 10 ? 10 : B <= 20 ? 20 : B <= 32 ? 32 : 0; }
+
+size_t fast_lds_for(int B, int S) {
+  const int nb = fast_nb_for(B);
+  return nb ? fast_lds_bytes(nb, FAST_NW, S, nullptr, nullptr) : (size_t)-1;
+}
+
+hipError_t launch_encode_fast(const EncArgs &A, int grid, hipStream_t st) {
+  switch (fast_nb_for(A.B)) {
+    case 10: return launch_fast_t<10, FAST_NW>(A, grid, st);
+    case 20: return launch_fast_t<20, FAST_NW>(A, grid, st);
+    case 32: return launch_fast_t<32, FAST_NW>(A, grid, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_decode(const DecArgs &A, int grid, hipStream_t st) {
+  hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(256), 0, st, A);
+  return hipGetLastError();
+}
+
+hipError_t launch_uniform_int(int64_t seed, int64_t n, int32_t *out, hipStream_t st) {
+  const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(uniform_int_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, st, seed, n, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce_scatter_test(const float *in, float *out, int width, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_scatter_test_kernel, dim3(1), dim3(64), 0, st, in, out, width);
+  return hipGetLastError();
+}
+
+} // namespace irec

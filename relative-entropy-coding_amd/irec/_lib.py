@@ -1,0 +1,78 @@
+"""ctypes binding of libirec_hip.so (include/irec.h).  Fails loudly when the library has not been built."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libirec_hip.so")
+
+IREC_OK = 0
+IREC_E_INVALID = -1
+IREC_E_HIP = -2
+IREC_E_NO_DEVICE = -3
+IREC_E_WORKSPACE = -4
+IREC_FLAG_FORCE_GENERIC = 1
+BIG_PRIME = 10007
+MAX_BEAMS = 64
+MAX_PARTITIONS = 65536
+
+
+class IrecParams(ctypes.Structure):
+    _fields_ = [("kl_per_partition", ctypes.c_float), ("n_samples", ctypes.c_int32), ("n_beams", ctypes.c_int32),
+                ("flags", ctypes.c_int32)]
+
+
+class IrecLibraryError(RuntimeError):
+    pass
+
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_i32 = ctypes.c_int32
+_PP = ctypes.POINTER(IrecParams)
+
+# name -> (restype, argtypes); every symbol declared in include/irec.h
+SIGNATURES = {
+    "irec_last_error": (ctypes.c_char_p, []),
+    "irec_version": (ctypes.c_char_p, []),
+    "irec_n_samples": (_i32, [ctypes.c_double, ctypes.c_double]),
+    "irec_codelength": (ctypes.c_double, [_i64, _i32]),
+    "irec_build_lut": (ctypes.c_int, [_vp]),
+    "irec_tf_shuffle_perm": (ctypes.c_int, [_i64, _i64, _vp]),
+    "irec_philox_uniform_int": (ctypes.c_int, [_i64, _i64, _vp]),
+    "irec_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
+    "irec_destroy": (None, [_vp]),
+    "irec_encode_workspace_bytes": (ctypes.c_size_t, [_vp, _PP, _i32, _i32]),
+    "irec_block_kl": (ctypes.c_int, [_vp, _PP, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "irec_beam_encode": (ctypes.c_int, [_vp, _PP, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32,
+                                        _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
+    "irec_beam_decode": (ctypes.c_int, [_vp, _PP, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "irec_device_uniform_int": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
+    "irec_test_reduce_scatter": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp]),
+    "irec_device_tables": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                                          ctypes.POINTER(_vp)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libirec_hip.so.  No fallback of any kind: a missing library is an error."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IrecLibraryError(
+                f"{LIB_PATH} not found: build it with `make -C relative-entropy-coding_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`).  irec has no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(status, what=""):
+    if status != IREC_OK:
+        msg = load().irec_last_error().decode("utf-8", "replace")
+        raise IrecLibraryError(f"{what}: irec_status {status}: {msg}")

@@ -1,0 +1,195 @@
+"""Per-device engine: owns the irec_context, the cached block descriptors / permutations / scratch slabs, and
+launches the C-ABI entry points on the current torch stream.  PyTorch is used for device memory and streams only.
+
+Host-side counterpart of the loops in the reference's
+    GaussianCoder.encode / decode   rec/coding/coder.py:412-491
+    Coder.split / merge             rec/coding/coder.py:38-122   (here: gather/scatter through `perm` inside the kernels)
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_engines = {}
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def tf_shuffle_perm(seed, n):
+    """tf.random.set_seed(seed); tf.random.shuffle(tf.range(n))  (reference: coder.py:62-64).  Host numpy int64."""
+    perm = np.empty(n, dtype=np.int64)
+    _lib.check(_lib.load().irec_tf_shuffle_perm(int(seed), int(n), perm.ctypes.data_as(ctypes.c_void_p)),
+               "irec_tf_shuffle_perm")
+    return perm
+
+
+def build_lut():
+    lut = np.empty(_lib.BIG_PRIME, dtype=np.float32)
+    _lib.check(_lib.load().irec_build_lut(lut.ctypes.data_as(ctypes.c_void_p)), "irec_build_lut")
+    return lut
+
+
+def philox_uniform_int(seed, n):
+    out = np.empty(n, dtype=np.int32)
+    _lib.check(_lib.load().irec_philox_uniform_int(int(seed), int(n), out.ctypes.data_as(ctypes.c_void_p)),
+               "irec_philox_uniform_int")
+    return out
+
+
+class BlockLayout:
+    """Descriptors of the blocks of `n_tensors` latent tensors of `n` dims each, cut into <= block_size slices of the
+    shuffled order (coder.py:69-83).  Blocks are listed largest first so the persistent kernels end on short ones;
+    `natural` maps (tensor, block) -> row of the descriptor arrays."""
+
+    def __init__(self, device, n_tensors, n, block_size, seed):
+        self.n_tensors, self.n, self.block_size, self.seed = n_tensors, n, block_size, seed
+        bs = n if block_size is None else int(block_size)
+        if bs < 1:
+            raise ValueError("block_size must be >= 1")
+        starts = np.arange(0, n, bs, dtype=np.int64)
+        dims = np.minimum(bs, n - starts).astype(np.int64)
+        self.blocks_per_tensor = len(starts)
+        base = np.repeat(np.arange(n_tensors, dtype=np.int64) * n, len(starts))
+        pos = np.tile(starts, n_tensors)
+        dim = np.tile(dims, n_tensors)
+        order = np.argsort(-dim, kind="stable")
+        self.order = order                              # row r describes natural block order[r]
+        self.natural = np.empty_like(order)
+        self.natural[order] = np.arange(len(order))     # natural block b sits in row natural[b]
+        self.n_blocks = len(order)
+        self.max_dim = int(dims.max())
+        self.block_base = torch.from_numpy(base[order]).to(device)
+        self.block_pos = torch.from_numpy(pos[order].astype(np.int32)).to(device)
+        self.block_dim = torch.from_numpy(dim[order].astype(np.int32)).to(device)
+        if block_size is None:
+            self.perm_host = None
+            self.perm = None
+        else:
+            self.perm_host = tf_shuffle_perm(seed, n)
+            self.perm = torch.from_numpy(self.perm_host.astype(np.int32)).to(device)
+
+
+class Engine:
+    def __init__(self, device):
+        if not torch.cuda.is_available():
+            raise _lib.IrecLibraryError("irec needs a HIP device (MI355X / gfx950); there is no CPU fallback")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.IrecLibraryError(f"irec engine needs a cuda (HIP) device, got {device}")
+        self.index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", self.index)
+        self.lib = _lib.load()
+        ctx = ctypes.c_void_p()
+        _lib.check(self.lib.irec_create(self.index, ctypes.byref(ctx)), "irec_create")
+        self.ctx = ctx
+        self._layouts = {}
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.irec_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    # ---- caches ----------------------------------------------------------------------------------------------
+    def layout(self, n_tensors, n, block_size, seed):
+        key = (n_tensors, n, block_size, seed if block_size is not None else None)
+        lay = self._layouts.get(key)
+        if lay is None:
+            if len(self._layouts) > 64:
+                self._layouts.clear()
+            lay = BlockLayout(self.device, n_tensors, n, block_size, seed)
+            self._layouts[key] = lay
+        return lay
+
+    def workspace(self, params, max_dim, max_K):
+        need = self.lib.irec_encode_workspace_bytes(self.ctx, ctypes.byref(params), int(max_dim), int(max_K))
+        if need == 0:
+            raise _lib.IrecLibraryError("irec_encode_workspace_bytes rejected the parameters: " +
+                                        self.lib.irec_last_error().decode())
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws, need
+
+    @staticmethod
+    def params(kl_per_partition, n_samples, n_beams, flags=0):
+        return _lib.IrecParams(float(np.float32(kl_per_partition)), int(n_samples), int(n_beams), int(flags))
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- device entry points -----------------------------------------------------------------------------------
+    def block_kl(self, params, lay, q_loc, q_scale, p_loc, p_scale):
+        out_kl = torch.empty(lay.n_blocks, dtype=torch.float32, device=self.device)
+        out_K = torch.empty(lay.n_blocks, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.irec_block_kl(self.ctx, ctypes.byref(params), lay.n_blocks, _ptr(lay.block_base),
+                                          _ptr(lay.block_pos), _ptr(lay.block_dim), _ptr(lay.perm), _ptr(q_loc),
+                                          _ptr(q_scale), _ptr(p_loc), _ptr(p_scale), _ptr(out_kl), _ptr(out_K),
+                                          self._stream()), "irec_block_kl")
+        return out_kl, out_K
+
+    def encode_blocks(self, params, lay, q_loc, q_scale, p_loc, p_scale, seed, max_K, out=None):
+        """Asynchronous.  Returns device tensors (K [n_blocks], indices [n_blocks, max_K], sample [like q_loc]),
+        rows in `lay` order."""
+        for t in (q_loc, q_scale, p_loc, p_scale):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device
+            assert t.numel() == lay.n_tensors * lay.n
+        if out is None:
+            out_K = torch.empty(lay.n_blocks, dtype=torch.int32, device=self.device)
+            out_idx = torch.empty((lay.n_blocks, max(max_K, 1)), dtype=torch.int32, device=self.device)
+            sample = torch.empty_like(q_loc)
+        else:
+            out_K, out_idx, sample = out
+        ws, need = self.workspace(params, lay.max_dim, max_K)
+        _lib.check(self.lib.irec_beam_encode(self.ctx, ctypes.byref(params), lay.n_blocks, _ptr(lay.block_base),
+                                             _ptr(lay.block_pos), _ptr(lay.block_dim), lay.max_dim, _ptr(lay.perm),
+                                             _ptr(q_loc), _ptr(q_scale), _ptr(p_loc), _ptr(p_scale), int(seed),
+                                             int(max_K), _ptr(out_K), _ptr(out_idx), _ptr(sample), _ptr(ws),
+                                             ws.numel(), self._stream()), "irec_beam_encode")
+        return out_K, out_idx, sample
+
+    def decode_blocks(self, params, lay, p_loc, p_scale, seed, K, indices):
+        for t in (p_loc, p_scale):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device
+        assert K.dtype == torch.int32 and indices.dtype == torch.int32 and indices.is_contiguous()
+        sample = torch.empty_like(p_loc)
+        _lib.check(self.lib.irec_beam_decode(self.ctx, ctypes.byref(params), lay.n_blocks, _ptr(lay.block_base),
+                                             _ptr(lay.block_pos), _ptr(lay.block_dim), _ptr(lay.perm), _ptr(p_loc),
+                                             _ptr(p_scale), int(seed), int(indices.shape[1]), _ptr(K), _ptr(indices),
+                                             _ptr(sample), self._stream()), "irec_beam_decode")
+        return sample
+
+    # ---- test hooks ------------------------------------------------------------------------------------------------
+    def device_uniform_int(self, seed, n):
+        out = torch.empty(n, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.irec_device_uniform_int(self.ctx, int(seed), int(n), _ptr(out), self._stream()),
+                   "irec_device_uniform_int")
+        return out
+
+    def test_reduce_scatter(self, x):
+        width = x.shape[1]
+        out = torch.empty(64, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.irec_test_reduce_scatter(self.ctx, _ptr(x), _ptr(out), int(width), self._stream()),
+                   "irec_test_reduce_scatter")
+        return out
+
+
+def get_engine(device=None):
+    """One engine (irec_context) per HIP device of this process."""
+    if device is None:
+        if not torch.cuda.is_available():
+            raise _lib.IrecLibraryError("irec needs a HIP device (MI355X / gfx950); there is no CPU fallback")
+        device = torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    eng = _engines.get(idx)
+    if eng is None:
+        eng = Engine(torch.device("cuda", idx))
+        _engines[idx] = eng
+    return eng

@@ -1,0 +1,148 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every symbol include/irec.h declares,
+host helpers agree with the oracle, the Python mirror keeps the reference's API, and nothing falls back to a CPU path."""
+import ctypes
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "irec.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(irec_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import irec
+    lib = irec._lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/irec.h but not exported"
+    assert set(declared) == set(irec._lib.SIGNATURES), "ctypes signature table out of sync with include/irec.h"
+    assert b"gfx950" in lib.irec_version()
+
+
+def test_host_helpers_match_oracle(oracle):
+    from irec import engine
+    assert np.array_equal(engine.build_lut(), oracle.build_lut())
+    for seed, n in [(42, 8192), (0, 10), (7, 1), (5, 2), (69420, 12288), (-3, 100)]:
+        assert np.array_equal(engine.tf_shuffle_perm(seed, n), oracle.tf_shuffle_perm(seed, n))
+    for seed in (0, 42, 45, 2 ** 31 + 3):
+        assert np.array_equal(engine.philox_uniform_int(seed, 4001), oracle.uniform_int(seed, 4001))
+    import irec
+    lib = irec._lib.load()
+    assert lib.irec_n_samples(3.0, 1.2) == 36 and lib.irec_n_samples(6.0, 1.0) == 403
+    assert lib.irec_n_samples(5.0, 1.0) == 148 and lib.irec_n_samples(3.0, 1.0) == 20
+    assert abs(lib.irec_codelength(8, 36) - 8 * np.log(36)) < 1e-12
+
+
+def test_bad_arguments_are_rejected_not_crashed():
+    import irec
+    lib = irec._lib.load()
+    assert lib.irec_build_lut(None) == irec._lib.IREC_E_INVALID
+    assert b"null" in lib.irec_last_error()
+    assert lib.irec_tf_shuffle_perm(1, -1, None) == irec._lib.IREC_E_INVALID
+    assert lib.irec_create(0, None) == irec._lib.IREC_E_INVALID
+    p = irec._lib.IrecParams(3.0, 36, 20, 0)
+    assert lib.irec_beam_encode(None, ctypes.byref(p), 1, None, None, None, 1000, None, None, None, None, None, 42, 8,
+                                None, None, None, None, 0, None) == irec._lib.IREC_E_INVALID
+    assert lib.irec_encode_workspace_bytes(None, ctypes.byref(p), 1000, 8) == 0
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_cpu_fallback():
+    import irec
+    with pytest.raises(irec._lib.IrecLibraryError):
+        irec.get_engine()
+    ctx = ctypes.c_void_p()
+    assert irec._lib.load().irec_create(0, ctypes.byref(ctx)) == irec._lib.IREC_E_NO_DEVICE
+    coder = irec.BeamSearchCoder(kl_per_partition=3., n_beams=20, extra_samples=1.2, block_size=1000)
+    q = torch.distributions.Normal(torch.zeros(1, 8), torch.ones(1, 8))
+    with pytest.raises(irec._lib.IrecLibraryError):
+        coder.encode(q, q, seed=42)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "relative-entropy-coding_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("test oracle's restatement", ""), os.path.join(dirpath, f)
+
+
+def test_coder_api_mirrors_reference():
+    import irec
+    from irec.coding import BeamSearchCoder, Coder, GaussianCoder, CodingError
+    c = BeamSearchCoder(kl_per_partition=3., n_beams=20, extra_samples=1.2, block_size=1000)
+    assert isinstance(c, GaussianCoder) and isinstance(c, Coder)
+    assert c.n_samples == 36 and c.n_beams == 20 and c.big_prime == 10007 and c.block_size == 1000
+    assert c.kl_per_partition == np.float32(3.)
+    sig = inspect.signature(BeamSearchCoder.__init__)
+    assert list(sig.parameters)[:6] == ["self", "kl_per_partition", "n_beams", "extra_samples",
+                                         "extrapolate_auxiliary_ratios", "name"]
+    assert list(inspect.signature(c.encode).parameters)[:3] == ["target_dist", "coding_dist", "seed"]
+    assert list(inspect.signature(c.decode).parameters)[:3] == ["coding_dist", "indices", "seed"]
+    assert list(inspect.signature(c.encode_block).parameters)[:3] == ["target_dist", "coding_dist", "seed"]
+    assert list(inspect.signature(c.decode_block).parameters) == ["coding_dist", "indices", "seed"]
+    assert c.get_codelength([1, 2, 3]) == 3 * np.log(36)
+    assert c.get_auxiliary_ratio(0) == 1.0 and abs(c.get_auxiliary_ratio(1) - 0.5798) < 1e-4
+    q = torch.distributions.Normal(torch.zeros(2, 8), torch.ones(2, 8))
+    with pytest.raises(CodingError, match="batch size must be 1"):
+        c.encode(q, q, seed=1)
+    with pytest.raises(CodingError, match="batch size must be 1"):
+        c.encode_block(q, q, seed=1)
+
+
+def test_simple_hash_mirror(oracle):
+    import irec
+    c = irec.BeamSearchCoder(kl_per_partition=3., n_beams=20)
+    rng = np.random.default_rng(0)
+    m = rng.integers(0, 403, size=(7, 900))
+    h = c.simple_hash(m)
+    for row, hv in zip(m, h):
+        assert hv == oracle.simple_hash(row)
+    assert c.simple_hash(np.zeros((1, 0), dtype=np.int32))[0] == 1
+
+
+def test_split_merge_round_trip(oracle):
+    import irec
+    from irec.coding import CodingError
+    c = irec.BeamSearchCoder(kl_per_partition=3., n_beams=20, block_size=1000)
+    x = torch.arange(8192, dtype=torch.float32).reshape(1, 16, 16, 32)
+    y = -x
+    bx, by = c.split(x, y, seed=42)
+    assert [len(b) for b in bx] == [1000] * 8 + [192]
+    perm = oracle.tf_shuffle_perm(42, 8192)
+    assert torch.equal(torch.cat(bx), x.reshape(-1)[torch.from_numpy(perm)])
+    assert torch.equal(torch.cat(by), -torch.cat(bx))
+    mx, = c.merge(bx, shape=x.shape, seed=42)
+    assert torch.equal(mx, x)
+    with pytest.raises(CodingError):
+        c.split(x, y.reshape(-1), seed=42)
+    with pytest.raises(CodingError):
+        c.merge(bx, seed=42)
+
+
+def test_block_layout_descriptors(oracle):
+    from irec.engine import BlockLayout
+    lay = BlockLayout(torch.device("cpu"), 3, 8192, 1000, 42)
+    assert lay.n_blocks == 27 and lay.blocks_per_tensor == 9 and lay.max_dim == 1000
+    dims = lay.block_dim.numpy()
+    assert (np.diff(dims) <= 0).all() and dims[:24].tolist() == [1000] * 24 and dims[24:].tolist() == [192] * 3
+    # natural[(tensor, block)] -> row holding exactly that block
+    for t in range(3):
+        for b in range(9):
+            r = lay.natural[t * 9 + b]
+            assert lay.block_base[r] == t * 8192 and lay.block_pos[r] == b * 1000
+            assert lay.block_dim[r] == (1000 if b < 8 else 192)
+    assert np.array_equal(lay.perm_host, oracle.tf_shuffle_perm(42, 8192))
+    lay1 = BlockLayout(torch.device("cpu"), 2, 50, None, 42)
+    assert lay1.perm is None and lay1.n_blocks == 2 and lay1.block_dim.tolist() == [50, 50]
