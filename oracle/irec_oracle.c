@@ -22,8 +22,10 @@
  *                           (log_prob with divisions and logs, sequential float32 reduce_sum).
  *   IREC_ORACLE_CANONICAL : the bit-exact specification the HIP kernels implement:
  *                           the same sample arithmetic, but the per-candidate score is the algebraically
- *                           equal quadratic form accumulated with fma in a FIXED reduction tree, so that
- *                           GPU == oracle holds bit for bit by construction.  TF's own reduce_sum order
+ *                           equal quadratic form, expanded around the carried beam
+ *                               score(s,b) = C_b + sum_d (G_bd + H_d z) z ,   z = quantile of the proposal,
+ *                           accumulated with fma in a FIXED reduction tree, so that GPU == oracle holds bit
+ *                           for bit by construction.  TF's own reduce_sum order
  *                           is not reproducible, so neither mode can claim more than
  *                           "equal to TF unless a near tie".
  *
@@ -343,6 +345,7 @@ typedef struct {
   float v;       /* a_t + c_t                                           */
   float m, var;  /* auxiliary target mean / variance                    */
   float A, Bv;   /* canonical quadratic coefficients (centred on m)     */
+  float H;       /* canonical: A * sa^2 (coefficient of z^2)            */
   float s_t, s_v;/* literal: sqrt(var), sqrt(v)                          */
 } step_dim;
 
@@ -357,6 +360,7 @@ static void step_constants(float rho, float mq, float sq, float mp, float sp, fl
   o->v = v; o->m = m; o->var = var;
   o->A = 0.5f * (1.0f / v - 1.0f / var);
   o->Bv = m / v;
+  o->H = o->A * (o->sa * o->sa);
   o->s_t = sqrtf(var);
   o->s_v = sqrtf(v);
   *a_out = a;
@@ -414,6 +418,8 @@ int32_t irec_oracle_encode_block(int mode, float omega, int S, int B, int D, con
   int32_t *npath = (int32_t *)calloc((size_t)B * K, sizeof(int32_t));
   int32_t hsum[64 * 16], nhsum[64 * 16]; /* B <= 1024 */
   unsigned char *taken = (unsigned char *)malloc((size_t)S * B);
+  float *Gtab = (float *)calloc((size_t)B * D, sizeof(float)); /* canonical: G_bd = ((A+A) p + Bv) sa, p = beam - m */
+  float Cb[64 * 16];                                            /* canonical: C_b = tree-sum (A p + Bv) p        */
   int Bcur = 1;
   hsum[0] = 0;
 
@@ -422,6 +428,30 @@ int32_t irec_oracle_encode_block(int mode, float omega, int S, int B, int D, con
     float rho = irec_oracle_aux_ratio(i);
     for (int d = 0; d < D; ++d) step_constants(rho, mq[d], sq[d], mp[d], sp[d], c[d], &a[d], &sd[d]);
     irec_oracle_uniform_int(seed + t, (int64_t)S * D, r);
+    if (mode == IREC_ORACLE_CANONICAL) {
+      int ng = (D + 255) / 256;
+      for (int b = 0; b < Bcur; ++b) {
+        const float *beam = beams + (size_t)b * D;
+        float cb = 0.0f;
+        for (int g = 0; g < ng; ++g) {
+          float part[64];
+          for (int l = 0; l < 64; ++l) {
+            float acc = 0.0f;
+            for (int q = 0; q < 4; ++q) {
+              int d = g * 256 + l * 4 + q;
+              if (d >= D) continue;
+              float p = beam[d] - sd[d].m;
+              Gtab[(size_t)b * D + d] = fmaf(sd[d].A + sd[d].A, p, sd[d].Bv) * sd[d].sa;
+              acc = fmaf(fmaf(sd[d].A, p, sd[d].Bv), p, acc);
+            }
+            part[l] = acc;
+          }
+          float gs = tree64_f32(part);
+          cb = (g == 0) ? gs : cb + gs;
+        }
+        Cb[b] = cb;
+      }
+    }
 
     for (int s = 0; s < S; ++s) {
       for (int b = 0; b < Bcur; ++b) {
@@ -441,7 +471,9 @@ int32_t irec_oracle_encode_block(int mode, float omega, int S, int B, int D, con
             sc = sc + lp;
           }
         } else {
+          /* T(s,b) = tree-sum over dims of (G_bd + H_d z) z */
           int ng = (D + 255) / 256;
+          const float *Gb = Gtab + (size_t)b * D;
           sc = 0.0f;
           for (int g = 0; g < ng; ++g) {
             float part[64];
@@ -451,16 +483,16 @@ int32_t irec_oracle_encode_block(int mode, float omega, int S, int B, int D, con
                 int d = g * 256 + l * 4 + q;
                 if (d >= D) continue;
                 int32_t k = (int32_t)(((int64_t)rs[d] * h) % IREC_P);
-                float y = sd[d].sa * lut[k];
-                float w = (beam[d] - sd[d].m) + y;      /* x - m, formed without the big-x rounding */
-                float uu = fmaf(sd[d].A, w, sd[d].Bv);
-                acc = fmaf(uu, w, acc);
+                float z = lut[k];
+                float uu = fmaf(sd[d].H, z, Gb[d]);
+                acc = fmaf(uu, z, acc);
               }
               part[l] = acc;
             }
             float gs = tree64_f32(part);
             sc = (g == 0) ? gs : sc + gs;
           }
+          sc = sc + Cb[b];
         }
         score[s * Bcur + b] = sc;
       }
@@ -510,7 +542,7 @@ int32_t irec_oracle_encode_block(int mode, float omega, int S, int B, int D, con
   for (int t = 0; t < K; ++t) out_indices[t] = path[t];
   for (int d = 0; d < D; ++d) out_sample[d] = beams[d] + mp[d]; /* :122 */
 
-  free(beams); free(nbeams); free(c); free(a); free(sd); free(r); free(score); free(path); free(npath); free(taken);
+  free(Gtab); free(beams); free(nbeams); free(c); free(a); free(sd); free(r); free(score); free(path); free(npath); free(taken);
   return K;
 }
 

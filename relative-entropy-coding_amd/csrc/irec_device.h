@@ -128,7 +128,7 @@ __device__ __forceinline__ int32_t num_aux(float kl, float omega) {
 
 // ---- per-dim, per-step constants of the Gaussian partition algebra ------------------------------------------
 // reference: beam_search_coder.py:67-77 with coder.py:141-154 (get_auxiliary_coder / get_auxiliary_target).
-struct StepConst { float a, sa, m, A, Bv; };
+struct StepConst { float a, sa, m, A, Bv, H; };
 
 __device__ __forceinline__ StepConst step_constants(float rho, float dmu, float var_q, float var_p, float c) {
   StepConst o;
@@ -141,15 +141,25 @@ __device__ __forceinline__ StepConst step_constants(float rho, float dmu, float 
   o.m = m;
   o.A = 0.5f * (1.0f / v - 1.0f / var);   // score(x) = const + (A*w + Bv)*w,  w = x - m
   o.Bv = m / v;
+  o.H = o.A * (o.sa * o.sa);              // coefficient of z^2 once w = p + sa*z is expanded (p = beam - m)
   return o;
 }
 
-// one proposal's contribution to a candidate's score: log N(x; m, s_t) - log N(x; 0, sqrt(v)) up to a constant
-// that is the same for every candidate of the step (beam_search_coder.py:82-84).
-__device__ __forceinline__ float score_term(float acc, float beam, float y, float m, float A, float Bv) {
-  const float w = (beam - m) + y;
-  const float u = fmaf(A, w, Bv);
-  return fmaf(u, w, acc);
+// Score of candidate (s, b), up to a constant shared by all candidates of the step (beam_search_coder.py:82-84):
+//   sum_d [log N(x; m, s_t) - log N(x; 0, sqrt(v))] = const + sum_d (A w + Bv) w,   w = x - m = p + sa z,  p = beam - m
+//                                                   = const + C_b + sum_d (G_bd + H_d z) z
+// with   G_bd = ((A+A) p + Bv) sa,   H_d = A sa^2,   C_b = sum_d (A p + Bv) p.
+// Only z depends on the sample index s, so the inner loop is two fma per proposal.
+__device__ __forceinline__ float beam_G(float beam, float m, float A, float Bv, float sa) {
+  const float p = beam - m;
+  return fmaf(A + A, p, Bv) * sa;
+}
+__device__ __forceinline__ float beam_C_term(float acc, float beam, float m, float A, float Bv) {
+  const float p = beam - m;
+  return fmaf(fmaf(A, p, Bv), p, acc);
+}
+__device__ __forceinline__ float proposal_term(float acc, float z, float H, float G) {
+  return fmaf(fmaf(H, z, G), z, acc);
 }
 
 // ---- ordering of candidates: tf.argsort(DESCENDING) == top_k: value desc, ties -> lower flat index ----
@@ -163,12 +173,36 @@ __device__ __forceinline__ unsigned long long cand_pack(uint32_t key, uint32_t f
   return key ? (((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - flat)) : 0ull;
 }
 
+// ---- cross-lane moves on the VALU (DPP / permlane swaps): they stay off the LDS pipe, which the LUT gathers own ----
+template <int CTRL, int BANK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t src) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xF, BANK, false);
+}
+// value held by lane (lane ^ DIST), DIST in {32,16,8,4,2,1}
+template <int DIST>
+__device__ __forceinline__ uint32_t xor_lane_u32(uint32_t v) {
+  if constexpr (DIST == 32) {
+    auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); // r[0]: [lo,lo]  r[1]: [hi,hi]
+    return (__lane_id() & 32) ? r[0] : r[1];
+  } else if constexpr (DIST == 16) {
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); // r[0]: even rows everywhere, r[1]: odd rows
+    return (__lane_id() & 16) ? r[0] : r[1];
+  } else if constexpr (DIST == 8) return dpp_u32<0x128, 0xF>(v, v);  // row_ror:8
+  else if constexpr (DIST == 4) {
+    const uint32_t r = dpp_u32<0x104, 0x5>(v, v);                     // row_shl:4 -> lanes with bit2 = 0 read lane+4
+    return dpp_u32<0x114, 0xA>(r, v);                                 // row_shr:4 -> lanes with bit2 = 1 read lane-4
+  } else if constexpr (DIST == 2) return dpp_u32<0x4E, 0xF>(v, v);   // quad_perm [2,3,0,1]
+  else return dpp_u32<0xB1, 0xF>(v, v);                               // quad_perm [1,0,3,2]
+}
+template <int DIST>
+__device__ __forceinline__ unsigned long long max_step_u64(unsigned long long v) {
+  const uint32_t lo = xor_lane_u32<DIST>((uint32_t)v), hi = xor_lane_u32<DIST>((uint32_t)(v >> 32));
+  const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+  return o > v ? o : v;
+}
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const unsigned long long o = __shfl_xor(v, off, 64);
-    v = o > v ? o : v;
-  }
+  v = max_step_u64<32>(v); v = max_step_u64<16>(v); v = max_step_u64<8>(v);
+  v = max_step_u64<4>(v); v = max_step_u64<2>(v); v = max_step_u64<1>(v);
   return v;
 }
 

@@ -331,9 +331,9 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
             irec::fast_lds_for(B, S) <= irec::FAST_LDS_LIMIT && (int64_t)S * B < (1 << 24);
   pl.grid_cap = 2 * (ctx->n_cu > 0 ? ctx->n_cu : 256);
   if (pl.fast) {
-    pl.ws_per_wg = round_up_sz((size_t)(max_K > 0 ? max_K : 1) * irec::fast_nb_for(B) * 4, 256);
+    pl.ws_per_wg = round_up_sz(irec::fast_ws_for(B, max_K), 256);
   } else {
-    pl.ws_per_wg = round_up_sz((size_t)9 * pl.dpad * 4 + (size_t)2 * B * pl.dpad * 4 +
+    pl.ws_per_wg = round_up_sz((size_t)10 * pl.dpad * 4 + (size_t)2 * B * pl.dpad * 4 +
                                    (size_t)(max_K > 0 ? max_K : 1) * B * 4 + (size_t)S * B * 4, 256);
   }
   return pl;

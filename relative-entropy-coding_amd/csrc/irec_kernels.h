@@ -42,6 +42,7 @@ size_t generic_lds_bytes();
 hipError_t launch_encode_generic(const EncArgs &A, int grid, hipStream_t st);
 int fast_nb_for(int B);
 size_t fast_lds_for(int B, int S);
+size_t fast_ws_for(int B, int max_K);
 hipError_t launch_encode_fast(const EncArgs &A, int grid, hipStream_t st);
 hipError_t launch_decode(const DecArgs &A, int grid, hipStream_t st);
 hipError_t launch_uniform_int(int64_t seed, int64_t n, int32_t *out, hipStream_t st);

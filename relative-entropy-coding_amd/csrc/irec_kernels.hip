@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void block_kl_kernel(EncArgs A, float *out_kl)
 
 // ======================================================================================================
 //  generic encoder: any D, B <= 64.  Scratch slab per workgroup:
-//    float dmu,vq,vp,mp,c,sa,m,A,Bv [9][Dpad] | float beams[2][B][Dpad] | int32 bp[max_K][B] | uint32 key[S*B]
+//    float dmu,vq,vp,mp,c,sa,m,A,Bv,H [10][Dpad] | float beams[2][B][Dpad] | int32 bp[max_K][B] | uint32 key[S*B]
 // ======================================================================================================
 constexpr int GEN_NT = 256;
 constexpr int GEN_NSC = 8192; // score/key entries kept in LDS; larger candidate sets go to the scratch slab
@@ -125,6 +125,7 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
   int32_t *sel_b = sel_s + 64;                                                 // [64]
   int32_t *hsum = sel_b + 64;                                                  // [2][64]
   int32_t *misc = hsum + 128;                                                  // [4]
+  float *Cb_s = reinterpret_cast<float *>(misc + 4);                           // [64] C_b of the live beams
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform by construction: keep it in an SGPR
@@ -135,8 +136,8 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
   char *slab = A.ws + (size_t)blockIdx.x * A.ws_per_wg;
   float *f_dmu = reinterpret_cast<float *>(slab);
   float *f_vq = f_dmu + Dpad, *f_vp = f_vq + Dpad, *f_mp = f_vp + Dpad, *f_c = f_mp + Dpad;
-  float *f_sa = f_c + Dpad, *f_m = f_sa + Dpad, *f_A = f_m + Dpad, *f_Bv = f_A + Dpad;
-  float *beams = f_Bv + Dpad;                                                 // [2][B][Dpad]
+  float *f_sa = f_c + Dpad, *f_m = f_sa + Dpad, *f_A = f_m + Dpad, *f_Bv = f_A + Dpad, *f_H = f_Bv + Dpad;
+  float *beams = f_H + Dpad;                                                  // [2][B][Dpad]
   int32_t *bp = reinterpret_cast<int32_t *>(beams + (size_t)2 * B * Dpad);    // [max_K][B]
   uint32_t *key_glb = reinterpret_cast<uint32_t *>(bp + (size_t)A.max_K * B); // [S*B]
 
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
             dmu = mq - mp; vq = sq * sq; vp = sp * sp;
           }
           f_dmu[d] = dmu; f_vq[d] = vq; f_vp[d] = vp; f_mp[d] = mp; f_c[d] = 0.f;
-          f_sa[d] = 0.f; f_m[d] = 0.f; f_A[d] = 0.f; f_Bv[d] = 0.f;
+          f_sa[d] = 0.f; f_m[d] = 0.f; f_A[d] = 0.f; f_Bv[d] = 0.f; f_H[d] = 0.f;
         }
       }
       const double gs = wave_tree_sum(acc);
@@ -202,14 +203,30 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
       // phase 1: per-dim constants; c <- c + a  (beam_search_coder.py:67-77,109)
       for (int d = tid; d < D; d += GEN_NT) {
         const StepConst sc = step_constants(rho, f_dmu[d], f_vq[d], f_vp[d], f_c[d]);
-        f_sa[d] = sc.sa; f_m[d] = sc.m; f_A[d] = sc.A; f_Bv[d] = sc.Bv;
+        f_sa[d] = sc.sa; f_m[d] = sc.m; f_A[d] = sc.A; f_Bv[d] = sc.Bv; f_H[d] = sc.H;
         f_c[d] = f_c[d] + sc.a;
+      }
+      __syncthreads();
+      const float *bcur = beams + (size_t)cur * B * Dpad;
+      // phase 1b: C_b = sum_d (A p + Bv) p of every live beam, canonical tree
+      for (int b = wave; b < Bcur; b += GEN_NT / 64) {
+        float cb = 0.f;
+        for (int g = 0; g < NG; ++g) {
+          float acc = 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int d = g * 256 + lane * 4 + i;
+            if (d < D) acc = beam_C_term(acc, t ? bcur[(size_t)b * Dpad + d] : 0.f, f_m[d], f_A[d], f_Bv[d]);
+          }
+          const float gs = wave_tree_sum(acc);
+          cb = g == 0 ? gs : cb + gs;
+        }
+        if (lane == 0) Cb_s[b] = cb;
       }
       __syncthreads();
       // phase 2: score every candidate (s, b); one wave per candidate, canonical tree over dims
       const int N = S * Bcur;
       uint32_t *key = (N <= GEN_NSC) ? key_lds : key_glb;
-      const float *bcur = beams + (size_t)cur * B * Dpad;
       for (int f = wave; f < N; f += GEN_NT / 64) {
         const int s = f / Bcur, b = f - s * Bcur;
         const uint32_t h = hash_from_sum(hsum[cur * 64 + b]);
@@ -225,16 +242,16 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
               const int d = d0 + i;
               if (d < D) {
                 const uint32_t k = ((rm1[i] + 1u) * h) % IREC_P; // floormod(r * hash, 10007), :45-47
-                const float y = f_sa[d] * lut_s[k];              // dist.quantile(k / 10007), :48-49
+                const float z = lut_s[k];                        // ndtri(k / 10007): dist.quantile / scale, :48-49
                 const float bv = t ? bcur[(size_t)b * Dpad + d] : 0.f;
-                acc = score_term(acc, bv, y, f_m[d], f_A[d], f_Bv[d]);
+                acc = proposal_term(acc, z, f_H[d], beam_G(bv, f_m[d], f_A[d], f_Bv[d], f_sa[d]));
               }
             }
           }
           const float gs = wave_tree_sum(acc);
           sc = g == 0 ? gs : sc + gs;
         }
-        if (lane == 0) key[f] = __float_as_uint(sc);
+        if (lane == 0) key[f] = __float_as_uint(sc + Cb_s[b]);
       }
       __syncthreads();
       // phase 3: top-B (beam_search_coder.py:85-89 / :104)
@@ -353,6 +370,11 @@ __device__ __forceinline__ float reduce_scatter(float (&v)[N0], int lane) {
   return v[0];
 }
 
+// The fast kernel addresses its LUT by ABSOLUTE LDS byte address (the table is the first thing in the dynamic LDS
+// region, which starts at 0 because the kernel has no static __shared__): saves one VALU add per proposal.
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+__device__ __forceinline__ float lds_abs_f32(uint32_t byte_addr) { return *(lds_cfloat *)(uintptr_t)(byte_addr); }
+
 template <int NB>
 struct FastCfg {
   static constexpr int RW = NB <= 21 ? 64 : 32;   // accumulators reduced together
@@ -360,16 +382,19 @@ struct FastCfg {
   static_assert(SPC >= 1, "NB too large");
 };
 
-// LDS carve (bytes): lut2 40032 | dlog 20016 | region | small 1024.
-// region holds [part | key] during scoring/selection and is re-used as the beam staging area during the update.
-__host__ __device__ inline size_t fast_lds_bytes(int NB, int NW, int S, size_t *off_key, size_t *off_small) {
+// LDS carve (bytes): lut2 40032 | dlog 20016 | part [4][S][NB] f32 | key [S*NB] u32 | small 1536
+__host__ __device__ inline size_t fast_lds_bytes(int NB, int S, size_t *off_key, size_t *off_small) {
   const size_t part = (((size_t)4 * S * NB * 4) + 15) & ~(size_t)15;
   const size_t key = (((size_t)S * NB * 4) + 15) & ~(size_t)15;
-  const size_t stage = (size_t)NW * NB * 64 * 4;
-  const size_t region = (part + key) > stage ? (part + key) : stage;
   if (off_key) *off_key = 40032 + 20016 + part;
-  if (off_small) *off_small = 40032 + 20016 + region;
-  return 40032 + 20016 + region + 1024;
+  if (off_small) *off_small = 40032 + 20016 + part + key;
+  return 40032 + 20016 + part + key + 1536;
+}
+
+// Scratch slab of one workgroup (bytes): bp int32 [max_K][NB] | beams float [2][NB][1024]
+__host__ __device__ inline size_t fast_ws_bytes(int NB, int max_K) {
+  const size_t bp = (((size_t)(max_K > 0 ? max_K : 1) * NB * 4) + 255) & ~(size_t)255;
+  return bp + (size_t)2 * NB * FAST_MAX_DIM * 4;
 }
 
 template <int NB, int NW>
@@ -380,11 +405,10 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int S = A.S, B = A.B;
   size_t off_key, off_small;
-  fast_lds_bytes(NB, NW, S, &off_key, &off_small);
+  fast_lds_bytes(NB, S, &off_key, &off_small);
   char *lut2_b = smem;                                                        // float [10006], dlog order
   const uint16_t *dlog_s = reinterpret_cast<const uint16_t *>(smem + 40032);  // [10006] 4*dlog(j+1)
-  float *part_s = reinterpret_cast<float *>(smem + 40032 + 20016);            // [NG][S][NB]
-  float *stage_s = part_s;                                                    // [NW][NB][64] (aliases part)
+  float *part_s = reinterpret_cast<float *>(smem + 40032 + 20016);            // [4][S][NB] per-group partial scores
   uint32_t *key_s = reinterpret_cast<uint32_t *>(smem + off_key);             // [S*NB]
   char *small = smem + off_small;
   unsigned long long *wb = reinterpret_cast<unsigned long long *>(small);     // [2][NW] (<= 16 entries)
@@ -394,16 +418,21 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
   int32_t *hsum = sel_b + 32;                                                 // [2][32]
   uint32_t *beta4 = reinterpret_cast<uint32_t *>(hsum + 64);                  // [2][32] 4*dlog(hash(beam))
   int32_t *misc = reinterpret_cast<int32_t *>(beta4 + 64);                    // [4]
+  float *cpart_s = reinterpret_cast<float *>(misc + 4);                       // [4][32] per-group partial C_b
+  float *Cb_s = cpart_s + 128;                                                // [32]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform by construction: keep it in an SGPR
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap(); // see lds_abs_f32
   {
     float *l2 = reinterpret_cast<float *>(lut2_b);
     for (int k = tid; k < (int)IREC_PM1; k += NT) l2[k] = A.lut2[k];
     uint16_t *dl = reinterpret_cast<uint16_t *>(smem + 40032);
     for (int k = tid; k < (int)IREC_PM1; k += NT) dl[k] = A.dlog4r[k];
   }
-  int32_t *bp = reinterpret_cast<int32_t *>(A.ws + (size_t)blockIdx.x * A.ws_per_wg); // [max_K][NB]
+  char *slab = A.ws + (size_t)blockIdx.x * A.ws_per_wg;
+  int32_t *bp = reinterpret_cast<int32_t *>(slab);                                            // [max_K][NB]
+  float *beams_g = reinterpret_cast<float *>(slab + A.ws_per_wg - (size_t)2 * NB * FAST_MAX_DIM * 4); // [2][NB][1024]
 
   for (;;) {
     __syncthreads();
@@ -418,28 +447,24 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
       if (tid == 0) A.out_K[blk] = -1;
       continue;
     }
-    const int NG = (D + 255) >> 8;          // 1..4
+    const int NG = (D + 255) >> 8;          // 1..4 dim groups
     const int NSW = NW / NG;                // sample stripes
     const bool active = wave < NG * NSW;
     const int g = wave % NG, sw = wave / NG;
     const int d0 = g * 256 + lane * 4;
 
-    // ---- load my 4 dims (split == gather through perm) and the block's KL ----
-    float dmu[4], vq[4], vp[4], mp[4], c[4];
+    // ---- my 4 dims (split == gather through perm) and the block's KL ----
+    float c[4];
     bool valid[4];
+    int64_t ix[4];
     double klacc = 0.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int d = d0 + i;
       valid[i] = d < D;
-      dmu[i] = 0.f; vq[i] = 1.f; vp[i] = 1.f; mp[i] = 0.f; c[i] = 0.f;
-      if (valid[i]) {
-        const int64_t ix = src_index(A, base, pos, d);
-        const float mq = A.q_loc[ix], sq = A.q_scale[ix], sp = A.p_scale[ix];
-        mp[i] = A.p_loc[ix];
-        klacc = klacc + kl_dim(mq, sq, mp[i], sp);
-        dmu[i] = mq - mp[i]; vq[i] = sq * sq; vp[i] = sp * sp;
-      }
+      c[i] = 0.f;
+      ix[i] = valid[i] ? src_index(A, base, pos, d) : src_index(A, base, pos, 0);
+      if (valid[i]) klacc = klacc + kl_dim(A.q_loc[ix[i]], A.q_scale[ix[i]], A.p_loc[ix[i]], A.p_scale[ix[i]]);
     }
     {
       const double gs = wave_tree_sum(klacc);
@@ -458,25 +483,60 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
     }
     const int K = misc[1];
     if (K > A.max_K || K > IREC_MAX_PARTITIONS_DEV) continue;
+    if (K == 0) { // nothing to code: sample = p.loc
+      if (active && sw == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (valid[i]) A.out_sample[ix[i]] = 0.f + A.p_loc[ix[i]];
+      }
+      continue;
+    }
 
-    float beam[NB][4];
+    // Per step the lane keeps, for its 4 dims: sa (sample scale), H (z^2 coefficient) and, per live beam, G.
+    float sa[4], cH[4];
+    float G[NB][4];
+    // constants of step `t_next` from the running cumulative variance; returns m, A, Bv for the G / C_b update
+    auto step_consts = [&](int t_next, float (&m)[4], float (&cA)[4], float (&cBv)[4]) {
+      const float rho = A.rho[K - 1 - t_next];
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+      for (int i = 0; i < 4; ++i) {
+        // the block's statistics are re-read (L2) every step rather than held in VGPRs for the whole block
+        const float mq_ = A.q_loc[ix[i]], sq_ = A.q_scale[ix[i]], mp_ = A.p_loc[ix[i]], sp_ = A.p_scale[ix[i]];
+        const StepConst sc = step_constants(rho, mq_ - mp_, sq_ * sq_, sp_ * sp_, c[i]);
+        sa[i] = valid[i] ? sc.sa : 0.f; cH[i] = valid[i] ? sc.H : 0.f;
+        m[i] = valid[i] ? sc.m : 0.f; cA[i] = valid[i] ? sc.A : 0.f; cBv[i] = valid[i] ? sc.Bv : 0.f;
+        c[i] = c[i] + sc.a; // cumulative_auxiliary_variance += auxiliary_var (:109)
+        __builtin_amdgcn_sched_barrier(0); // one dim at a time: the division sequences are register hungry
+      }
+    };
+    // ---- prologue: step 0 has one (all-zero) beam ----
+    {
+      float m[4], cA[4], cBv[4];
+      step_consts(0, m, cA, cBv);
+      float cacc = 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) beam[b][i] = 0.f;
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) G[b][i] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        G[0][i] = beam_G(0.f, m[i], cA[i], cBv[i], sa[i]);
+        cacc = beam_C_term(cacc, 0.f, m[i], cA[i], cBv[i]);
+      }
+      const float cg = wave_tree_sum(cacc);
+      if (active && sw == 0 && lane == 0) cpart_s[g * 32 + 0] = cg;
+      __syncthreads();
+      if (tid == 0) {
+        float cb = cpart_s[0];
+        for (int gg = 1; gg < NG; ++gg) cb = cb + cpart_s[gg * 32];
+        Cb_s[0] = cb;
+      }
+      // (visibility of Cb_s: the barrier after scoring)
+    }
 
     int cur = 0, Bcur = 1;
     for (int t = 0; t < K; ++t) {
       const StepSeed ss = make_step_seed(A.seed + t);
-      const float rho = A.rho[K - 1 - t];
-      float sa[4], m[4], cA[4], cBv[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const StepConst sc = step_constants(rho, dmu[i], vq[i], vp[i], c[i]);
-        sa[i] = valid[i] ? sc.sa : 0.f; m[i] = valid[i] ? sc.m : 0.f;
-        cA[i] = valid[i] ? sc.A : 0.f; cBv[i] = valid[i] ? sc.Bv : 0.f;
-        c[i] = c[i] + sc.a; // cumulative_auxiliary_variance += auxiliary_var (:109)
-      }
       uint32_t bet[NB];
 #pragma unroll
       for (int b = 0; b < NB; ++b) bet[b] = __builtin_amdgcn_readfirstlane(beta4[cur * 32 + (b < Bcur ? b : 0)]);
@@ -498,17 +558,34 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
               uint32_t al[4];
 #pragma unroll
               for (int i = 0; i < 4; ++i) al[i] = dlog_s[rm1[i]];
+              if (Bcur == NB) {
+                // steady state: all NB beams alive -> branch-free; the NB gathers of one dim are issued back to back
 #pragma unroll
-              for (int b = 0; b < NB; ++b) {
-                if (b < Bcur) { // wave-uniform
+                for (int i = 0; i < 4; ++i) {
+                  float z[NB];
 #pragma unroll
-                  for (int i = 0; i < 4; ++i) {
+                  for (int b = 0; b < NB; ++b) {
                     uint32_t ad = al[i] + bet[b];                       // 4*(dlog r + dlog h)
                     const uint32_t ad2 = ad - IREC_LUT2_BYTES;
                     ad = ad2 < ad ? ad2 : ad;                           // mod 10006 (one conditional subtract)
-                    const float z = *reinterpret_cast<const float *>(lut2_b + ad);
-                    const float y = sa[i] * z;
-                    acc[cc * NB + b] = score_term(acc[cc * NB + b], beam[b][i], y, m[i], cA[i], cBv[i]);
+                    z[b] = lds_abs_f32(ad);
+                  }
+#pragma unroll
+                  for (int b = 0; b < NB; ++b) acc[cc * NB + b] = proposal_term(acc[cc * NB + b], z[b], cH[i], G[b][i]);
+                  __builtin_amdgcn_sched_barrier(0); // one dim's NB gathers in flight at a time (VGPR budget)
+                }
+              } else {
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                  if (b < Bcur) { // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                      uint32_t ad = al[i] + bet[b];
+                      const uint32_t ad2 = ad - IREC_LUT2_BYTES;
+                      ad = ad2 < ad ? ad2 : ad;
+                      const float z = lds_abs_f32(ad);
+                      acc[cc * NB + b] = proposal_term(acc[cc * NB + b], z, cH[i], G[b][i]);
+                    }
                   }
                 }
               }
@@ -522,13 +599,13 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
         }
       }
       __syncthreads();
-      // ---------------- combine dim groups in order, build sort keys ----------------
+      // ---------------- combine dim groups in order, add C_b, build sort keys ----------------
       const int N = S * Bcur;
       for (int f = tid; f < N; f += NT) {
         const int s = f / Bcur, b = f - s * Bcur;
         float sc = part_s[((size_t)0 * S + s) * NB + b];
         for (int gg = 1; gg < NG; ++gg) sc = sc + part_s[((size_t)gg * S + s) * NB + b];
-        key_s[f] = score_key(sc);
+        key_s[f] = score_key(sc + Cb_s[b]);
       }
       const int Bnew = B < N ? B : N;
       select_topB<NT>(key_s, N, Bnew, Bcur, wb, sel_s, sel_b); // first barrier inside orders key_s writes
@@ -540,49 +617,70 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
         beta4[(cur ^ 1) * 32 + tid] = dlog_s[hash_from_sum(nh) - 1u];
         bp[(size_t)t * NB + tid] = (sp_ << 6) | bp_;
       }
-      // ---------------- gather the surviving beams in registers (beam_search_coder.py:92-93) ----------------
+      // ---------------- gather the surviving beams (beam_search_coder.py:92-93), prepare the next step ----------------
+      const bool last = (t == K - 1);
       if (active) {
-        uint32_t apk[NB][2];
+        const float sa_t[4] = {sa[0], sa[1], sa[2], sa[3]};   // this step's sample scale
+        float m[4], cA[4], cBv[4];
+        if (!last) step_consts(t + 1, m, cA, cBv);            // overwrites sa / cH with the next step's
+        const float *bold = beams_g + ((size_t)cur * NB) * FAST_MAX_DIM + d0;
+        float *bnew = beams_g + ((size_t)(cur ^ 1) * NB) * FAST_MAX_DIM + d0;
+        float cacc[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) cacc[j] = 0.f;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-          apk[j][0] = 0u; apk[j][1] = 0u;
-          if (j < Bnew) {
+          if (j < Bnew) { // wave-uniform
             const int32_t sp_ = __builtin_amdgcn_readfirstlane(sel_s[j]);
+            const int32_t bp_ = __builtin_amdgcn_readfirstlane(sel_b[j]);
+            const uint32_t bet_old = __builtin_amdgcn_readfirstlane(beta4[cur * 32 + bp_]);
             uint32_t rm1[4];
             draw_rm1_x4(ss, (uint64_t)sp_ * (uint64_t)D + (uint64_t)d0, rm1);
-            apk[j][0] = (uint32_t)dlog_s[rm1[0]] | ((uint32_t)dlog_s[rm1[1]] << 16);
-            apk[j][1] = (uint32_t)dlog_s[rm1[2]] | ((uint32_t)dlog_s[rm1[3]] << 16);
-          }
-        }
-        float *st = stage_s + (size_t)wave * NB * 64 + lane; // lane-private column, dynamic row = old beam id
+            float4 ob = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t) ob = *reinterpret_cast<const float4 *>(bold + (size_t)bp_ * FAST_MAX_DIM);
+            const float obv[4] = {ob.x, ob.y, ob.z, ob.w};
+            float nb[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-          for (int b = 0; b < NB; ++b) st[b * 64] = beam[b][i];
-#pragma unroll
-          for (int j = 0; j < NB; ++j) {
-            if (j < Bnew) {
-              const int32_t bp_ = __builtin_amdgcn_readfirstlane(sel_b[j]);
-              const uint32_t a16 = (i & 1) ? (apk[j][i >> 1] >> 16) : (apk[j][i >> 1] & 0xFFFFu);
-              uint32_t ad = a16 + beta4[cur * 32 + bp_];
+            for (int i = 0; i < 4; ++i) {
+              uint32_t ad = (uint32_t)dlog_s[rm1[i]] + bet_old;
               const uint32_t ad2 = ad - IREC_LUT2_BYTES;
               ad = ad2 < ad ? ad2 : ad;
-              const float y = sa[i] * *reinterpret_cast<const float *>(lut2_b + ad);
-              beam[j][i] = st[bp_ * 64] + y; // combined_samples[best_ind_aux, best_ind_beam], :81,92-93
+              const float y = sa_t[i] * lds_abs_f32(ad); // dist.quantile(.), :48-49
+              nb[i] = obv[i] + y;                          // combined_samples[best_ind_aux, best_ind_beam], :81,92-93
+            }
+            if (last) {
+              if (j == 0 && sw == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                  if (valid[i]) A.out_sample[ix[i]] = nb[i] + A.p_loc[ix[i]]; // beams[0] + coding_dist.loc, :122
+              }
+            } else {
+              if (sw == 0) *reinterpret_cast<float4 *>(bnew + (size_t)j * FAST_MAX_DIM) = make_float4(nb[0], nb[1], nb[2], nb[3]);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                G[j][i] = beam_G(nb[i], m[i], cA[i], cBv[i], sa[i]);
+                cacc[j] = beam_C_term(cacc[j], nb[i], m[i], cA[i], cBv[i]);
+              }
             }
           }
+          __builtin_amdgcn_sched_barrier(0); // one surviving beam at a time (keeps 20 Philox chains from interleaving)
+        }
+        if (!last) {
+          const float ctot = reduce_scatter<32>(cacc, lane);  // lane l holds beam (l >> 1)
+          const int j = lane >> 1;
+          if (sw == 0 && (lane & 1) == 0 && j < Bnew) cpart_s[g * 32 + j] = ctot;
         }
       }
       __syncthreads();
+      if (!last && tid < Bnew) {
+        float cb = cpart_s[tid];
+        for (int gg = 1; gg < NG; ++gg) cb = cb + cpart_s[gg * 32 + tid];
+        Cb_s[tid] = cb; // read after the next scoring barrier
+      }
       cur ^= 1;
       Bcur = Bnew;
     }
-    // ---- outputs ----
-    if (active && sw == 0) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (valid[i]) A.out_sample[src_index(A, base, pos, d0 + i)] = beam[0][i] + mp[i]; // beams[0] + coding_dist.loc
-    }
+    // ---- index path of beam 0 (beam_search_coder.py:118-121) ----
     __syncthreads();
     if (tid == 0) {
       int j = 0;
@@ -664,7 +762,7 @@ hipError_t launch_block_kl(const EncArgs &A, float *out_kl, int grid, hipStream_
   return hipGetLastError();
 }
 
-size_t generic_lds_bytes() { return 40032 + (size_t)GEN_NSC * 4 + 64 + 32 + 8 + 64 * 4 * 2 + 128 * 4 + 16 + 64; }
+size_t generic_lds_bytes() { return 40032 + (size_t)GEN_NSC * 4 + 64 + 32 + 8 + 64 * 4 * 2 + 128 * 4 + 16 + 256 + 64; }
 
 hipError_t launch_encode_generic(const EncArgs &A, int grid, hipStream_t st) {
   const size_t lds = generic_lds_bytes();
@@ -677,7 +775,7 @@ hipError_t launch_encode_generic(const EncArgs &A, int grid, hipStream_t st) {
 
 template <int NB, int NW>
 static hipError_t launch_fast_t(const EncArgs &A, int grid, hipStream_t st) {
-  const size_t lds = fast_lds_bytes(NB, NW, A.S, nullptr, nullptr);
+  const size_t lds = fast_lds_bytes(NB, A.S, nullptr, nullptr);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_fast_kernel<NB, NW>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -689,8 +787,10 @@ int fast_nb_for(int B) { return B <= 10 ? 10 : B <= 20 ? 20 : B <= 32 ? 32 : 0; 
 
 size_t fast_lds_for(int B, int S) {
   const int nb = fast_nb_for(B);
-  return nb ? fast_lds_bytes(nb, FAST_NW, S, nullptr, nullptr) : (size_t)-1;
+  return nb ? fast_lds_bytes(nb, S, nullptr, nullptr) : (size_t)-1;
 }
+
+size_t fast_ws_for(int B, int max_K) { return fast_ws_bytes(fast_nb_for(B), max_K); }
 
 hipError_t launch_encode_fast(const EncArgs &A, int grid, hipStream_t st) {
   switch (fast_nb_for(A.B)) {
