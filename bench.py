@@ -122,9 +122,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    from irec import sharding
+
+    def exchange(K):
+        # the path's only exchange step: per-latent code length (nats), all ranks <- all ranks (RCCL over xGMI)
+        return sharding.gather_per_item(sharding.code_nats_per_tensor(K, lay, S), world * L, rank, world, dist)
+
     log(f"rank {rank}/{world}: {L} latents, {lay.n_blocks} blocks per step")
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1)):
         eng.encode_blocks(params, lay, *q, SEED, max_K, out=out)
+        exchange(out[0])
     barrier()
     log("warm-up done")
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -133,16 +140,8 @@ def main():
         a.record()
         eng.encode_blocks(params, lay, *q, SEED, max_K, out=out)   # same stream as the events (torch current stream)
         b.record()
-    # the path's only exchange: per-latent code length (nats) gathered over RCCL
     K = out[0]
-    bits = torch.zeros(L, dtype=torch.float32, device=device)
-    row_tensor = torch.from_numpy(lay.order // lay.blocks_per_tensor).to(device)
-    bits.index_add_(0, row_tensor, K.float() * float(np.log(S)))
-    if dist is not None:
-        gathered = torch.empty(world * L, dtype=torch.float32, device=device)
-        dist.all_gather_into_tensor(gathered, bits)
-    else:
-        gathered = bits
+    gathered = exchange(K)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -158,6 +157,13 @@ def main():
     algo_bytes = int((24 * dims + 4 * Kh).sum())                        # 24 D + 4 K per block
     evals = int((S * dims * (1 + np.maximum(Kh - 1, 0) * BEAMS) * (Kh > 0)).sum())
     clk_ghz = 2.4
+    # HBM-side traffic per launch from the committed PMC profile (FETCH_SIZE / WRITE_SIZE passes, corrected as
+    # MI355X_MICROARCH.md prescribes: KiB units, FETCH_SIZE x2 for 16 B/lane streams); scaled by the latent count.
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tj):
+        tr = json.load(open(tj))
+        traffic = tr["hbm_bytes_per_latent"] * L
 
     result = {
         "metric": "encoded latents/sec", "value": world * L * args.steps / elapsed, "unit": "latents/s",
@@ -168,7 +174,7 @@ def main():
                    "latents_per_step_per_gpu": L, "blocks_per_step_per_gpu": int(lay.n_blocks),
                    "parallelism": f"latents sharded over {world} GPU(s), no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": algo_bytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": algo_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": algo_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "encode_fast_kernel<20,4>", "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes},
         "secondary": {"proposal_evals_per_s": evals / (kernel_ms * 1e-3),
                       "evals_per_clk_per_cu": evals / (kernel_ms * 1e-3) / (N_CU * clk_ghz * 1e9),

@@ -50,9 +50,14 @@ typedef struct {
   int32_t n_samples;      /* S = int(exp(kl_per_partition * extra_samples)) (beam_search_coder.py:29)          */
   int32_t n_beams;        /* B (beam_search_coder.py:28)                                                       */
   int32_t flags;          /* IREC_FLAG_* below; 0 = defaults                                                   */
+  int32_t table_dims[4];  /* optional hint: the distinct block_dim values of the call (0-terminated, <= 4).     */
+                          /* With it the encoder evaluates the shared-seed Philox draw once per call into a     */
+                          /* proposal table (same seed for every block, coder.py:444-449) instead of once per   */
+                          /* block; a block whose dim is not listed gets out_K = -1.  All zero = no hint.       */
 } irec_params;
 
-#define IREC_FLAG_FORCE_GENERIC 1 /* use the generic (any D, any B) kernel even where the fast kernel applies  */
+#define IREC_FLAG_FORCE_GENERIC 1 /* use the generic (any D, any B) kernel even where the fast kernels apply   */
+#define IREC_FLAG_FUSED_PHILOX 2  /* keep the Philox draw fused in the block kernel even when table_dims is set */
 
 typedef struct irec_context irec_context;
 

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -196,6 +197,7 @@ struct irec_context {
   float *d_lut2 = nullptr;
   uint16_t *d_dlog4r = nullptr;
   float *d_rho = nullptr;
+  unsigned long long *d_dbg = nullptr; // IREC_STAMPS=1 diagnostics only
 };
 
 extern "C" {
@@ -294,6 +296,9 @@ irec_status irec_create(int device, irec_context **out) {
   HIP_TRY(hipMemcpy(ctx->d_lut2, lut2.data(), (P - 1) * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(ctx->d_dlog4r, dlog4r.data(), (P - 1) * sizeof(uint16_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(ctx->d_rho, rho.data(), rho.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (const char *e = std::getenv("IREC_STAMPS"); e && e[0] == '1') {
+    HIP_TRY(hipMalloc(&ctx->d_dbg, 4096 * 8 * sizeof(unsigned long long)));
+  }
   *out = ctx;
   return IREC_OK;
 }
@@ -309,10 +314,15 @@ void irec_destroy(irec_context *ctx) {
 namespace {
 
 struct Plan {
-  bool fast;
+  bool fast;         // register-resident fast encoder with the Philox draw fused in
+  bool striped;      // beam-striped fast encoder fed by per-call proposal tables
   int grid_cap;      // resident workgroups (persistent kernels pull blocks from an atomic counter)
   size_t ws_per_wg;
   int dpad;
+  int n_tab;
+  int tab_dim[4];
+  size_t tab_off[4]; // byte offsets of the proposal tables inside the workspace (after the 256-byte counter block)
+  size_t tab_bytes;  // total
 };
 
 irec_status check_params(const irec_params *p) {
@@ -330,7 +340,22 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
   pl.fast = !(p->flags & IREC_FLAG_FORCE_GENERIC) && max_dim <= irec::FAST_MAX_DIM && irec::fast_nb_for(B) != 0 &&
             irec::fast_lds_for(B, S) <= irec::FAST_LDS_LIMIT && (int64_t)S * B < (1 << 24);
   pl.grid_cap = 2 * (ctx->n_cu > 0 ? ctx->n_cu : 256);
-  if (pl.fast) {
+  pl.striped = false; pl.n_tab = 0; pl.tab_bytes = 0;
+  if (pl.fast && !(p->flags & IREC_FLAG_FUSED_PHILOX) && p->table_dims[0] > 0 && irec::fast3_supports(B, S) &&
+      irec::fast3_lds_for(B, S) <= irec::FAST_LDS_LIMIT / 2) {
+    pl.striped = true;
+    for (int q = 0; q < 4 && p->table_dims[q] > 0; ++q) {
+      if (p->table_dims[q] > irec::FAST_MAX_DIM) { pl.striped = false; break; }
+      pl.tab_dim[pl.n_tab] = p->table_dims[q];
+      pl.tab_off[pl.n_tab] = pl.tab_bytes;
+      pl.tab_bytes += round_up_sz((size_t)(max_K > 0 ? max_K : 1) * S * round_up(p->table_dims[q], 4) * 2, 256);
+      ++pl.n_tab;
+    }
+    if (!pl.striped) { pl.n_tab = 0; pl.tab_bytes = 0; }
+  }
+  if (pl.striped) {
+    pl.ws_per_wg = round_up_sz(irec::fast_ws_bytes_nb(B, max_K), 256);
+  } else if (pl.fast) {
     pl.ws_per_wg = round_up_sz(irec::fast_ws_for(B, max_K), 256);
   } else {
     pl.ws_per_wg = round_up_sz((size_t)10 * pl.dpad * 4 + (size_t)2 * B * pl.dpad * 4 +
@@ -346,7 +371,7 @@ extern "C" {
 size_t irec_encode_workspace_bytes(const irec_context *ctx, const irec_params *p, int32_t max_dim, int32_t max_K) {
   if (!ctx || check_params(p) != IREC_OK || max_dim < 1 || max_K < 0) return 0;
   const Plan pl = make_plan(ctx, p, max_dim, max_K);
-  return 256 + (size_t)pl.grid_cap * pl.ws_per_wg;
+  return 256 + pl.tab_bytes + (size_t)pl.grid_cap * pl.ws_per_wg;
 }
 
 irec_status irec_block_kl(irec_context *ctx, const irec_params *p, int64_t n_blocks, const int64_t *block_base,
@@ -384,7 +409,7 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   if (max_K > 0 && !out_indices) return fail(IREC_E_INVALID, "irec_beam_encode: null out_indices");
   if (max_block_dim < 1 || max_block_dim > (1 << 22)) return fail(IREC_E_INVALID, "irec_beam_encode: max_block_dim %d out of range", max_block_dim);
   const Plan pl = make_plan(ctx, p, max_block_dim, max_K);
-  const size_t need = 256 + (size_t)pl.grid_cap * pl.ws_per_wg;
+  const size_t need = 256 + pl.tab_bytes + (size_t)pl.grid_cap * pl.ws_per_wg;
   if (!workspace || workspace_bytes < need)
     return fail(IREC_E_WORKSPACE, "irec_beam_encode: workspace %zu bytes < required %zu", workspace_bytes, need);
   if (((uintptr_t)workspace & 255) != 0) return fail(IREC_E_WORKSPACE, "irec_beam_encode: workspace must be 256-byte aligned");
@@ -398,13 +423,37 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   A.out_K = out_K; A.out_indices = out_indices; A.out_sample = out_sample;
   A.lut = ctx->d_lut; A.lut2 = ctx->d_lut2; A.dlog4r = ctx->d_dlog4r; A.rho = ctx->d_rho;
   A.counter = (unsigned int *)workspace;
-  A.ws = (char *)workspace + 256;
+  A.ws = (char *)workspace + 256 + pl.tab_bytes;
   A.ws_per_wg = pl.ws_per_wg;
   A.max_dim_pad = pl.dpad;
   HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));
   const int grid = (int)std::min<int64_t>(n_blocks, pl.grid_cap);
-  if (pl.fast) HIP_TRY(irec::launch_encode_fast(A, grid, st));
-  else HIP_TRY(irec::launch_encode_generic(A, grid, st));
+  A.dbg = ctx->d_dbg;
+  if (ctx->d_dbg) HIP_TRY(hipMemsetAsync(ctx->d_dbg, 0, 4096 * 8 * sizeof(unsigned long long), st));
+  if (pl.striped) {
+    for (int q = 0; q < 4; ++q) { A.tab[q] = nullptr; A.tab_dim[q] = -1; }
+    for (int q = 0; q < pl.n_tab; ++q) {
+      uint16_t *tab = (uint16_t *)((char *)workspace + 256 + pl.tab_off[q]);
+      HIP_TRY(irec::launch_alpha_table(seed, p->n_samples, pl.tab_dim[q], max_K > 0 ? max_K : 1, ctx->d_dlog4r, tab, st));
+      A.tab[q] = tab; A.tab_dim[q] = pl.tab_dim[q];
+    }
+    HIP_TRY(irec::launch_encode_fast3(A, grid, st));
+  } else if (pl.fast) {
+    HIP_TRY(irec::launch_encode_fast(A, grid, st));
+  } else {
+    HIP_TRY(irec::launch_encode_generic(A, grid, st));
+  }
+  if (ctx->d_dbg) { // diagnostic build only: synchronous read-back of the phase stamps
+    std::vector<unsigned long long> h((size_t)grid * 8);
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(h.data(), ctx->d_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double sum[8] = {0};
+    for (int w = 0; w < grid; ++w) for (int k = 0; k < 8; ++k) sum[k] += (double)h[(size_t)w * 8 + k];
+    const double tot = sum[0] + sum[1] + sum[2] + sum[3];
+    fprintf(stderr, "[irec stamps] %s grid=%d cycles/WG: prologue %.0f (%.1f%%) scoring %.0f (%.1f%%) select %.0f (%.1f%%) update %.0f (%.1f%%)\n",
+            pl.striped ? "striped" : pl.fast ? "fused" : "generic", grid, sum[0] / grid, 100 * sum[0] / tot, sum[1] / grid,
+            100 * sum[1] / tot, sum[2] / grid, 100 * sum[2] / tot, sum[3] / grid, 100 * sum[3] / tot);
+  }
   return IREC_OK;
 }
 

@@ -27,6 +27,10 @@ struct EncArgs {
   const float *rho;        // [IREC_MAX_PARTITIONS_DEV] rho[i] = float32((i+1)^-0.7864636765648174)
   // scratch
   unsigned int *counter; char *ws; size_t ws_per_wg; int32_t max_dim_pad;
+  // shared proposal tables (beam-striped encoder): tab[q] serves blocks with block_dim == tab_dim[q]
+  const uint16_t *tab[4]; int32_t tab_dim[4];
+  // diagnostics (IREC_STAMPS=1): per-workgroup cycle sums [grid][8]; nullptr in normal runs
+  unsigned long long *dbg;
 };
 
 struct DecArgs {
@@ -43,7 +47,13 @@ hipError_t launch_encode_generic(const EncArgs &A, int grid, hipStream_t st);
 int fast_nb_for(int B);
 size_t fast_lds_for(int B, int S);
 size_t fast_ws_for(int B, int max_K);
+size_t fast_ws_bytes_nb(int NB, int max_K);
 hipError_t launch_encode_fast(const EncArgs &A, int grid, hipStream_t st);
+size_t fast3_lds_for(int B, int S);
+bool fast3_supports(int B, int S);
+hipError_t launch_encode_fast3(const EncArgs &A, int grid, hipStream_t st);
+hipError_t launch_alpha_table(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *dlog4r, uint16_t *tab,
+                              hipStream_t st);
 hipError_t launch_decode(const DecArgs &A, int grid, hipStream_t st);
 hipError_t launch_uniform_int(int64_t seed, int64_t n, int32_t *out, hipStream_t st);
 hipError_t launch_reduce_scatter_test(const float *in, float *out, int width, hipStream_t st);

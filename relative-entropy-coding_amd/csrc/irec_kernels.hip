@@ -30,13 +30,45 @@ __device__ __forceinline__ int64_t src_index(const EncArgs &A, int64_t base, int
   return base + (A.perm ? (int64_t)A.perm[pos + d] : (int64_t)(pos + d));
 }
 
-// Block-wide top-Bnew selection over key[0..N) (uint32 sort keys; 0 = taken).  NT threads, NT/64 waves.
-// Element f is owned (scanned, cleared) by thread f % NT.  One barrier per selected beam.
+// Block-wide top-Bnew selection over key[0..N) (uint32 sort keys; 0 = taken), NT threads.
+// tf.argsort(DESCENDING)[:B] semantics (beam_search_coder.py:85-89): value descending, ties to the lower flat index.
+//  - N <= 1024: wave 0 pulls the candidates into registers (16 per lane) and runs Bnew rounds of
+//    {lane-local max, DPP wave max, clear the winner}; the other waves wait at ONE barrier.
+//  - larger N: all waves scan LDS/global keys, one barrier per selected beam (element f owned by thread f % NT).
 template <int NT>
 __device__ __forceinline__ void select_topB(uint32_t *key, int N, int Bnew, int Bcur, unsigned long long *wb,
                                             int32_t *sel_s, int32_t *sel_b) {
   constexpr int NWV = NT / 64;
   const int tid = threadIdx.x;
+  if (N <= 1024) {
+    __syncthreads(); // keys written by all waves
+    if (tid < 64) {
+      const int nslots = (N + 63) >> 6;
+      unsigned long long c[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int f = k * 64 + tid;
+        c[k] = (k < nslots && f < N) ? cand_pack(key[f], (uint32_t)f) : 0ull;
+      }
+      for (int it = 0; it < Bnew; ++it) {
+        unsigned long long best = c[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k)
+          if (k < nslots) best = c[k] > best ? c[k] : best; // wave-uniform predicate
+        const unsigned long long g = wave_max_u64(best);
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (k < nslots) c[k] = (c[k] == g) ? 0ull : c[k];
+        if (tid == 0) {
+          const uint32_t fstar = 0xFFFFFFFFu - (uint32_t)g;
+          sel_s[it] = (int32_t)(fstar / (uint32_t)Bcur); // best_ind_aux  (beam_search_coder.py:89)
+          sel_b[it] = (int32_t)(fstar % (uint32_t)Bcur); // best_ind_beam (beam_search_coder.py:88)
+        }
+      }
+    }
+    __syncthreads();
+    return;
+  }
   for (int it = 0; it < Bnew; ++it) {
     unsigned long long best = 0ull;
     for (int f = tid; f < N; f += NT) {
@@ -55,8 +87,8 @@ __device__ __forceinline__ void select_topB(uint32_t *key, int N, int Bnew, int 
     const uint32_t fstar = 0xFFFFFFFFu - (uint32_t)g;
     if ((uint32_t)tid == fstar % (uint32_t)NT) key[fstar] = 0u;
     if (tid == 0) {
-      sel_s[it] = (int32_t)(fstar / (uint32_t)Bcur); // best_ind_aux  (beam_search_coder.py:89)
-      sel_b[it] = (int32_t)(fstar % (uint32_t)Bcur); // best_ind_beam (beam_search_coder.py:88)
+      sel_s[it] = (int32_t)(fstar / (uint32_t)Bcur);
+      sel_b[it] = (int32_t)(fstar % (uint32_t)Bcur);
     }
   }
   __syncthreads();
@@ -370,6 +402,17 @@ __device__ __forceinline__ float reduce_scatter(float (&v)[N0], int lane) {
   return v[0];
 }
 
+// Diagnostic phase stamps (only when EncArgs.dbg != nullptr; the values never reach an output of the coder).
+__device__ __forceinline__ unsigned long long stamp_now() { return __builtin_amdgcn_s_memtime(); }
+#define IREC_STAMP(slot)                                                    \
+  do {                                                                      \
+    if (A.dbg && tid == 0) {                                                \
+      const unsigned long long now_ = stamp_now();                          \
+      A.dbg[(size_t)blockIdx.x * 8 + (slot)] += now_ - stamp_prev;          \
+      stamp_prev = now_;                                                    \
+    }                                                                       \
+  } while (0)
+
 // The fast kernel addresses its LUT by ABSOLUTE LDS byte address (the table is the first thing in the dynamic LDS
 // region, which starts at 0 because the kernel has no static __shared__): saves one VALU add per proposal.
 typedef __attribute__((address_space(3))) const float lds_cfloat;
@@ -391,10 +434,10 @@ __host__ __device__ inline size_t fast_lds_bytes(int NB, int S, size_t *off_key,
   return 40032 + 20016 + part + key + 1536;
 }
 
-// Scratch slab of one workgroup (bytes): bp int32 [max_K][NB] | beams float [2][NB][1024]
+// Scratch slab of one workgroup (bytes): bp int32 [max_K][NB] | stats float [3][1024] | beams float [2][NB][1024]
 __host__ __device__ inline size_t fast_ws_bytes(int NB, int max_K) {
   const size_t bp = (((size_t)(max_K > 0 ? max_K : 1) * NB * 4) + 255) & ~(size_t)255;
-  return bp + (size_t)2 * NB * FAST_MAX_DIM * 4;
+  return bp + (size_t)3 * FAST_MAX_DIM * 4 + (size_t)2 * NB * FAST_MAX_DIM * 4;
 }
 
 template <int NB, int NW>
@@ -434,6 +477,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
   int32_t *bp = reinterpret_cast<int32_t *>(slab);                                            // [max_K][NB]
   float *beams_g = reinterpret_cast<float *>(slab + A.ws_per_wg - (size_t)2 * NB * FAST_MAX_DIM * 4); // [2][NB][1024]
 
+  unsigned long long stamp_prev = A.dbg ? stamp_now() : 0ull;
   for (;;) {
     __syncthreads();
     if (tid == 0) misc[0] = (int32_t)atomicAdd(A.counter, 1u);
@@ -534,6 +578,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
       // (visibility of Cb_s: the barrier after scoring)
     }
 
+    IREC_STAMP(0);
     int cur = 0, Bcur = 1;
     for (int t = 0; t < K; ++t) {
       const StepSeed ss = make_step_seed(A.seed + t);
@@ -599,6 +644,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
         }
       }
       __syncthreads();
+      IREC_STAMP(1);
       // ---------------- combine dim groups in order, add C_b, build sort keys ----------------
       const int N = S * Bcur;
       for (int f = tid; f < N; f += NT) {
@@ -609,6 +655,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
       }
       const int Bnew = B < N ? B : N;
       select_topB<NT>(key_s, N, Bnew, Bcur, wb, sel_s, sel_b); // first barrier inside orders key_s writes
+      IREC_STAMP(2);
       // ---------------- new hashes / back-pointers (beam_search_coder.py:94-95) ----------------
       if (tid < Bnew) {
         const int32_t sp_ = sel_s[tid], bp_ = sel_b[tid];
@@ -672,6 +719,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
         }
       }
       __syncthreads();
+      IREC_STAMP(3);
       if (!last && tid < Bnew) {
         float cb = cpart_s[tid];
         for (int gg = 1; gg < NG; ++gg) cb = cb + cpart_s[gg * 32 + tid];
@@ -679,6 +727,381 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
       }
       cur ^= 1;
       Bcur = Bnew;
+    }
+    // ---- index path of beam 0 (beam_search_coder.py:118-121) ----
+    __syncthreads();
+    if (tid == 0) {
+      int j = 0;
+      for (int t = K - 1; t >= 0; --t) {
+        const int32_t v = __builtin_nontemporal_load(&bp[(size_t)t * NB + j]);
+        A.out_indices[blk * (int64_t)A.max_K + t] = v >> 6;
+        j = v & 63;
+      }
+    }
+  }
+}
+
+// ======================================================================================================
+//  shared proposal table: the int32 draw of get_pseudo_random_sample depends only on (seed + t, S, D) -- it is the
+//  same for every block of D dims in the call (every caller passes one seed: coder.py:444-449) -- so the Philox
+//  stream is evaluated ONCE per call, fused with "% 10006" and the discrete-log map, into
+//      tab[t][s][d] = 4 * dlog_g(r[s, d])   (uint16, row stride = D rounded up to 4)
+//  which the beam-striped encoder streams from L2 (8 bytes per lane per sample).
+// ======================================================================================================
+__global__ __launch_bounds__(256) void alpha_table_kernel(int64_t seed, int32_t S, int32_t D, int32_t K_tab,
+                                                          const uint16_t *__restrict__ dlog4r, uint16_t *__restrict__ tab) {
+  const int Dp = (D + 3) & ~3;
+  const int64_t per_step = (int64_t)S * Dp;
+  const int64_t total = per_step * K_tab;
+  for (int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; q < total; q += (int64_t)gridDim.x * 256 * 4) {
+    const int t = (int)(q / per_step);
+    const int64_t rem = q - (int64_t)t * per_step;
+    const int s = (int)(rem / Dp), d0 = (int)(rem - (int64_t)s * Dp);
+    const StepSeed ss = make_step_seed(seed + t);
+    uint16_t v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (d0 + i < D) ? dlog4r[draw_rm1(ss, (uint64_t)s * (uint64_t)D + (uint64_t)(d0 + i))] : (uint16_t)0;
+    *reinterpret_cast<uint2 *>(tab + q) = make_uint2((uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16));
+  }
+}
+
+// ======================================================================================================
+//  beam-striped fast encoder (v3): D <= 1024, B <= NB <= 32, proposal table available.
+//  8 waves per workgroup: wave -> (dim group g, beam half h, sample stripe sw); lane owns dims 256 g + 4 l .. +3
+//  and keeps G for its NB/NH beams only (<= 128 VGPRs -> 4 waves per SIMD, 2 workgroups per CU).
+// ======================================================================================================
+constexpr int F3_NW = 8;
+#ifndef F3_SPC_MAX
+#define F3_SPC_MAX 2
+#endif
+
+// LDS carve (bytes): lut2 40032 | part [4][S][NB] f32 | key [S*NB] u32 | small 1536
+__host__ __device__ inline size_t fast3_lds_bytes(int NB, int S, size_t *off_key, size_t *off_small) {
+  const size_t part = (((size_t)4 * S * NB * 4) + 15) & ~(size_t)15;
+  const size_t key = (((size_t)S * NB * 4) + 15) & ~(size_t)15;
+  if (off_key) *off_key = 40032 + part;
+  if (off_small) *off_small = 40032 + part + key;
+  return 40032 + part + key + 1536;
+}
+
+template <int NB, int NH>
+__global__ __launch_bounds__(F3_NW * 64, 4) void encode_fast3_kernel(EncArgs A) {
+  constexpr int NT = F3_NW * 64;
+  constexpr int HB = NB / NH;            // beams per wave
+  constexpr int SPC = (32 / HB) < F3_SPC_MAX ? (32 / HB) : F3_SPC_MAX; // samples per chunk (<= 32 accumulators)
+  static_assert(NB % NH == 0 && HB <= 16 && SPC >= 1, "bad beam split");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int S = A.S;                     // host guarantees A.B == NB and S >= NB for this kernel
+  size_t off_key, off_small;
+  fast3_lds_bytes(NB, S, &off_key, &off_small);
+  float *part_s = reinterpret_cast<float *>(smem + 40032);                    // [4][S][NB] per-group partial scores
+  uint32_t *key_s = reinterpret_cast<uint32_t *>(smem + off_key);             // [S*NB]
+  char *small = smem + off_small;
+  unsigned long long *wb = reinterpret_cast<unsigned long long *>(small);     // [2][8]
+  double *gpart = reinterpret_cast<double *>(small + 128);                    // [4]
+  int32_t *sel_s = reinterpret_cast<int32_t *>(small + 160);                  // [32]
+  int32_t *sel_b = sel_s + 32;                                                // [32]
+  int32_t *hsum = sel_b + 32;                                                 // [2][32]
+  uint32_t *beta4 = reinterpret_cast<uint32_t *>(hsum + 64);                  // [2][32] 4*dlog(hash(beam))
+  int32_t *misc = reinterpret_cast<int32_t *>(beta4 + 64);                    // [4]
+  float *cpart_s = reinterpret_cast<float *>(misc + 4);                       // [4][32] per-group partial C_b
+  float *Cb_s = cpart_s + 128;                                                // [32]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap(); // see lds_abs_f32
+  {
+    float *l2 = reinterpret_cast<float *>(smem);
+    for (int k = tid; k < (int)IREC_PM1; k += NT) l2[k] = A.lut2[k];
+  }
+  char *slab = A.ws + (size_t)blockIdx.x * A.ws_per_wg;
+  int32_t *bp = reinterpret_cast<int32_t *>(slab);                                                     // [max_K][NB]
+  float *beams_g = reinterpret_cast<float *>(slab + A.ws_per_wg - (size_t)2 * NB * FAST_MAX_DIM * 4); // [2][NB][1024]
+  float *stats_g = beams_g - 3 * FAST_MAX_DIM;  // [3][1024]: mq - mp, sq^2, sp^2 of the block, coalesced
+
+  unsigned long long stamp_prev = A.dbg ? stamp_now() : 0ull;
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) misc[0] = (int32_t)atomicAdd(A.counter, 1u);
+    __syncthreads();
+    const int64_t blk = misc[0];
+    if (blk >= A.n_blocks) break; // every wave of every workgroup reaches this
+    const int D = A.block_dim[blk];
+    const int64_t base = A.block_base[blk];
+    const int32_t pos = A.block_pos[blk];
+    // proposal table of this block's dim count (host listed the distinct dims of the call)
+    const uint16_t *tab = nullptr;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (A.tab_dim[q] == D) tab = A.tab[q];
+    if (D < 1 || D > FAST_MAX_DIM || tab == nullptr) {
+      if (tid == 0) A.out_K[blk] = -1;
+      continue;
+    }
+    const int Dp = (D + 3) & ~3;
+    const int NG = (D + 255) >> 8;              // 1..4 dim groups
+    const int NSW = F3_NW / (NG * NH);          // sample stripes (>= 1 because NG * NH <= 8)
+    const bool active = wave < NG * NH * NSW;
+    const int g = wave % NG, h = (wave / NG) % NH, sw = wave / (NG * NH);
+    const int d0 = g * 256 + lane * 4;
+    const int b_lo = h * HB;                    // my beams: b_lo .. b_lo + HB - 1
+    // flat element index of my dim i (split == gather through perm); recomputed where needed, not kept in VGPRs
+    auto elem = [&](int i) -> int64_t { return src_index(A, base, pos, d0 + i < D ? d0 + i : 0); };
+
+    // ---- the block's KL and K ----
+    {
+      double klacc = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float st3[3] = {0.f, 1.f, 1.f};
+        if (d0 + i < D) {
+          const int64_t e = elem(i);
+          const float mq_ = A.q_loc[e], sq_ = A.q_scale[e], mp_ = A.p_loc[e], sp_ = A.p_scale[e];
+          klacc = klacc + kl_dim(mq_, sq_, mp_, sp_);
+          st3[0] = mq_ - mp_; st3[1] = sq_ * sq_; st3[2] = sp_ * sp_;
+        }
+        if (active && h == 0 && sw == 0) { // one wave per dim group publishes the block's statistics
+          stats_g[d0 + i] = st3[0]; stats_g[FAST_MAX_DIM + d0 + i] = st3[1]; stats_g[2 * FAST_MAX_DIM + d0 + i] = st3[2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const double gs = wave_tree_sum(klacc);
+      if (active && h == 0 && sw == 0 && lane == 0) gpart[g] = gs;
+      __syncthreads();
+      if (tid == 0) {
+        double tot = gpart[0];
+        for (int gg = 1; gg < NG; ++gg) tot = tot + gpart[gg];
+        const int32_t K = num_aux((float)tot, A.omega);
+        misc[1] = K;
+        A.out_K[blk] = K;
+        hsum[0] = 0;
+        beta4[0] = 0u; // hash of the empty path is 1 = g^0
+      }
+      __syncthreads();
+    }
+    const int K = misc[1];
+    if (K > A.max_K || K > IREC_MAX_PARTITIONS_DEV) continue;
+    if (K == 0) { // nothing to code: sample = p.loc
+      if (active && h == 0 && sw == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (d0 + i < D) { const int64_t e = elem(i); A.out_sample[e] = 0.f + A.p_loc[e]; }
+      }
+      continue;
+    }
+
+    float c[4] = {0.f, 0.f, 0.f, 0.f};  // cumulative auxiliary variance of my dims
+    float sa[4], cH[4];                  // this step's sample scale and z^2 coefficient
+    float G[HB][4];                      // z coefficient of my beams
+    auto step_consts = [&](int t_next, float (&m)[4], float (&cA)[4], float (&cBv)[4]) {
+      const float rho = A.rho[K - 1 - t_next];
+      // three coalesced 16-byte reads of the slab instead of holding 12 VGPRs for the whole block
+      const float4 q0 = *reinterpret_cast<const float4 *>(stats_g + d0);
+      const float4 q1 = *reinterpret_cast<const float4 *>(stats_g + FAST_MAX_DIM + d0);
+      const float4 q2 = *reinterpret_cast<const float4 *>(stats_g + 2 * FAST_MAX_DIM + d0);
+      const float dmu_[4] = {q0.x, q0.y, q0.z, q0.w}, vq_[4] = {q1.x, q1.y, q1.z, q1.w}, vp_[4] = {q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = d0 + i < D;
+        const StepConst sc = step_constants(rho, dmu_[i], vq_[i], vp_[i], c[i]);
+        sa[i] = ok ? sc.sa : 0.f; cH[i] = ok ? sc.H : 0.f;
+        m[i] = ok ? sc.m : 0.f; cA[i] = ok ? sc.A : 0.f; cBv[i] = ok ? sc.Bv : 0.f;
+        c[i] = c[i] + sc.a; // cumulative_auxiliary_variance += auxiliary_var (:109)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+
+    // ================= step 0: one all-zero beam (beam_search_coder.py:96-106) =================
+    {
+      float m[4], cA[4], cBv[4];
+      step_consts(0, m, cA, cBv);
+      float G0[4], cacc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        G0[i] = beam_G(0.f, m[i], cA[i], cBv[i], sa[i]);
+        cacc = beam_C_term(cacc, 0.f, m[i], cA[i], cBv[i]);
+      }
+      const float cg = wave_tree_sum(cacc);
+      if (active && h == 0 && sw == 0 && lane == 0) cpart_s[g * 32] = cg;
+      if (active && h == 0) { // the single beam lives in half 0; up to 32 samples share one reduce-scatter
+        const int s_per_stripe = (S + NSW - 1) / NSW;
+        for (int ch = 0; ch * 32 < s_per_stripe; ++ch) {
+          float acc[32];
+#pragma unroll
+          for (int j = 0; j < 32; ++j) {
+            acc[j] = 0.f;
+            const int s = (ch * 32 + j) * NSW + sw;
+            if (s < S) { // wave-uniform
+              const uint2 ap = *reinterpret_cast<const uint2 *>(tab + d0 + (size_t)s * Dp);
+              const uint32_t al[4] = {ap.x & 0xFFFFu, ap.x >> 16, ap.y & 0xFFFFu, ap.y >> 16};
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[j] = proposal_term(acc[j], lds_abs_f32(al[i]), cH[i], G0[i]); // beta = 0
+            }
+            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0); // 4 samples in flight at a time (VGPR budget)
+          }
+          const float tot = reduce_scatter<32>(acc, lane);
+          const int s = (ch * 32 + (lane >> 1)) * NSW + sw;
+          if ((lane & 1) == 0 && s < S) part_s[((size_t)g * S + s) * NB] = tot;
+        }
+      }
+      __syncthreads();
+      const float c0 = [&] { float cb = cpart_s[0]; for (int gg = 1; gg < NG; ++gg) cb = cb + cpart_s[gg * 32]; return cb; }();
+      for (int f = tid; f < S; f += NT) {
+        float sc = part_s[(size_t)f * NB];
+        for (int gg = 1; gg < NG; ++gg) sc = sc + part_s[((size_t)gg * S + f) * NB];
+        key_s[f] = score_key(sc + c0);
+      }
+    }
+
+    IREC_STAMP(0); // block prologue: load, KL, step-0 constants and scores
+    int cur = 0;
+    for (int t = 0; t < K; ++t) {
+      const uint16_t *tab_t = tab + (size_t)t * S * Dp + d0; // row s at + s * Dp
+      const int Bcur = t ? NB : 1;
+      if (t) {
+        // ---------------- scoring: S x (my HB beams) candidates (beam_search_coder.py:80-84) ----------------
+        if (active) {
+          uint32_t bet[HB];
+#pragma unroll
+          for (int b = 0; b < HB; ++b) bet[b] = __builtin_amdgcn_readfirstlane(beta4[cur * 32 + b_lo + b]);
+          const int s_per_stripe = (S + NSW - 1) / NSW;
+          const int nchunks = (s_per_stripe + SPC - 1) / SPC;
+          // proposal rows (4 x uint16 byte offsets 4*dlog(r) of my 4 dims) are fetched one chunk ahead of their use
+          uint2 alp_next[SPC];
+#pragma unroll
+          for (int cc = 0; cc < SPC; ++cc) {
+            const int s = cc * NSW + sw;
+            alp_next[cc] = make_uint2(0u, 0u);
+            if (s < S) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)s * Dp);
+          }
+          for (int ch = 0; ch < nchunks; ++ch) {
+            float acc[32];
+#pragma unroll
+            for (int p = 0; p < 32; ++p) acc[p] = 0.f;
+            uint2 alp[SPC];
+#pragma unroll
+            for (int cc = 0; cc < SPC; ++cc) {
+              alp[cc] = alp_next[cc];
+              const int sn = ((ch + 1) * SPC + cc) * NSW + sw;
+              if (sn < S) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sn * Dp);
+            }
+#pragma unroll
+            for (int cc = 0; cc < SPC; ++cc) {
+              const int s = (ch * SPC + cc) * NSW + sw;
+              if (s < S) { // wave-uniform
+                const uint32_t al[4] = {alp[cc].x & 0xFFFFu, alp[cc].x >> 16, alp[cc].y & 0xFFFFu, alp[cc].y >> 16};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  float z[HB];
+#pragma unroll
+                  for (int b = 0; b < HB; ++b) {
+                    uint32_t ad = al[i] + bet[b];                       // 4*(dlog r + dlog h)
+                    const uint32_t ad2 = ad - IREC_LUT2_BYTES;
+                    ad = ad2 < ad ? ad2 : ad;                           // mod 10006 (one conditional subtract)
+                    z[b] = lds_abs_f32(ad);
+                  }
+#pragma unroll
+                  for (int b = 0; b < HB; ++b) acc[cc * HB + b] = proposal_term(acc[cc * HB + b], z[b], cH[i], G[b][i]);
+                  __builtin_amdgcn_sched_barrier(0); // one dim's HB gathers in flight at a time (VGPR budget)
+                }
+              }
+            }
+            const float tot = reduce_scatter<32>(acc, lane);
+            const int p = lane >> 1;
+            const int cc = p / HB, bl = p - cc * HB;
+            const int s = (ch * SPC + cc) * NSW + sw;
+            if (cc < SPC && s < S && (lane & 1) == 0) part_s[((size_t)g * S + s) * NB + b_lo + bl] = tot;
+          }
+        }
+        __syncthreads();
+        IREC_STAMP(1); // scoring
+        // ---------------- combine dim groups in order, add C_b, build sort keys ----------------
+        for (int f = tid; f < S * NB; f += NT) {
+          const int s = f / NB, b = f - s * NB;
+          float sc = part_s[((size_t)0 * S + s) * NB + b];
+          for (int gg = 1; gg < NG; ++gg) sc = sc + part_s[((size_t)gg * S + s) * NB + b];
+          key_s[f] = score_key(sc + Cb_s[b]);
+        }
+      }
+      const int N = S * Bcur;
+      select_topB<NT>(key_s, N, NB, Bcur, wb, sel_s, sel_b); // S >= NB: always NB survivors
+      IREC_STAMP(2); // combine + top-B
+      // ---------------- new hashes / back-pointers (beam_search_coder.py:94-95) ----------------
+      if (tid < NB) {
+        const int32_t sp_ = sel_s[tid], bp_ = sel_b[tid];
+        const int32_t nh = (int32_t)((uint32_t)hsum[cur * 32 + bp_] + (uint32_t)sp_ * (uint32_t)(69 + t));
+        hsum[(cur ^ 1) * 32 + tid] = nh;
+        beta4[(cur ^ 1) * 32 + tid] = A.dlog4r[hash_from_sum(nh) - 1u];
+        bp[(size_t)t * NB + tid] = (sp_ << 6) | bp_;
+      }
+      // ---------------- gather my surviving beams (beam_search_coder.py:92-93), prepare the next step ----------------
+      const bool last = (t == K - 1);
+      if (active) {
+        const float sa_t[4] = {sa[0], sa[1], sa[2], sa[3]};   // this step's sample scale
+        float m[4], cA[4], cBv[4];
+        if (!last) step_consts(t + 1, m, cA, cBv);            // overwrites sa / cH with the next step's
+        const float *bold = beams_g + ((size_t)cur * NB) * FAST_MAX_DIM + d0;
+        float *bnew = beams_g + ((size_t)(cur ^ 1) * NB) * FAST_MAX_DIM + d0;
+        float cacc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) cacc[j] = 0.f;
+        // all global reads of the update are issued up front (G is dead here: its registers take the old beams)
+        uint2 apv[HB];
+        float4 obv4[HB];
+        uint32_t bet_old[HB];
+#pragma unroll
+        for (int jl = 0; jl < HB; ++jl) {
+          const int j = b_lo + jl;
+          const int32_t sp_ = __builtin_amdgcn_readfirstlane(sel_s[j]);
+          const int32_t bp_ = __builtin_amdgcn_readfirstlane(sel_b[j]);
+          bet_old[jl] = __builtin_amdgcn_readfirstlane(beta4[cur * 32 + bp_]);
+          apv[jl] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sp_ * Dp);
+          obv4[jl] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (t) obv4[jl] = *reinterpret_cast<const float4 *>(bold + (size_t)bp_ * FAST_MAX_DIM);
+        }
+#pragma unroll
+        for (int jl = 0; jl < HB; ++jl) {
+          const int j = b_lo + jl;
+          const uint32_t al[4] = {apv[jl].x & 0xFFFFu, apv[jl].x >> 16, apv[jl].y & 0xFFFFu, apv[jl].y >> 16};
+          const float obv[4] = {obv4[jl].x, obv4[jl].y, obv4[jl].z, obv4[jl].w};
+          float nb[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            uint32_t ad = al[i] + bet_old[jl];
+            const uint32_t ad2 = ad - IREC_LUT2_BYTES;
+            ad = ad2 < ad ? ad2 : ad;
+            const float y = sa_t[i] * lds_abs_f32(ad);   // dist.quantile(.), :48-49
+            nb[i] = obv[i] + y;                          // combined_samples[best_ind_aux, best_ind_beam], :81,92-93
+          }
+          if (last) {
+            if (j == 0 && sw == 0) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if (d0 + i < D) { const int64_t e = elem(i); A.out_sample[e] = nb[i] + A.p_loc[e]; } // beams[0] + loc, :122
+            }
+          } else {
+            if (sw == 0) *reinterpret_cast<float4 *>(bnew + (size_t)j * FAST_MAX_DIM) = make_float4(nb[0], nb[1], nb[2], nb[3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              G[jl][i] = beam_G(nb[i], m[i], cA[i], cBv[i], sa[i]);
+              cacc[jl] = beam_C_term(cacc[jl], nb[i], m[i], cA[i], cBv[i]);
+            }
+          }
+        }
+        if (!last) {
+          const float ctot = reduce_scatter<16>(cacc, lane);  // lane l holds my beam (l >> 2)
+          const int jl = lane >> 2;
+          if (sw == 0 && (lane & 3) == 0 && jl < HB) cpart_s[g * 32 + b_lo + jl] = ctot;
+        }
+      }
+      __syncthreads();
+      IREC_STAMP(3); // beam update + next step's constants
+      if (!last && tid < NB) {
+        float cb = cpart_s[tid];
+        for (int gg = 1; gg < NG; ++gg) cb = cb + cpart_s[gg * 32 + tid];
+        Cb_s[tid] = cb; // read after the next scoring barrier
+      }
+      cur ^= 1;
     }
     // ---- index path of beam 0 (beam_search_coder.py:118-121) ----
     __syncthreads();
@@ -791,6 +1214,7 @@ size_t fast_lds_for(int B, int S) {
 }
 
 size_t fast_ws_for(int B, int max_K) { return fast_ws_bytes(fast_nb_for(B), max_K); }
+size_t fast_ws_bytes_nb(int NB, int max_K) { return fast_ws_bytes(NB, max_K); }
 
 hipError_t launch_encode_fast(const EncArgs &A, int grid, hipStream_t st) {
   switch (fast_nb_for(A.B)) {
@@ -799,6 +1223,37 @@ hipError_t launch_encode_fast(const EncArgs &A, int grid, hipStream_t st) {
     case 32: return launch_fast_t<32, FAST_NW>(A, grid, st);
     default: return hipErrorInvalidValue;
   }
+}
+
+template <int NB, int NH>
+static hipError_t launch_fast3_t(const EncArgs &A, int grid, hipStream_t st) {
+  const size_t lds = fast3_lds_bytes(NB, A.S, nullptr, nullptr);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_fast3_kernel<NB, NH>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((encode_fast3_kernel<NB, NH>), dim3(grid), dim3(F3_NW * 64), lds, st, A);
+  return hipGetLastError();
+}
+
+size_t fast3_lds_for(int B, int S) { return fast3_lds_bytes(B, S, nullptr, nullptr); }
+
+// beam counts the beam-striped encoder is instantiated for (it needs B == NB exactly and S >= B)
+bool fast3_supports(int B, int S) { return (B == 10 || B == 20) && S >= B; }
+
+hipError_t launch_encode_fast3(const EncArgs &A, int grid, hipStream_t st) {
+  switch (A.B) {
+    case 10: return launch_fast3_t<10, 1>(A, grid, st);
+    case 20: return launch_fast3_t<20, 2>(A, grid, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_alpha_table(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *dlog4r, uint16_t *tab,
+                              hipStream_t st) {
+  const int64_t quads = ((int64_t)S * ((D + 3) & ~3) * K_tab + 3) / 4;
+  const int grid = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
+  hipLaunchKernelGGL(alpha_table_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, st, seed, S, D, K_tab, dlog4r, tab);
+  return hipGetLastError();
 }
 
 hipError_t launch_decode(const DecArgs &A, int grid, hipStream_t st) {

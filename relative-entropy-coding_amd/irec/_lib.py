@@ -11,6 +11,7 @@ IREC_E_HIP = -2
 IREC_E_NO_DEVICE = -3
 IREC_E_WORKSPACE = -4
 IREC_FLAG_FORCE_GENERIC = 1
+IREC_FLAG_FUSED_PHILOX = 2
 BIG_PRIME = 10007
 MAX_BEAMS = 64
 MAX_PARTITIONS = 65536
@@ -18,7 +19,7 @@ MAX_PARTITIONS = 65536
 
 class IrecParams(ctypes.Structure):
     _fields_ = [("kl_per_partition", ctypes.c_float), ("n_samples", ctypes.c_int32), ("n_beams", ctypes.c_int32),
-                ("flags", ctypes.c_int32)]
+                ("flags", ctypes.c_int32), ("table_dims", ctypes.c_int32 * 4)]
 
 
 class IrecLibraryError(RuntimeError):

@@ -23,6 +23,7 @@ class BeamSearchCoder(GaussianCoder):
         self.n_samples = int(np.exp(kl_per_partition * extra_samples))
         self.big_prime = 10007
         self.force_generic = False   # debugging / testing knob: IREC_FLAG_FORCE_GENERIC
+        self.fused_philox = False    # debugging / testing knob: IREC_FLAG_FUSED_PHILOX
         self._max_K_hint = 32
 
     # ---- small host-side mirrors ---------------------------------------------------------------------------------
@@ -45,7 +46,8 @@ class BeamSearchCoder(GaussianCoder):
             raise CodingError(f"n_beams must be in [1, {_lib.MAX_BEAMS}], got {self.n_beams}")
         if self.n_samples < 1:
             raise CodingError(f"n_samples = {self.n_samples} < 1")
-        flags = _lib.IREC_FLAG_FORCE_GENERIC if self.force_generic else 0
+        flags = (_lib.IREC_FLAG_FORCE_GENERIC if self.force_generic else 0) | \
+                (_lib.IREC_FLAG_FUSED_PHILOX if self.fused_philox else 0)
         return get_engine().params(self.kl_per_partition, self.n_samples, self.n_beams, flags)
 
     @staticmethod

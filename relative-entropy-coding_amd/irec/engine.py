@@ -62,6 +62,7 @@ class BlockLayout:
         self.natural[order] = np.arange(len(order))     # natural block b sits in row natural[b]
         self.n_blocks = len(order)
         self.max_dim = int(dims.max())
+        self.distinct_dims = sorted(set(int(d) for d in dims), reverse=True)
         self.block_base = torch.from_numpy(base[order]).to(device)
         self.block_pos = torch.from_numpy(pos[order].astype(np.int32)).to(device)
         self.block_dim = torch.from_numpy(dim[order].astype(np.int32)).to(device)
@@ -118,8 +119,17 @@ class Engine:
         return self._ws, need
 
     @staticmethod
-    def params(kl_per_partition, n_samples, n_beams, flags=0):
-        return _lib.IrecParams(float(np.float32(kl_per_partition)), int(n_samples), int(n_beams), int(flags))
+    def params(kl_per_partition, n_samples, n_beams, flags=0, table_dims=()):
+        dims = list(table_dims)[:4] if len(table_dims) <= 4 else []
+        dims = dims + [0] * (4 - len(dims))
+        return _lib.IrecParams(float(np.float32(kl_per_partition)), int(n_samples), int(n_beams), int(flags),
+                               (ctypes.c_int32 * 4)(*dims))
+
+    @staticmethod
+    def with_table_dims(params, lay):
+        """Copy of `params` carrying the layout's distinct block dims (enables the per-call proposal tables)."""
+        return Engine.params(params.kl_per_partition, params.n_samples, params.n_beams, params.flags,
+                             lay.distinct_dims)
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -140,6 +150,7 @@ class Engine:
         for t in (q_loc, q_scale, p_loc, p_scale):
             assert t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device
             assert t.numel() == lay.n_tensors * lay.n
+        params = self.with_table_dims(params, lay)
         if out is None:
             out_K = torch.empty(lay.n_blocks, dtype=torch.int32, device=self.device)
             out_idx = torch.empty((lay.n_blocks, max(max_K, 1)), dtype=torch.int32, device=self.device)

@@ -17,10 +17,14 @@ def _normal(loc, scale, device="cuda"):
                                       validate_args=False)
 
 
-def _coder(omega, B, eps1, block_size=None, generic=False):
+VARIANTS = ["striped", "fused", "generic"]   # proposal-table beam-striped kernel / Philox-fused kernel / fallback
+
+
+def _coder(omega, B, eps1, block_size=None, variant="striped"):
     import irec
     c = irec.BeamSearchCoder(kl_per_partition=omega, n_beams=B, extra_samples=eps1, block_size=block_size)
-    c.force_generic = generic
+    c.force_generic = variant == "generic"
+    c.fused_philox = variant == "fused"
     return c
 
 
@@ -70,11 +74,11 @@ def test_block_kl_and_partition_count(engine, oracle):
             assert K[row] == oracle.num_aux(ref, 3.0)
 
 
-@pytest.mark.parametrize("generic", [False, True], ids=["fast", "generic"])
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("path", golden_files("block"), ids=os.path.basename)
-def test_golden_blocks(engine, path, generic):
+def test_golden_blocks(engine, path, variant):
     g = np.load(path)
-    c = _coder(float(g["kl_per_partition"]), int(g["n_beams"]), float(g["extra_samples"]), generic=generic)
+    c = _coder(float(g["kl_per_partition"]), int(g["n_beams"]), float(g["extra_samples"]), variant=variant)
     assert c.n_samples == int(g["n_samples"])
     q = _normal(g["q_loc"][None], g["q_scale"][None])
     p = _normal(g["p_loc"][None], g["p_scale"][None])
@@ -89,11 +93,11 @@ def test_golden_blocks(engine, path, generic):
     assert torch.equal(rec, sample)
 
 
-@pytest.mark.parametrize("generic", [False, True], ids=["fast", "generic"])
-def test_golden_tensor_rvae_shape(engine, generic):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_golden_tensor_rvae_shape(engine, variant):
     g = np.load(golden_files("tensor")[0])
     c = _coder(float(g["kl_per_partition"]), int(g["n_beams"]), float(g["extra_samples"]),
-               block_size=int(g["block_size"]), generic=generic)
+               block_size=int(g["block_size"]), variant=variant)
     q = _normal(g["q_loc"], g["q_scale"])
     p = _normal(g["p_loc"], g["p_scale"])
     idx, sample = c.encode(q, p, seed=int(g["seed"]))
@@ -128,12 +132,12 @@ def test_cpu_tensors_and_cuda_tensors_agree(engine, oracle):
     assert i1 == i2 and torch.equal(s1, s2.cpu()) and s1.device.type == "cpu" and s2.device.type == "cuda"
 
 
-@pytest.mark.parametrize("generic", [False, True], ids=["fast", "generic"])
-def test_batched_latents_match_oracle(engine, oracle, generic):
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_batched_latents_match_oracle(engine, oracle, variant):
     n_t, shape, bs = 3, (16, 16, 32), 1000
     stats = [oracle.synthetic_latent(50 + i, 8192) for i in range(n_t)]
     ql, qs, pl, ps = (np.stack([s[k].reshape(shape) for s in stats]) for k in range(4))
-    c = _coder(3.0, 20, 1.2, block_size=bs, generic=generic)
+    c = _coder(3.0, 20, 1.2, block_size=bs, variant=variant)
     idx, sample = c.encode(_normal(ql, qs), _normal(pl, ps), seed=42, batched=True)
     assert len(idx) == n_t and sample.shape == (n_t,) + shape
     for t in range(n_t):
@@ -188,14 +192,15 @@ def test_high_kl_block_many_partitions(engine, oracle):
     assert len(ridx) > 64 and [int(i) for i in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
 
 
-def test_full_size_properties(engine, oracle):
+@pytest.mark.parametrize("flags", [0, 2], ids=["striped", "fused"])
+def test_full_size_properties(engine, oracle, flags):
     """BASELINE config 2 at bench size: properties that need no oracle run (round trip, ranges), plus a sampled
     subset of blocks checked against the oracle."""
     n_t, n, bs = 96, 8192, 1000
     stats = [oracle.synthetic_latent(1000 + i, n) for i in range(n_t)]
     ql, qs, pl, ps = (torch.from_numpy(np.stack([s[k] for s in stats])).cuda().contiguous() for k in range(4))
     lay = engine.layout(n_t, n, bs, 42)
-    params = engine.params(3.0, 36, 20)
+    params = engine.params(3.0, 36, 20, flags)
     K, idx, sample = engine.encode_blocks(params, lay, ql, qs, pl, ps, 42, 32)
     rec = engine.decode_blocks(params, lay, pl, ps, 42, K, idx)
     assert torch.equal(rec, sample)                                  # decode(encode) == sample, every dim
