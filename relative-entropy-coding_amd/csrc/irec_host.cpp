@@ -315,7 +315,7 @@ namespace {
 
 struct Plan {
   bool fast;         // register-resident fast encoder with the Philox draw fused in
-  bool striped;      // beam-striped fast encoder fed by per-call proposal tables
+  bool table;        // fast encoder fed by per-call proposal tables (Philox hoisted out of the block kernel)
   int grid_cap;      // resident workgroups (persistent kernels pull blocks from an atomic counter)
   size_t ws_per_wg;
   int dpad;
@@ -338,24 +338,21 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
   const int B = p->n_beams, S = p->n_samples;
   pl.dpad = round_up(max_dim > 0 ? max_dim : 1, 256);
   pl.fast = !(p->flags & IREC_FLAG_FORCE_GENERIC) && max_dim <= irec::FAST_MAX_DIM && irec::fast_nb_for(B) != 0 &&
-            irec::fast_lds_for(B, S) <= irec::FAST_LDS_LIMIT && (int64_t)S * B < (1 << 24);
-  pl.grid_cap = 2 * (ctx->n_cu > 0 ? ctx->n_cu : 256);
-  pl.striped = false; pl.n_tab = 0; pl.tab_bytes = 0;
-  if (pl.fast && !(p->flags & IREC_FLAG_FUSED_PHILOX) && p->table_dims[0] > 0 && irec::fast3_supports(B, S) &&
-      irec::fast3_lds_for(B, S) <= irec::FAST_LDS_LIMIT / 2) {
-    pl.striped = true;
+            irec::fast_lds_for(B, S, false) <= irec::FAST_LDS_LIMIT && (int64_t)S * B < (1 << 24);
+  pl.grid_cap = 2 * (ctx->n_cu > 0 ? ctx->n_cu : 256); // measured residency: 2 workgroups per CU for every encoder
+  pl.table = false; pl.n_tab = 0; pl.tab_bytes = 0;
+  if (pl.fast && !(p->flags & IREC_FLAG_FUSED_PHILOX) && p->table_dims[0] > 0) {
+    pl.table = true;
     for (int q = 0; q < 4 && p->table_dims[q] > 0; ++q) {
-      if (p->table_dims[q] > irec::FAST_MAX_DIM) { pl.striped = false; break; }
+      if (p->table_dims[q] > irec::FAST_MAX_DIM) { pl.table = false; break; }
       pl.tab_dim[pl.n_tab] = p->table_dims[q];
       pl.tab_off[pl.n_tab] = pl.tab_bytes;
       pl.tab_bytes += round_up_sz((size_t)(max_K > 0 ? max_K : 1) * S * round_up(p->table_dims[q], 4) * 2, 256);
       ++pl.n_tab;
     }
-    if (!pl.striped) { pl.n_tab = 0; pl.tab_bytes = 0; }
+    if (!pl.table) { pl.n_tab = 0; pl.tab_bytes = 0; }
   }
-  if (pl.striped) {
-    pl.ws_per_wg = round_up_sz(irec::fast_ws_bytes_nb(B, max_K), 256);
-  } else if (pl.fast) {
+  if (pl.fast) {
     pl.ws_per_wg = round_up_sz(irec::fast_ws_for(B, max_K), 256);
   } else {
     pl.ws_per_wg = round_up_sz((size_t)10 * pl.dpad * 4 + (size_t)2 * B * pl.dpad * 4 +
@@ -430,16 +427,16 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   const int grid = (int)std::min<int64_t>(n_blocks, pl.grid_cap);
   A.dbg = ctx->d_dbg;
   if (ctx->d_dbg) HIP_TRY(hipMemsetAsync(ctx->d_dbg, 0, 4096 * 8 * sizeof(unsigned long long), st));
-  if (pl.striped) {
+  if (pl.table) {
     for (int q = 0; q < 4; ++q) { A.tab[q] = nullptr; A.tab_dim[q] = -1; }
     for (int q = 0; q < pl.n_tab; ++q) {
       uint16_t *tab = (uint16_t *)((char *)workspace + 256 + pl.tab_off[q]);
       HIP_TRY(irec::launch_alpha_table(seed, p->n_samples, pl.tab_dim[q], max_K > 0 ? max_K : 1, ctx->d_dlog4r, tab, st));
       A.tab[q] = tab; A.tab_dim[q] = pl.tab_dim[q];
     }
-    HIP_TRY(irec::launch_encode_fast3(A, grid, st));
+    HIP_TRY(irec::launch_encode_fast(A, true, grid, st));
   } else if (pl.fast) {
-    HIP_TRY(irec::launch_encode_fast(A, grid, st));
+    HIP_TRY(irec::launch_encode_fast(A, false, grid, st));
   } else {
     HIP_TRY(irec::launch_encode_generic(A, grid, st));
   }
@@ -450,8 +447,16 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
     double sum[8] = {0};
     for (int w = 0; w < grid; ++w) for (int k = 0; k < 8; ++k) sum[k] += (double)h[(size_t)w * 8 + k];
     const double tot = sum[0] + sum[1] + sum[2] + sum[3];
+    {
+      int zero = 0; unsigned long long t0 = ~0ull, late = 0;
+      for (int w = 0; w < grid; ++w) { if (h[(size_t)w * 8 + 4] == 0) ++zero; else if (h[(size_t)w * 8 + 5] < t0) t0 = h[(size_t)w * 8 + 5]; }
+      for (int w = 0; w < grid; ++w) if (h[(size_t)w * 8 + 4] && h[(size_t)w * 8 + 5] - t0 > 100000ull) ++late; // > 1 ms at 100 MHz
+      fprintf(stderr, "[irec stamps] census: %d of %d workgroups coded no block, %llu started > 1 ms after the first\n", zero, grid, late);
+    }
+    fprintf(stderr, "[irec stamps] occupancy API: %d workgroups/CU, LDS %zu B\n",
+            irec::fast_blocks_per_cu(p->n_beams, p->n_samples, pl.table), irec::fast_lds_for(p->n_beams, p->n_samples, pl.table));
     fprintf(stderr, "[irec stamps] %s grid=%d cycles/WG: prologue %.0f (%.1f%%) scoring %.0f (%.1f%%) select %.0f (%.1f%%) update %.0f (%.1f%%)\n",
-            pl.striped ? "striped" : pl.fast ? "fused" : "generic", grid, sum[0] / grid, 100 * sum[0] / tot, sum[1] / grid,
+            pl.table ? "table" : pl.fast ? "fused" : "generic", grid, sum[0] / grid, 100 * sum[0] / tot, sum[1] / grid,
             100 * sum[1] / tot, sum[2] / grid, 100 * sum[2] / tot, sum[3] / grid, 100 * sum[3] / tot);
   }
   return IREC_OK;

@@ -30,45 +30,93 @@ __device__ __forceinline__ int64_t src_index(const EncArgs &A, int64_t base, int
   return base + (A.perm ? (int64_t)A.perm[pos + d] : (int64_t)(pos + d));
 }
 
-// Block-wide top-Bnew selection over key[0..N) (uint32 sort keys; 0 = taken), NT threads.
+// Small per-workgroup LDS state shared by the encoders.
+struct SmallLds {
+  union {                           // the two selection paths never run at the same time
+    unsigned long long wb[16];      // per-wave maxima of the scan-based selection, double buffered
+    unsigned long long cand[64];    // compacted (key, flat) survivors of the threshold selection
+  };
+  int32_t sel_s[64], sel_b[64];     // selected (sample, beam) per new beam
+  int32_t hsum[2][64];              // running int32 sum of simple_hash per beam, double buffered
+  uint32_t beta4[2][64];            // 4 * dlog(hash) per beam, double buffered
+  int32_t misc[8];                  // [0] block id, [1] K, [7] selection path flag
+  union {                           // KL partials are consumed before the first C_b partial is written
+    double gpart[4];                // per dim-group KL partial sums
+    float cpart[4][32];             // per dim-group partial C_b
+  };
+  float Cb[32];                     // C_b of the live beams
+};
+constexpr size_t SMALL_LDS_BYTES = (sizeof(SmallLds) + 15) & ~(size_t)15;
+
+// Block-wide top-Bnew selection over key[0..N) (uint32 sort keys, 0 = taken / empty), NT threads.
 // tf.argsort(DESCENDING)[:B] semantics (beam_search_coder.py:85-89): value descending, ties to the lower flat index.
-//  - N <= 1024: wave 0 pulls the candidates into registers (16 per lane) and runs Bnew rounds of
-//    {lane-local max, DPP wave max, clear the winner}; the other waves wait at ONE barrier.
-//  - larger N: all waves scan LDS/global keys, one barrier per selected beam (element f owned by thread f % NT).
+//  - N <= 1024 (every BASELINE config but the S=403 stress case): wave 0 alone, candidates in registers:
+//      1. lane maxima; T = Bnew-th largest lane maximum  => at least Bnew candidates are >= T
+//      2. compact the candidates >= T (a few dozen) to one per lane through LDS
+//      3. rank them by (key desc, flat asc); rank r < Bnew IS new beam r
+//    ~600 wave instructions and ONE barrier instead of Bnew barrier rounds.
+//  - otherwise: all waves scan the keys, one barrier per selected beam (element f owned by thread f % NT).
 template <int NT>
-__device__ __forceinline__ void select_topB(uint32_t *key, int N, int Bnew, int Bcur, unsigned long long *wb,
-                                            int32_t *sel_s, int32_t *sel_b) {
+__device__ __forceinline__ void select_topB(uint32_t *key, int N, int Bnew, int Bcur, SmallLds *sm) {
   constexpr int NWV = NT / 64;
   const int tid = threadIdx.x;
+  int32_t *sel_s = sm->sel_s, *sel_b = sm->sel_b;
+  __syncthreads(); // keys written by all waves
+  bool done = false;
   if (N <= 1024) {
-    __syncthreads(); // keys written by all waves
     if (tid < 64) {
       const int nslots = (N + 63) >> 6;
-      unsigned long long c[16];
+      uint32_t k[16];
+      uint32_t M = 0u;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const int f = k * 64 + tid;
-        c[k] = (k < nslots && f < N) ? cand_pack(key[f], (uint32_t)f) : 0ull;
+      for (int q = 0; q < 16; ++q) {
+        const int f = q * 64 + tid;
+        k[q] = (q < nslots && f < N) ? key[f] : 0u;
+        M = k[q] > M ? k[q] : M;
       }
-      for (int it = 0; it < Bnew; ++it) {
-        unsigned long long best = c[0];
+      // 1. threshold: #lanes with a strictly larger maximum
+      uint32_t cnt_gt = 0u;
 #pragma unroll
-        for (int k = 1; k < 16; ++k)
-          if (k < nslots) best = c[k] > best ? c[k] : best; // wave-uniform predicate
-        const unsigned long long g = wave_max_u64(best);
+      for (int l = 0; l < 64; ++l) cnt_gt += (uint32_t)__builtin_amdgcn_readlane((int)M, l) > M ? 1u : 0u;
+      uint32_t T = cnt_gt < (uint32_t)Bnew ? M : 0xFFFFFFFFu;
+      T = 0xFFFFFFFFu - (uint32_t)wave_max_u64((unsigned long long)(0xFFFFFFFFu - T)); // wave min
+      // 2. compact candidates >= T (T >= 1 because at least Bnew <= N lanes hold a real key)
+      uint32_t base = 0u;
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-          if (k < nslots) c[k] = (c[k] == g) ? 0ull : c[k];
-        if (tid == 0) {
-          const uint32_t fstar = 0xFFFFFFFFu - (uint32_t)g;
-          sel_s[it] = (int32_t)(fstar / (uint32_t)Bcur); // best_ind_aux  (beam_search_coder.py:89)
-          sel_b[it] = (int32_t)(fstar % (uint32_t)Bcur); // best_ind_beam (beam_search_coder.py:88)
+      for (int q = 0; q < 16; ++q) {
+        if (q < nslots) { // wave-uniform
+          const bool in = k[q] >= T;
+          const unsigned long long mask = __ballot(in);
+          const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+          if (in && pos < 64u) sm->cand[pos] = ((unsigned long long)k[q] << 32) | (uint32_t)(q * 64 + tid);
+          base += (uint32_t)__popcll(mask);
         }
+      }
+      const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      if (C <= 64u) {
+        // 3. rank the C survivors; lanes >= C hold a null candidate
+        const unsigned long long mine = tid < (int)C ? sm->cand[tid] : 0ull;
+        const uint32_t mk = (uint32_t)(mine >> 32), mf = (uint32_t)mine;
+        uint32_t rank = 0u;
+        for (uint32_t l = 0; l < C; ++l) {
+          const uint32_t ok_ = (uint32_t)__builtin_amdgcn_readlane((int)mk, (int)l);
+          const uint32_t of_ = (uint32_t)__builtin_amdgcn_readlane((int)mf, (int)l);
+          rank += (ok_ > mk || (ok_ == mk && of_ < mf)) ? 1u : 0u;
+        }
+        if (tid < (int)C && rank < (uint32_t)Bnew) {
+          sel_s[rank] = (int32_t)(mf / (uint32_t)Bcur); // best_ind_aux  (beam_search_coder.py:89)
+          sel_b[rank] = (int32_t)(mf % (uint32_t)Bcur); // best_ind_beam (beam_search_coder.py:88)
+        }
+        sm->misc[7] = 1;
+      } else {
+        sm->misc[7] = 0; // pathological tie storm: fall back to the scan below
       }
     }
     __syncthreads();
-    return;
+    done = sm->misc[7] != 0;
   }
+  if (done) return;
+  unsigned long long *wb = sm->wb;
   for (int it = 0; it < Bnew; ++it) {
     unsigned long long best = 0ull;
     for (int f = tid; f < N; f += NT) {
@@ -150,14 +198,13 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *lut_s = reinterpret_cast<float *>(smem);                              // [10008]
   uint32_t *key_lds = reinterpret_cast<uint32_t *>(smem + 40032);              // [GEN_NSC]
-  unsigned long long *wb = reinterpret_cast<unsigned long long *>(smem + 40032 + GEN_NSC * 4); // [8]
-  double *gpart = reinterpret_cast<double *>(wb + 8);                          // [4]
-  double *total_s = gpart + 4;                                                 // [1]
-  int32_t *sel_s = reinterpret_cast<int32_t *>(total_s + 1);                   // [64]
-  int32_t *sel_b = sel_s + 64;                                                 // [64]
-  int32_t *hsum = sel_b + 64;                                                  // [2][64]
-  int32_t *misc = hsum + 128;                                                  // [4]
-  float *Cb_s = reinterpret_cast<float *>(misc + 4);                           // [64] C_b of the live beams
+  SmallLds *sm = reinterpret_cast<SmallLds *>(smem + 40032 + GEN_NSC * 4);
+  double *gpart = sm->gpart;                                                   // [4]
+  double *total_s = reinterpret_cast<double *>(smem + 40032 + GEN_NSC * 4 + SMALL_LDS_BYTES); // [1]
+  int32_t *sel_s = sm->sel_s, *sel_b = sm->sel_b;                              // [64]
+  int32_t *hsum = &sm->hsum[0][0];                                             // [2][64]
+  int32_t *misc = sm->misc;
+  float *Cb_s = reinterpret_cast<float *>(total_s + 1);                        // [64] C_b of the live beams
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform by construction: keep it in an SGPR
@@ -289,7 +336,7 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
       // phase 3: top-B (beam_search_coder.py:85-89 / :104)
       const int Bnew = B < N ? B : N;
       for (int f = tid; f < N; f += GEN_NT) key[f] = score_key(__uint_as_float(key[f]));
-      select_topB<GEN_NT>(key, N, Bnew, Bcur, wb, sel_s, sel_b);
+      select_topB<GEN_NT>(key, N, Bnew, Bcur, sm);
       // phase 4: gather the surviving beams, extend their index paths (:92-95 / :105-106)
       if (tid < Bnew) {
         const int32_t sp_ = sel_s[tid], bp_ = sel_b[tid];
@@ -418,20 +465,23 @@ __device__ __forceinline__ unsigned long long stamp_now() { return __builtin_amd
 typedef __attribute__((address_space(3))) const float lds_cfloat;
 __device__ __forceinline__ float lds_abs_f32(uint32_t byte_addr) { return *(lds_cfloat *)(uintptr_t)(byte_addr); }
 
-template <int NB>
+template <int NB, bool TABLE>
 struct FastCfg {
-  static constexpr int RW = NB <= 21 ? 64 : 32;   // accumulators reduced together
+  // accumulators reduced together
+  static constexpr int RW = NB <= 21 ? 64 : 32;
   static constexpr int SPC = RW / NB;             // samples per chunk
   static_assert(SPC >= 1, "NB too large");
 };
 
-// LDS carve (bytes): lut2 40032 | dlog 20016 | part [4][S][NB] f32 | key [S*NB] u32 | small 1536
-__host__ __device__ inline size_t fast_lds_bytes(int NB, int S, size_t *off_key, size_t *off_small) {
-  const size_t part = (((size_t)4 * S * NB * 4) + 15) & ~(size_t)15;
-  const size_t key = (((size_t)S * NB * 4) + 15) & ~(size_t)15;
-  if (off_key) *off_key = 40032 + 20016 + part;
-  if (off_small) *off_small = 40032 + 20016 + part + key;
-  return 40032 + 20016 + part + key + 1536;
+// LDS carve (bytes): lut2 40032 | [dlog 20016 unless TABLE] | part [4][S][NB] f32 (sort keys overwrite group 0) | SmallLds
+__host__ __device__ inline bool fast_keys_alias(int NB, int S) { return S * NB <= 1024; }
+__host__ __device__ inline size_t fast_lds_bytes(int NB, int S, bool table, size_t *off_part, size_t *off_small) {
+  size_t part = (((size_t)4 * S * NB * 4) + 15) & ~(size_t)15;
+  if (!fast_keys_alias(NB, S)) part += (((size_t)S * NB * 4) + 15) & ~(size_t)15; // separate key array behind the partials
+  const size_t head = (table ? 40032 - 8 : 40032 + 20016); // the table variant must fit three workgroups per CU
+  if (off_part) *off_part = head;
+  if (off_small) *off_small = head + part;
+  return head + part + SMALL_LDS_BYTES;
 }
 
 // Scratch slab of one workgroup (bytes): bp int32 [max_K][NB] | stats float [3][1024] | beams float [2][NB][1024]
@@ -440,29 +490,29 @@ __host__ __device__ inline size_t fast_ws_bytes(int NB, int max_K) {
   return bp + (size_t)3 * FAST_MAX_DIM * 4 + (size_t)2 * NB * FAST_MAX_DIM * 4;
 }
 
-template <int NB, int NW>
+template <int NB, int NW, bool TABLE>
 __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
-  using Cfg = FastCfg<NB>;
+  using Cfg = FastCfg<NB, TABLE>;
   constexpr int NT = NW * 64;
   constexpr int RW = Cfg::RW, SPC = Cfg::SPC;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int S = A.S, B = A.B;
-  size_t off_key, off_small;
-  fast_lds_bytes(NB, S, &off_key, &off_small);
+  size_t off_part, off_small;
+  fast_lds_bytes(NB, S, TABLE, &off_part, &off_small);
   char *lut2_b = smem;                                                        // float [10006], dlog order
-  const uint16_t *dlog_s = reinterpret_cast<const uint16_t *>(smem + 40032);  // [10006] 4*dlog(j+1)
-  float *part_s = reinterpret_cast<float *>(smem + 40032 + 20016);            // [4][S][NB] per-group partial scores
-  uint32_t *key_s = reinterpret_cast<uint32_t *>(smem + off_key);             // [S*NB]
-  char *small = smem + off_small;
-  unsigned long long *wb = reinterpret_cast<unsigned long long *>(small);     // [2][NW] (<= 16 entries)
-  double *gpart = reinterpret_cast<double *>(small + 128);                    // [4]
-  int32_t *sel_s = reinterpret_cast<int32_t *>(small + 160);                  // [32]
-  int32_t *sel_b = sel_s + 32;                                                // [32]
-  int32_t *hsum = sel_b + 32;                                                 // [2][32]
-  uint32_t *beta4 = reinterpret_cast<uint32_t *>(hsum + 64);                  // [2][32] 4*dlog(hash(beam))
-  int32_t *misc = reinterpret_cast<int32_t *>(beta4 + 64);                    // [4]
-  float *cpart_s = reinterpret_cast<float *>(misc + 4);                       // [4][32] per-group partial C_b
-  float *Cb_s = cpart_s + 128;                                                // [32]
+  const uint16_t *dlog_s = TABLE ? A.dlog4r : reinterpret_cast<const uint16_t *>(smem + 40032); // [10006] 4*dlog(j+1)
+  float *part_s = reinterpret_cast<float *>(smem + off_part);                 // [4][S][NB] per-group partial scores
+  const bool keys_alias = fast_keys_alias(NB, S);
+  uint32_t *key_s = reinterpret_cast<uint32_t *>(smem + off_part) +           // [S*NB] sort keys: over group 0 of the
+                    (keys_alias ? 0 : (size_t)4 * S * NB);                    // partials when they fit in registers
+  SmallLds *sm = reinterpret_cast<SmallLds *>(smem + off_small);
+  double *gpart = sm->gpart;
+  int32_t *sel_s = sm->sel_s, *sel_b = sm->sel_b;
+  int32_t *hsum = &sm->hsum[0][0];                                            // [2][64]
+  uint32_t *beta4 = &sm->beta4[0][0];                                         // [2][64] 4*dlog(hash(beam))
+  int32_t *misc = sm->misc;
+  float *cpart_s = &sm->cpart[0][0];                                          // [4][32] per-group partial C_b
+  float *Cb_s = sm->Cb;                                                       // [32]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform by construction: keep it in an SGPR
@@ -470,12 +520,15 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
   {
     float *l2 = reinterpret_cast<float *>(lut2_b);
     for (int k = tid; k < (int)IREC_PM1; k += NT) l2[k] = A.lut2[k];
-    uint16_t *dl = reinterpret_cast<uint16_t *>(smem + 40032);
-    for (int k = tid; k < (int)IREC_PM1; k += NT) dl[k] = A.dlog4r[k];
+    if (!TABLE) {
+      uint16_t *dl = reinterpret_cast<uint16_t *>(smem + 40032);
+      for (int k = tid; k < (int)IREC_PM1; k += NT) dl[k] = A.dlog4r[k];
+    }
   }
   char *slab = A.ws + (size_t)blockIdx.x * A.ws_per_wg;
   int32_t *bp = reinterpret_cast<int32_t *>(slab);                                            // [max_K][NB]
   float *beams_g = reinterpret_cast<float *>(slab + A.ws_per_wg - (size_t)2 * NB * FAST_MAX_DIM * 4); // [2][NB][1024]
+  float *stats_g = beams_g - 3 * FAST_MAX_DIM;  // [3][1024]: mq - mp, sq^2, sp^2 of the block, coalesced
 
   unsigned long long stamp_prev = A.dbg ? stamp_now() : 0ull;
   for (;;) {
@@ -487,10 +540,18 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
     const int D = A.block_dim[blk];
     const int64_t base = A.block_base[blk];
     const int32_t pos = A.block_pos[blk];
-    if (D < 1 || D > FAST_MAX_DIM) { // host promised D <= 1024
+    // proposal table of this block's dim count (the host listed the distinct dims of the call)
+    const uint16_t *tab = nullptr;
+    if (TABLE) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (A.tab_dim[q] == D) tab = A.tab[q];
+    }
+    if (D < 1 || D > FAST_MAX_DIM || (TABLE && tab == nullptr)) { // host promised D <= 1024 and listed dims
       if (tid == 0) A.out_K[blk] = -1;
       continue;
     }
+    const int Dp = (D + 3) & ~3;            // row stride of the proposal table
     const int NG = (D + 255) >> 8;          // 1..4 dim groups
     const int NSW = NW / NG;                // sample stripes
     const bool active = wave < NG * NSW;
@@ -508,7 +569,15 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
       valid[i] = d < D;
       c[i] = 0.f;
       ix[i] = valid[i] ? src_index(A, base, pos, d) : src_index(A, base, pos, 0);
-      if (valid[i]) klacc = klacc + kl_dim(A.q_loc[ix[i]], A.q_scale[ix[i]], A.p_loc[ix[i]], A.p_scale[ix[i]]);
+      float st3[3] = {0.f, 1.f, 1.f};
+      if (valid[i] && active && sw == 0) { // one wave per dim group does the float64 KL and publishes the statistics
+        const float mq_ = A.q_loc[ix[i]], sq_ = A.q_scale[ix[i]], mp_ = A.p_loc[ix[i]], sp_ = A.p_scale[ix[i]];
+        klacc = klacc + kl_dim(mq_, sq_, mp_, sp_);
+        st3[0] = mq_ - mp_; st3[1] = sq_ * sq_; st3[2] = sp_ * sp_;
+      }
+      if (active && sw == 0) {
+        stats_g[d0 + i] = st3[0]; stats_g[FAST_MAX_DIM + d0 + i] = st3[1]; stats_g[2 * FAST_MAX_DIM + d0 + i] = st3[2];
+      }
     }
     {
       const double gs = wave_tree_sum(klacc);
@@ -542,11 +611,14 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
     // constants of step `t_next` from the running cumulative variance; returns m, A, Bv for the G / C_b update
     auto step_consts = [&](int t_next, float (&m)[4], float (&cA)[4], float (&cBv)[4]) {
       const float rho = A.rho[K - 1 - t_next];
+      // three coalesced 16-byte reads of the slab per step instead of 12 VGPRs held for the whole block
+      const float4 q0 = *reinterpret_cast<const float4 *>(stats_g + d0);
+      const float4 q1 = *reinterpret_cast<const float4 *>(stats_g + FAST_MAX_DIM + d0);
+      const float4 q2 = *reinterpret_cast<const float4 *>(stats_g + 2 * FAST_MAX_DIM + d0);
+      const float dmu_[4] = {q0.x, q0.y, q0.z, q0.w}, vq_[4] = {q1.x, q1.y, q1.z, q1.w}, vp_[4] = {q2.x, q2.y, q2.z, q2.w};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        // the block's statistics are re-read (L2) every step rather than held in VGPRs for the whole block
-        const float mq_ = A.q_loc[ix[i]], sq_ = A.q_scale[ix[i]], mp_ = A.p_loc[ix[i]], sp_ = A.p_scale[ix[i]];
-        const StepConst sc = step_constants(rho, mq_ - mp_, sq_ * sq_, sp_ * sp_, c[i]);
+        const StepConst sc = step_constants(rho, dmu_[i], vq_[i], vp_[i], c[i]);
         sa[i] = valid[i] ? sc.sa : 0.f; cH[i] = valid[i] ? sc.H : 0.f;
         m[i] = valid[i] ? sc.m : 0.f; cA[i] = valid[i] ? sc.A : 0.f; cBv[i] = valid[i] ? sc.Bv : 0.f;
         c[i] = c[i] + sc.a; // cumulative_auxiliary_variance += auxiliary_var (:109)
@@ -579,30 +651,60 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
     }
 
     IREC_STAMP(0);
+    if (A.dbg && tid == 0) {
+      A.dbg[(size_t)blockIdx.x * 8 + 4] += 1ull;                                       // blocks coded by this workgroup
+      if (A.dbg[(size_t)blockIdx.x * 8 + 5] == 0ull) A.dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime(); // first block
+      A.dbg[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+    }
     int cur = 0, Bcur = 1;
     for (int t = 0; t < K; ++t) {
       const StepSeed ss = make_step_seed(A.seed + t);
+      const uint16_t *tab_t = TABLE ? tab + (size_t)t * S * Dp + d0 : nullptr; // row s at + s * Dp
       uint32_t bet[NB];
 #pragma unroll
-      for (int b = 0; b < NB; ++b) bet[b] = __builtin_amdgcn_readfirstlane(beta4[cur * 32 + (b < Bcur ? b : 0)]);
+      for (int b = 0; b < NB; ++b) bet[b] = __builtin_amdgcn_readfirstlane(beta4[cur * 64 + (b < Bcur ? b : 0)]);
 
       // ---------------- scoring: all S x Bcur candidates (beam_search_coder.py:80-84) ----------------
       if (active) {
         const int s_per_stripe = (S + NSW - 1) / NSW;
         const int nchunks = (s_per_stripe + SPC - 1) / SPC;
+        // table variant: proposal rows (4 x uint16 byte offsets 4*dlog(r) of my dims) are fetched one chunk ahead
+        uint2 alp_next[SPC];
+        if (TABLE) {
+#pragma unroll
+          for (int cc = 0; cc < SPC; ++cc) {
+            const int s0 = cc * NSW + sw;
+            alp_next[cc] = make_uint2(0u, 0u);
+            if (s0 < S) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)s0 * Dp);
+          }
+        }
         for (int ch = 0; ch < nchunks; ++ch) {
           float acc[RW];
 #pragma unroll
           for (int p = 0; p < RW; ++p) acc[p] = 0.f;
+          uint2 alp[SPC];
+          if (TABLE) {
+#pragma unroll
+            for (int cc = 0; cc < SPC; ++cc) {
+              alp[cc] = alp_next[cc];
+              const int sn = ((ch + 1) * SPC + cc) * NSW + sw;
+              if (sn < S) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sn * Dp);
+            }
+          }
 #pragma unroll
           for (int cc = 0; cc < SPC; ++cc) {
             const int s = (ch * SPC + cc) * NSW + sw;
             if (s < S) { // wave-uniform
-              uint32_t rm1[4];
-              draw_rm1_x4(ss, (uint64_t)s * (uint64_t)D + (uint64_t)d0, rm1);
               uint32_t al[4];
+              if (TABLE) {
+                const uint2 ap = alp[cc];
+                al[0] = ap.x & 0xFFFFu; al[1] = ap.x >> 16; al[2] = ap.y & 0xFFFFu; al[3] = ap.y >> 16;
+              } else {
+                uint32_t rm1[4];
+                draw_rm1_x4(ss, (uint64_t)s * (uint64_t)D + (uint64_t)d0, rm1);
 #pragma unroll
-              for (int i = 0; i < 4; ++i) al[i] = dlog_s[rm1[i]];
+                for (int i = 0; i < 4; ++i) al[i] = dlog_s[rm1[i]];
+              }
               if (Bcur == NB) {
                 // steady state: all NB beams alive -> branch-free; the NB gathers of one dim are issued back to back
 #pragma unroll
@@ -646,71 +748,128 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
       __syncthreads();
       IREC_STAMP(1);
       // ---------------- combine dim groups in order, add C_b, build sort keys ----------------
+      // the sort keys are written over group 0 of the partial scores: two passes with a barrier in between because
+      // key f = s * Bcur + b and partial (s, b) = s * NB + b only coincide when Bcur == NB
       const int N = S * Bcur;
-      for (int f = tid; f < N; f += NT) {
-        const int s = f / Bcur, b = f - s * Bcur;
-        float sc = part_s[((size_t)0 * S + s) * NB + b];
-        for (int gg = 1; gg < NG; ++gg) sc = sc + part_s[((size_t)gg * S + s) * NB + b];
-        key_s[f] = score_key(sc + Cb_s[b]);
+      if (keys_alias) {
+        constexpr int MK = (1024 + NT - 1) / NT;
+        uint32_t mykey[MK];
+#pragma unroll
+        for (int q = 0; q < MK; ++q) {
+          const int f = q * NT + tid;
+          mykey[q] = 0u;
+          if (f < N) {
+            const int s = f / Bcur, b = f - s * Bcur;
+            float sc = part_s[((size_t)0 * S + s) * NB + b];
+            for (int gg = 1; gg < NG; ++gg) sc = sc + part_s[((size_t)gg * S + s) * NB + b];
+            mykey[q] = score_key(sc + Cb_s[b]);
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < MK; ++q) {
+          const int f = q * NT + tid;
+          if (f < N) key_s[f] = mykey[q];
+        }
+      } else {
+        for (int f = tid; f < N; f += NT) {
+          const int s = f / Bcur, b = f - s * Bcur;
+          float sc = part_s[((size_t)0 * S + s) * NB + b];
+          for (int gg = 1; gg < NG; ++gg) sc = sc + part_s[((size_t)gg * S + s) * NB + b];
+          key_s[f] = score_key(sc + Cb_s[b]);
+        }
       }
       const int Bnew = B < N ? B : N;
-      select_topB<NT>(key_s, N, Bnew, Bcur, wb, sel_s, sel_b); // first barrier inside orders key_s writes
+      select_topB<NT>(key_s, N, Bnew, Bcur, sm); // first barrier inside orders key_s writes
       IREC_STAMP(2);
       // ---------------- new hashes / back-pointers (beam_search_coder.py:94-95) ----------------
       if (tid < Bnew) {
         const int32_t sp_ = sel_s[tid], bp_ = sel_b[tid];
-        const int32_t nh = (int32_t)((uint32_t)hsum[cur * 32 + bp_] + (uint32_t)sp_ * (uint32_t)(69 + t));
-        hsum[(cur ^ 1) * 32 + tid] = nh;
-        beta4[(cur ^ 1) * 32 + tid] = dlog_s[hash_from_sum(nh) - 1u];
+        const int32_t nh = (int32_t)((uint32_t)hsum[cur * 64 + bp_] + (uint32_t)sp_ * (uint32_t)(69 + t));
+        hsum[(cur ^ 1) * 64 + tid] = nh;
+        beta4[(cur ^ 1) * 64 + tid] = dlog_s[hash_from_sum(nh) - 1u];
         bp[(size_t)t * NB + tid] = (sp_ << 6) | bp_;
       }
       // ---------------- gather the surviving beams (beam_search_coder.py:92-93), prepare the next step ----------------
       const bool last = (t == K - 1);
       if (active) {
         const float sa_t[4] = {sa[0], sa[1], sa[2], sa[3]};   // this step's sample scale
-        float m[4], cA[4], cBv[4];
-        if (!last) step_consts(t + 1, m, cA, cBv);            // overwrites sa / cH with the next step's
         const float *bold = beams_g + ((size_t)cur * NB) * FAST_MAX_DIM + d0;
         float *bnew = beams_g + ((size_t)(cur ^ 1) * NB) * FAST_MAX_DIM + d0;
+        // G is dead from the end of scoring until it is rebuilt below: every entry is redefined here, so nothing of it
+        // has to survive the selection (no spills), and its registers take the in-flight loads of the update.
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) G[j][i] = 0.f;
+        float m[4], cA[4], cBv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { m[i] = 0.f; cA[i] = 0.f; cBv[i] = 0.f; }
         float cacc[32];
 #pragma unroll
         for (int j = 0; j < 32; ++j) cacc[j] = 0.f;
+        constexpr int UB = NB <= 10 ? NB : (NB + 1) / 2;      // beams per load batch
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          if (j < Bnew) { // wave-uniform
-            const int32_t sp_ = __builtin_amdgcn_readfirstlane(sel_s[j]);
-            const int32_t bp_ = __builtin_amdgcn_readfirstlane(sel_b[j]);
-            const uint32_t bet_old = __builtin_amdgcn_readfirstlane(beta4[cur * 32 + bp_]);
-            uint32_t rm1[4];
-            draw_rm1_x4(ss, (uint64_t)sp_ * (uint64_t)D + (uint64_t)d0, rm1);
-            float4 ob = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t) ob = *reinterpret_cast<const float4 *>(bold + (size_t)bp_ * FAST_MAX_DIM);
-            const float obv[4] = {ob.x, ob.y, ob.z, ob.w};
-            float nb[4];
+        for (int j0 = 0; j0 < NB; j0 += UB) {
+          // ---- issue the batch's global reads (proposal rows, old beams) back to back ----
+          uint2 apv[UB];
+          float4 obv4[UB];
+          uint32_t bet_old[UB];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              uint32_t ad = (uint32_t)dlog_s[rm1[i]] + bet_old;
-              const uint32_t ad2 = ad - IREC_LUT2_BYTES;
-              ad = ad2 < ad ? ad2 : ad;
-              const float y = sa_t[i] * lds_abs_f32(ad); // dist.quantile(.), :48-49
-              nb[i] = obv[i] + y;                          // combined_samples[best_ind_aux, best_ind_beam], :81,92-93
-            }
-            if (last) {
-              if (j == 0 && sw == 0) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                  if (valid[i]) A.out_sample[ix[i]] = nb[i] + A.p_loc[ix[i]]; // beams[0] + coding_dist.loc, :122
+          for (int u = 0; u < UB; ++u) {
+            const int j = j0 + u;
+            apv[u] = make_uint2(0u, 0u);
+            obv4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            bet_old[u] = 0u;
+            if (j < NB && j < Bnew) { // wave-uniform
+              const int32_t sp_ = __builtin_amdgcn_readfirstlane(sel_s[j]);
+              const int32_t bp_ = __builtin_amdgcn_readfirstlane(sel_b[j]);
+              bet_old[u] = __builtin_amdgcn_readfirstlane(beta4[cur * 64 + bp_]);
+              if (TABLE) {
+                apv[u] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sp_ * Dp);
+              } else {
+                uint32_t rm1[4];
+                draw_rm1_x4(ss, (uint64_t)sp_ * (uint64_t)D + (uint64_t)d0, rm1);
+                apv[u] = make_uint2((uint32_t)dlog_s[rm1[0]] | ((uint32_t)dlog_s[rm1[1]] << 16),
+                                    (uint32_t)dlog_s[rm1[2]] | ((uint32_t)dlog_s[rm1[3]] << 16));
               }
-            } else {
-              if (sw == 0) *reinterpret_cast<float4 *>(bnew + (size_t)j * FAST_MAX_DIM) = make_float4(nb[0], nb[1], nb[2], nb[3]);
+              if (t) obv4[u] = *reinterpret_cast<const float4 *>(bold + (size_t)bp_ * FAST_MAX_DIM);
+            }
+          }
+          if (j0 == 0 && !last) step_consts(t + 1, m, cA, cBv); // next step's constants, under the loads' latency
+          // ---- new beams, their G and C terms ----
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            const int j = j0 + u;
+            if (j < NB && j < Bnew) { // wave-uniform
+              const uint32_t al[4] = {apv[u].x & 0xFFFFu, apv[u].x >> 16, apv[u].y & 0xFFFFu, apv[u].y >> 16};
+              const float obv[4] = {obv4[u].x, obv4[u].y, obv4[u].z, obv4[u].w};
+              float nb[4];
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
-                G[j][i] = beam_G(nb[i], m[i], cA[i], cBv[i], sa[i]);
-                cacc[j] = beam_C_term(cacc[j], nb[i], m[i], cA[i], cBv[i]);
+                uint32_t ad = al[i] + bet_old[u];
+                const uint32_t ad2 = ad - IREC_LUT2_BYTES;
+                ad = ad2 < ad ? ad2 : ad;
+                const float y = sa_t[i] * lds_abs_f32(ad); // dist.quantile(.), :48-49
+                nb[i] = obv[i] + y;                          // combined_samples[best_ind_aux, best_ind_beam], :81,92-93
+              }
+              if (last) {
+                if (j == 0 && sw == 0) {
+#pragma unroll
+                  for (int i = 0; i < 4; ++i)
+                    if (valid[i]) A.out_sample[ix[i]] = nb[i] + A.p_loc[ix[i]]; // beams[0] + coding_dist.loc, :122
+                }
+              } else {
+                if (sw == 0) *reinterpret_cast<float4 *>(bnew + (size_t)j * FAST_MAX_DIM) = make_float4(nb[0], nb[1], nb[2], nb[3]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  G[j][i] = beam_G(nb[i], m[i], cA[i], cBv[i], sa[i]);
+                  cacc[j] = beam_C_term(cacc[j], nb[i], m[i], cA[i], cBv[i]);
+                }
               }
             }
           }
-          __builtin_amdgcn_sched_barrier(0); // one surviving beam at a time (keeps 20 Philox chains from interleaving)
+          __builtin_amdgcn_sched_barrier(0);
         }
         if (!last) {
           const float ctot = reduce_scatter<32>(cacc, lane);  // lane l holds beam (l >> 1)
@@ -762,357 +921,6 @@ __global__ __launch_bounds__(256) void alpha_table_kernel(int64_t seed, int32_t 
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = (d0 + i < D) ? dlog4r[draw_rm1(ss, (uint64_t)s * (uint64_t)D + (uint64_t)(d0 + i))] : (uint16_t)0;
     *reinterpret_cast<uint2 *>(tab + q) = make_uint2((uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16));
-  }
-}
-
-// ======================================================================================================
-//  beam-striped fast encoder (v3): D <= 1024, B <= NB <= 32, proposal table available.
-//  8 waves per workgroup: wave -> (dim group g, beam half h, sample stripe sw); lane owns dims 256 g + 4 l .. +3
-//  and keeps G for its NB/NH beams only (<= 128 VGPRs -> 4 waves per SIMD, 2 workgroups per CU).
-// ======================================================================================================
-constexpr int F3_NW = 8;
-#ifndef F3_SPC_MAX
-#define F3_SPC_MAX 2
-#endif
-
-// LDS carve (bytes): lut2 40032 | part [4][S][NB] f32 | key [S*NB] u32 | small 1536
-__host__ __device__ inline size_t fast3_lds_bytes(int NB, int S, size_t *off_key, size_t *off_small) {
-  const size_t part = (((size_t)4 * S * NB * 4) + 15) & ~(size_t)15;
-  const size_t key = (((size_t)S * NB * 4) + 15) & ~(size_t)15;
-  if (off_key) *off_key = 40032 + part;
-  if (off_small) *off_small = 40032 + part + key;
-  return 40032 + part + key + 1536;
-}
-
-template <int NB, int NH>
-__global__ __launch_bounds__(F3_NW * 64, 4) void encode_fast3_kernel(EncArgs A) {
-  constexpr int NT = F3_NW * 64;
-  constexpr int HB = NB / NH;            // beams per wave
-  constexpr int SPC = (32 / HB) < F3_SPC_MAX ? (32 / HB) : F3_SPC_MAX; // samples per chunk (<= 32 accumulators)
-  static_assert(NB % NH == 0 && HB <= 16 && SPC >= 1, "bad beam split");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int S = A.S;                     // host guarantees A.B == NB and S >= NB for this kernel
-  size_t off_key, off_small;
-  fast3_lds_bytes(NB, S, &off_key, &off_small);
-  float *part_s = reinterpret_cast<float *>(smem + 40032);                    // [4][S][NB] per-group partial scores
-  uint32_t *key_s = reinterpret_cast<uint32_t *>(smem + off_key);             // [S*NB]
-  char *small = smem + off_small;
-  unsigned long long *wb = reinterpret_cast<unsigned long long *>(small);     // [2][8]
-  double *gpart = reinterpret_cast<double *>(small + 128);                    // [4]
-  int32_t *sel_s = reinterpret_cast<int32_t *>(small + 160);                  // [32]
-  int32_t *sel_b = sel_s + 32;                                                // [32]
-  int32_t *hsum = sel_b + 32;                                                 // [2][32]
-  uint32_t *beta4 = reinterpret_cast<uint32_t *>(hsum + 64);                  // [2][32] 4*dlog(hash(beam))
-  int32_t *misc = reinterpret_cast<int32_t *>(beta4 + 64);                    // [4]
-  float *cpart_s = reinterpret_cast<float *>(misc + 4);                       // [4][32] per-group partial C_b
-  float *Cb_s = cpart_s + 128;                                                // [32]
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap(); // see lds_abs_f32
-  {
-    float *l2 = reinterpret_cast<float *>(smem);
-    for (int k = tid; k < (int)IREC_PM1; k += NT) l2[k] = A.lut2[k];
-  }
-  char *slab = A.ws + (size_t)blockIdx.x * A.ws_per_wg;
-  int32_t *bp = reinterpret_cast<int32_t *>(slab);                                                     // [max_K][NB]
-  float *beams_g = reinterpret_cast<float *>(slab + A.ws_per_wg - (size_t)2 * NB * FAST_MAX_DIM * 4); // [2][NB][1024]
-  float *stats_g = beams_g - 3 * FAST_MAX_DIM;  // [3][1024]: mq - mp, sq^2, sp^2 of the block, coalesced
-
-  unsigned long long stamp_prev = A.dbg ? stamp_now() : 0ull;
-  for (;;) {
-    __syncthreads();
-    if (tid == 0) misc[0] = (int32_t)atomicAdd(A.counter, 1u);
-    __syncthreads();
-    const int64_t blk = misc[0];
-    if (blk >= A.n_blocks) break; // every wave of every workgroup reaches this
-    const int D = A.block_dim[blk];
-    const int64_t base = A.block_base[blk];
-    const int32_t pos = A.block_pos[blk];
-    // proposal table of this block's dim count (host listed the distinct dims of the call)
-    const uint16_t *tab = nullptr;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (A.tab_dim[q] == D) tab = A.tab[q];
-    if (D < 1 || D > FAST_MAX_DIM || tab == nullptr) {
-      if (tid == 0) A.out_K[blk] = -1;
-      continue;
-    }
-    const int Dp = (D + 3) & ~3;
-    const int NG = (D + 255) >> 8;              // 1..4 dim groups
-    const int NSW = F3_NW / (NG * NH);          // sample stripes (>= 1 because NG * NH <= 8)
-    const bool active = wave < NG * NH * NSW;
-    const int g = wave % NG, h = (wave / NG) % NH, sw = wave / (NG * NH);
-    const int d0 = g * 256 + lane * 4;
-    const int b_lo = h * HB;                    // my beams: b_lo .. b_lo + HB - 1
-    // flat element index of my dim i (split == gather through perm); recomputed where needed, not kept in VGPRs
-    auto elem = [&](int i) -> int64_t { return src_index(A, base, pos, d0 + i < D ? d0 + i : 0); };
-
-    // ---- the block's KL and K ----
-    {
-      double klacc = 0.0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float st3[3] = {0.f, 1.f, 1.f};
-        if (d0 + i < D) {
-          const int64_t e = elem(i);
-          const float mq_ = A.q_loc[e], sq_ = A.q_scale[e], mp_ = A.p_loc[e], sp_ = A.p_scale[e];
-          klacc = klacc + kl_dim(mq_, sq_, mp_, sp_);
-          st3[0] = mq_ - mp_; st3[1] = sq_ * sq_; st3[2] = sp_ * sp_;
-        }
-        if (active && h == 0 && sw == 0) { // one wave per dim group publishes the block's statistics
-          stats_g[d0 + i] = st3[0]; stats_g[FAST_MAX_DIM + d0 + i] = st3[1]; stats_g[2 * FAST_MAX_DIM + d0 + i] = st3[2];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      const double gs = wave_tree_sum(klacc);
-      if (active && h == 0 && sw == 0 && lane == 0) gpart[g] = gs;
-      __syncthreads();
-      if (tid == 0) {
-        double tot = gpart[0];
-        for (int gg = 1; gg < NG; ++gg) tot = tot + gpart[gg];
-        const int32_t K = num_aux((float)tot, A.omega);
-        misc[1] = K;
-        A.out_K[blk] = K;
-        hsum[0] = 0;
-        beta4[0] = 0u; // hash of the empty path is 1 = g^0
-      }
-      __syncthreads();
-    }
-    const int K = misc[1];
-    if (K > A.max_K || K > IREC_MAX_PARTITIONS_DEV) continue;
-    if (K == 0) { // nothing to code: sample = p.loc
-      if (active && h == 0 && sw == 0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (d0 + i < D) { const int64_t e = elem(i); A.out_sample[e] = 0.f + A.p_loc[e]; }
-      }
-      continue;
-    }
-
-    float c[4] = {0.f, 0.f, 0.f, 0.f};  // cumulative auxiliary variance of my dims
-    float sa[4], cH[4];                  // this step's sample scale and z^2 coefficient
-    float G[HB][4];                      // z coefficient of my beams
-    auto step_consts = [&](int t_next, float (&m)[4], float (&cA)[4], float (&cBv)[4]) {
-      const float rho = A.rho[K - 1 - t_next];
-      // three coalesced 16-byte reads of the slab instead of holding 12 VGPRs for the whole block
-      const float4 q0 = *reinterpret_cast<const float4 *>(stats_g + d0);
-      const float4 q1 = *reinterpret_cast<const float4 *>(stats_g + FAST_MAX_DIM + d0);
-      const float4 q2 = *reinterpret_cast<const float4 *>(stats_g + 2 * FAST_MAX_DIM + d0);
-      const float dmu_[4] = {q0.x, q0.y, q0.z, q0.w}, vq_[4] = {q1.x, q1.y, q1.z, q1.w}, vp_[4] = {q2.x, q2.y, q2.z, q2.w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool ok = d0 + i < D;
-        const StepConst sc = step_constants(rho, dmu_[i], vq_[i], vp_[i], c[i]);
-        sa[i] = ok ? sc.sa : 0.f; cH[i] = ok ? sc.H : 0.f;
-        m[i] = ok ? sc.m : 0.f; cA[i] = ok ? sc.A : 0.f; cBv[i] = ok ? sc.Bv : 0.f;
-        c[i] = c[i] + sc.a; // cumulative_auxiliary_variance += auxiliary_var (:109)
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-
-    // ================= step 0: one all-zero beam (beam_search_coder.py:96-106) =================
-    {
-      float m[4], cA[4], cBv[4];
-      step_consts(0, m, cA, cBv);
-      float G0[4], cacc = 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        G0[i] = beam_G(0.f, m[i], cA[i], cBv[i], sa[i]);
-        cacc = beam_C_term(cacc, 0.f, m[i], cA[i], cBv[i]);
-      }
-      const float cg = wave_tree_sum(cacc);
-      if (active && h == 0 && sw == 0 && lane == 0) cpart_s[g * 32] = cg;
-      if (active && h == 0) { // the single beam lives in half 0; up to 32 samples share one reduce-scatter
-        const int s_per_stripe = (S + NSW - 1) / NSW;
-        for (int ch = 0; ch * 32 < s_per_stripe; ++ch) {
-          float acc[32];
-#pragma unroll
-          for (int j = 0; j < 32; ++j) {
-            acc[j] = 0.f;
-            const int s = (ch * 32 + j) * NSW + sw;
-            if (s < S) { // wave-uniform
-              const uint2 ap = *reinterpret_cast<const uint2 *>(tab + d0 + (size_t)s * Dp);
-              const uint32_t al[4] = {ap.x & 0xFFFFu, ap.x >> 16, ap.y & 0xFFFFu, ap.y >> 16};
-#pragma unroll
-              for (int i = 0; i < 4; ++i) acc[j] = proposal_term(acc[j], lds_abs_f32(al[i]), cH[i], G0[i]); // beta = 0
-            }
-            if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0); // 4 samples in flight at a time (VGPR budget)
-          }
-          const float tot = reduce_scatter<32>(acc, lane);
-          const int s = (ch * 32 + (lane >> 1)) * NSW + sw;
-          if ((lane & 1) == 0 && s < S) part_s[((size_t)g * S + s) * NB] = tot;
-        }
-      }
-      __syncthreads();
-      const float c0 = [&] { float cb = cpart_s[0]; for (int gg = 1; gg < NG; ++gg) cb = cb + cpart_s[gg * 32]; return cb; }();
-      for (int f = tid; f < S; f += NT) {
-        float sc = part_s[(size_t)f * NB];
-        for (int gg = 1; gg < NG; ++gg) sc = sc + part_s[((size_t)gg * S + f) * NB];
-        key_s[f] = score_key(sc + c0);
-      }
-    }
-
-    IREC_STAMP(0); // block prologue: load, KL, step-0 constants and scores
-    int cur = 0;
-    for (int t = 0; t < K; ++t) {
-      const uint16_t *tab_t = tab + (size_t)t * S * Dp + d0; // row s at + s * Dp
-      const int Bcur = t ? NB : 1;
-      if (t) {
-        // ---------------- scoring: S x (my HB beams) candidates (beam_search_coder.py:80-84) ----------------
-        if (active) {
-          uint32_t bet[HB];
-#pragma unroll
-          for (int b = 0; b < HB; ++b) bet[b] = __builtin_amdgcn_readfirstlane(beta4[cur * 32 + b_lo + b]);
-          const int s_per_stripe = (S + NSW - 1) / NSW;
-          const int nchunks = (s_per_stripe + SPC - 1) / SPC;
-          // proposal rows (4 x uint16 byte offsets 4*dlog(r) of my 4 dims) are fetched one chunk ahead of their use
-          uint2 alp_next[SPC];
-#pragma unroll
-          for (int cc = 0; cc < SPC; ++cc) {
-            const int s = cc * NSW + sw;
-            alp_next[cc] = make_uint2(0u, 0u);
-            if (s < S) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)s * Dp);
-          }
-          for (int ch = 0; ch < nchunks; ++ch) {
-            float acc[32];
-#pragma unroll
-            for (int p = 0; p < 32; ++p) acc[p] = 0.f;
-            uint2 alp[SPC];
-#pragma unroll
-            for (int cc = 0; cc < SPC; ++cc) {
-              alp[cc] = alp_next[cc];
-              const int sn = ((ch + 1) * SPC + cc) * NSW + sw;
-              if (sn < S) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sn * Dp);
-            }
-#pragma unroll
-            for (int cc = 0; cc < SPC; ++cc) {
-              const int s = (ch * SPC + cc) * NSW + sw;
-              if (s < S) { // wave-uniform
-                const uint32_t al[4] = {alp[cc].x & 0xFFFFu, alp[cc].x >> 16, alp[cc].y & 0xFFFFu, alp[cc].y >> 16};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                  float z[HB];
-#pragma unroll
-                  for (int b = 0; b < HB; ++b) {
-                    uint32_t ad = al[i] + bet[b];                       // 4*(dlog r + dlog h)
-                    const uint32_t ad2 = ad - IREC_LUT2_BYTES;
-                    ad = ad2 < ad ? ad2 : ad;                           // mod 10006 (one conditional subtract)
-                    z[b] = lds_abs_f32(ad);
-                  }
-#pragma unroll
-                  for (int b = 0; b < HB; ++b) acc[cc * HB + b] = proposal_term(acc[cc * HB + b], z[b], cH[i], G[b][i]);
-                  __builtin_amdgcn_sched_barrier(0); // one dim's HB gathers in flight at a time (VGPR budget)
-                }
-              }
-            }
-            const float tot = reduce_scatter<32>(acc, lane);
-            const int p = lane >> 1;
-            const int cc = p / HB, bl = p - cc * HB;
-            const int s = (ch * SPC + cc) * NSW + sw;
-            if (cc < SPC && s < S && (lane & 1) == 0) part_s[((size_t)g * S + s) * NB + b_lo + bl] = tot;
-          }
-        }
-        __syncthreads();
-        IREC_STAMP(1); // scoring
-        // ---------------- combine dim groups in order, add C_b, build sort keys ----------------
-        for (int f = tid; f < S * NB; f += NT) {
-          const int s = f / NB, b = f - s * NB;
-          float sc = part_s[((size_t)0 * S + s) * NB + b];
-          for (int gg = 1; gg < NG; ++gg) sc = sc + part_s[((size_t)gg * S + s) * NB + b];
-          key_s[f] = score_key(sc + Cb_s[b]);
-        }
-      }
-      const int N = S * Bcur;
-      select_topB<NT>(key_s, N, NB, Bcur, wb, sel_s, sel_b); // S >= NB: always NB survivors
-      IREC_STAMP(2); // combine + top-B
-      // ---------------- new hashes / back-pointers (beam_search_coder.py:94-95) ----------------
-      if (tid < NB) {
-        const int32_t sp_ = sel_s[tid], bp_ = sel_b[tid];
-        const int32_t nh = (int32_t)((uint32_t)hsum[cur * 32 + bp_] + (uint32_t)sp_ * (uint32_t)(69 + t));
-        hsum[(cur ^ 1) * 32 + tid] = nh;
-        beta4[(cur ^ 1) * 32 + tid] = A.dlog4r[hash_from_sum(nh) - 1u];
-        bp[(size_t)t * NB + tid] = (sp_ << 6) | bp_;
-      }
-      // ---------------- gather my surviving beams (beam_search_coder.py:92-93), prepare the next step ----------------
-      const bool last = (t == K - 1);
-      if (active) {
-        const float sa_t[4] = {sa[0], sa[1], sa[2], sa[3]};   // this step's sample scale
-        float m[4], cA[4], cBv[4];
-        if (!last) step_consts(t + 1, m, cA, cBv);            // overwrites sa / cH with the next step's
-        const float *bold = beams_g + ((size_t)cur * NB) * FAST_MAX_DIM + d0;
-        float *bnew = beams_g + ((size_t)(cur ^ 1) * NB) * FAST_MAX_DIM + d0;
-        float cacc[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) cacc[j] = 0.f;
-        // all global reads of the update are issued up front (G is dead here: its registers take the old beams)
-        uint2 apv[HB];
-        float4 obv4[HB];
-        uint32_t bet_old[HB];
-#pragma unroll
-        for (int jl = 0; jl < HB; ++jl) {
-          const int j = b_lo + jl;
-          const int32_t sp_ = __builtin_amdgcn_readfirstlane(sel_s[j]);
-          const int32_t bp_ = __builtin_amdgcn_readfirstlane(sel_b[j]);
-          bet_old[jl] = __builtin_amdgcn_readfirstlane(beta4[cur * 32 + bp_]);
-          apv[jl] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sp_ * Dp);
-          obv4[jl] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (t) obv4[jl] = *reinterpret_cast<const float4 *>(bold + (size_t)bp_ * FAST_MAX_DIM);
-        }
-#pragma unroll
-        for (int jl = 0; jl < HB; ++jl) {
-          const int j = b_lo + jl;
-          const uint32_t al[4] = {apv[jl].x & 0xFFFFu, apv[jl].x >> 16, apv[jl].y & 0xFFFFu, apv[jl].y >> 16};
-          const float obv[4] = {obv4[jl].x, obv4[jl].y, obv4[jl].z, obv4[jl].w};
-          float nb[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            uint32_t ad = al[i] + bet_old[jl];
-            const uint32_t ad2 = ad - IREC_LUT2_BYTES;
-            ad = ad2 < ad ? ad2 : ad;
-            const float y = sa_t[i] * lds_abs_f32(ad);   // dist.quantile(.), :48-49
-            nb[i] = obv[i] + y;                          // combined_samples[best_ind_aux, best_ind_beam], :81,92-93
-          }
-          if (last) {
-            if (j == 0 && sw == 0) {
-#pragma unroll
-              for (int i = 0; i < 4; ++i)
-                if (d0 + i < D) { const int64_t e = elem(i); A.out_sample[e] = nb[i] + A.p_loc[e]; } // beams[0] + loc, :122
-            }
-          } else {
-            if (sw == 0) *reinterpret_cast<float4 *>(bnew + (size_t)j * FAST_MAX_DIM) = make_float4(nb[0], nb[1], nb[2], nb[3]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              G[jl][i] = beam_G(nb[i], m[i], cA[i], cBv[i], sa[i]);
-              cacc[jl] = beam_C_term(cacc[jl], nb[i], m[i], cA[i], cBv[i]);
-            }
-          }
-        }
-        if (!last) {
-          const float ctot = reduce_scatter<16>(cacc, lane);  // lane l holds my beam (l >> 2)
-          const int jl = lane >> 2;
-          if (sw == 0 && (lane & 3) == 0 && jl < HB) cpart_s[g * 32 + b_lo + jl] = ctot;
-        }
-      }
-      __syncthreads();
-      IREC_STAMP(3); // beam update + next step's constants
-      if (!last && tid < NB) {
-        float cb = cpart_s[tid];
-        for (int gg = 1; gg < NG; ++gg) cb = cb + cpart_s[gg * 32 + tid];
-        Cb_s[tid] = cb; // read after the next scoring barrier
-      }
-      cur ^= 1;
-    }
-    // ---- index path of beam 0 (beam_search_coder.py:118-121) ----
-    __syncthreads();
-    if (tid == 0) {
-      int j = 0;
-      for (int t = K - 1; t >= 0; --t) {
-        const int32_t v = __builtin_nontemporal_load(&bp[(size_t)t * NB + j]);
-        A.out_indices[blk * (int64_t)A.max_K + t] = v >> 6;
-        j = v & 63;
-      }
-    }
   }
 }
 
@@ -1185,7 +993,7 @@ hipError_t launch_block_kl(const EncArgs &A, float *out_kl, int grid, hipStream_
   return hipGetLastError();
 }
 
-size_t generic_lds_bytes() { return 40032 + (size_t)GEN_NSC * 4 + 64 + 32 + 8 + 64 * 4 * 2 + 128 * 4 + 16 + 256 + 64; }
+size_t generic_lds_bytes() { return 40032 + (size_t)GEN_NSC * 4 + SMALL_LDS_BYTES + 8 + 256 + 64; }
 
 hipError_t launch_encode_generic(const EncArgs &A, int grid, hipStream_t st) {
   const size_t lds = generic_lds_bytes();
@@ -1196,54 +1004,46 @@ hipError_t launch_encode_generic(const EncArgs &A, int grid, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int NB, int NW>
+template <int NB, int NW, bool TABLE>
 static hipError_t launch_fast_t(const EncArgs &A, int grid, hipStream_t st) {
-  const size_t lds = fast_lds_bytes(NB, A.S, nullptr, nullptr);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_fast_kernel<NB, NW>),
+  const size_t lds = fast_lds_bytes(NB, A.S, TABLE, nullptr, nullptr);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_fast_kernel<NB, NW, TABLE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((encode_fast_kernel<NB, NW>), dim3(grid), dim3(NW * 64), lds, st, A);
+  hipLaunchKernelGGL((encode_fast_kernel<NB, NW, TABLE>), dim3(grid), dim3(NW * 64), lds, st, A);
   return hipGetLastError();
 }
 
 int fast_nb_for(int B) { return B <= 10 ? 10 : B <= 20 ? 20 : B <= 32 ? 32 : 0; }
 
-size_t fast_lds_for(int B, int S) {
+size_t fast_lds_for(int B, int S, bool table) {
   const int nb = fast_nb_for(B);
-  return nb ? fast_lds_bytes(nb, S, nullptr, nullptr) : (size_t)-1;
+  return nb ? fast_lds_bytes(nb, S, table, nullptr, nullptr) : (size_t)-1;
 }
 
 size_t fast_ws_for(int B, int max_K) { return fast_ws_bytes(fast_nb_for(B), max_K); }
 size_t fast_ws_bytes_nb(int NB, int max_K) { return fast_ws_bytes(NB, max_K); }
 
-hipError_t launch_encode_fast(const EncArgs &A, int grid, hipStream_t st) {
-  switch (fast_nb_for(A.B)) {
-    case 10: return launch_fast_t<10, FAST_NW>(A, grid, st);
-    case 20: return launch_fast_t<20, FAST_NW>(A, grid, st);
-    case 32: return launch_fast_t<32, FAST_NW>(A, grid, st);
-    default: return hipErrorInvalidValue;
+int fast_blocks_per_cu(int B, int S, bool table) {
+  int n = 0;
+  const size_t lds = fast_lds_for(B, S, table);
+  const void *fn = nullptr;
+  switch (fast_nb_for(B)) {
+    case 10: fn = table ? (const void *)encode_fast_kernel<10, FAST_NW, true> : (const void *)encode_fast_kernel<10, FAST_NW, false>; break;
+    case 20: fn = table ? (const void *)encode_fast_kernel<20, FAST_NW, true> : (const void *)encode_fast_kernel<20, FAST_NW, false>; break;
+    case 32: fn = table ? (const void *)encode_fast_kernel<32, FAST_NW, true> : (const void *)encode_fast_kernel<32, FAST_NW, false>; break;
+    default: return 0;
   }
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, FAST_NW * 64, lds) != hipSuccess) return 0;
+  return n;
 }
 
-template <int NB, int NH>
-static hipError_t launch_fast3_t(const EncArgs &A, int grid, hipStream_t st) {
-  const size_t lds = fast3_lds_bytes(NB, A.S, nullptr, nullptr);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_fast3_kernel<NB, NH>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((encode_fast3_kernel<NB, NH>), dim3(grid), dim3(F3_NW * 64), lds, st, A);
-  return hipGetLastError();
-}
-
-size_t fast3_lds_for(int B, int S) { return fast3_lds_bytes(B, S, nullptr, nullptr); }
-
-// beam counts the beam-striped encoder is instantiated for (it needs B == NB exactly and S >= B)
-bool fast3_supports(int B, int S) { return (B == 10 || B == 20) && S >= B; }
-
-hipError_t launch_encode_fast3(const EncArgs &A, int grid, hipStream_t st) {
-  switch (A.B) {
-    case 10: return launch_fast3_t<10, 1>(A, grid, st);
-    case 20: return launch_fast3_t<20, 2>(A, grid, st);
+hipError_t launch_encode_fast(const EncArgs &A, bool table, int grid, hipStream_t st) {
+  switch (fast_nb_for(A.B)) {
+    case 10: return table ? launch_fast_t<10, FAST_NW, true>(A, grid, st) : launch_fast_t<10, FAST_NW, false>(A, grid, st);
+    case 20: return table ? launch_fast_t<20, FAST_NW, true>(A, grid, st) : launch_fast_t<20, FAST_NW, false>(A, grid, st);
+    case 32: return table ? launch_fast_t<32, FAST_NW, true>(A, grid, st) : launch_fast_t<32, FAST_NW, false>(A, grid, st);
     default: return hipErrorInvalidValue;
   }
 }

@@ -1,15 +1,15 @@
-"""Times one encode variant (IREC_VARIANT = striped | fused | generic) on the bench workload; diagnostics only."""
+"""Times one encode variant (IREC_VARIANT = table | fused | generic) on the bench workload; diagnostics only."""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "relative-entropy-coding_amd")]
 import bench, irec
-variant = os.environ.get("IREC_VARIANT", "striped")
+variant = os.environ.get("IREC_VARIANT", "table")
 L = int(os.environ.get("LATENTS", "1024"))
 B = int(os.environ.get("BEAMS", "20")); omega = float(os.environ.get("OMEGA", "3.0")); eps1 = float(os.environ.get("EPS1", "1.2"))
 eng = irec.get_engine()
 S = int(np.exp(omega * eps1))
-flags = {"striped": 0, "fused": 2, "generic": 1}[variant]
+flags = {"table": 0, "fused": 2, "generic": 1}[variant]
 params = eng.params(omega, S, B, flags)
 q = bench.synthetic_batch(L, eng.device, 0)
 lay = eng.layout(L, bench.N_DIMS, bench.BLOCK_SIZE, bench.SEED)

@@ -17,10 +17,10 @@ def _normal(loc, scale, device="cuda"):
                                       validate_args=False)
 
 
-VARIANTS = ["striped", "fused", "generic"]   # proposal-table beam-striped kernel / Philox-fused kernel / fallback
+VARIANTS = ["table", "fused", "generic"]   # proposal-table beam-table kernel / Philox-fused kernel / fallback
 
 
-def _coder(omega, B, eps1, block_size=None, variant="striped"):
+def _coder(omega, B, eps1, block_size=None, variant="table"):
     import irec
     c = irec.BeamSearchCoder(kl_per_partition=omega, n_beams=B, extra_samples=eps1, block_size=block_size)
     c.force_generic = variant == "generic"
@@ -192,7 +192,7 @@ def test_high_kl_block_many_partitions(engine, oracle):
     assert len(ridx) > 64 and [int(i) for i in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
 
 
-@pytest.mark.parametrize("flags", [0, 2], ids=["striped", "fused"])
+@pytest.mark.parametrize("flags", [0, 2], ids=["table", "fused"])
 def test_full_size_properties(engine, oracle, flags):
     """BASELINE config 2 at bench size: properties that need no oracle run (round trip, ranges), plus a sampled
     subset of blocks checked against the oracle."""
