@@ -124,6 +124,21 @@ irec_status irec_beam_decode(irec_context *ctx, const irec_params *p, int64_t n_
                              const float *p_loc, const float *p_scale, int64_t seed, int32_t max_K, const int32_t *K,
                              const int32_t *indices, float *out_sample, void *hip_stream);
 
+/* ---- .rec wire format: entropy coder of the index streams (host memory; the reference's is CPU Cython too) ------------ */
+const char *irec_io_last_error(void);
+/* ArithmeticCoder(counts, precision).encode(message) -- rec/io/entropy_coding.pyx:51-121.  out_bits: one ASCII '0'/'1'
+ * per code bit; *n_bits = code length (also when it exceeds cap, in which case an error is returned). */
+irec_status irec_ac_encode(const int64_t *counts, int32_t n_symbols, const int64_t *message, int64_t n_message,
+                           int32_t precision, uint8_t *out_bits, int64_t cap, int64_t *n_bits);
+/* ArithmeticCoder.decode_fast(code) -- rec/io/entropy_coding.pyx:213-302 (symbol lookup of data_structures.py:186-213
+ * by binary search).  Decodes up to and including the terminator symbol 0. */
+irec_status irec_ac_decode(const int64_t *counts, int32_t n_symbols, const uint8_t *bits, int64_t n_bits,
+                           int32_t precision, int64_t *out_message, int64_t cap, int64_t *n_message);
+/* int('1' + code, 2).to_bytes(ceil((len + 1) / 8), 'big') -- rec/io/utils.py:66-72,100-106.  Returns bytes written or -1. */
+int64_t irec_rec_pack_bits(const uint8_t *bits, int64_t n_bits, uint8_t *out_bytes, int64_t cap);
+/* bin(int.from_bytes(bytes, 'big'))[3:] -- rec/io/utils.py:158-170.  Returns code bits written or -1. */
+int64_t irec_rec_unpack_bits(const uint8_t *bytes, int64_t n_bytes, uint8_t *out_bits, int64_t cap);
+
 /* ---- test hooks (device pointers) ---------------------------------------------------------------------------- */
 /* r[s*D + d] of get_pseudo_random_sample's int32 draw, generated by the in-kernel Philox stream.  out: int32 [n]. */
 irec_status irec_device_uniform_int(irec_context *ctx, int64_t seed, int64_t n, int32_t *out, void *hip_stream);

@@ -47,6 +47,11 @@ SIGNATURES = {
     "irec_beam_encode": (ctypes.c_int, [_vp, _PP, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32,
                                         _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "irec_beam_decode": (ctypes.c_int, [_vp, _PP, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "irec_io_last_error": (ctypes.c_char_p, []),
+    "irec_ac_encode": (ctypes.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _i64, ctypes.POINTER(_i64)]),
+    "irec_ac_decode": (ctypes.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _i64, ctypes.POINTER(_i64)]),
+    "irec_rec_pack_bits": (_i64, [_vp, _i64, _vp, _i64]),
+    "irec_rec_unpack_bits": (_i64, [_vp, _i64, _vp, _i64]),
     "irec_device_uniform_int": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "irec_test_reduce_scatter": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "irec_device_tables": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),

@@ -1,0 +1,111 @@
+"""CPU tests of the .rec wire format: the C++ arithmetic coder and the container writer /
+reader against golden vectors produced by the REAL reference code (tests/golden/make_golden_rec.py), and -- when the
+build container has /root/reference and oracle/_ref -- against the live reference on fresh random inputs."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR
+
+
+def _ac_cases():
+    g = np.load(os.path.join(GOLDEN_DIR, "rec_ac_vectors.npz"))
+    return [(g[f"P{i}"], g[f"msg{i}"], g[f"code{i}"].tobytes().decode()) for i in range(int(g["n_cases"]))]
+
+
+@pytest.mark.parametrize("case", range(7))
+def test_arithmetic_coder_matches_reference_vectors(case):
+    from irec.io import ArithmeticCoder
+    P, msg, code = _ac_cases()[case]
+    ac = ArithmeticCoder(P, precision=32)
+    assert "".join(ac.encode(msg)) == code                    # bit-identical to the reference's encoder
+    assert ac.decode_fast(list(code)) == msg.tolist()
+    assert ac.decode(list(code)) == msg.tolist()
+
+
+def _rec_sets():
+    g = np.load(os.path.join(GOLDEN_DIR, "rec_files.npz"))
+    out = []
+    for name in g["names"]:
+        seed, bs, max_index, h, w, c = (int(v) for v in g[f"{name}_meta"])
+        flat, lens, nblocks = g[f"{name}_flat"], g[f"{name}_lens"], g[f"{name}_nblocks"]
+        blocks, pos, li = [], 0, 0
+        for nb in nblocks:
+            blk = []
+            for _ in range(int(nb)):
+                blk.append(flat[pos:pos + lens[li]].tolist())
+                pos += int(lens[li]); li += 1
+            blocks.append(blk)
+        out.append((str(name), seed, (h, w, c), bs, max_index, blocks, g[f"{name}_bytes"].tobytes()))
+    return out
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_rec_file_bytes_match_reference(tmp_path, which):
+    from irec.io import write_compressed_code, read_compressed_code
+    name, seed, shape, bs, max_index, blocks, golden = _rec_sets()[which]
+    path = tmp_path / f"{name}.rec"
+    write_compressed_code(str(path), seed, shape, bs, blocks, max_index)
+    assert path.read_bytes() == golden                        # byte-identical container
+    gpath = tmp_path / "golden.rec"
+    gpath.write_bytes(golden)
+    rseed, rshape, rbs, rblocks = read_compressed_code(str(gpath))
+    assert (rseed, rshape, rbs) == (seed, shape, bs)
+    assert rblocks == blocks
+
+
+def test_rec_rejects_index_beyond_max_index(tmp_path):
+    # the reference overflows its 21-entry count table when S = 36 > max_index = 20; we refuse
+    from irec.io import write_compressed_code
+    with pytest.raises(ValueError, match="max_index"):
+        write_compressed_code(str(tmp_path / "x.rec"), 42, (32, 32, 3), 1000, [[[3, 35]]], 20)
+    with pytest.raises(ValueError, match="rank 3"):
+        write_compressed_code(str(tmp_path / "x.rec"), 42, (32, 32), 1000, [[[3]]], 20)
+
+
+def test_coder_rejects_bad_input():
+    from irec.io import ArithmeticCoder
+    with pytest.raises(ValueError):
+        ArithmeticCoder(np.array([1, 0, 5]))
+    ac = ArithmeticCoder(np.array([1, 5, 5]))
+    with pytest.raises(ValueError, match="out of range"):
+        ac.encode([1, 3, 0])
+    try:   # garbage in: must terminate, either with a message ending in the terminator or with an error
+        out = ac.decode_fast(list("1111111111111111111111111111111111111111"))
+        assert out[-1] == 0
+    except ValueError:
+        pass
+
+
+def test_empty_message_round_trip():
+    from irec.io import ArithmeticCoder
+    ac = ArithmeticCoder(np.array([1, 1001, 1001]))
+    code = ac.encode([0])
+    assert ac.decode_fast(code) == [0]
+
+
+def test_against_live_reference_when_available(tmp_path):
+    from oracle import ref_io
+    if not ref_io.available():
+        pytest.skip("reference rec.io not built here (GPU box)")
+    from irec.io import ArithmeticCoder, write_compressed_code
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        U = ref_io.load()
+        rng = np.random.default_rng(99)
+        for trial in range(25):
+            nsym = int(rng.integers(2, 300))
+            P = rng.integers(1, 2000, size=nsym).astype(np.int32)
+            msg = np.concatenate([rng.integers(1, nsym, size=int(rng.integers(0, 400))), [0]]).astype(np.int64)
+            ref_code = "".join(U.ArithmeticCoder(P, precision=32).encode(msg))
+            mine = ArithmeticCoder(P, precision=32)
+            assert "".join(mine.encode(msg)) == ref_code, trial
+            assert mine.decode_fast(list(ref_code)) == msg.tolist()
+        blocks = [[rng.integers(0, 36, size=int(k)).tolist() for k in rng.integers(1, 15, size=9)] for _ in range(24)]
+        ref_path, my_path = tmp_path / "ref.rec", tmp_path / "mine.rec"
+        U.write_compressed_code(str(ref_path), 42, (32, 32, 3), 1000, blocks, 40)
+        write_compressed_code(str(my_path), 42, (32, 32, 3), 1000, blocks, 40)
+        assert ref_path.read_bytes() == my_path.read_bytes()
+        assert U.read_compressed_code(str(my_path))[3] == blocks
