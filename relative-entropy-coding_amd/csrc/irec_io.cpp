@@ -2,7 +2,7 @@
 // (rec/io/entropy_coding.pyx:19-302, 32-bit-precision integer arithmetic coding with "middle" rescaling), behind the
 // C ABI of include/irec.h.  Host code: the reference's coder is CPU code too (its only native component), and the
 // streams are a few hundred bits per image.  Bit-for-bit the reference's output (tests/test_rec_io.py pins it against
-// the reference's own coder compiled into oracle/_ref and against committed golden .rec files).
+// the real reference coder, built by the test infrastructure, and against committed golden .rec files).
 #include <cstdint>
 #include <cstring>
 #include <string>
