@@ -353,6 +353,7 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
     if (!pl.table) { pl.n_tab = 0; pl.tab_bytes = 0; }
   }
   if (pl.fast) {
+    if (irec::fast_waves_for(B, S, pl.table) == 8) pl.grid_cap /= 2; // big-LDS configurations: one 8-wave workgroup per CU
     pl.ws_per_wg = round_up_sz(irec::fast_ws_for(B, max_K), 256);
   } else {
     pl.ws_per_wg = round_up_sz((size_t)10 * pl.dpad * 4 + (size_t)2 * B * pl.dpad * 4 +
@@ -453,8 +454,8 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
       for (int w = 0; w < grid; ++w) if (h[(size_t)w * 8 + 4] && h[(size_t)w * 8 + 5] - t0 > 100000ull) ++late; // > 1 ms at 100 MHz
       fprintf(stderr, "[irec stamps] census: %d of %d workgroups coded no block, %llu started > 1 ms after the first\n", zero, grid, late);
     }
-    fprintf(stderr, "[irec stamps] occupancy API: %d workgroups/CU, LDS %zu B\n",
-            irec::fast_blocks_per_cu(p->n_beams, p->n_samples, pl.table), irec::fast_lds_for(p->n_beams, p->n_samples, pl.table));
+    fprintf(stderr, "[irec stamps] waves/workgroup %d, LDS %zu B\n",
+            irec::fast_waves_for(p->n_beams, p->n_samples, pl.table), irec::fast_lds_for(p->n_beams, p->n_samples, pl.table));
     fprintf(stderr, "[irec stamps] %s grid=%d cycles/WG: prologue %.0f (%.1f%%) scoring %.0f (%.1f%%) select %.0f (%.1f%%) update %.0f (%.1f%%)\n",
             pl.table ? "table" : pl.fast ? "fused" : "generic", grid, sum[0] / grid, 100 * sum[0] / tot, sum[1] / grid,
             100 * sum[1] / tot, sum[2] / grid, 100 * sum[2] / tot, sum[3] / grid, 100 * sum[3] / tot);

@@ -49,7 +49,7 @@ size_t fast_lds_for(int B, int S, bool table);
 size_t fast_ws_for(int B, int max_K);
 size_t fast_ws_bytes_nb(int NB, int max_K);
 hipError_t launch_encode_fast(const EncArgs &A, bool table, int grid, hipStream_t st);
-int fast_blocks_per_cu(int B, int S, bool table);
+int fast_waves_for(int B, int S, bool table);
 hipError_t launch_alpha_table(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *dlog4r, uint16_t *tab,
                               hipStream_t st);
 hipError_t launch_decode(const DecArgs &A, int grid, hipStream_t st);

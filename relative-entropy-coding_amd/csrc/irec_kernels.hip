@@ -474,14 +474,32 @@ struct FastCfg {
 };
 
 // LDS carve (bytes): lut2 40032 | [dlog 20016 unless TABLE] | part [4][S][NB] f32 (sort keys overwrite group 0) | SmallLds
-__host__ __device__ inline bool fast_keys_alias(int NB, int S) { return S * NB <= 1024; }
-__host__ __device__ inline size_t fast_lds_bytes(int NB, int S, bool table, size_t *off_part, size_t *off_small) {
-  size_t part = (((size_t)4 * S * NB * 4) + 15) & ~(size_t)15;
-  if (!fast_keys_alias(NB, S)) part += (((size_t)S * NB * 4) + 15) & ~(size_t)15; // separate key array behind the partials
-  const size_t head = (table ? 40032 - 8 : 40032 + 20016); // the table variant must fit three workgroups per CU
-  if (off_part) *off_part = head;
-  if (off_small) *off_small = head + part;
-  return head + part + SMALL_LDS_BYTES;
+// Sample passes.  The per-group partial scores of S_pass samples sit in LDS at a time ([4][S_pass][NB] f32); a step
+// scores S in ceil(S / S_pass) passes, each followed by the group combine into the sort keys.  With one pass and at
+// most 1024 candidates the keys are written over group 0 of the partials; otherwise they get their own array.
+struct FastPlan { int s_pass; bool alias; int nw; size_t off_part, off_key, off_small, bytes; };
+__host__ __device__ inline FastPlan fast_plan(int NB, int S, bool table) {
+  FastPlan p;
+  const size_t head = (table ? 40032 - 8 : 40032 + 20016);
+  const size_t row = (size_t)4 * NB * 4;                       // partial-score bytes per sample
+  const size_t keys = (((size_t)S * NB * 4) + 15) & ~(size_t)15;
+  auto total = [&](int s_pass, bool alias) { return head + (((size_t)s_pass * row + 15) & ~(size_t)15) + (alias ? 0 : keys) + SMALL_LDS_BYTES; };
+  const size_t two_per_cu = 80 * 1024 - 256, one_per_cu = 160 * 1024 - 1024;
+  p.alias = S * NB <= 1024 && total(S, true) <= two_per_cu;
+  if (p.alias) { p.s_pass = S; p.nw = 4; }
+  else {
+    // largest pass that still lets two workgroups share a CU, if that leaves passes of >= 16 samples
+    long long fit2 = ((long long)two_per_cu - (long long)(head + keys + SMALL_LDS_BYTES + 16)) / (long long)row;
+    long long fit1 = ((long long)one_per_cu - (long long)(head + keys + SMALL_LDS_BYTES + 16)) / (long long)row;
+    if (fit2 >= 16 || fit2 >= S) { p.s_pass = (int)(fit2 < S ? fit2 : S); p.nw = 4; }
+    else { p.s_pass = (int)(fit1 < S ? fit1 : S); p.nw = 8; }   // one 8-wave workgroup per CU
+    if (p.s_pass < 1) p.s_pass = 0;                              // does not fit at all -> caller falls back
+  }
+  p.off_part = head;
+  p.off_key = head + (p.alias ? 0 : (((size_t)p.s_pass * row + 15) & ~(size_t)15));
+  p.off_small = p.off_key + (p.alias ? (((size_t)p.s_pass * row + 15) & ~(size_t)15) : keys);
+  p.bytes = p.off_small + SMALL_LDS_BYTES;
+  return p;
 }
 
 // Scratch slab of one workgroup (bytes): bp int32 [max_K][NB] | stats float [3][1024] | beams float [2][NB][1024]
@@ -497,15 +515,14 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
   constexpr int RW = Cfg::RW, SPC = Cfg::SPC;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int S = A.S, B = A.B;
-  size_t off_part, off_small;
-  fast_lds_bytes(NB, S, TABLE, &off_part, &off_small);
+  const FastPlan plan = fast_plan(NB, S, TABLE);
+  const int SP = plan.s_pass;                                                 // samples scored per pass
+  const bool keys_alias = plan.alias;
   char *lut2_b = smem;                                                        // float [10006], dlog order
   const uint16_t *dlog_s = TABLE ? A.dlog4r : reinterpret_cast<const uint16_t *>(smem + 40032); // [10006] 4*dlog(j+1)
-  float *part_s = reinterpret_cast<float *>(smem + off_part);                 // [4][S][NB] per-group partial scores
-  const bool keys_alias = fast_keys_alias(NB, S);
-  uint32_t *key_s = reinterpret_cast<uint32_t *>(smem + off_part) +           // [S*NB] sort keys: over group 0 of the
-                    (keys_alias ? 0 : (size_t)4 * S * NB);                    // partials when they fit in registers
-  SmallLds *sm = reinterpret_cast<SmallLds *>(smem + off_small);
+  float *part_s = reinterpret_cast<float *>(smem + plan.off_part);            // [4][SP][NB] per-group partial scores
+  uint32_t *key_s = reinterpret_cast<uint32_t *>(smem + plan.off_key);        // [S*NB] sort keys (over group 0 if aliased)
+  SmallLds *sm = reinterpret_cast<SmallLds *>(smem + plan.off_small);
   double *gpart = sm->gpart;
   int32_t *sel_s = sm->sel_s, *sel_b = sm->sel_b;
   int32_t *hsum = &sm->hsum[0][0];                                            // [2][64]
@@ -664,18 +681,21 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
 #pragma unroll
       for (int b = 0; b < NB; ++b) bet[b] = __builtin_amdgcn_readfirstlane(beta4[cur * 64 + (b < Bcur ? b : 0)]);
 
-      // ---------------- scoring: all S x Bcur candidates (beam_search_coder.py:80-84) ----------------
+      const int N = S * Bcur;
+      for (int s_base = 0; s_base < S; s_base += SP) {
+      const int s_end = s_base + SP < S ? s_base + SP : S;
+      // ---------------- scoring: samples [s_base, s_end) x Bcur candidates (beam_search_coder.py:80-84) ----------------
       if (active) {
-        const int s_per_stripe = (S + NSW - 1) / NSW;
+        const int s_per_stripe = (s_end - s_base + NSW - 1) / NSW;
         const int nchunks = (s_per_stripe + SPC - 1) / SPC;
         // table variant: proposal rows (4 x uint16 byte offsets 4*dlog(r) of my dims) are fetched one chunk ahead
         uint2 alp_next[SPC];
         if (TABLE) {
 #pragma unroll
           for (int cc = 0; cc < SPC; ++cc) {
-            const int s0 = cc * NSW + sw;
+            const int s0 = s_base + cc * NSW + sw;
             alp_next[cc] = make_uint2(0u, 0u);
-            if (s0 < S) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)s0 * Dp);
+            if (s0 < s_end) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)s0 * Dp);
           }
         }
         for (int ch = 0; ch < nchunks; ++ch) {
@@ -687,14 +707,14 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
 #pragma unroll
             for (int cc = 0; cc < SPC; ++cc) {
               alp[cc] = alp_next[cc];
-              const int sn = ((ch + 1) * SPC + cc) * NSW + sw;
-              if (sn < S) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sn * Dp);
+              const int sn = s_base + ((ch + 1) * SPC + cc) * NSW + sw;
+              if (sn < s_end) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sn * Dp);
             }
           }
 #pragma unroll
           for (int cc = 0; cc < SPC; ++cc) {
-            const int s = (ch * SPC + cc) * NSW + sw;
-            if (s < S) { // wave-uniform
+            const int s = s_base + (ch * SPC + cc) * NSW + sw;
+            if (s < s_end) { // wave-uniform
               uint32_t al[4];
               if (TABLE) {
                 const uint2 ap = alp[cc];
@@ -741,17 +761,17 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
           const float tot = reduce_scatter<RW>(acc, lane);
           const int p = RW == 64 ? lane : (lane >> 1);
           const int cc = p / NB, b = p - cc * NB;
-          const int s = (ch * SPC + cc) * NSW + sw;
-          if (cc < SPC && s < S && b < Bcur && (RW == 64 || (lane & 1) == 0)) part_s[((size_t)g * S + s) * NB + b] = tot;
+          const int s = s_base + (ch * SPC + cc) * NSW + sw;
+          if (cc < SPC && s < s_end && b < Bcur && (RW == 64 || (lane & 1) == 0))
+            part_s[((size_t)g * SP + (s - s_base)) * NB + b] = tot;
         }
       }
       __syncthreads();
-      IREC_STAMP(1);
+      if (s_base == 0) IREC_STAMP(1);
       // ---------------- combine dim groups in order, add C_b, build sort keys ----------------
-      // the sort keys are written over group 0 of the partial scores: two passes with a barrier in between because
-      // key f = s * Bcur + b and partial (s, b) = s * NB + b only coincide when Bcur == NB
-      const int N = S * Bcur;
       if (keys_alias) {
+        // single pass, keys written over group 0 of the partials: two phases with a barrier in between because
+        // key f = s * Bcur + b and partial (s, b) = s * NB + b only coincide when Bcur == NB
         constexpr int MK = (1024 + NT - 1) / NT;
         uint32_t mykey[MK];
 #pragma unroll
@@ -760,8 +780,8 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
           mykey[q] = 0u;
           if (f < N) {
             const int s = f / Bcur, b = f - s * Bcur;
-            float sc = part_s[((size_t)0 * S + s) * NB + b];
-            for (int gg = 1; gg < NG; ++gg) sc = sc + part_s[((size_t)gg * S + s) * NB + b];
+            float sc = part_s[((size_t)0 * SP + s) * NB + b];
+            for (int gg = 1; gg < NG; ++gg) sc = sc + part_s[((size_t)gg * SP + s) * NB + b];
             mykey[q] = score_key(sc + Cb_s[b]);
           }
         }
@@ -772,13 +792,15 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
           if (f < N) key_s[f] = mykey[q];
         }
       } else {
-        for (int f = tid; f < N; f += NT) {
+        for (int f = s_base * Bcur + tid; f < s_end * Bcur; f += NT) {
           const int s = f / Bcur, b = f - s * Bcur;
-          float sc = part_s[((size_t)0 * S + s) * NB + b];
-          for (int gg = 1; gg < NG; ++gg) sc = sc + part_s[((size_t)gg * S + s) * NB + b];
+          float sc = part_s[((size_t)0 * SP + (s - s_base)) * NB + b];
+          for (int gg = 1; gg < NG; ++gg) sc = sc + part_s[((size_t)gg * SP + (s - s_base)) * NB + b];
           key_s[f] = score_key(sc + Cb_s[b]);
         }
+        if (s_end < S) __syncthreads(); // the next pass overwrites the partials
       }
+      } // sample passes
       const int Bnew = B < N ? B : N;
       select_topB<NT>(key_s, N, Bnew, Bcur, sm); // first barrier inside orders key_s writes
       IREC_STAMP(2);
@@ -1006,7 +1028,7 @@ hipError_t launch_encode_generic(const EncArgs &A, int grid, hipStream_t st) {
 
 template <int NB, int NW, bool TABLE>
 static hipError_t launch_fast_t(const EncArgs &A, int grid, hipStream_t st) {
-  const size_t lds = fast_lds_bytes(NB, A.S, TABLE, nullptr, nullptr);
+  const size_t lds = fast_plan(NB, A.S, TABLE).bytes;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_fast_kernel<NB, NW, TABLE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -1016,34 +1038,28 @@ static hipError_t launch_fast_t(const EncArgs &A, int grid, hipStream_t st) {
 
 int fast_nb_for(int B) { return B <= 10 ? 10 : B <= 20 ? 20 : B <= 32 ? 32 : 0; }
 
+// LDS bytes of the fast encoder for (B, S), or (size_t)-1 when it cannot run (B too large / nothing fits)
 size_t fast_lds_for(int B, int S, bool table) {
   const int nb = fast_nb_for(B);
-  return nb ? fast_lds_bytes(nb, S, table, nullptr, nullptr) : (size_t)-1;
+  if (!nb) return (size_t)-1;
+  const FastPlan p = fast_plan(nb, S, table);
+  return p.s_pass >= 1 ? p.bytes : (size_t)-1;
 }
+int fast_waves_for(int B, int S, bool table) { const int nb = fast_nb_for(B); return nb ? fast_plan(nb, S, table).nw : 0; }
 
 size_t fast_ws_for(int B, int max_K) { return fast_ws_bytes(fast_nb_for(B), max_K); }
 size_t fast_ws_bytes_nb(int NB, int max_K) { return fast_ws_bytes(NB, max_K); }
 
-int fast_blocks_per_cu(int B, int S, bool table) {
-  int n = 0;
-  const size_t lds = fast_lds_for(B, S, table);
-  const void *fn = nullptr;
-  switch (fast_nb_for(B)) {
-    case 10: fn = table ? (const void *)encode_fast_kernel<10, FAST_NW, true> : (const void *)encode_fast_kernel<10, FAST_NW, false>; break;
-    case 20: fn = table ? (const void *)encode_fast_kernel<20, FAST_NW, true> : (const void *)encode_fast_kernel<20, FAST_NW, false>; break;
-    case 32: fn = table ? (const void *)encode_fast_kernel<32, FAST_NW, true> : (const void *)encode_fast_kernel<32, FAST_NW, false>; break;
-    default: return 0;
-  }
-  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, FAST_NW * 64, lds) != hipSuccess) return 0;
-  return n;
+template <int NB, bool TABLE>
+static hipError_t launch_fast_nw(const EncArgs &A, int grid, hipStream_t st) {
+  return fast_plan(NB, A.S, TABLE).nw == 8 ? launch_fast_t<NB, 8, TABLE>(A, grid, st) : launch_fast_t<NB, 4, TABLE>(A, grid, st);
 }
 
 hipError_t launch_encode_fast(const EncArgs &A, bool table, int grid, hipStream_t st) {
   switch (fast_nb_for(A.B)) {
-    case 10: return table ? launch_fast_t<10, FAST_NW, true>(A, grid, st) : launch_fast_t<10, FAST_NW, false>(A, grid, st);
-    case 20: return table ? launch_fast_t<20, FAST_NW, true>(A, grid, st) : launch_fast_t<20, FAST_NW, false>(A, grid, st);
-    case 32: return table ? launch_fast_t<32, FAST_NW, true>(A, grid, st) : launch_fast_t<32, FAST_NW, false>(A, grid, st);
+    case 10: return table ? launch_fast_nw<10, true>(A, grid, st) : launch_fast_nw<10, false>(A, grid, st);
+    case 20: return table ? launch_fast_nw<20, true>(A, grid, st) : launch_fast_nw<20, false>(A, grid, st);
+    case 32: return table ? launch_fast_nw<32, true>(A, grid, st) : launch_fast_nw<32, false>(A, grid, st);
     default: return hipErrorInvalidValue;
   }
 }

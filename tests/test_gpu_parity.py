@@ -166,6 +166,19 @@ def test_wide_beam_uses_generic_path(engine, oracle):
     assert [int(i) for i in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
 
 
+@pytest.mark.parametrize("variant", ["table", "fused"])
+def test_stress_config_multi_pass_eight_wave_path(engine, oracle, variant):
+    # BASELINE config 5 with eps = 0.2: B = 30, S = 403 -> 12090 candidates per step; the partial scores no longer fit
+    # LDS in one go (sample passes) and only one workgroup fits per CU (8-wave variant of the fast encoder)
+    mq, sq, mp, sp = oracle.synthetic_latent(4242, 1000)
+    c = _coder(5.0, 30, 1.2, variant=variant)
+    assert c.n_samples == 403
+    idx, sample = c.encode(_normal(mq[None], sq[None]), _normal(mp[None], sp[None]), seed=42)
+    ridx, rs = oracle.encode_block(mq, sq, mp, sp, 42, 5.0, 403, 30)
+    assert [int(i) for i in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
+    assert torch.equal(c.decode(_normal(mp[None], sp[None]), idx, seed=42), sample)
+
+
 def test_zero_kl_block(engine):
     mp = torch.tensor([[0.3, -1.0, 2.0]]); sp = torch.tensor([[1.0, 2.0, 0.5]])
     c = _coder(3.0, 10, 1.0)
