@@ -86,8 +86,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--latents", type=int, default=2048, help="latent tensors per step per GPU")
-    ap.add_argument("--cpu-ref-latents", type=int, default=8)
-    ap.add_argument("--cpu-opt-latents", type=int, default=32)
+    ap.add_argument("--cpu-ref-latents", type=int, default=48)
+    ap.add_argument("--cpu-opt-latents", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
