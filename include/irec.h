@@ -145,6 +145,10 @@ irec_status irec_device_uniform_int(irec_context *ctx, int64_t seed, int64_t n, 
 /* in: float [64 lanes][width], width in {64, 32}; out[lane] = sum over lanes of in[.][lane*width/64] in the canonical
  * 64-lane reduction tree of the score kernels. */
 irec_status irec_test_reduce_scatter(irec_context *ctx, const float *in, float *out, int32_t width, void *hip_stream);
+/* tf.argsort(scores, DESCENDING)[:n_select] split into (index // n_beams_cur, index % n_beams_cur) -- the top-B step of
+ * beam_search_coder.py:85-89 in isolation.  scores: float [n]; scratch_keys: uint32 [n]; out_sel: int32 [n_select][2]. */
+irec_status irec_test_select(irec_context *ctx, const float *scores, int32_t n, int32_t n_select, int32_t n_beams_cur,
+                             uint32_t *scratch_keys, int32_t *out_sel, void *hip_stream);
 /* device addresses of the context's constant tables (lut [10007], lut2 [10006], dlog4r [10006] u16, rho [65536]). */
 irec_status irec_device_tables(irec_context *ctx, const float **lut, const float **lut2, const uint16_t **dlog4r,
                                const float **rho);

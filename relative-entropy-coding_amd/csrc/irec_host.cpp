@@ -297,7 +297,7 @@ irec_status irec_create(int device, irec_context **out) {
   HIP_TRY(hipMemcpy(ctx->d_dlog4r, dlog4r.data(), (P - 1) * sizeof(uint16_t), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(ctx->d_rho, rho.data(), rho.size() * sizeof(float), hipMemcpyHostToDevice));
   if (const char *e = std::getenv("IREC_STAMPS"); e && e[0] == '1') {
-    HIP_TRY(hipMalloc(&ctx->d_dbg, 4096 * 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&ctx->d_dbg, 4096 * 16 * sizeof(unsigned long long)));
   }
   *out = ctx;
   return IREC_OK;
@@ -427,7 +427,7 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));
   const int grid = (int)std::min<int64_t>(n_blocks, pl.grid_cap);
   A.dbg = ctx->d_dbg;
-  if (ctx->d_dbg) HIP_TRY(hipMemsetAsync(ctx->d_dbg, 0, 4096 * 8 * sizeof(unsigned long long), st));
+  if (ctx->d_dbg) HIP_TRY(hipMemsetAsync(ctx->d_dbg, 0, 4096 * 16 * sizeof(unsigned long long), st));
   if (pl.table) {
     for (int q = 0; q < 4; ++q) { A.tab[q] = nullptr; A.tab_dim[q] = -1; }
     for (int q = 0; q < pl.n_tab; ++q) {
@@ -442,18 +442,20 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
     HIP_TRY(irec::launch_encode_generic(A, grid, st));
   }
   if (ctx->d_dbg) { // diagnostic build only: synchronous read-back of the phase stamps
-    std::vector<unsigned long long> h((size_t)grid * 8);
+    std::vector<unsigned long long> h((size_t)grid * 16);
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipMemcpy(h.data(), ctx->d_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    double sum[8] = {0};
-    for (int w = 0; w < grid; ++w) for (int k = 0; k < 8; ++k) sum[k] += (double)h[(size_t)w * 8 + k];
+    double sum[16] = {0};
+    for (int w = 0; w < grid; ++w) for (int k = 0; k < 16; ++k) sum[k] += (double)h[(size_t)w * 16 + k];
     const double tot = sum[0] + sum[1] + sum[2] + sum[3];
     {
       int zero = 0; unsigned long long t0 = ~0ull, late = 0;
-      for (int w = 0; w < grid; ++w) { if (h[(size_t)w * 8 + 4] == 0) ++zero; else if (h[(size_t)w * 8 + 5] < t0) t0 = h[(size_t)w * 8 + 5]; }
-      for (int w = 0; w < grid; ++w) if (h[(size_t)w * 8 + 4] && h[(size_t)w * 8 + 5] - t0 > 100000ull) ++late; // > 1 ms at 100 MHz
+      for (int w = 0; w < grid; ++w) { if (h[(size_t)w * 16 + 4] == 0) ++zero; else if (h[(size_t)w * 16 + 5] < t0) t0 = h[(size_t)w * 16 + 5]; }
+      for (int w = 0; w < grid; ++w) if (h[(size_t)w * 16 + 4] && h[(size_t)w * 16 + 5] - t0 > 100000ull) ++late; // > 1 ms at 100 MHz
       fprintf(stderr, "[irec stamps] census: %d of %d workgroups coded no block, %llu started > 1 ms after the first\n", zero, grid, late);
     }
+    fprintf(stderr, "[irec stamps] top-B detail cycles/WG: combine %.0f, wait-for-keys barrier %.0f, wave-0 select %.0f, closing barrier %.0f\n",
+            sum[11] / grid, sum[8] / grid, sum[9] / grid, sum[10] / grid);
     fprintf(stderr, "[irec stamps] waves/workgroup %d, LDS %zu B\n",
             irec::fast_waves_for(p->n_beams, p->n_samples, pl.table), irec::fast_lds_for(p->n_beams, p->n_samples, pl.table));
     fprintf(stderr, "[irec stamps] %s grid=%d cycles/WG: prologue %.0f (%.1f%%) scoring %.0f (%.1f%%) select %.0f (%.1f%%) update %.0f (%.1f%%)\n",
@@ -496,6 +498,16 @@ irec_status irec_test_reduce_scatter(irec_context *ctx, const float *in, float *
   if (!ctx || !in || !out || (width != 64 && width != 32)) return fail(IREC_E_INVALID, "irec_test_reduce_scatter: bad arguments");
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(irec::launch_reduce_scatter_test(in, out, width, (hipStream_t)hip_stream));
+  return IREC_OK;
+}
+
+irec_status irec_test_select(irec_context *ctx, const float *scores, int32_t n, int32_t n_select, int32_t n_beams_cur,
+                             uint32_t *scratch_keys, int32_t *out_sel, void *hip_stream) {
+  if (!ctx || !scores || !scratch_keys || !out_sel || n < 1 || n_select < 1 || n_select > n || n_select > IREC_MAX_BEAMS ||
+      n_beams_cur < 1)
+    return fail(IREC_E_INVALID, "irec_test_select: bad arguments");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(irec::launch_select_test(scores, n, n_select, n_beams_cur, scratch_keys, out_sel, (hipStream_t)hip_stream));
   return IREC_OK;
 }
 

@@ -54,6 +54,7 @@ hipError_t launch_alpha_table(int64_t seed, int32_t S, int32_t D, int32_t K_tab,
                               hipStream_t st);
 hipError_t launch_decode(const DecArgs &A, int grid, hipStream_t st);
 hipError_t launch_uniform_int(int64_t seed, int64_t n, int32_t *out, hipStream_t st);
+hipError_t launch_select_test(const float *scores, int N, int Bnew, int Bcur, uint32_t *keys, int32_t *sel, hipStream_t st);
 hipError_t launch_reduce_scatter_test(const float *in, float *out, int width, hipStream_t st);
 
 } // namespace irec

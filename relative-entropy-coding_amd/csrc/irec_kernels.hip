@@ -30,6 +30,17 @@ __device__ __forceinline__ int64_t src_index(const EncArgs &A, int64_t base, int
   return base + (A.perm ? (int64_t)A.perm[pos + d] : (int64_t)(pos + d));
 }
 
+// Diagnostic phase stamps (only when EncArgs.dbg != nullptr; the values never reach an output of the coder).
+__device__ __forceinline__ unsigned long long stamp_now() { return __builtin_amdgcn_s_memtime(); }
+#define IREC_STAMP(slot)                                                    \
+  do {                                                                      \
+    if (A.dbg && tid == 0) {                                                \
+      const unsigned long long now_ = stamp_now();                          \
+      A.dbg[(size_t)blockIdx.x * 16 + (slot)] += now_ - stamp_prev;          \
+      stamp_prev = now_;                                                    \
+    }                                                                       \
+  } while (0)
+
 // Small per-workgroup LDS state shared by the encoders.
 struct SmallLds {
   union {                           // the two selection paths never run at the same time
@@ -57,14 +68,18 @@ constexpr size_t SMALL_LDS_BYTES = (sizeof(SmallLds) + 15) & ~(size_t)15;
 //    ~600 wave instructions and ONE barrier instead of Bnew barrier rounds.
 //  - otherwise: all waves scan the keys, one barrier per selected beam (element f owned by thread f % NT).
 template <int NT>
-__device__ __forceinline__ void select_topB(uint32_t *key, int N, int Bnew, int Bcur, SmallLds *sm) {
+__device__ __forceinline__ void select_topB(uint32_t *key, int N, int Bnew, int Bcur, SmallLds *sm,
+                                            unsigned long long *dbg = nullptr) {
   constexpr int NWV = NT / 64;
   const int tid = threadIdx.x;
   int32_t *sel_s = sm->sel_s, *sel_b = sm->sel_b;
+  unsigned long long t0 = dbg ? stamp_now() : 0ull;
   __syncthreads(); // keys written by all waves
+  if (dbg && tid == 0) { const unsigned long long t1 = stamp_now(); dbg[8] += t1 - t0; t0 = t1; } // wait for keys
   bool done = false;
   if (N <= 1024) {
     if (tid < 64) {
+      __builtin_amdgcn_s_setprio(3); // the whole workgroup waits for this wave: win issue arbitration on its SIMD
       const int nslots = (N + 63) >> 6;
       uint32_t k[16];
       uint32_t M = 0u;
@@ -111,8 +126,11 @@ __device__ __forceinline__ void select_topB(uint32_t *key, int N, int Bnew, int 
       } else {
         sm->misc[7] = 0; // pathological tie storm: fall back to the scan below
       }
+      __builtin_amdgcn_s_setprio(0);
+      if (dbg && tid == 0) { const unsigned long long t1 = stamp_now(); dbg[9] += t1 - t0; t0 = t1; } // wave-0 selection
     }
     __syncthreads();
+    if (dbg && tid == 0) { const unsigned long long t1 = stamp_now(); dbg[10] += t1 - t0; t0 = t1; } // closing barrier
     done = sm->misc[7] != 0;
   }
   if (done) return;
@@ -449,17 +467,6 @@ __device__ __forceinline__ float reduce_scatter(float (&v)[N0], int lane) {
   return v[0];
 }
 
-// Diagnostic phase stamps (only when EncArgs.dbg != nullptr; the values never reach an output of the coder).
-__device__ __forceinline__ unsigned long long stamp_now() { return __builtin_amdgcn_s_memtime(); }
-#define IREC_STAMP(slot)                                                    \
-  do {                                                                      \
-    if (A.dbg && tid == 0) {                                                \
-      const unsigned long long now_ = stamp_now();                          \
-      A.dbg[(size_t)blockIdx.x * 8 + (slot)] += now_ - stamp_prev;          \
-      stamp_prev = now_;                                                    \
-    }                                                                       \
-  } while (0)
-
 // The fast kernel addresses its LUT by ABSOLUTE LDS byte address (the table is the first thing in the dynamic LDS
 // region, which starts at 0 because the kernel has no static __shared__): saves one VALU add per proposal.
 typedef __attribute__((address_space(3))) const float lds_cfloat;
@@ -669,9 +676,9 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
 
     IREC_STAMP(0);
     if (A.dbg && tid == 0) {
-      A.dbg[(size_t)blockIdx.x * 8 + 4] += 1ull;                                       // blocks coded by this workgroup
-      if (A.dbg[(size_t)blockIdx.x * 8 + 5] == 0ull) A.dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime(); // first block
-      A.dbg[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+      A.dbg[(size_t)blockIdx.x * 16 + 4] += 1ull;                                       // blocks coded by this workgroup
+      if (A.dbg[(size_t)blockIdx.x * 16 + 5] == 0ull) A.dbg[(size_t)blockIdx.x * 16 + 5] = __builtin_amdgcn_s_memrealtime(); // first block
+      A.dbg[(size_t)blockIdx.x * 16 + 6] = __builtin_amdgcn_s_memrealtime();
     }
     int cur = 0, Bcur = 1;
     for (int t = 0; t < K; ++t) {
@@ -802,7 +809,8 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
       }
       } // sample passes
       const int Bnew = B < N ? B : N;
-      select_topB<NT>(key_s, N, Bnew, Bcur, sm); // first barrier inside orders key_s writes
+      if (A.dbg && tid == 0) { const unsigned long long now_ = stamp_now(); A.dbg[(size_t)blockIdx.x * 16 + 11] += now_ - stamp_prev; } // combine
+      select_topB<NT>(key_s, N, Bnew, Bcur, sm, A.dbg ? A.dbg + (size_t)blockIdx.x * 16 : nullptr); // first barrier inside orders key_s writes
       IREC_STAMP(2);
       // ---------------- new hashes / back-pointers (beam_search_coder.py:94-95) ----------------
       if (tid < Bnew) {
@@ -814,6 +822,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
       }
       // ---------------- gather the surviving beams (beam_search_coder.py:92-93), prepare the next step ----------------
       const bool last = (t == K - 1);
+      __builtin_amdgcn_s_setprio(2); // serial phase: ahead of the co-resident workgroup's scoring waves
       if (active) {
         const float sa_t[4] = {sa[0], sa[1], sa[2], sa[3]};   // this step's sample scale
         const float *bold = beams_g + ((size_t)cur * NB) * FAST_MAX_DIM + d0;
@@ -900,6 +909,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
         }
       }
       __syncthreads();
+      __builtin_amdgcn_s_setprio(0);
       IREC_STAMP(3);
       if (!last && tid < Bnew) {
         float cb = cpart_s[tid];
@@ -991,6 +1001,15 @@ __global__ void uniform_int_kernel(int64_t seed, int64_t n, int32_t *out) {
     out[e] = 1 + (int32_t)draw_rm1(ss, (uint64_t)e);
 }
 
+// scores[N] float -> sel[2 * Bnew] = (sample, beam) of the Bnew best candidates in order (tie -> lower flat index)
+__global__ __launch_bounds__(256) void select_test_kernel(const float *scores, int N, int Bnew, int Bcur, uint32_t *keys,
+                                                          int32_t *sel) {
+  __shared__ SmallLds sm;
+  for (int f = threadIdx.x; f < N; f += 256) keys[f] = score_key(scores[f]);
+  select_topB<256>(keys, N, Bnew, Bcur, &sm);
+  if (threadIdx.x < Bnew) { sel[2 * threadIdx.x] = sm.sel_s[threadIdx.x]; sel[2 * threadIdx.x + 1] = sm.sel_b[threadIdx.x]; }
+}
+
 // in: [64 lanes][width] floats; out[lane] = canonical-tree total of column (lane >> shift)
 __global__ void reduce_scatter_test_kernel(const float *in, float *out, int width) {
   const int lane = threadIdx.x & 63;
@@ -1080,6 +1099,11 @@ hipError_t launch_decode(const DecArgs &A, int grid, hipStream_t st) {
 hipError_t launch_uniform_int(int64_t seed, int64_t n, int32_t *out, hipStream_t st) {
   const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
   hipLaunchKernelGGL(uniform_int_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, st, seed, n, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_select_test(const float *scores, int N, int Bnew, int Bcur, uint32_t *keys, int32_t *sel, hipStream_t st) {
+  hipLaunchKernelGGL(select_test_kernel, dim3(1), dim3(256), 0, st, scores, N, Bnew, Bcur, keys, sel);
   return hipGetLastError();
 }
 

@@ -54,6 +54,7 @@ SIGNATURES = {
     "irec_rec_unpack_bits": (_i64, [_vp, _i64, _vp, _i64]),
     "irec_device_uniform_int": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "irec_test_reduce_scatter": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp]),
+    "irec_test_select": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "irec_device_tables": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                           ctypes.POINTER(_vp)]),
 }

@@ -183,6 +183,14 @@ class Engine:
                    "irec_device_uniform_int")
         return out
 
+    def test_select(self, scores, n_select, n_beams_cur):
+        n = scores.numel()
+        keys = torch.empty(n, dtype=torch.int32, device=self.device)
+        sel = torch.empty((n_select, 2), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.irec_test_select(self.ctx, _ptr(scores), n, int(n_select), int(n_beams_cur), _ptr(keys),
+                                             _ptr(sel), self._stream()), "irec_test_select")
+        return sel
+
     def test_reduce_scatter(self, x):
         width = x.shape[1]
         out = torch.empty(64, dtype=torch.float32, device=self.device)

@@ -50,6 +50,35 @@ def test_reduce_scatter_is_the_canonical_tree(engine, width):
         assert got[lane] == part[0], (lane, got[lane], part[0])
 
 
+def _ref_select(scores, n_select, bcur):
+    # tf.argsort(DESCENDING) == top_k: value descending, ties -> lower index; NaN after every number
+    keyed = sorted(range(len(scores)), key=lambda i: (np.isnan(scores[i]), -scores[i] if not np.isnan(scores[i]) else 0.0, i))
+    return [(i // bcur, i % bcur) for i in keyed[:n_select]]
+
+
+@pytest.mark.parametrize("case", ["random720", "tiny", "ties_small", "tie_storm", "nan_inf_zero", "n1024", "n4440_scan"])
+def test_top_b_selection(engine, case):
+    rng = np.random.default_rng(5)
+    if case == "random720":
+        sc, B, bcur = rng.standard_normal(720).astype(np.float32) * 30, 20, 20
+    elif case == "tiny":
+        sc, B, bcur = rng.standard_normal(36).astype(np.float32), 20, 1
+    elif case == "ties_small":
+        sc, B, bcur = rng.integers(-3, 3, 720).astype(np.float32), 20, 20        # many exact ties, resolved by index
+    elif case == "tie_storm":
+        sc, B, bcur = np.full(720, -7.25, np.float32), 20, 20                      # > 64 survivors -> fallback scan
+    elif case == "nan_inf_zero":
+        sc = rng.standard_normal(300).astype(np.float32)
+        sc[::7] = np.nan; sc[3] = np.inf; sc[11] = -np.inf; sc[20] = 0.0; sc[21] = -0.0
+        B, bcur = 30, 10
+    elif case == "n1024":
+        sc, B, bcur = rng.standard_normal(1024).astype(np.float32), 64, 32
+    else:
+        sc, B, bcur = rng.standard_normal(4440).astype(np.float32), 30, 30
+    got = engine.test_select(torch.from_numpy(sc).cuda(), B, bcur).cpu().numpy().tolist()
+    assert [tuple(g) for g in got] == _ref_select(sc.tolist(), B, bcur)
+
+
 def test_in_kernel_philox_stream(engine, oracle):
     for seed, n in [(42, 36 * 1000), (43, 4097), (0, 64), (2 ** 31 - 1, 64), (69420 + 3, 403)]:
         got = engine.device_uniform_int(seed, n).cpu().numpy()
