@@ -683,7 +683,10 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
     int cur = 0, Bcur = 1;
     for (int t = 0; t < K; ++t) {
       const StepSeed ss = make_step_seed(A.seed + t);
-      const uint16_t *tab_t = TABLE ? tab + (size_t)t * S * Dp + d0 : nullptr; // row s at + s * Dp
+      // row s at + s * Dp.  Lanes past the padded row end (d0 >= Dp, all their dims invalid) read the row START instead:
+      // their coefficients are zero, but the offsets they gather with must still be table entries (finite z) --
+      // reading past the last row would hand them arbitrary bits, and 0 * NaN is not 0.
+      const uint16_t *tab_t = TABLE ? tab + (size_t)t * S * Dp + (d0 < Dp ? d0 : 0) : nullptr;
       uint32_t bet[NB];
 #pragma unroll
       for (int b = 0; b < NB; ++b) bet[b] = __builtin_amdgcn_readfirstlane(beta4[cur * 64 + (b < Bcur ? b : 0)]);

@@ -1,0 +1,58 @@
+"""Randomised parity soak (GPU box): random block shapes / coder settings / statistics, every encoder variant against
+the CPU oracle.  Not part of the pytest suite (minutes of oracle time); prints a summary and exits non-zero on mismatch."""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "relative-entropy-coding_amd")]
+import irec
+from oracle import oracle as O
+
+n_cases = int(os.environ.get("SOAK_CASES", "150"))
+rng = np.random.default_rng(int(os.environ.get("SOAK_SEED", "1")))
+eng = irec.get_engine()
+bad, done, t0 = [], 0, time.time()
+stats = {"K": [], "evals": 0}
+for case in range(n_cases):
+    D = int(rng.choice([1, 2, 3, 5, 63, 64, 65, 192, 255, 256, 257, 511, 777, 1000, 1023, 1024, int(rng.integers(1, 1025))]))
+    B = int(rng.choice([1, 2, 7, 10, 11, 20, 21, 30, 32, int(rng.integers(1, 33))]))
+    omega = float(rng.choice([1.0, 2.0, 3.0, 4.0, float(rng.uniform(0.7, 5.0))]))
+    eps1 = float(rng.choice([1.0, 1.2, 1.5]))
+    S = int(np.exp(omega * eps1))
+    if S * B * D > 6e6:          # keep the oracle fast
+        continue
+    style = rng.integers(0, 5)
+    mp = rng.normal(0, 1, D); lsp = rng.normal(0, 0.5, D); sp = np.exp(lsp)
+    if style == 0:   # benign
+        mq = mp + sp * rng.normal(0, 0.2, D); sq = np.exp(lsp - np.abs(rng.normal(0, 0.05, D)))
+    elif style == 1: # tight posteriors -> many partitions
+        mq = mp + sp * rng.normal(0, 1.0, D); sq = sp * rng.uniform(0.05, 0.5, D)
+    elif style == 2: # posterior wider than prior on some dims
+        mq = mp + sp * rng.normal(0, 0.3, D); sq = sp * rng.uniform(0.5, 1.5, D)
+    elif style == 3: # extreme scales
+        sp = np.exp(rng.normal(0, 3.0, D)); mq = mp + sp * rng.normal(0, 0.5, D); sq = sp * rng.uniform(0.2, 1.0, D)
+    else:            # nearly identical q and p (K small, near ties)
+        mq = mp + sp * rng.normal(0, 0.02, D); sq = sp * np.exp(rng.normal(0, 0.01, D))
+    mq, sq, mp, sp = (a.astype(np.float32) for a in (mq, sq, mp, sp))
+    K = O.num_aux(O.block_kl(mq, sq, mp, sp), omega)
+    if K > 300 or K * S * B * D > 4e8:
+        continue
+    seed = int(rng.integers(0, 2 ** 31))
+    ridx, rs = O.encode_block(mq, sq, mp, sp, seed, omega, S, B, max_K=512)
+    q = torch.distributions.Normal(torch.from_numpy(mq[None]).cuda(), torch.from_numpy(sq[None]).cuda(), validate_args=False)
+    p = torch.distributions.Normal(torch.from_numpy(mp[None]).cuda(), torch.from_numpy(sp[None]).cuda(), validate_args=False)
+    for variant in ("table", "fused", "generic"):
+        c = irec.BeamSearchCoder(kl_per_partition=omega, n_beams=B, extra_samples=eps1)
+        c.n_samples = S
+        c.force_generic = variant == "generic"; c.fused_philox = variant == "fused"
+        idx, sample = c.encode(q, p, seed=seed)
+        ok = [int(i) for i in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
+        if ok and K:
+            ok = torch.equal(c.decode(p, idx, seed=seed), sample)
+        if not ok:
+            bad.append((case, variant, D, B, S, omega, K, style, seed))
+    done += 1; stats["K"].append(K); stats["evals"] += S * D * (1 + max(K - 1, 0) * B)
+print(f"soak: {done} random blocks x 3 variants in {time.time() - t0:.0f} s; K range {min(stats['K'])}..{max(stats['K'])}; "
+      f"{stats['evals'] / 1e9:.2f} G proposal evals checked; mismatches: {len(bad)}")
+for b in bad[:20]:
+    print("MISMATCH case=%d variant=%s D=%d B=%d S=%d omega=%.3f K=%d style=%d seed=%d" % b)
+sys.exit(1 if bad else 0)

@@ -208,6 +208,23 @@ def test_stress_config_multi_pass_eight_wave_path(engine, oracle, variant):
     assert torch.equal(c.decode(_normal(mp[None], sp[None]), idx, seed=42), sample)
 
 
+@pytest.mark.parametrize("D", [5, 65, 130, 250])
+def test_ragged_dims_with_idle_lanes_many_partitions(engine, oracle, D):
+    # found by scripts/soak_parity.py: with the proposal table, lanes beyond the padded row end must not read past the
+    # row (0 * garbage-NaN poisoned the scores).  Tight posteriors -> K ~ 100 steps, S = 2 < B = 27.
+    rng = np.random.default_rng(D)
+    mp = rng.normal(0, 1, D); sp = np.exp(rng.normal(0, 0.5, D))
+    mq = mp + sp * rng.normal(0, 1.0, D); sq = sp * rng.uniform(0.05, 0.5, D)
+    mq, sq, mp, sp = (a.astype(np.float32) for a in (mq, sq, mp, sp))
+    for variant in VARIANTS:
+        c = _coder(1.0, 27, 1.0, variant=variant)
+        assert c.n_samples == 2
+        idx, sample = c.encode(_normal(mq[None], sq[None]), _normal(mp[None], sp[None]), seed=949676964)
+        ridx, rs = oracle.encode_block(mq, sq, mp, sp, 949676964, 1.0, 2, 27, max_K=2048)
+        assert [int(i) for i in idx] == ridx, variant
+        assert np.array_equal(sample.cpu().numpy()[0], rs), variant
+
+
 def test_zero_kl_block(engine):
     mp = torch.tensor([[0.3, -1.0, 2.0]]); sp = torch.tensor([[1.0, 2.0, 0.5]])
     c = _coder(3.0, 10, 1.0)
