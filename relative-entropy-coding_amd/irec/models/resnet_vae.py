@@ -1,0 +1,177 @@
+"""PyTorch-ROCm host shim of the reference's bidirectional ResNet VAE (rec/models/resnet_vae.py) -- ONLY what the
+compression path touches: the block / model constructors with the reference's keyword surface, the inference pass,
+and the sequential generative pass that hands each residual block's posterior and prior to `coder.encode`
+(resnet_vae.py:462-476, 803-836) or `coder.decode`.
+
+Not a re-implementation of the model family: the convolutions are stock `torch.nn.Conv2d` (the reference's
+weight-normalised `ReparameterizedConv2D` with data-dependent init, IAF posteriors, likelihoods, EMA and training are
+out of scope -- no checkpoints or datasets exist in the reference tree), so weights are random-init.  What
+the shim pins is the hand-off: tensors are presented to the coder in the reference's NHWC order, the residual blocks
+are coded strictly in sequence (the prior of block n+1 depends on the coded latent of block n), and the keyword
+arguments (`sampler`, `sampler_args`, `coder_args`, `kl_per_partition`, `encoder_args`, `decoder_args`) keep their
+names and meaning.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..coding import BeamSearchCoder
+
+
+class ModelError(Exception):
+    """rec/models/resnet_vae.py (ModelError)."""
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def _nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+class _Normal:
+    """Duck-typed distribution: the coder reads only .loc and .scale (coder.py:427-430)."""
+
+    def __init__(self, loc, scale):
+        self.loc, self.scale = loc, scale
+
+
+class BidirectionalResidualBlock(nn.Module):
+    """resnet_vae.py:20-497 (compression-relevant subset)."""
+
+    def __init__(self, stochastic_filters, deterministic_filters, sampler, sampler_args={}, coder_args={},
+                 distribution="gaussian", kernel_size=(3, 3), use_iaf=False, is_last=False, kl_per_partition=8.,
+                 use_sig_convs=False, name="bidirectional_resnet_block", **kwargs):
+        super().__init__()
+        if distribution != "gaussian":
+            raise ValueError("Distribution must be 'gaussian' on the beam-search path, "
+                             f"but {distribution} was given!")
+        if use_iaf or use_sig_convs:
+            raise ModelError("IAF posteriors / SignalConv2D are outside the compression shim")
+        self.name = name
+        self.stochastic_filters, self.deterministic_filters = stochastic_filters, deterministic_filters
+        self.is_last = is_last
+        pad = (kernel_size[0] // 2, kernel_size[1] // 2)
+
+        def conv(cin, cout):
+            return nn.Conv2d(cin, cout, kernel_size, padding=pad)
+
+        d, s = deterministic_filters, stochastic_filters
+        if not is_last:
+            self.infer_conv1, self.infer_conv2 = conv(d, d), conv(d, d)
+        self.infer_posterior_loc_head, self.infer_posterior_log_scale_head = conv(d, s), conv(d, s)
+        self.gen_conv1, self.gen_conv2 = conv(d, d), conv(d + s, d)
+        self.prior_loc_head, self.prior_log_scale_head = conv(d, s), conv(d, s)
+        self.gen_posterior_loc_head, self.gen_posterior_log_scale_head = conv(d, s), conv(d, s)
+        self.infer_posterior_loc = self.infer_posterior_log_scale = 0.
+        self.gen_posterior_loc = self.gen_posterior_log_scale = 0.
+        self.posterior = self.prior = None
+        # ---- stuff for compression (resnet_vae.py:118-141) ----
+        if sampler == "beam_search":
+            self.coder = BeamSearchCoder(kl_per_partition=kl_per_partition, n_beams=sampler_args['n_beams'],
+                                         extra_samples=sampler_args['extra_samples'], name=f"encoder_for_{self.name}",
+                                         **coder_args)
+        elif sampler in ("rejection", "importance"):
+            raise ModelError(f"sampler '{sampler}' is outside the beam-search path of this build")
+        else:
+            raise ModelError("Sampler must be one of ['rejection', 'importance', 'beam_search'],"
+                             f"but got {sampler}!")
+
+    @property
+    def posterior_loc(self):
+        return self.infer_posterior_loc + self.gen_posterior_loc
+
+    @property
+    def posterior_scale(self):
+        return torch.exp(self.infer_posterior_log_scale + self.gen_posterior_log_scale)
+
+    def forward(self, tensor, inference_pass=True, encoder_args=None, decoder_args=None):
+        """resnet_vae.py:372-497."""
+        inp = tensor
+        tensor = F.elu(tensor)
+        indices = None
+        if inference_pass:
+            self.infer_posterior_loc = self.infer_posterior_loc_head(tensor)
+            self.infer_posterior_log_scale = self.infer_posterior_log_scale_head(tensor)
+            if not self.is_last:
+                tensor = self.infer_conv2(F.elu(self.infer_conv1(tensor)))
+        else:
+            prior_loc = self.prior_loc_head(tensor)
+            prior_scale = torch.exp(self.prior_log_scale_head(tensor))
+            self.prior = _Normal(_nhwc(prior_loc), _nhwc(prior_scale))            # coder sees NHWC, as in the reference
+            if encoder_args is None and decoder_args is None:
+                raise ModelError("training / sampling passes are outside the compression shim")
+            if encoder_args is not None:                                          # :462-470
+                self.gen_posterior_loc = self.gen_posterior_loc_head(tensor)
+                self.gen_posterior_log_scale = self.gen_posterior_log_scale_head(tensor)
+                self.posterior = _Normal(_nhwc(self.posterior_loc), _nhwc(self.posterior_scale))
+                indices, latent_code = self.coder.encode(self.posterior, self.prior, **encoder_args)
+            else:                                                                 # :475-476
+                latent_code = self.coder.decode(self.prior, **decoder_args)
+            latent_code = _nchw(latent_code)
+            tensor = self.gen_conv1(tensor)
+            tensor = torch.cat([tensor, latent_code], dim=1)
+            tensor = self.gen_conv2(F.elu(tensor))
+        tensor = inp + 0.1 * tensor
+        if encoder_args is not None:
+            return indices, tensor
+        return tensor
+
+
+class BidirectionalResNetVAE(nn.Module):
+    """resnet_vae.py:512-860 (compression-relevant subset)."""
+
+    def __init__(self, num_res_blocks, sampler, sampler_args={}, coder_args={}, likelihood_function="discretized_logistic",
+                 learn_likelihood_scale=True, first_kernel_size=(5, 5), first_strides=(2, 2), kernel_size=(3, 3),
+                 strides=(1, 1), deterministic_filters=160, stochastic_filters=32, use_iaf=False, kl_per_partition=8.,
+                 latent_size="variable", ema_decay=0.999, name="resnet_vae", **kwargs):
+        super().__init__()
+        self.sampler_name = str(sampler)
+        self.num_res_blocks = num_res_blocks
+        self.deterministic_filters, self.stochastic_filters = deterministic_filters, stochastic_filters
+        self.kl_per_partition = kl_per_partition
+        pad = (first_kernel_size[0] // 2, first_kernel_size[1] // 2)
+        self.first_infer_conv = nn.Conv2d(3, deterministic_filters, first_kernel_size, stride=first_strides, padding=pad)
+        self.last_gen_conv = nn.ConvTranspose2d(deterministic_filters, 3, first_kernel_size, stride=first_strides,
+                                                padding=pad, output_padding=(first_strides[0] - 1, first_strides[1] - 1))
+        self.residual_blocks = nn.ModuleList([
+            BidirectionalResidualBlock(stochastic_filters=stochastic_filters, deterministic_filters=deterministic_filters,
+                                       sampler=self.sampler_name, sampler_args=sampler_args, coder_args=coder_args,
+                                       kernel_size=kernel_size, is_last=res_block_idx == 0, use_iaf=use_iaf,
+                                       kl_per_partition=kl_per_partition, name=f"resnet_block_{res_block_idx}")
+            for res_block_idx in range(num_res_blocks)])
+        self._generative_base = nn.Parameter(torch.zeros(deterministic_filters))
+
+    def generative_base(self, batch_size, height, width):
+        """resnet_vae.py:619-623."""
+        return self._generative_base.reshape(1, -1, 1, 1).expand(batch_size, -1, height // 2, width // 2).contiguous()
+
+    def _finish(self, tensor):
+        reconstruction = self.last_gen_conv(F.elu(tensor))
+        return torch.clamp(reconstruction, -0.5 + 1. / 512., 0.5 - 1. / 512.)
+
+    @torch.no_grad()
+    def compress(self, image, seed, update_sampler=False):
+        """resnet_vae.py:803-836.  image: [1, 3, H, W] in [-0.5, 0.5].  Returns (block_indices, reconstruction)."""
+        batch_size, _, height, width = image.shape
+        tensor = self.first_infer_conv(image)
+        for resnet_block in list(self.residual_blocks)[::-1]:                 # inference pass, reverse order (:811-813)
+            tensor = resnet_block(tensor, inference_pass=True)
+        tensor = self.generative_base(batch_size=batch_size, width=width, height=height)
+        block_indices = []
+        for resnet_block in self.residual_blocks:                             # strictly sequential (:821-826)
+            indices, tensor = resnet_block(tensor, inference_pass=False,
+                                           encoder_args={"seed": seed, "update_sampler": update_sampler})
+            block_indices.append(indices)
+        return block_indices, self._finish(tensor)
+
+    @torch.no_grad()
+    def decompress(self, block_indices, seed, image_shape):
+        """The generative pass driven by the stored indices.  (The reference's own decompress, resnet_vae.py:844-860,
+        is an unfinished stub; this is the pass its decoder_args plumbing implies.)"""
+        batch_size, _, height, width = image_shape
+        tensor = self.generative_base(batch_size=batch_size, width=width, height=height)
+        for resnet_block, indices in zip(self.residual_blocks, block_indices):
+            tensor = resnet_block(tensor, inference_pass=False, decoder_args={"seed": seed, "indices": indices})
+        return self._finish(tensor)

@@ -1,0 +1,77 @@
+"""Model call-surface shim: constructor surface on CPU; on the GPU the sequential res-block <->
+coder hand-off, checked in situ against the oracle and by a compress -> decompress round trip."""
+import inspect
+
+import numpy as np
+import pytest
+import torch
+
+
+def _model(device="cpu", blocks=3, det=16, sto=8):
+    from irec.models import BidirectionalResNetVAE
+    torch.manual_seed(0)
+    m = BidirectionalResNetVAE(num_res_blocks=blocks, sampler="beam_search",
+                               sampler_args={"n_beams": 20, "extra_samples": 1.2}, coder_args={"block_size": 1000},
+                               deterministic_filters=det, stochastic_filters=sto, kl_per_partition=3.)
+    with torch.no_grad():   # random-init weights (no checkpoints exist); keep posteriors close to priors so K stays small
+        for b in m.residual_blocks:
+            for head in (b.gen_posterior_loc_head, b.gen_posterior_log_scale_head, b.infer_posterior_loc_head,
+                         b.infer_posterior_log_scale_head, b.prior_loc_head, b.prior_log_scale_head):
+                head.weight.mul_(0.3)
+        m._generative_base.normal_(0, 0.5)
+    return m.to(device).eval()
+
+
+def test_constructor_surface_matches_reference():
+    from irec.models import BidirectionalResNetVAE, BidirectionalResidualBlock, ModelError
+    blk = list(inspect.signature(BidirectionalResidualBlock.__init__).parameters)
+    assert blk[1:6] == ["stochastic_filters", "deterministic_filters", "sampler", "sampler_args", "coder_args"]
+    assert {"kernel_size", "is_last", "kl_per_partition", "name"} <= set(blk)
+    vae = list(inspect.signature(BidirectionalResNetVAE.__init__).parameters)
+    assert vae[1:5] == ["num_res_blocks", "sampler", "sampler_args", "coder_args"]
+    assert {"first_kernel_size", "first_strides", "deterministic_filters", "stochastic_filters", "kl_per_partition"} <= set(vae)
+    assert list(inspect.signature(BidirectionalResNetVAE.compress).parameters) == ["self", "image", "seed", "update_sampler"]
+    m = _model()
+    assert [b.is_last for b in m.residual_blocks] == [True, False, False]
+    assert m.residual_blocks[0].coder.n_samples == 36 and m.residual_blocks[0].coder.block_size == 1000
+    assert m.residual_blocks[2].coder.name == "encoder_for_resnet_block_2"
+    with pytest.raises(ModelError, match="Sampler must be one of"):
+        BidirectionalResNetVAE(num_res_blocks=1, sampler="nope")
+    with pytest.raises(ModelError):
+        BidirectionalResNetVAE(num_res_blocks=1, sampler="rejection")
+
+
+@pytest.mark.gpu
+def test_compress_decompress_round_trip_and_in_situ_parity(engine, oracle):
+    m = _model("cuda")
+    torch.manual_seed(1)
+    image = (torch.rand(1, 3, 32, 32, device="cuda") - 0.5)
+    # capture what each residual block hands to its coder
+    seen = []
+    for b in m.residual_blocks:
+        orig = b.coder.encode
+
+        def spy(target_dist, coding_dist, seed, _orig=orig, **kw):
+            out = _orig(target_dist, coding_dist, seed, **kw)
+            seen.append((target_dist.loc.clone(), target_dist.scale.clone(), coding_dist.loc.clone(),
+                         coding_dist.scale.clone(), out))
+            return out
+        b.coder.encode = spy
+    block_indices, recon = m.compress(image, seed=42)
+    assert len(block_indices) == 3 and all(len(bi) == 3 for bi in block_indices)      # 2048 dims -> 1000 + 1000 + 48
+    assert recon.shape == image.shape and torch.isfinite(recon).all()
+    assert len(seen) == 3
+    for ql, qs, pl, ps, (idx, sample) in seen:                                         # NHWC, batch 1, as in the reference
+        assert ql.shape == (1, 16, 16, 8)
+        ridx, rs = oracle.encode_tensor(ql.cpu().numpy(), qs.cpu().numpy(), pl.cpu().numpy(), ps.cpu().numpy(), 42, 3.0,
+                                        36, 20, block_size=1000)
+        assert idx == ridx
+        assert np.array_equal(sample.cpu().numpy(), rs)
+    for b in m.residual_blocks:
+        del b.coder.encode
+    recon2 = m.decompress(block_indices, seed=42, image_shape=image.shape)
+    assert torch.equal(recon2, recon)                                                   # decoder reproduces the encoder's pass
+    # sequential dependence: a different latent in block 0 changes the prior block 1 sees
+    alt = [[list(ix) for ix in bi] for bi in block_indices]
+    alt[0][0][0] = (alt[0][0][0] + 1) % 36
+    assert not torch.equal(m.decompress(alt, seed=42, image_shape=image.shape), recon)
