@@ -75,3 +75,31 @@ def test_compress_decompress_round_trip_and_in_situ_parity(engine, oracle):
     alt = [[list(ix) for ix in bi] for bi in block_indices]
     alt[0][0][0] = (alt[0][0][0] + 1) % 36
     assert not torch.equal(m.decompress(alt, seed=42, image_shape=image.shape), recon)
+
+
+@pytest.mark.gpu
+def test_lossy_two_level_compress_file_decompress(engine, tmp_path):
+    # BASELINE config 4 settings (B = 10, Omega = 3, eps = 0 -> S = 20, block_size 1000, max_index 20) on a 128 x 192 crop:
+    # level 2 = [1, 2, 3, 128] (768 dims, 1 block), level 1 = [1, 8, 12, 196] (18 816 dims, 19 blocks)
+    import irec
+    from irec.models import Large2LevelVAE
+    torch.manual_seed(3)
+    m = Large2LevelVAE().cuda().eval()
+    with torch.no_grad():
+        for mod in (m.analysis_transform[-1], m.hyper_analysis_transform[-1], m.hyper_synthesis_transform[-1],
+                    m._prior_loc_head, m._prior_log_scale_head, m._level_1_posterior_loc_combiner,
+                    m._level_1_posterior_log_scale_combiner):
+            mod.weight.mul_(0.2)
+    sampler = irec.BeamSearchCoder(kl_per_partition=3., n_beams=10, extra_samples=1., block_size=1000)
+    image = torch.rand(128, 192, 3, device="cuda") - 0.5
+    path = str(tmp_path / "kodak_crop.rec")
+    recon = m.compress(path, image, seed=42, sampler=sampler, block_size=1000, max_index=20)
+    assert recon.shape == (1, 3, 128, 192) and torch.isfinite(recon).all()
+    seed, shape, bs, block_indices = irec.io.read_compressed_code(path)
+    assert (seed, shape, bs) == (42, (128, 192, 3), 1000)
+    assert [len(b) for b in block_indices] == [1, 19]
+    assert m.level_1_posterior.loc.shape == (1, 8, 12, 196) and m.level_2_posterior.loc.shape == (1, 2, 3, 128)
+    recon2 = m.decompress(path, sampler)
+    assert torch.equal(recon2, recon)
+    import os
+    assert os.path.getsize(path) < 4000          # a few hundred indices, arithmetic coded
