@@ -286,3 +286,61 @@ def test_full_size_properties(engine, oracle, flags):
         row = lay.natural[t * lay.blocks_per_tensor + b]
         assert ih[row, :Kh[row]].tolist() == ridx
         assert np.array_equal(sh[t][g], rs)
+
+
+def _full_size_check(engine, oracle, n_t, n, bs, omega, eps1, B, n_oracle_blocks, gen_seed=5000):
+    """encode -> decode round trip on every dim, index ranges, K == ceil(KL / Omega) from the KL kernel, run-to-run
+    determinism, and a random subset of blocks against the oracle."""
+    S = oracle.n_samples(omega, eps1)
+    g = torch.Generator(device="cuda"); g.manual_seed(gen_seed)
+    shape = (n_t, n)
+    mp = torch.randn(shape, generator=g, device="cuda")
+    lsp = 0.25 * torch.randn(shape, generator=g, device="cuda")
+    sp = torch.exp(lsp)
+    mq = mp + sp * 0.2 * torch.randn(shape, generator=g, device="cuda")
+    sq = torch.exp(lsp - (0.05 * torch.randn(shape, generator=g, device="cuda")).abs())
+    lay = engine.layout(n_t, n, bs, 42)
+    params = engine.params(omega, S, B)
+    K, idx, sample = engine.encode_blocks(params, lay, mq, sq, mp, sp, 42, 48)
+    Kh = K.cpu().numpy()
+    assert Kh.min() >= 1 and Kh.max() <= 48
+    assert torch.equal(engine.decode_blocks(params, lay, mp, sp, 42, K, idx), sample)
+    _, K_kl = engine.block_kl(params, lay, mq, sq, mp, sp)
+    assert torch.equal(K_kl, K)
+    ih = idx.cpu().numpy()
+    valid = np.arange(ih.shape[1])[None, :] < Kh[:, None]
+    assert (ih[valid] >= 0).all() and (ih[valid] < S).all()
+    K2, idx2, sample2 = engine.encode_blocks(params, lay, mq, sq, mp, sp, 42, 48)
+    assert torch.equal(K2, K) and torch.equal(sample2, sample) and np.array_equal(idx2.cpu().numpy()[valid], ih[valid])
+    perm = oracle.tf_shuffle_perm(42, n)
+    blocks = oracle.split_blocks(n, bs)
+    rng = np.random.default_rng(1)
+    host = [t.cpu().numpy() for t in (mq, sq, mp, sp)]
+    sh = sample.cpu().numpy()
+    for t, b in zip(rng.integers(0, n_t, n_oracle_blocks), rng.integers(0, len(blocks), n_oracle_blocks)):
+        lo, hi = blocks[b]
+        gsel = perm[lo:hi]
+        ridx, rs = oracle.encode_block(*(h[t][gsel] for h in host), 42, omega, S, B)
+        row = lay.natural[t * lay.blocks_per_tensor + b]
+        assert ih[row, :Kh[row]].tolist() == ridx
+        assert np.array_equal(sh[t][gsel], rs)
+    return Kh
+
+
+def test_config3_300_images_full_size(engine, oracle):
+    # BASELINE configs[2]: 300 Cifar10-shaped images x 24 latent tensors [16,16,32] each = 7200 latents, 64 800 blocks
+    Kh = _full_size_check(engine, oracle, 300 * 24, 8192, 1000, 3.0, 1.2, 20, n_oracle_blocks=10)
+    assert len(Kh) == 300 * 24 * 9
+
+
+def test_config4_kodak_shapes_full_size(engine, oracle):
+    # BASELINE configs[3]: Kodak 768 x 512, level 2 [1,8,12,128] = 12 288 dims (13 blocks), level 1 [1,32,48,196] =
+    # 301 056 dims (302 blocks); B = 10, Omega = 3, eps = 0 -> S = 20
+    Kh2 = _full_size_check(engine, oracle, 1, 12288, 1000, 3.0, 1.0, 10, n_oracle_blocks=4, gen_seed=61)
+    Kh1 = _full_size_check(engine, oracle, 1, 301056, 1000, 3.0, 1.0, 10, n_oracle_blocks=6, gen_seed=62)
+    assert len(Kh2) == 13 and len(Kh1) == 302
+
+
+def test_config5_stress_full_size(engine, oracle):
+    # BASELINE configs[4]: ImageNet32 RVAE latents, B = 30, Omega = 5 (S = 148): 4440 candidates per step
+    _full_size_check(engine, oracle, 96, 8192, 1000, 5.0, 1.0, 30, n_oracle_blocks=6, gen_seed=63)
