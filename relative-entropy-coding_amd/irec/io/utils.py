@@ -1,44 +1,48 @@
-"""The `.rec` container of the reference (rec/io/utils.py:7-215): struct header + arithmetic-coded streams of
-(number of auxiliary variables per block, sample indices) per residual block.  Same signatures, same bytes."""
-import ctypes
+"""The `.rec` container (wire format of the reference, rec/io/utils.py:7-215).
+
+Layout, all little-endian native `struct` fields as the reference writes them:
+
+    static header  'IIIIIHHHH'   seed, block_size, max_index, height, width, channels,
+                                 uses_num_aux_var_counts_file, uses_index_counts_file, R   (R = residual blocks)
+    dynamic header 4 x R x 'I'   blocks per residual block | byte length of each "count" stream |
+                                 byte length of each index stream | largest partition count per residual block
+    R count streams, then R index streams
+
+A stream is an arithmetic-coded message (values + 1, terminated by symbol 0; model = counts of 1 for the terminator and
+101 / 1001 for everything else) with a marker 1 bit in front, right-aligned in big-endian bytes.  The entropy coder
+is the C++ one of libirec_hip.so (irec.io.ArithmeticCoder).  Bytes are identical to the reference's writer
+(tests/test_rec_io.py).
+"""
 import struct
+from dataclasses import dataclass
+from typing import List, Sequence, Tuple
 
 import numpy as np
 
 from .. import _lib
 from .entropy_coding import ArithmeticCoder
 
-STATIC_HEADER = "IIIIIHHHH"  # seed, block_size, max_index, h, w, c, 2 flags, num_res_blocks (utils.py:81-95)
+_STATIC = struct.Struct("IIIIIHHHH")
 
 
-def _index_counts(max_index):
-    counts = np.ones(max_index + 1, dtype=np.int64)   # utils.py:31-35
-    counts[1:] += 1000
-    return counts
+def _uniform_model(n_values: int, weight: int) -> np.ndarray:
+    """Terminator count 1, every value symbol `1 + weight` (utils.py:31-35 with weight 1000, :41-47 with weight 100)."""
+    model = np.full(n_values + 1, 1 + weight, dtype=np.int64)
+    model[0] = 1
+    return model
 
 
-def _nav_counts(nav_max):
-    counts = np.ones(nav_max + 2, dtype=np.int64)     # utils.py:41-47
-    counts[1:] += 100
-    return counts
-
-
-def _to_message(msg):
-    return np.concatenate([np.asarray(msg, dtype=np.int64).reshape(-1) + 1, [0]], axis=0)  # utils.py:58-59
-
-
-def _pack(code):
-    """'1' + code as a big-endian integer in ceil(len/8) bytes (utils.py:66-72,100-106)."""
+def _bits_to_bytes(code: Sequence[str]) -> bytes:
     lib = _lib.load()
     bits = np.frombuffer("".join(code).encode("ascii"), dtype=np.uint8) if len(code) else np.zeros(0, np.uint8)
-    out = np.empty((bits.size + 1 + 7) // 8, dtype=np.uint8)
+    out = np.empty((bits.size + 8) // 8, dtype=np.uint8)
     n = lib.irec_rec_pack_bits(bits.ctypes.data if bits.size else None, bits.size, out.ctypes.data, out.size)
     if n < 0:
         raise ValueError("irec_rec_pack_bits failed")
     return out[:n].tobytes()
 
 
-def _unpack(data):
+def _bytes_to_bits(data: bytes) -> str:
     lib = _lib.load()
     buf = np.frombuffer(data, dtype=np.uint8)
     out = np.empty(max(buf.size * 8, 1), dtype=np.uint8)
@@ -48,78 +52,92 @@ def _unpack(data):
     return out[:n].tobytes().decode("ascii")
 
 
+def _encode_stream(model: np.ndarray, values) -> bytes:
+    message = np.append(np.asarray(values, dtype=np.int64).reshape(-1) + 1, 0)
+    return _bits_to_bytes(ArithmeticCoder(model, precision=32).encode(message))
+
+
+def _decode_stream(model: np.ndarray, data: bytes) -> np.ndarray:
+    message = ArithmeticCoder(model, precision=32).decode_fast(_bytes_to_bits(data))
+    return np.asarray(message[:-1], dtype=np.int64) - 1
+
+
+@dataclass
+class RecHeader:
+    seed: int
+    block_size: int
+    max_index: int
+    image_shape: Tuple[int, int, int]
+    uses_count_file: bool
+    uses_index_file: bool
+    blocks_per_res_block: List[int]
+    count_stream_bytes: List[int]
+    index_stream_bytes: List[int]
+    max_partitions: List[int]
+
+    def pack(self) -> bytes:
+        r = len(self.blocks_per_res_block)
+        tail = [*self.blocks_per_res_block, *self.count_stream_bytes, *self.index_stream_bytes,
+                *[m & 0xFFFFFFFF for m in self.max_partitions]]
+        return _STATIC.pack(self.seed, self.block_size, self.max_index, *self.image_shape, int(self.uses_count_file),
+                            int(self.uses_index_file), r) + struct.pack(f"{4 * r}I", *tail)
+
+    @classmethod
+    def read(cls, fh, static_header_size=_STATIC.size) -> "RecHeader":
+        seed, block_size, max_index, h, w, c, f_counts, f_index, r = _STATIC.unpack(fh.read(static_header_size))
+        tail = struct.unpack(f"{4 * r}I", fh.read(16 * r))
+        return cls(seed, block_size, max_index, (h, w, c), bool(f_counts), bool(f_index), list(tail[:r]),
+                   list(tail[r:2 * r]), list(tail[2 * r:3 * r]), list(tail[3 * r:]))
+
+
 def write_compressed_code(file_path, seed, image_shape, block_size, block_indices, max_index,
                           num_aux_var_counts_file=None, index_counts_file=None):
-    """rec/io/utils.py:7-106.  block_indices: per residual block, per coded block, the list of sample indices."""
+    """Same signature as rec/io/utils.py:7.  block_indices[r][k] = sample indices of coded block k of residual block r."""
     if len(image_shape) != 3:
         raise ValueError(f"Image shape must be rank 3, but was {image_shape}!")
-    img_h, img_w, img_c = image_shape
-    num_res_blocks = len(block_indices)
-    num_blocks = list(map(len, block_indices))
-    num_aux_vars = [list(map(len, block)) for block in block_indices]
-    flattened = [np.concatenate([np.asarray(b, dtype=np.int64).reshape(-1) for b in block], axis=0)
-                 for block in block_indices]
-    index_counts = _index_counts(max_index) if index_counts_file is None else np.load(index_counts_file)
-    for f in flattened:
-        if f.size and (f.min() < 0 or f.max() + 1 > len(index_counts) - 1):
-            # the reference overflows its count table silently here (SURVEY.md §7: max_index=20 with S=36)
-            raise ValueError(f"index {int(f.max())} does not fit max_index={len(index_counts) - 1}")
+    partition_counts = [[len(ix) for ix in res_block] for res_block in block_indices]
+    flat_indices = [np.concatenate([np.asarray(ix, dtype=np.int64).reshape(-1) for ix in res_block])
+                    for res_block in block_indices]
+    index_model = _uniform_model(max_index, 1000) if index_counts_file is None else np.load(index_counts_file)
+    for vec in flat_indices:
+        if vec.size and (vec.min() < 0 or vec.max() + 1 >= len(index_model)):
+            # the reference overruns its count table silently here (SURVEY.md §7: max_index=20 with S=36)
+            raise ValueError(f"index {int(vec.max())} does not fit max_index={len(index_model) - 1}")
     if num_aux_var_counts_file is None:
-        num_aux_var_maxes = [int(np.max(nav)) for nav in num_aux_vars]
-        num_aux_var_counts = [_nav_counts(m) for m in num_aux_var_maxes]
+        max_partitions = [int(max(pc)) for pc in partition_counts]
+        count_models = [_uniform_model(m + 1, 100) for m in max_partitions]
     else:
-        num_aux_var_counts = np.load(num_aux_var_counts_file, allow_pickle=True)
-        num_aux_var_maxes = [-1] * num_res_blocks
-    nav_coders = [ArithmeticCoder(c, precision=32) for c in num_aux_var_counts]
-    index_coder = ArithmeticCoder(index_counts, precision=32)
-    nav_bytes = [_pack(coder.encode(_to_message(nav))) for nav, coder in zip(num_aux_vars, nav_coders)]
-    index_bytes = [_pack(index_coder.encode(_to_message(ix))) for ix in flattened]
-    header = struct.pack(f"{STATIC_HEADER}{num_res_blocks}I{num_res_blocks}I{num_res_blocks}I{num_res_blocks}I",
-                         seed, block_size, max_index, img_h, img_w, img_c,
-                         1 - int(num_aux_var_counts_file is None), 1 - int(index_counts_file is None), num_res_blocks,
-                         *num_blocks, *[len(b) for b in nav_bytes], *[len(b) for b in index_bytes],
-                         *[m & 0xFFFFFFFF for m in num_aux_var_maxes])
-    with open(file_path, "wb") as rec_file:
-        rec_file.write(header)
-        for b in nav_bytes:
-            rec_file.write(b)
-        for b in index_bytes:
-            rec_file.write(b)
+        count_models = np.load(num_aux_var_counts_file, allow_pickle=True)
+        max_partitions = [-1] * len(block_indices)
+    count_streams = [_encode_stream(model, pc) for model, pc in zip(count_models, partition_counts)]
+    index_streams = [_encode_stream(index_model, vec) for vec in flat_indices]
+    header = RecHeader(seed, block_size, max_index, tuple(int(v) for v in image_shape),
+                       num_aux_var_counts_file is not None, index_counts_file is not None,
+                       [len(rb) for rb in block_indices], [len(s) for s in count_streams],
+                       [len(s) for s in index_streams], max_partitions)
+    with open(file_path, "wb") as fh:
+        fh.write(header.pack())
+        fh.writelines(count_streams)
+        fh.writelines(index_streams)
 
 
 def read_compressed_code(file_path, static_header_size=28, num_aux_var_counts_file=None, index_counts_file=None):
-    """rec/io/utils.py:109-215.  Returns (seed, image_shape, block_size, block_indices)."""
-    with open(file_path, "rb") as rec_file:
-        info = struct.unpack(STATIC_HEADER, rec_file.read(static_header_size))
-        seed, block_size, max_index = info[0], info[1], info[2]
-        image_shape = tuple(info[3:6])
-        use_nav_file, use_index_file, num_res_blocks = bool(info[6]), bool(info[7]), info[8]
-        if use_index_file and index_counts_file is None:
+    """Same signature and return value as rec/io/utils.py:109: (seed, image_shape, block_size, block_indices)."""
+    with open(file_path, "rb") as fh:
+        hdr = RecHeader.read(fh, static_header_size)
+        if hdr.uses_index_file and index_counts_file is None:
             raise ValueError("The compressed file is using empirical index counts, but no counts file was supplied!")
-        if use_nav_file and num_aux_var_counts_file is None:
+        if hdr.uses_count_file and num_aux_var_counts_file is None:
             raise ValueError("The compressed file is using empirical num_aux_var counts, but no counts file was supplied!")
-        fmt = f"{num_res_blocks}I{num_res_blocks}I{num_res_blocks}I{num_res_blocks}I"
-        dyn = struct.unpack(fmt, rec_file.read(struct.calcsize(fmt)))
-        nav_lens = dyn[num_res_blocks:2 * num_res_blocks]
-        index_lens = dyn[2 * num_res_blocks:3 * num_res_blocks]
-        nav_maxes = dyn[3 * num_res_blocks:]
-        nav_codes = [_unpack(rec_file.read(n)) for n in nav_lens]
-        index_codes = [_unpack(rec_file.read(n)) for n in index_lens]
-    index_counts = np.load(index_counts_file) if use_index_file else _index_counts(max_index)
-    if use_nav_file:
-        nav_counts = np.load(num_aux_var_counts_file, allow_pickle=True)
-    else:
-        nav_counts = [_nav_counts(m) for m in nav_maxes]
-    nav_coders = [ArithmeticCoder(c, precision=32) for c in nav_counts]
-    index_coder = ArithmeticCoder(index_counts, precision=32)
-
-    def from_message(msg):
-        return np.array(msg, dtype=np.int64)[:-1] - 1
-
-    num_aux_vars = [from_message(c.decode_fast(code)) for c, code in zip(nav_coders, nav_codes)]
-    flattened = [from_message(index_coder.decode_fast(code)) for code in index_codes]
+        count_streams = [fh.read(n) for n in hdr.count_stream_bytes]
+        index_streams = [fh.read(n) for n in hdr.index_stream_bytes]
+    index_model = np.load(index_counts_file) if hdr.uses_index_file else _uniform_model(hdr.max_index, 1000)
+    count_models = (np.load(num_aux_var_counts_file, allow_pickle=True) if hdr.uses_count_file
+                    else [_uniform_model(m + 1, 100) for m in hdr.max_partitions])
     block_indices = []
-    for nav, vec in zip(num_aux_vars, flattened):
-        bounds = np.cumsum(np.concatenate([[0], nav], axis=0))
-        block_indices.append([vec[bounds[i - 1]:bounds[i]].tolist() for i in range(1, len(bounds))])
-    return seed, image_shape, block_size, block_indices
+    for model, cs, xs in zip(count_models, count_streams, index_streams):
+        counts = _decode_stream(model, cs)
+        values = _decode_stream(index_model, xs)
+        cuts = np.concatenate([[0], np.cumsum(counts)])
+        block_indices.append([values[cuts[i]:cuts[i + 1]].tolist() for i in range(len(counts))])
+    return hdr.seed, hdr.image_shape, hdr.block_size, block_indices
