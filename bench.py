@@ -96,13 +96,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % n_dev          # (test rigs may run several ranks on one GPU: IREC_DIST_BACKEND=gloo)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
+    backend = os.environ.get("IREC_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     import irec
     eng = irec.get_engine(device)
@@ -116,6 +122,8 @@ def main():
            torch.empty((lay.n_blocks, max_K), dtype=torch.int32, device=device), torch.empty_like(q[0]))
     eng.workspace(params, lay.max_dim, max_K)  # allocate scratch outside the timed region
 
+    coll_dev = device if backend == "nccl" else torch.device("cpu")   # gloo rigs exchange through host tensors
+
     def barrier():
         torch.cuda.synchronize(device)
         if dist is not None:
@@ -126,7 +134,7 @@ def main():
 
     def exchange(K):
         # the path's only exchange step: per-latent code length (nats), all ranks <- all ranks (RCCL over xGMI)
-        return sharding.gather_per_item(sharding.code_nats_per_tensor(K, lay, S), world * L, rank, world, dist)
+        return sharding.gather_per_item(sharding.code_nats_per_tensor(K, lay, S).to(coll_dev), world * L, rank, world, dist)
 
     log(f"rank {rank}/{world}: {L} latents, {lay.n_blocks} blocks per step")
     for _ in range(max(args.warmup, 1)):
@@ -145,7 +153,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
