@@ -475,7 +475,7 @@ __device__ __forceinline__ float lds_abs_f32(uint32_t byte_addr) { return *(lds_
 template <int NB, bool TABLE>
 struct FastCfg {
   // accumulators reduced together
-  static constexpr int RW = NB <= 21 ? 64 : 32;
+  static constexpr int RW = NB <= 10 ? 64 : 32;   // accumulators reduced together (32 keeps the 20/32-beam builds nearly spill-free)
   static constexpr int SPC = RW / NB;             // samples per chunk
   static_assert(SPC >= 1, "NB too large");
 };

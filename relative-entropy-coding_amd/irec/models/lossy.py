@@ -13,7 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..io import read_compressed_code, write_compressed_code
-from .resnet_vae import _Normal, _nchw, _nhwc
+from .resnet_vae import _Normal, _nchw, _nhwc, deterministic_transforms
 
 
 def _down(cin, cout, n):
@@ -86,7 +86,8 @@ class Large2LevelVAE(nn.Module):
         """large_2_level_vae.py:406-419.  image: [H, W, 3] tensor (the reference's layout)."""
         sampling_fn = lambda target, coder: sampler.encode(target, coder, seed=seed)  # noqa: E731  (:408)
         x = image.permute(2, 0, 1)[None].contiguous()
-        block_indices, reconstruction = self(x, sampling_fn=sampling_fn)
+        with deterministic_transforms():
+            block_indices, reconstruction = self(x, sampling_fn=sampling_fn)
         write_compressed_code(file_path=file_path, seed=seed, image_shape=tuple(image.shape), block_size=block_size,
                               block_indices=block_indices, max_index=max_index)
         return reconstruction
@@ -96,10 +97,11 @@ class Large2LevelVAE(nn.Module):
         """large_2_level_vae.py:421-456 (the reference unpacks image_shape as (batch, height, width); here (h, w, c))."""
         seed, image_shape, block_size, block_indices = read_compressed_code(file_path=file_path)
         height, width, _ = image_shape
-        l2_prior_loc, l2_prior_scale = self._level_2_prior(1, height, width)
-        self.level_2_prior = _Normal(_nhwc(l2_prior_loc), _nhwc(l2_prior_scale))
-        z = sampler.decode(self.level_2_prior, seed=seed, indices=block_indices[0])                           # :441
-        l1_prior_loc, l1_prior_scale, _ = self._level_1_prior(_nchw(z))
-        self.level_1_prior = _Normal(_nhwc(l1_prior_loc), _nhwc(l1_prior_scale))
-        y = sampler.decode(self.level_1_prior, seed=seed, indices=block_indices[1])                           # :451
-        return self.synthesis_transform(_nchw(y))
+        with deterministic_transforms():
+            l2_prior_loc, l2_prior_scale = self._level_2_prior(1, height, width)
+            self.level_2_prior = _Normal(_nhwc(l2_prior_loc), _nhwc(l2_prior_scale))
+            z = sampler.decode(self.level_2_prior, seed=seed, indices=block_indices[0])                       # :441
+            l1_prior_loc, l1_prior_scale, _ = self._level_1_prior(_nchw(z))
+            self.level_1_prior = _Normal(_nhwc(l1_prior_loc), _nhwc(l1_prior_scale))
+            y = sampler.decode(self.level_1_prior, seed=seed, indices=block_indices[1])                       # :451
+            return self.synthesis_transform(_nchw(y))

@@ -22,6 +22,21 @@ class ModelError(Exception):
     """rec/models/resnet_vae.py (ModelError)."""
 
 
+class deterministic_transforms:
+    """Encoder and decoder must evaluate the SAME bits for every prior: a relative-entropy code is only decodable if the
+    decoder's coding distribution equals the encoder's exactly.  MIOpen may pick different (or atomically accumulating)
+    convolution algorithms from call to call, so compress / decompress pin the deterministic ones for their duration."""
+
+    def __enter__(self):
+        self._prev = (torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark)
+        torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = True, False
+        return self
+
+    def __exit__(self, *exc):
+        torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = self._prev
+        return False
+
+
 def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
@@ -155,23 +170,25 @@ class BidirectionalResNetVAE(nn.Module):
     def compress(self, image, seed, update_sampler=False):
         """resnet_vae.py:803-836.  image: [1, 3, H, W] in [-0.5, 0.5].  Returns (block_indices, reconstruction)."""
         batch_size, _, height, width = image.shape
-        tensor = self.first_infer_conv(image)
-        for resnet_block in list(self.residual_blocks)[::-1]:                 # inference pass, reverse order (:811-813)
-            tensor = resnet_block(tensor, inference_pass=True)
-        tensor = self.generative_base(batch_size=batch_size, width=width, height=height)
-        block_indices = []
-        for resnet_block in self.residual_blocks:                             # strictly sequential (:821-826)
-            indices, tensor = resnet_block(tensor, inference_pass=False,
-                                           encoder_args={"seed": seed, "update_sampler": update_sampler})
-            block_indices.append(indices)
-        return block_indices, self._finish(tensor)
+        with deterministic_transforms():
+            tensor = self.first_infer_conv(image)
+            for resnet_block in list(self.residual_blocks)[::-1]:             # inference pass, reverse order (:811-813)
+                tensor = resnet_block(tensor, inference_pass=True)
+            tensor = self.generative_base(batch_size=batch_size, width=width, height=height)
+            block_indices = []
+            for resnet_block in self.residual_blocks:                         # strictly sequential (:821-826)
+                indices, tensor = resnet_block(tensor, inference_pass=False,
+                                               encoder_args={"seed": seed, "update_sampler": update_sampler})
+                block_indices.append(indices)
+            return block_indices, self._finish(tensor)
 
     @torch.no_grad()
     def decompress(self, block_indices, seed, image_shape):
         """The generative pass driven by the stored indices.  (The reference's own decompress, resnet_vae.py:844-860,
         is an unfinished stub; this is the pass its decoder_args plumbing implies.)"""
         batch_size, _, height, width = image_shape
-        tensor = self.generative_base(batch_size=batch_size, width=width, height=height)
-        for resnet_block, indices in zip(self.residual_blocks, block_indices):
-            tensor = resnet_block(tensor, inference_pass=False, decoder_args={"seed": seed, "indices": indices})
-        return self._finish(tensor)
+        with deterministic_transforms():
+            tensor = self.generative_base(batch_size=batch_size, width=width, height=height)
+            for resnet_block, indices in zip(self.residual_blocks, block_indices):
+                tensor = resnet_block(tensor, inference_pass=False, decoder_args={"seed": seed, "indices": indices})
+            return self._finish(tensor)
