@@ -58,6 +58,8 @@ typedef struct {
 
 #define IREC_FLAG_FORCE_GENERIC 1 /* use the generic (any D, any B) kernel even where the fast kernels apply   */
 #define IREC_FLAG_FUSED_PHILOX 2  /* keep the Philox draw fused in the block kernel even when table_dims is set */
+#define IREC_FLAG_ONE_TABLE 4     /* with table_dims: the one-table-copy encoder (one workgroup per block) instead of  */
+                                  /* the default two-teams-per-CU encoder over three table copies; same outputs      */
 
 typedef struct irec_context irec_context;
 
@@ -149,6 +151,11 @@ irec_status irec_test_reduce_scatter(irec_context *ctx, const float *in, float *
  * beam_search_coder.py:85-89 in isolation.  scores: float [n]; scratch_keys: uint32 [n]; out_sel: int32 [n_select][2]. */
 irec_status irec_test_select(irec_context *ctx, const float *scores, int32_t n, int32_t n_select, int32_t n_beams_cur,
                              uint32_t *scratch_keys, int32_t *out_sel, void *hip_stream);
+/* The per-call proposal table of the default encoder for blocks of `dim` dims: out_tab uint16 [n_steps][n_samples][dim
+ * rounded up to 4] = dlog_g(r) + 10006 * c, r the int32 draw of beam_search_coder.py:38-43 at seed + t, c the copy bit
+ * that spreads each 32-lane look-up group over the LDS banks. */
+irec_status irec_test_proposal_table(irec_context *ctx, int64_t seed, int32_t n_samples, int32_t dim, int32_t n_steps,
+                                     uint16_t *out_tab, void *hip_stream);
 /* device addresses of the context's constant tables (lut [10007], lut2 [10006], dlog4r [10006] u16, rho [65536]). */
 irec_status irec_device_tables(irec_context *ctx, const float **lut, const float **lut2, const uint16_t **dlog4r,
                                const float **rho);

@@ -316,6 +316,7 @@ namespace {
 struct Plan {
   bool fast;         // register-resident fast encoder with the Philox draw fused in
   bool table;        // fast encoder fed by per-call proposal tables (Philox hoisted out of the block kernel)
+  bool team;         // table && two-teams-per-CU encoder over three table copies (the default where it applies)
   int grid_cap;      // resident workgroups (persistent kernels pull blocks from an atomic counter)
   size_t ws_per_wg;
   int dpad;
@@ -340,7 +341,7 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
   pl.fast = !(p->flags & IREC_FLAG_FORCE_GENERIC) && max_dim <= irec::FAST_MAX_DIM && irec::fast_nb_for(B) != 0 &&
             irec::fast_lds_for(B, S, false) <= irec::FAST_LDS_LIMIT && (int64_t)S * B < (1 << 24);
   pl.grid_cap = 2 * (ctx->n_cu > 0 ? ctx->n_cu : 256); // measured residency: 2 workgroups per CU for every encoder
-  pl.table = false; pl.n_tab = 0; pl.tab_bytes = 0;
+  pl.table = false; pl.team = false; pl.n_tab = 0; pl.tab_bytes = 0;
   if (pl.fast && !(p->flags & IREC_FLAG_FUSED_PHILOX) && p->table_dims[0] > 0) {
     pl.table = true;
     for (int q = 0; q < 4 && p->table_dims[q] > 0; ++q) {
@@ -351,9 +352,10 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
       ++pl.n_tab;
     }
     if (!pl.table) { pl.n_tab = 0; pl.tab_bytes = 0; }
+    pl.team = pl.table && !(p->flags & IREC_FLAG_ONE_TABLE) && irec::team_lds_for(B, S) != (size_t)-1;
   }
   if (pl.fast) {
-    if (irec::fast_waves_for(B, S, pl.table) == 8) pl.grid_cap /= 2; // big-LDS configurations: one 8-wave workgroup per CU
+    if (!pl.team && irec::fast_waves_for(B, S, pl.table) == 8) pl.grid_cap /= 2; // big-LDS configurations: one 8-wave workgroup per CU
     pl.ws_per_wg = round_up_sz(irec::fast_ws_for(B, max_K), 256);
   } else {
     pl.ws_per_wg = round_up_sz((size_t)10 * pl.dpad * 4 + (size_t)2 * B * pl.dpad * 4 +
@@ -432,10 +434,14 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
     for (int q = 0; q < 4; ++q) { A.tab[q] = nullptr; A.tab_dim[q] = -1; }
     for (int q = 0; q < pl.n_tab; ++q) {
       uint16_t *tab = (uint16_t *)((char *)workspace + 256 + pl.tab_off[q]);
-      HIP_TRY(irec::launch_alpha_table(seed, p->n_samples, pl.tab_dim[q], max_K > 0 ? max_K : 1, ctx->d_dlog4r, tab, st));
+      if (pl.team) HIP_TRY(irec::launch_alpha_choice(seed, p->n_samples, pl.tab_dim[q], max_K > 0 ? max_K : 1, ctx->d_dlog4r, tab, st));
+      else HIP_TRY(irec::launch_alpha_table(seed, p->n_samples, pl.tab_dim[q], max_K > 0 ? max_K : 1, ctx->d_dlog4r, tab, st));
       A.tab[q] = tab; A.tab_dim[q] = pl.tab_dim[q];
     }
-    HIP_TRY(irec::launch_encode_fast(A, true, grid, st));
+    if (pl.team) { // grid_cap counts teams (= scratch slabs): two per workgroup, one workgroup per CU
+      A.dbg = nullptr;
+      HIP_TRY(irec::launch_encode_team(A, (int)std::min<int64_t>((n_blocks + 1) / 2, pl.grid_cap / 2), st));
+    } else HIP_TRY(irec::launch_encode_fast(A, true, grid, st));
   } else if (pl.fast) {
     HIP_TRY(irec::launch_encode_fast(A, false, grid, st));
   } else {
@@ -508,6 +514,15 @@ irec_status irec_test_select(irec_context *ctx, const float *scores, int32_t n, 
     return fail(IREC_E_INVALID, "irec_test_select: bad arguments");
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(irec::launch_select_test(scores, n, n_select, n_beams_cur, scratch_keys, out_sel, (hipStream_t)hip_stream));
+  return IREC_OK;
+}
+
+irec_status irec_test_proposal_table(irec_context *ctx, int64_t seed, int32_t n_samples, int32_t dim, int32_t n_steps,
+                                     uint16_t *out_tab, void *hip_stream) {
+  if (!ctx || !out_tab || n_samples < 1 || dim < 1 || dim > irec::FAST_MAX_DIM || n_steps < 1)
+    return fail(IREC_E_INVALID, "irec_test_proposal_table: bad arguments");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(irec::launch_alpha_choice(seed, n_samples, dim, n_steps, ctx->d_dlog4r, out_tab, (hipStream_t)hip_stream));
   return IREC_OK;
 }
 

@@ -20,18 +20,10 @@
 
 #include "irec_device.h"
 #include "irec_kernels.h"
+#include "irec_fast_common.h"
 
 namespace irec {
 
-// ======================================================================================================
-//  small shared pieces
-// ======================================================================================================
-__device__ __forceinline__ int64_t src_index(const EncArgs &A, int64_t base, int32_t pos, int d) {
-  return base + (A.perm ? (int64_t)A.perm[pos + d] : (int64_t)(pos + d));
-}
-
-// Diagnostic phase stamps (only when EncArgs.dbg != nullptr; the values never reach an output of the coder).
-__device__ __forceinline__ unsigned long long stamp_now() { return __builtin_amdgcn_s_memtime(); }
 #define IREC_STAMP(slot)                                                    \
   do {                                                                      \
     if (A.dbg && tid == 0) {                                                \
@@ -41,124 +33,7 @@ __device__ __forceinline__ unsigned long long stamp_now() { return __builtin_amd
     }                                                                       \
   } while (0)
 
-// Small per-workgroup LDS state shared by the encoders.
-struct SmallLds {
-  union {                           // the two selection paths never run at the same time
-    unsigned long long wb[16];      // per-wave maxima of the scan-based selection, double buffered
-    unsigned long long cand[64];    // compacted (key, flat) survivors of the threshold selection
-  };
-  int32_t sel_s[64], sel_b[64];     // selected (sample, beam) per new beam
-  int32_t hsum[2][64];              // running int32 sum of simple_hash per beam, double buffered
-  uint32_t beta4[2][64];            // 4 * dlog(hash) per beam, double buffered
-  int32_t misc[8];                  // [0] block id, [1] K, [7] selection path flag
-  union {                           // KL partials are consumed before the first C_b partial is written
-    double gpart[4];                // per dim-group KL partial sums
-    float cpart[4][32];             // per dim-group partial C_b
-  };
-  float Cb[32];                     // C_b of the live beams
-};
-constexpr size_t SMALL_LDS_BYTES = (sizeof(SmallLds) + 15) & ~(size_t)15;
 
-// Block-wide top-Bnew selection over key[0..N) (uint32 sort keys, 0 = taken / empty), NT threads.
-// tf.argsort(DESCENDING)[:B] semantics (beam_search_coder.py:85-89): value descending, ties to the lower flat index.
-//  - N <= 1024 (every BASELINE config but the S=403 stress case): wave 0 alone, candidates in registers:
-//      1. lane maxima; T = Bnew-th largest lane maximum  => at least Bnew candidates are >= T
-//      2. compact the candidates >= T (a few dozen) to one per lane through LDS
-//      3. rank them by (key desc, flat asc); rank r < Bnew IS new beam r
-//    ~600 wave instructions and ONE barrier instead of Bnew barrier rounds.
-//  - otherwise: all waves scan the keys, one barrier per selected beam (element f owned by thread f % NT).
-template <int NT>
-__device__ __forceinline__ void select_topB(uint32_t *key, int N, int Bnew, int Bcur, SmallLds *sm,
-                                            unsigned long long *dbg = nullptr) {
-  constexpr int NWV = NT / 64;
-  const int tid = threadIdx.x;
-  int32_t *sel_s = sm->sel_s, *sel_b = sm->sel_b;
-  unsigned long long t0 = dbg ? stamp_now() : 0ull;
-  __syncthreads(); // keys written by all waves
-  if (dbg && tid == 0) { const unsigned long long t1 = stamp_now(); dbg[8] += t1 - t0; t0 = t1; } // wait for keys
-  bool done = false;
-  if (N <= 1024) {
-    if (tid < 64) {
-      __builtin_amdgcn_s_setprio(3); // the whole workgroup waits for this wave: win issue arbitration on its SIMD
-      const int nslots = (N + 63) >> 6;
-      uint32_t k[16];
-      uint32_t M = 0u;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int f = q * 64 + tid;
-        k[q] = (q < nslots && f < N) ? key[f] : 0u;
-        M = k[q] > M ? k[q] : M;
-      }
-      // 1. threshold: #lanes with a strictly larger maximum
-      uint32_t cnt_gt = 0u;
-#pragma unroll
-      for (int l = 0; l < 64; ++l) cnt_gt += (uint32_t)__builtin_amdgcn_readlane((int)M, l) > M ? 1u : 0u;
-      uint32_t T = cnt_gt < (uint32_t)Bnew ? M : 0xFFFFFFFFu;
-      T = 0xFFFFFFFFu - (uint32_t)wave_max_u64((unsigned long long)(0xFFFFFFFFu - T)); // wave min
-      // 2. compact candidates >= T (T >= 1 because at least Bnew <= N lanes hold a real key)
-      uint32_t base = 0u;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        if (q < nslots) { // wave-uniform
-          const bool in = k[q] >= T;
-          const unsigned long long mask = __ballot(in);
-          const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-          if (in && pos < 64u) sm->cand[pos] = ((unsigned long long)k[q] << 32) | (uint32_t)(q * 64 + tid);
-          base += (uint32_t)__popcll(mask);
-        }
-      }
-      const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      if (C <= 64u) {
-        // 3. rank the C survivors; lanes >= C hold a null candidate
-        const unsigned long long mine = tid < (int)C ? sm->cand[tid] : 0ull;
-        const uint32_t mk = (uint32_t)(mine >> 32), mf = (uint32_t)mine;
-        uint32_t rank = 0u;
-        for (uint32_t l = 0; l < C; ++l) {
-          const uint32_t ok_ = (uint32_t)__builtin_amdgcn_readlane((int)mk, (int)l);
-          const uint32_t of_ = (uint32_t)__builtin_amdgcn_readlane((int)mf, (int)l);
-          rank += (ok_ > mk || (ok_ == mk && of_ < mf)) ? 1u : 0u;
-        }
-        if (tid < (int)C && rank < (uint32_t)Bnew) {
-          sel_s[rank] = (int32_t)(mf / (uint32_t)Bcur); // best_ind_aux  (beam_search_coder.py:89)
-          sel_b[rank] = (int32_t)(mf % (uint32_t)Bcur); // best_ind_beam (beam_search_coder.py:88)
-        }
-        sm->misc[7] = 1;
-      } else {
-        sm->misc[7] = 0; // pathological tie storm: fall back to the scan below
-      }
-      __builtin_amdgcn_s_setprio(0);
-      if (dbg && tid == 0) { const unsigned long long t1 = stamp_now(); dbg[9] += t1 - t0; t0 = t1; } // wave-0 selection
-    }
-    __syncthreads();
-    if (dbg && tid == 0) { const unsigned long long t1 = stamp_now(); dbg[10] += t1 - t0; t0 = t1; } // closing barrier
-    done = sm->misc[7] != 0;
-  }
-  if (done) return;
-  unsigned long long *wb = sm->wb;
-  for (int it = 0; it < Bnew; ++it) {
-    unsigned long long best = 0ull;
-    for (int f = tid; f < N; f += NT) {
-      const unsigned long long c = cand_pack(key[f], (uint32_t)f);
-      best = c > best ? c : best;
-    }
-    best = wave_max_u64(best);
-    if ((tid & 63) == 0) wb[(it & 1) * NWV + (tid >> 6)] = best;
-    __syncthreads();
-    unsigned long long g = 0ull;
-#pragma unroll
-    for (int w = 0; w < NWV; ++w) {
-      const unsigned long long o = wb[(it & 1) * NWV + w];
-      g = o > g ? o : g;
-    }
-    const uint32_t fstar = 0xFFFFFFFFu - (uint32_t)g;
-    if ((uint32_t)tid == fstar % (uint32_t)NT) key[fstar] = 0u;
-    if (tid == 0) {
-      sel_s[it] = (int32_t)(fstar / (uint32_t)Bcur);
-      sel_b[it] = (int32_t)(fstar % (uint32_t)Bcur);
-    }
-  }
-  __syncthreads();
-}
 
 // ======================================================================================================
 //  KL / K kernel  (beam_search_coder.py:57-59)
@@ -395,90 +270,6 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
   }
 }
 
-// ======================================================================================================
-//  fast encoder: D <= 1024, B <= NB <= 32.
-//  wave w -> (dim group g = w % NG, sample stripe sw = w / NG); lane l owns dims 256 g + 4 l .. +3.
-// ======================================================================================================
-
-// ---- reduce-scatter over the 64 lanes in the canonical tree order (lane bits 5,4,3,2,1,0) -----------------
-__device__ __forceinline__ void swap32(float &a, float &b) { // a[32+i] <-> b[i]
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
-}
-__device__ __forceinline__ void swap16(float &a, float &b) { // a[16+i] <-> b[i], a[48+i] <-> b[32+i]
-  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
-}
-template <int CTRL, int BANK>
-__device__ __forceinline__ float dpp_f(float old, float src) {
-  return __uint_as_float(
-      (uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(old), (int)__float_as_uint(src), CTRL, 0xF, BANK, false));
-}
-// value of the partner lane (lane ^ DIST) for DIST in {8,4,2,1}
-template <int DIST>
-__device__ __forceinline__ float partner(float v) {
-  if constexpr (DIST == 8) return dpp_f<0x128, 0xF>(v, v);             // row_ror:8
-  else if constexpr (DIST == 4) {
-    float r = dpp_f<0x104, 0x5>(v, v);                                 // row_shl:4 -> lanes with bit2 = 0 read lane+4
-    return dpp_f<0x114, 0xA>(r, v);                                    // row_shr:4 -> lanes with bit2 = 1 read lane-4
-  } else if constexpr (DIST == 2) return dpp_f<0x4E, 0xF>(v, v);       // quad_perm [2,3,0,1]
-  else return dpp_f<0xB1, 0xF>(v, v);                                  // quad_perm [1,0,3,2]
-}
-
-// One stage of the reduce-scatter: lanes at distance DIST exchange halves of their N values and add.
-// With N == 1 it degenerates into an all-reduce add (both partners end with the same bits).
-template <int DIST, int N>
-__device__ __forceinline__ void rs_stage(float *v, int lane) {
-  if constexpr (N >= 2) {
-    constexpr int H = N / 2;
-    if constexpr (DIST == 32) {
-#pragma unroll
-      for (int j = 0; j < H; ++j) { swap32(v[j], v[j + H]); v[j] = v[j] + v[j + H]; }
-    } else if constexpr (DIST == 16) {
-#pragma unroll
-      for (int j = 0; j < H; ++j) { swap16(v[j], v[j + H]); v[j] = v[j] + v[j + H]; }
-    } else {
-      const bool hi = (lane & DIST) != 0;
-#pragma unroll
-      for (int j = 0; j < H; ++j) {
-        const float keep = hi ? v[j + H] : v[j], send = hi ? v[j] : v[j + H];
-        v[j] = keep + partner<DIST>(send);
-      }
-    }
-  } else {
-    static_assert(DIST <= 8, "all-reduce stages only exist inside a row");
-    v[0] = v[0] + partner<DIST>(v[0]);
-  }
-}
-constexpr int rs_half(int n) { return n >= 2 ? n / 2 : 1; }
-
-// v[0..N0) per lane -> every lane l returns the sum over all 64 lanes of v[l * N0 / 64], added in the canonical
-// tree (pairs at lane distance 32, 16, 8, 4, 2, 1).  N0 in {64, 32, 16}.
-template <int N0>
-__device__ __forceinline__ float reduce_scatter(float (&v)[N0], int lane) {
-  static_assert(N0 == 64 || N0 == 32 || N0 == 16, "unsupported width");
-  constexpr int n4 = rs_half(N0), n3 = rs_half(n4), n2 = rs_half(n3), n1 = rs_half(n2), n0 = rs_half(n1);
-  rs_stage<32, N0>(v, lane);
-  rs_stage<16, n4>(v, lane);
-  rs_stage<8, n3>(v, lane);
-  rs_stage<4, n2>(v, lane);
-  rs_stage<2, n1>(v, lane);
-  rs_stage<1, n0>(v, lane);
-  return v[0];
-}
-
-// The fast kernel addresses its LUT by ABSOLUTE LDS byte address (the table is the first thing in the dynamic LDS
-// region, which starts at 0 because the kernel has no static __shared__): saves one VALU add per proposal.
-typedef __attribute__((address_space(3))) const float lds_cfloat;
-__device__ __forceinline__ float lds_abs_f32(uint32_t byte_addr) { return *(lds_cfloat *)(uintptr_t)(byte_addr); }
-
-template <int NB, bool TABLE>
-struct FastCfg {
-  // accumulators reduced together
-  static constexpr int RW = NB <= 10 ? 64 : 32;   // accumulators reduced together (32 keeps the 20/32-beam builds nearly spill-free)
-  static constexpr int SPC = RW / NB;             // samples per chunk
-  static_assert(SPC >= 1, "NB too large");
-};
 
 // LDS carve (bytes): lut2 40032 | [dlog 20016 unless TABLE] | part [4][S][NB] f32 (sort keys overwrite group 0) | SmallLds
 // Sample passes.  The per-group partial scores of S_pass samples sit in LDS at a time ([4][S_pass][NB] f32); a step
@@ -509,11 +300,6 @@ __host__ __device__ inline FastPlan fast_plan(int NB, int S, bool table) {
   return p;
 }
 
-// Scratch slab of one workgroup (bytes): bp int32 [max_K][NB] | stats float [3][1024] | beams float [2][NB][1024]
-__host__ __device__ inline size_t fast_ws_bytes(int NB, int max_K) {
-  const size_t bp = (((size_t)(max_K > 0 ? max_K : 1) * NB * 4) + 255) & ~(size_t)255;
-  return bp + (size_t)3 * FAST_MAX_DIM * 4 + (size_t)2 * NB * FAST_MAX_DIM * 4;
-}
 
 template <int NB, int NW, bool TABLE>
 __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {

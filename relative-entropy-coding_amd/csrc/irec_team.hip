@@ -1,0 +1,548 @@
+// irec_team.hip -- the default gfx950 encoder: two independent 4-wave TEAMS per workgroup, one workgroup per CU.
+//
+// Hot path (reference file:line): BeamSearchCoder.encode_block rec/coding/beam_search_coder.py:53-122, as in
+// irec_kernels.hip; the arithmetic specification and therefore every emitted bit are the same.
+//
+// What is different is how the look-up  z = quantile((r * hash) mod 10007 / 10007) = lut2[(dlog r + dlog hash) mod 10006]
+// reaches the LDS (scripts/microbench/gather_rates.hip):
+//   * a random 4-byte gather costs a 32-lane group as many LDS cycles as the busiest of the 32 banks has distinct
+//     addresses (3.5 on average) -- the 8.9 look-ups/clk/CU ceiling the one-table encoders sit under;
+//   * here the table is stored THREE times back to back (120 KB, shared by both teams of the CU).  Entry
+//     e = alpha' + beta with alpha' = dlog r + 10006 c, c in {0, 1}, beta = dlog hash never leaves the three copies, so
+//     the address is ONE add (no "mod 10006"), and bank(e) = (dlog r + 22 c + beta) mod 32: the copy bit c moves a
+//     lane by 22 banks whatever the beam.  c is chosen once per call for every (step, sample, 32-lane group, dim
+//     slot) by alpha_choice_kernel -- an exact min-max assignment on two 16-rings of banks -- and travels inside the
+//     proposal table the block kernel streams anyway.  Busiest bank: 2.15 addresses instead of 3.5.
+//   * one workgroup of 8 waves owns the CU; its two teams code two blocks independently (own block counter pulls, own
+//     LDS scratch, own scratch slab) and synchronise with team barriers (an LDS counter), never with s_barrier, so one
+//     team's serial phases (top-B, beam update) overlap the other team's scoring.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "irec_device.h"
+#include "irec_kernels.h"
+#include "irec_fast_common.h"
+
+namespace irec {
+
+constexpr int TEAM_NW = 4;                       // waves per team
+constexpr int TEAM_NT = TEAM_NW * 64;            // threads per team
+constexpr int TEAMS = 2;                         // teams per workgroup
+constexpr uint32_t T3_FLOATS = 3u * IREC_PM1;    // three copies of lut2
+constexpr size_t T3_BYTES = ((size_t)T3_FLOATS * 4 + 15) & ~(size_t)15;
+
+__host__ __device__ inline size_t team_part_bytes(int NB, int S) { return (((size_t)4 * S * NB * 4) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t team_lds_one(int NB, int S) { return team_part_bytes(NB, S) + SMALL_LDS_BYTES + 16; }
+__host__ __device__ inline size_t team_lds_total(int NB, int S) { return T3_BYTES + (size_t)TEAMS * team_lds_one(NB, S); }
+
+// Barrier of the 4 waves of one team: a monotonic LDS counter.  LDS operations of one wave execute in program order and
+// the LDS serves one instruction at a time, so a wave's earlier writes are in place before its add lands; the fences
+// order the global slab traffic (vmcnt) the way __syncthreads would.
+struct TeamBarrier {
+  uint32_t *cnt;
+  uint32_t epoch;
+  __device__ __forceinline__ void operator()() {
+    epoch += (uint32_t)TEAM_NW;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (;;) {
+      const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+      if ((int32_t)(v - epoch) >= 0) break; // every wave of the team has arrived
+      __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+};
+
+// LDS carve (bytes): lut2 x 3 [120080] | team 0: part [4][S][NB] f32 (sort keys overwrite group 0) | SmallLds | barrier | team 1: same
+template <int NB>
+__global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs A) {
+  using Cfg = FastCfg<NB, true>;
+  constexpr int NT = TEAM_NT, NW = TEAM_NW;
+  constexpr int RW = Cfg::RW, SPC = Cfg::SPC;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int S = A.S, B = A.B;
+  const int lane = threadIdx.x & 63;
+  const int wave_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform by construction
+  const int team = wave_wg >> 2, wave = wave_wg & 3;
+  const int tid = (int)threadIdx.x & (NT - 1);                                  // index inside the team
+  char *tbase = smem + T3_BYTES + (size_t)team * team_lds_one(NB, S);
+  float *part_s = reinterpret_cast<float *>(tbase);                             // [4][S][NB] per-group partial scores
+  uint32_t *key_s = reinterpret_cast<uint32_t *>(tbase);                        // [S*NB] sort keys over group 0
+  SmallLds *sm = reinterpret_cast<SmallLds *>(tbase + team_part_bytes(NB, S));
+  uint32_t *bar_word = reinterpret_cast<uint32_t *>(tbase + team_part_bytes(NB, S) + SMALL_LDS_BYTES);
+  double *gpart = sm->gpart;
+  int32_t *sel_s = sm->sel_s, *sel_b = sm->sel_b;
+  int32_t *hsum = &sm->hsum[0][0];
+  uint32_t *beta4 = &sm->beta4[0][0];
+  int32_t *misc = sm->misc;
+  float *cpart_s = &sm->cpart[0][0];
+  float *Cb_s = sm->Cb;
+  const uint16_t *dlog_s = A.dlog4r;                                            // [10006] 4*dlog(j+1), global (L2)
+  const int SP = S;                                                             // one scoring pass per step
+
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap(); // see lds_abs_f32
+  {
+    float *l3 = reinterpret_cast<float *>(smem);
+    for (int k = (int)threadIdx.x; k < (int)IREC_PM1; k += TEAMS * NT) {
+      const float v = A.lut2[k];
+      l3[k] = v; l3[k + IREC_PM1] = v; l3[k + 2 * IREC_PM1] = v;
+    }
+    if (tid == 0) *bar_word = 0u;
+  }
+  __syncthreads(); // the only workgroup-wide barrier: from here on the teams never wait for each other
+  TeamBarrier tsync{bar_word, 0u};
+
+  char *slab = A.ws + ((size_t)blockIdx.x * TEAMS + team) * A.ws_per_wg;
+  int32_t *bp = reinterpret_cast<int32_t *>(slab);                                            // [max_K][NB]
+  float *beams_g = reinterpret_cast<float *>(slab + A.ws_per_wg - (size_t)2 * NB * FAST_MAX_DIM * 4); // [2][NB][1024]
+  float *stats_g = beams_g - 3 * FAST_MAX_DIM;  // [3][1024]: mq - mp, sq^2, sp^2 of the block, coalesced
+
+  for (;;) {
+    tsync();
+    if (tid == 0) misc[0] = (int32_t)atomicAdd(A.counter, 1u);
+    tsync();
+    const int64_t blk = misc[0];
+    if (blk >= A.n_blocks) break; // every wave of the team reaches this; the other team drains on its own
+    const int D = A.block_dim[blk];
+    const int64_t base = A.block_base[blk];
+    const int32_t pos = A.block_pos[blk];
+    const uint16_t *tab = nullptr;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (A.tab_dim[q] == D) tab = A.tab[q];
+    if (D < 1 || D > FAST_MAX_DIM || tab == nullptr) { // host promised D <= 1024 and listed dims
+      if (tid == 0) A.out_K[blk] = -1;
+      continue;
+    }
+    const int Dp = (D + 3) & ~3;            // row stride of the proposal table
+    const int NG = (D + 255) >> 8;          // 1..4 dim groups
+    const int NSW = NW / NG;                // sample stripes
+    const bool active = wave < NG * NSW;
+    const int g = wave % NG, sw = wave / NG;
+    const int d0 = g * 256 + lane * 4;
+
+    // ---- my 4 dims (split == gather through perm) and the block's KL ----
+    float c[4];
+    bool valid[4];
+    int64_t ix[4];
+    double klacc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d = d0 + i;
+      valid[i] = d < D;
+      c[i] = 0.f;
+      ix[i] = valid[i] ? src_index(A, base, pos, d) : src_index(A, base, pos, 0);
+      float st3[3] = {0.f, 1.f, 1.f};
+      if (valid[i] && active && sw == 0) { // one wave per dim group does the float64 KL and publishes the statistics
+        const float mq_ = A.q_loc[ix[i]], sq_ = A.q_scale[ix[i]], mp_ = A.p_loc[ix[i]], sp_ = A.p_scale[ix[i]];
+        klacc = klacc + kl_dim(mq_, sq_, mp_, sp_);
+        st3[0] = mq_ - mp_; st3[1] = sq_ * sq_; st3[2] = sp_ * sp_;
+      }
+      if (active && sw == 0) {
+        stats_g[d0 + i] = st3[0]; stats_g[FAST_MAX_DIM + d0 + i] = st3[1]; stats_g[2 * FAST_MAX_DIM + d0 + i] = st3[2];
+      }
+    }
+    {
+      const double gs = wave_tree_sum(klacc);
+      if (sw == 0 && active && lane == 0) gpart[g] = gs;
+      tsync();
+      if (tid == 0) {
+        double tot = gpart[0];
+        for (int gg = 1; gg < NG; ++gg) tot = tot + gpart[gg];
+        const int32_t K = num_aux((float)tot, A.omega);
+        misc[1] = K;
+        A.out_K[blk] = K;
+        hsum[0] = 0;
+        beta4[0] = 0u; // hash of the empty path is 1 = g^0
+      }
+      tsync();
+    }
+    const int K = misc[1];
+    if (K > A.max_K || K > IREC_MAX_PARTITIONS_DEV) continue;
+    if (K == 0) { // nothing to code: sample = p.loc
+      if (active && sw == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (valid[i]) A.out_sample[ix[i]] = 0.f + A.p_loc[ix[i]];
+      }
+      continue;
+    }
+
+    float sa[4], cH[4];
+    float G[NB][4];
+    auto step_consts = [&](int t_next, float (&m)[4], float (&cA)[4], float (&cBv)[4]) {
+      const float rho = A.rho[K - 1 - t_next];
+      const float4 q0 = *reinterpret_cast<const float4 *>(stats_g + d0);
+      const float4 q1 = *reinterpret_cast<const float4 *>(stats_g + FAST_MAX_DIM + d0);
+      const float4 q2 = *reinterpret_cast<const float4 *>(stats_g + 2 * FAST_MAX_DIM + d0);
+      const float dmu_[4] = {q0.x, q0.y, q0.z, q0.w}, vq_[4] = {q1.x, q1.y, q1.z, q1.w}, vp_[4] = {q2.x, q2.y, q2.z, q2.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const StepConst sc = step_constants(rho, dmu_[i], vq_[i], vp_[i], c[i]);
+        sa[i] = valid[i] ? sc.sa : 0.f; cH[i] = valid[i] ? sc.H : 0.f;
+        m[i] = valid[i] ? sc.m : 0.f; cA[i] = valid[i] ? sc.A : 0.f; cBv[i] = valid[i] ? sc.Bv : 0.f;
+        c[i] = c[i] + sc.a; // cumulative_auxiliary_variance += auxiliary_var (:109)
+        __builtin_amdgcn_sched_barrier(0); // one dim at a time: the division sequences are register hungry
+      }
+    };
+    // ---- prologue: step 0 has one (all-zero) beam ----
+    {
+      float m[4], cA[4], cBv[4];
+      step_consts(0, m, cA, cBv);
+      float cacc = 0.f;
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) G[b][i] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        G[0][i] = beam_G(0.f, m[i], cA[i], cBv[i], sa[i]);
+        cacc = beam_C_term(cacc, 0.f, m[i], cA[i], cBv[i]);
+      }
+      const float cg = wave_tree_sum(cacc);
+      if (active && sw == 0 && lane == 0) cpart_s[g * 32 + 0] = cg;
+      tsync();
+      if (tid == 0) {
+        float cb = cpart_s[0];
+        for (int gg = 1; gg < NG; ++gg) cb = cb + cpart_s[gg * 32];
+        Cb_s[0] = cb;
+      }
+      // (visibility of Cb_s: the barrier after scoring)
+    }
+
+    int cur = 0, Bcur = 1;
+    for (int t = 0; t < K; ++t) {
+      // row s at + s * Dp; lanes past the padded row end read the row START (finite z, zero coefficients)
+      const uint16_t *tab_t = tab + (size_t)t * S * Dp + (d0 < Dp ? d0 : 0);
+      uint32_t bet[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) bet[b] = __builtin_amdgcn_readfirstlane(beta4[cur * 64 + (b < Bcur ? b : 0)]);
+
+      const int N = S * Bcur;
+      // ---------------- scoring: S x Bcur candidates (beam_search_coder.py:80-84) ----------------
+      if (active) {
+        const int s_per_stripe = (S + NSW - 1) / NSW;
+        const int nchunks = (s_per_stripe + SPC - 1) / SPC;
+        // proposal rows (4 x uint16: dlog(r) + 10006 c of my dims) are fetched one chunk ahead
+        uint2 alp_next[SPC];
+#pragma unroll
+        for (int cc = 0; cc < SPC; ++cc) {
+          const int s0 = cc * NSW + sw;
+          alp_next[cc] = make_uint2(0u, 0u);
+          if (s0 < S) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)s0 * Dp);
+        }
+        for (int ch = 0; ch < nchunks; ++ch) {
+          float acc[RW];
+#pragma unroll
+          for (int p = 0; p < RW; ++p) acc[p] = 0.f;
+          uint2 alp[SPC];
+#pragma unroll
+          for (int cc = 0; cc < SPC; ++cc) {
+            alp[cc] = alp_next[cc];
+            const int sn = ((ch + 1) * SPC + cc) * NSW + sw;
+            if (sn < S) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sn * Dp);
+          }
+#pragma unroll
+          for (int cc = 0; cc < SPC; ++cc) {
+            const int s = (ch * SPC + cc) * NSW + sw;
+            if (s < S) { // wave-uniform
+              const uint2 ap = alp[cc];
+              // byte address of entry alpha' in copy 0 (the table starts at LDS address 0)
+              const uint32_t al[4] = {(ap.x & 0xFFFFu) << 2, (ap.x >> 16) << 2, (ap.y & 0xFFFFu) << 2, (ap.y >> 16) << 2};
+              if (Bcur == NB) {
+                // steady state: all NB beams alive -> branch-free; the NB gathers of one dim are issued back to back
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  float z[NB];
+#pragma unroll
+                  for (int b = 0; b < NB; ++b) z[b] = lds_abs_f32(al[i] + bet[b]); // 4*(dlog r + 10006 c + dlog h): no wrap
+#pragma unroll
+                  for (int b = 0; b < NB; ++b) acc[cc * NB + b] = proposal_term(acc[cc * NB + b], z[b], cH[i], G[b][i]);
+                  __builtin_amdgcn_sched_barrier(0); // one dim's NB gathers in flight at a time (VGPR budget)
+                }
+              } else {
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                  if (b < Bcur) { // wave-uniform
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                      const float z = lds_abs_f32(al[i] + bet[b]);
+                      acc[cc * NB + b] = proposal_term(acc[cc * NB + b], z, cH[i], G[b][i]);
+                    }
+                  }
+                }
+              }
+            }
+          }
+          const float tot = reduce_scatter<RW>(acc, lane);
+          const int p = RW == 64 ? lane : (lane >> 1);
+          const int cc = p / NB, b = p - cc * NB;
+          const int s = (ch * SPC + cc) * NSW + sw;
+          if (cc < SPC && s < S && b < Bcur && (RW == 64 || (lane & 1) == 0))
+            part_s[((size_t)g * SP + s) * NB + b] = tot;
+        }
+      }
+      tsync();
+      // ---------------- combine dim groups in order, add C_b, build sort keys ----------------
+      {
+        // keys are written over group 0 of the partials: two phases with a barrier in between because
+        // key f = s * Bcur + b and partial (s, b) = s * NB + b only coincide when Bcur == NB
+        constexpr int MK = (1024 + NT - 1) / NT;
+        uint32_t mykey[MK];
+#pragma unroll
+        for (int q = 0; q < MK; ++q) {
+          const int f = q * NT + tid;
+          mykey[q] = 0u;
+          if (f < N) {
+            const int s = f / Bcur, b = f - s * Bcur;
+            float sc = part_s[((size_t)0 * SP + s) * NB + b];
+            for (int gg = 1; gg < NG; ++gg) sc = sc + part_s[((size_t)gg * SP + s) * NB + b];
+            mykey[q] = score_key(sc + Cb_s[b]);
+          }
+        }
+        tsync();
+#pragma unroll
+        for (int q = 0; q < MK; ++q) {
+          const int f = q * NT + tid;
+          if (f < N) key_s[f] = mykey[q];
+        }
+      }
+      const int Bnew = B < N ? B : N;
+      select_topB_sync<NT>(key_s, N, Bnew, Bcur, sm, tid, tsync); // first barrier inside orders the key_s writes
+      // ---------------- new hashes / back-pointers (beam_search_coder.py:94-95) ----------------
+      if (tid < Bnew) {
+        const int32_t sp_ = sel_s[tid], bp_ = sel_b[tid];
+        const int32_t nh = (int32_t)((uint32_t)hsum[cur * 64 + bp_] + (uint32_t)sp_ * (uint32_t)(69 + t));
+        hsum[(cur ^ 1) * 64 + tid] = nh;
+        beta4[(cur ^ 1) * 64 + tid] = dlog_s[hash_from_sum(nh) - 1u];
+        bp[(size_t)t * NB + tid] = (sp_ << 6) | bp_;
+      }
+      // ---------------- gather the surviving beams (beam_search_coder.py:92-93), prepare the next step ----------------
+      const bool last = (t == K - 1);
+      __builtin_amdgcn_s_setprio(2); // serial phase: ahead of the other team's scoring waves
+      if (active) {
+        const float sa_t[4] = {sa[0], sa[1], sa[2], sa[3]};   // this step's sample scale
+        const float *bold = beams_g + ((size_t)cur * NB) * FAST_MAX_DIM + d0;
+        float *bnew = beams_g + ((size_t)(cur ^ 1) * NB) * FAST_MAX_DIM + d0;
+        // G is dead from the end of scoring until it is rebuilt below: every entry is redefined here
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) G[j][i] = 0.f;
+        float m[4], cA[4], cBv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { m[i] = 0.f; cA[i] = 0.f; cBv[i] = 0.f; }
+        float cacc[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) cacc[j] = 0.f;
+        constexpr int UB = NB <= 10 ? NB : (NB + 1) / 2;      // beams per load batch
+#pragma unroll
+        for (int j0 = 0; j0 < NB; j0 += UB) {
+          // ---- issue the batch's global reads (proposal rows, old beams) back to back ----
+          uint2 apv[UB];
+          float4 obv4[UB];
+          uint32_t bet_old[UB];
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            const int j = j0 + u;
+            apv[u] = make_uint2(0u, 0u);
+            obv4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            bet_old[u] = 0u;
+            if (j < NB && j < Bnew) { // wave-uniform
+              const int32_t sp_ = __builtin_amdgcn_readfirstlane(sel_s[j]);
+              const int32_t bp_ = __builtin_amdgcn_readfirstlane(sel_b[j]);
+              bet_old[u] = __builtin_amdgcn_readfirstlane(beta4[cur * 64 + bp_]);
+              apv[u] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sp_ * Dp);
+              if (t) obv4[u] = *reinterpret_cast<const float4 *>(bold + (size_t)bp_ * FAST_MAX_DIM);
+            }
+          }
+          if (j0 == 0 && !last) step_consts(t + 1, m, cA, cBv); // next step's constants, under the loads' latency
+          // ---- new beams, their G and C terms ----
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            const int j = j0 + u;
+            if (j < NB && j < Bnew) { // wave-uniform
+              const uint32_t al[4] = {(apv[u].x & 0xFFFFu) << 2, (apv[u].x >> 16) << 2, (apv[u].y & 0xFFFFu) << 2, (apv[u].y >> 16) << 2};
+              const float obv[4] = {obv4[u].x, obv4[u].y, obv4[u].z, obv4[u].w};
+              float nb[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const float y = sa_t[i] * lds_abs_f32(al[i] + bet_old[u]); // dist.quantile(.), :48-49
+                nb[i] = obv[i] + y;                                         // combined_samples[best_ind_aux, best_ind_beam], :81,92-93
+              }
+              if (last) {
+                if (j == 0 && sw == 0) {
+#pragma unroll
+                  for (int i = 0; i < 4; ++i)
+                    if (valid[i]) A.out_sample[ix[i]] = nb[i] + A.p_loc[ix[i]]; // beams[0] + coding_dist.loc, :122
+                }
+              } else {
+                if (sw == 0) *reinterpret_cast<float4 *>(bnew + (size_t)j * FAST_MAX_DIM) = make_float4(nb[0], nb[1], nb[2], nb[3]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  G[j][i] = beam_G(nb[i], m[i], cA[i], cBv[i], sa[i]);
+                  cacc[j] = beam_C_term(cacc[j], nb[i], m[i], cA[i], cBv[i]);
+                }
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!last) {
+          const float ctot = reduce_scatter<32>(cacc, lane);  // lane l holds beam (l >> 1)
+          const int j = lane >> 1;
+          if (sw == 0 && (lane & 1) == 0 && j < Bnew) cpart_s[g * 32 + j] = ctot;
+        }
+      }
+      tsync();
+      __builtin_amdgcn_s_setprio(0);
+      if (!last && tid < Bnew) {
+        float cb = cpart_s[tid];
+        for (int gg = 1; gg < NG; ++gg) cb = cb + cpart_s[gg * 32 + tid];
+        Cb_s[tid] = cb; // read after the next scoring barrier
+      }
+      cur ^= 1;
+      Bcur = Bnew;
+    }
+    // ---- index path of beam 0 (beam_search_coder.py:118-121) ----
+    tsync();
+    if (tid == 0) {
+      int j = 0;
+      for (int t = K - 1; t >= 0; --t) {
+        const int32_t v = __builtin_nontemporal_load(&bp[(size_t)t * NB + j]);
+        A.out_indices[blk * (int64_t)A.max_K + t] = v >> 6;
+        j = v & 63;
+      }
+    }
+  }
+}
+
+// ======================================================================================================
+//  proposal table with copy bits: tab[t][s][d] = dlog_g(r[s, d]) + 10006 * c   (uint16, row stride = D rounded up to 4)
+//
+//  The int32 draw of get_pseudo_random_sample (beam_search_coder.py:38-43) depends only on (seed + t, S, D): it is
+//  evaluated once per call.  The block kernel's lane l of dim group g reads the quad d = 256 g + 4 l .. +3 of a row and
+//  issues, per dim slot i and beam, one ds_read_b32 whose 32-lane groups are the quads [32 m, 32 m + 32) of the row.
+//  For every such group and slot the 32 look-ups are spread over the banks by choosing c per lane: lane with
+//  a = dlog mod 32 lands on bank a (c = 0) or a + 22 (c = 1), plus the beam's common rotation.  Since gcd(22, 32) = 2
+//  the banks form two rings of 16 (p -> p + 1 is bank -> bank + 22) and a lane is an edge between neighbours; the
+//  assignment minimising the busiest bank is found exactly: for L = 1, 2, ... and every x_0, push as many edges as
+//  node p still takes (x_p = min(n_p, L - n_{p-1} + x_{p-1})) and test the closing node.
+//  One half-wave per (t, s, m); choice bits never change any emitted value (all three table copies are identical).
+// ======================================================================================================
+__global__ __launch_bounds__(256) void alpha_choice_kernel(int64_t seed, int32_t S, int32_t D, int32_t K_tab,
+                                                           const uint16_t *__restrict__ dlog4r, uint16_t *__restrict__ tab) {
+  __shared__ uint8_t n_s[8][4][32]; // [half-wave][slot][bank] look-ups whose c = 0 bank this is
+  __shared__ uint8_t x_s[8][4][32]; // how many of them stay (c = 0)
+  const int Dp = (D + 3) & ~3;
+  const int NQ = Dp >> 2;             // quads per row
+  const int NM = (NQ + 31) >> 5;      // 32-lane groups per row
+  const int64_t n_hw = (int64_t)K_tab * S * NM;
+  const int hwl = threadIdx.x >> 5, j = threadIdx.x & 31;
+  for (int64_t hw0 = (int64_t)blockIdx.x * 8; hw0 < n_hw; hw0 += (int64_t)gridDim.x * 8) {
+    const int64_t hw = hw0 + hwl;
+    const bool hw_ok = hw < n_hw;
+    const int64_t row = hw_ok ? hw / NM : 0;           // t * S + s
+    const int m = hw_ok ? (int)(hw - row * NM) : 0;
+    const int t = (int)(row / S), s = (int)(row - (int64_t)t * S);
+    const int quad = 32 * m + j;
+    const bool q_ok = hw_ok && quad < NQ;
+    uint32_t al[4] = {0u, 0u, 0u, 0u};
+    if (q_ok) {
+      const StepSeed ss = make_step_seed(seed + t);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (4 * quad + i < D) al[i] = (uint32_t)dlog4r[draw_rm1(ss, (uint64_t)s * (uint64_t)D + (uint64_t)(4 * quad + i))] >> 2;
+    }
+    // rank of every look-up among those of its group with the same c = 0 bank, and the per-bank counts
+    uint32_t rank[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t a = al[i] & 31u;
+      uint32_t cnt_mine = 0u;
+      for (uint32_t v = 0; v < 32u; ++v) {
+        const unsigned long long mask = __ballot(q_ok && a == v);
+        const uint32_t half = (threadIdx.x & 32) ? (uint32_t)(mask >> 32) : (uint32_t)mask;
+        if (a == v) rank[i] = (uint32_t)__popc(half & ((1u << j) - 1u));
+        if ((uint32_t)j == v) cnt_mine = (uint32_t)__popc(half);
+      }
+      n_s[hwl][i][j] = (uint8_t)cnt_mine;
+    }
+    __syncthreads();
+    if (j < 8 && hw_ok) { // 4 slots x 2 rings per half-wave
+      const int slot = j >> 1, ring = j & 1;
+      int n[16], x[16];
+#pragma unroll
+      for (int p = 0; p < 16; ++p) { n[p] = n_s[hwl][slot][(ring + 22 * p) & 31]; x[p] = n[p]; }
+      bool done = false;
+      for (int L = 1; L <= 32 && !done; ++L)
+        for (int x0 = 0; x0 <= n[0] && !done; ++x0) {
+          int xx[16];
+          xx[0] = x0;
+          bool ok = true;
+#pragma unroll
+          for (int p = 1; p < 16; ++p) {
+            const int ub = L - n[p - 1] + xx[p - 1];
+            if (ub < 0) ok = false;
+            xx[p] = n[p] < ub ? n[p] : (ub < 0 ? 0 : ub);
+          }
+          if (ok && xx[0] + n[15] - xx[15] <= L) {
+            done = true;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) x[p] = xx[p];
+          }
+        }
+#pragma unroll
+      for (int p = 0; p < 16; ++p) x_s[hwl][slot][(ring + 22 * p) & 31] = (uint8_t)x[p];
+    }
+    __syncthreads();
+    if (q_ok) {
+      uint32_t v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = al[i] + (rank[i] < (uint32_t)x_s[hwl][i][al[i] & 31u] ? 0u : IREC_PM1);
+      *reinterpret_cast<uint2 *>(tab + (row * Dp + 4 * quad)) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+    }
+    __syncthreads(); // n_s / x_s are reused by the next round
+  }
+}
+
+// ======================================================================================================
+//  launchers
+// ======================================================================================================
+size_t team_lds_for(int B, int S) {
+  const int nb = fast_nb_for(B);
+  if (nb != 10 && nb != 20) return (size_t)-1;           // the 32-beam build does not fit the register budget of a team
+  if ((int64_t)S * nb > 1024) return (size_t)-1;         // one scoring pass, keys over group 0 of the partials
+  const size_t b = team_lds_total(nb, S);
+  return b <= FAST_LDS_LIMIT ? b : (size_t)-1;
+}
+
+template <int NB>
+static hipError_t launch_team_t(const EncArgs &A, int grid, hipStream_t st) {
+  const size_t lds = team_lds_total(NB, A.S);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_team_kernel<NB>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((encode_team_kernel<NB>), dim3(grid), dim3(TEAMS * TEAM_NT), lds, st, A);
+  return hipGetLastError();
+}
+
+hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
+  switch (fast_nb_for(A.B)) {
+    case 10: return launch_team_t<10>(A, grid, st);
+    case 20: return launch_team_t<20>(A, grid, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_alpha_choice(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *dlog4r, uint16_t *tab,
+                               hipStream_t st) {
+  const int64_t n_hw = (int64_t)K_tab * S * ((((D + 3) >> 2) + 31) >> 5);
+  const int64_t want = (n_hw + 7) / 8;
+  const int grid = (int)(want < 4096 ? want : 4096);
+  hipLaunchKernelGGL(alpha_choice_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, st, seed, S, D, K_tab, dlog4r, tab);
+  return hipGetLastError();
+}
+
+} // namespace irec

@@ -12,6 +12,7 @@ IREC_E_NO_DEVICE = -3
 IREC_E_WORKSPACE = -4
 IREC_FLAG_FORCE_GENERIC = 1
 IREC_FLAG_FUSED_PHILOX = 2
+IREC_FLAG_ONE_TABLE = 4
 BIG_PRIME = 10007
 MAX_BEAMS = 64
 MAX_PARTITIONS = 65536
@@ -55,6 +56,7 @@ SIGNATURES = {
     "irec_device_uniform_int": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "irec_test_reduce_scatter": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "irec_test_select": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "irec_test_proposal_table": (ctypes.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "irec_device_tables": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                           ctypes.POINTER(_vp)]),
 }

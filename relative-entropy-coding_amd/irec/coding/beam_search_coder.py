@@ -24,6 +24,7 @@ class BeamSearchCoder(GaussianCoder):
         self.big_prime = 10007
         self.force_generic = False   # debugging / testing knob: IREC_FLAG_FORCE_GENERIC
         self.fused_philox = False    # debugging / testing knob: IREC_FLAG_FUSED_PHILOX
+        self.one_table = False       # debugging / testing knob: IREC_FLAG_ONE_TABLE
         self._max_K_hint = 32
 
     # ---- small host-side mirrors ---------------------------------------------------------------------------------
@@ -47,7 +48,8 @@ class BeamSearchCoder(GaussianCoder):
         if self.n_samples < 1:
             raise CodingError(f"n_samples = {self.n_samples} < 1")
         flags = (_lib.IREC_FLAG_FORCE_GENERIC if self.force_generic else 0) | \
-                (_lib.IREC_FLAG_FUSED_PHILOX if self.fused_philox else 0)
+                (_lib.IREC_FLAG_FUSED_PHILOX if self.fused_philox else 0) | \
+                (_lib.IREC_FLAG_ONE_TABLE if self.one_table else 0)
         return get_engine().params(self.kl_per_partition, self.n_samples, self.n_beams, flags)
 
     @staticmethod

@@ -183,6 +183,13 @@ class Engine:
                    "irec_device_uniform_int")
         return out
 
+    def test_proposal_table(self, seed, n_samples, dim, n_steps):
+        dp = (dim + 3) // 4 * 4
+        out = torch.zeros((n_steps, n_samples, dp), dtype=torch.int16, device=self.device)
+        _lib.check(self.lib.irec_test_proposal_table(self.ctx, int(seed), int(n_samples), int(dim), int(n_steps), _ptr(out),
+                                                     self._stream()), "irec_test_proposal_table")
+        return out
+
     def test_select(self, scores, n_select, n_beams_cur):
         n = scores.numel()
         keys = torch.empty(n, dtype=torch.int32, device=self.device)

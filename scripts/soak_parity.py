@@ -40,10 +40,10 @@ for case in range(n_cases):
     ridx, rs = O.encode_block(mq, sq, mp, sp, seed, omega, S, B, max_K=512)
     q = torch.distributions.Normal(torch.from_numpy(mq[None]).cuda(), torch.from_numpy(sq[None]).cuda(), validate_args=False)
     p = torch.distributions.Normal(torch.from_numpy(mp[None]).cuda(), torch.from_numpy(sp[None]).cuda(), validate_args=False)
-    for variant in ("table", "fused", "generic"):
+    for variant in ("table", "one_table", "fused", "generic"):
         c = irec.BeamSearchCoder(kl_per_partition=omega, n_beams=B, extra_samples=eps1)
         c.n_samples = S
-        c.force_generic = variant == "generic"; c.fused_philox = variant == "fused"
+        c.force_generic = variant == "generic"; c.fused_philox = variant == "fused"; c.one_table = variant == "one_table"
         idx, sample = c.encode(q, p, seed=seed)
         ok = [int(i) for i in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
         if ok and K:
@@ -51,7 +51,7 @@ for case in range(n_cases):
         if not ok:
             bad.append((case, variant, D, B, S, omega, K, style, seed))
     done += 1; stats["K"].append(K); stats["evals"] += S * D * (1 + max(K - 1, 0) * B)
-print(f"soak: {done} random blocks x 3 variants in {time.time() - t0:.0f} s; K range {min(stats['K'])}..{max(stats['K'])}; "
+print(f"soak: {done} random blocks x 4 variants in {time.time() - t0:.0f} s; K range {min(stats['K'])}..{max(stats['K'])}; "
       f"{stats['evals'] / 1e9:.2f} G proposal evals checked; mismatches: {len(bad)}")
 for b in bad[:20]:
     print("MISMATCH case=%d variant=%s D=%d B=%d S=%d omega=%.3f K=%d style=%d seed=%d" % b)

@@ -17,7 +17,8 @@ def _normal(loc, scale, device="cuda"):
                                       validate_args=False)
 
 
-VARIANTS = ["table", "fused", "generic"]   # proposal-table beam-table kernel / Philox-fused kernel / fallback
+# two teams per CU over three table copies (default) / one-table proposal-table kernel / Philox-fused kernel / fallback
+VARIANTS = ["table", "one_table", "fused", "generic"]
 
 
 def _coder(omega, B, eps1, block_size=None, variant="table"):
@@ -25,6 +26,7 @@ def _coder(omega, B, eps1, block_size=None, variant="table"):
     c = irec.BeamSearchCoder(kl_per_partition=omega, n_beams=B, extra_samples=eps1, block_size=block_size)
     c.force_generic = variant == "generic"
     c.fused_philox = variant == "fused"
+    c.one_table = variant == "one_table"
     return c
 
 
@@ -83,6 +85,43 @@ def test_in_kernel_philox_stream(engine, oracle):
     for seed, n in [(42, 36 * 1000), (43, 4097), (0, 64), (2 ** 31 - 1, 64), (69420 + 3, 403)]:
         got = engine.device_uniform_int(seed, n).cpu().numpy()
         assert np.array_equal(got, oracle.uniform_int(seed, n)), seed
+
+
+@pytest.mark.parametrize("dim,S,steps", [(1000, 36, 3), (192, 36, 2), (1, 5, 2), (130, 20, 2), (1024, 7, 1), (999, 11, 2)])
+def test_proposal_table_dlogs_and_bank_spread(engine, oracle, dim, S, steps):
+    """tab[t][s][d] = dlog_g(r) + 10006 c: the dlog part must be the discrete log of the reference's int32 draw
+    (beam_search_coder.py:38-43), c in {0, 1}, and c must spread every 32-lane look-up group over the LDS banks."""
+    P = 10007
+    g = next(c for c in range(2, P) if len({pow(c, e, P) for e in range(P - 1)}) == P - 1)   # smallest primitive root
+    dlog = np.zeros(P, dtype=np.int64)
+    x = 1
+    for e in range(P - 1):
+        dlog[x] = e
+        x = x * g % P
+    tab = engine.test_proposal_table(42, S, dim, steps).cpu().numpy().view(np.uint16).astype(np.int64)
+    dp = tab.shape[2]
+    busiest_plain, busiest = [], []
+    for t in range(steps):
+        r = oracle.uniform_int(42 + t, S * dim).reshape(S, dim)
+        want = dlog[r]
+        got = tab[t, :, :dim]
+        assert np.array_equal(got % (P - 1), want), t
+        assert ((got // (P - 1)) <= 1).all()
+        assert (tab[t, :, dim:] % (P - 1) == 0).all()   # padding dims: entry 0 of either copy
+        for s in range(S):
+            row = np.concatenate([tab[t, s], np.zeros(-dp % 128, dtype=np.int64)])[: (dp + 127) // 128 * 128]
+            valid = np.arange(row.size) < dp
+            for m in range(row.size // 128):          # 32 lanes x 4 dim slots
+                for i in range(4):
+                    sel = slice(128 * m + i, 128 * m + 128, 4)
+                    v = row[sel][valid[sel]]
+                    if v.size:
+                        busiest.append(np.bincount(v % 32, minlength=32).max())
+                        busiest_plain.append(np.bincount((v % (P - 1)) % 32, minlength=32).max())
+    # exact optimum of the two-choice assignment: never worse than leaving every look-up in copy 0
+    assert np.mean(busiest) <= np.mean(busiest_plain)
+    if dim >= 999:
+        assert np.mean(busiest) < 2.3 and np.mean(busiest_plain) > 3.2, (np.mean(busiest), np.mean(busiest_plain))
 
 
 def test_block_kl_and_partition_count(engine, oracle):
@@ -251,7 +290,7 @@ def test_high_kl_block_many_partitions(engine, oracle):
     assert len(ridx) > 64 and [int(i) for i in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
 
 
-@pytest.mark.parametrize("flags", [0, 2], ids=["table", "fused"])
+@pytest.mark.parametrize("flags", [0, 4, 2], ids=["table", "one_table", "fused"])
 def test_full_size_properties(engine, oracle, flags):
     """BASELINE config 2 at bench size: properties that need no oracle run (round trip, ranges), plus a sampled
     subset of blocks checked against the oracle."""
