@@ -183,7 +183,7 @@ def main():
                    "parallelism": f"latents sharded over {world} GPU(s), no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": algo_bytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": algo_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "encode_fast_kernel<20,4,true>", "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes},
+                     "kernel": "encode_team_kernel<20>", "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes},
         "secondary": {"proposal_evals_per_s": evals / (kernel_ms * 1e-3),
                       "evals_per_clk_per_cu": evals / (kernel_ms * 1e-3) / (N_CU * clk_ghz * 1e9),
                       "lds_gather_frac_of_128B_per_clk": 4 * evals / (kernel_ms * 1e-3) / (N_CU * 128 * clk_ghz * 1e9),

@@ -219,6 +219,69 @@ __device__ __forceinline__ float reduce_scatter(float (&v)[N0], int lane) {
   return v[0];
 }
 
+// ---- reduce-scatter of an arbitrary number of values (2..64), same canonical tree ------------------------------
+// Stage DIST halves the value count to ceil(N/2): the lane whose bit DIST is clear keeps values [0, H), its partner
+// keeps [H, N) (and, for odd N, one unused slot).  The pairing of lanes (distance 32, 16, 8, 4, 2, 1) and therefore every
+// rounding is the same as in reduce_scatter<64|32|16>; only which lane ends up with which value differs.
+// 20 values cost 10+5+3+2+1+1 = 22 exchange+add pairs instead of the 31 of a zero-padded 32-wide reduce-scatter.
+template <int DIST>
+__device__ __forceinline__ float allreduce_pair(float v) { // v + (value of lane ^ DIST), both lanes get the same bits
+  if constexpr (DIST == 32) { float a = v, b = v; swap32(a, b); return a + b; }
+  else if constexpr (DIST == 16) { float a = v, b = v; swap16(a, b); return a + b; }
+  else return v + partner<DIST>(v);
+}
+template <int DIST, int N>
+__device__ __forceinline__ void rsn_stage(float *v, int lane) { // v has room for 2 * ceil(N / 2) values
+  if constexpr (N == 1) v[0] = allreduce_pair<DIST>(v[0]);
+  else {
+    constexpr int H = (N + 1) / 2;
+    if constexpr ((N & 1) != 0) v[N] = 0.f; // the partner of the middle value
+    if constexpr (DIST == 32) {
+#pragma unroll
+      for (int j = 0; j < H; ++j) { swap32(v[j], v[j + H]); v[j] = v[j] + v[j + H]; }
+    } else if constexpr (DIST == 16) {
+#pragma unroll
+      for (int j = 0; j < H; ++j) { swap16(v[j], v[j + H]); v[j] = v[j] + v[j + H]; }
+    } else {
+      const bool hi = (lane & DIST) != 0;
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        const float keep = hi ? v[j + H] : v[j], send = hi ? v[j] : v[j + H];
+        v[j] = keep + partner<DIST>(send);
+      }
+    }
+  }
+}
+constexpr int rsn_next(int n) { return n >= 2 ? (n + 1) / 2 : 1; }
+constexpr int rsn_room(int n) { return 2 * ((n + 1) / 2); }
+// v must have room for rsn_room(N0) values; returns the total this lane ends up with (see rsn_owner)
+template <int N0>
+__device__ __forceinline__ float reduce_scatter_n(float *v, int lane) {
+  static_assert(N0 >= 2 && N0 <= 64, "unsupported width");
+  constexpr int n4 = rsn_next(N0), n3 = rsn_next(n4), n2 = rsn_next(n3), n1 = rsn_next(n2), n0 = rsn_next(n1);
+  rsn_stage<32, N0>(v, lane);
+  rsn_stage<16, n4>(v, lane);
+  rsn_stage<8, n3>(v, lane);
+  rsn_stage<4, n2>(v, lane);
+  rsn_stage<2, n1>(v, lane);
+  rsn_stage<1, n0>(v, lane);
+  return v[0];
+}
+// index of the value whose total reduce_scatter_n<N0> leaves in this lane, or -1 if the lane holds an unused slot
+template <int N0>
+__device__ __forceinline__ int rsn_owner(int lane) {
+  int idx = 0, cnt = N0, n = N0;
+#pragma unroll
+  for (int dist = 32; dist >= 1; dist >>= 1) {
+    if (n >= 2) {
+      const int H = (n + 1) / 2;
+      if (lane & dist) { idx += H; cnt -= H; } else cnt = cnt < H ? cnt : H;
+      n = H;
+    }
+  }
+  return cnt >= 1 ? idx : -1;
+}
+
 // The fast kernel addresses its LUT by ABSOLUTE LDS byte address (the table is the first thing in the dynamic LDS
 // region, which starts at 0 because the kernel has no static __shared__): saves one VALU add per proposal.
 typedef __attribute__((address_space(3))) const float lds_cfloat;

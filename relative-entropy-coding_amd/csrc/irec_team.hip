@@ -54,12 +54,23 @@ struct TeamBarrier {
   }
 };
 
+// Diagnostic build (-DIREC_TEAM_STAMPS, scripts/gpu_stamps.sh): per-wave cycle sums per phase, written once at exit.
+#ifdef IREC_TEAM_STAMPS
+#define TSTAMP(slot) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[slot] += now_ - st_prev; st_prev = now_; } while (0)
+#else
+#define TSTAMP(slot) do { } while (0)
+#endif
+
 // LDS carve (bytes): lut2 x 3 [120080] | team 0: part [4][S][NB] f32 (sort keys overwrite group 0) | SmallLds | barrier | team 1: same
 template <int NB>
 __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs A) {
   using Cfg = FastCfg<NB, true>;
   constexpr int NT = TEAM_NT, NW = TEAM_NW;
-  constexpr int RW = Cfg::RW, SPC = Cfg::SPC;
+  // accumulators reduced together: 6 samples x 10 beams through the 64-wide reduce-scatter, or ONE sample x 20 beams
+  // through the 20-value one (22 exchange+add pairs per sample instead of 31, and 12 registers fewer)
+  constexpr bool RSN = NB == 20;
+  constexpr int RW = RSN ? NB : Cfg::RW, SPC = RSN ? 1 : Cfg::SPC;
+  constexpr int ACC_ROOM = RSN ? rsn_room(NB) : RW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int S = A.S, B = A.B;
   const int lane = threadIdx.x & 63;
@@ -80,6 +91,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
   float *Cb_s = sm->Cb;
   const uint16_t *dlog_s = A.dlog4r;                                            // [10006] 4*dlog(j+1), global (L2)
   const int SP = S;                                                             // one scoring pass per step
+  const int rs_b = RSN ? rsn_owner<NB>(lane) : 0;                               // beam whose total reduce_scatter_n leaves here
 
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap(); // see lds_abs_f32
   {
@@ -98,11 +110,16 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
   float *beams_g = reinterpret_cast<float *>(slab + A.ws_per_wg - (size_t)2 * NB * FAST_MAX_DIM * 4); // [2][NB][1024]
   float *stats_g = beams_g - 3 * FAST_MAX_DIM;  // [3][1024]: mq - mp, sq^2, sp^2 of the block, coalesced
 
+#ifdef IREC_TEAM_STAMPS
+  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+#endif
   for (;;) {
     tsync();
     if (tid == 0) misc[0] = (int32_t)atomicAdd(A.counter, 1u);
     tsync();
     const int64_t blk = misc[0];
+    TSTAMP(0);
     if (blk >= A.n_blocks) break; // every wave of the team reaches this; the other team drains on its own
     const int D = A.block_dim[blk];
     const int64_t base = A.block_base[blk];
@@ -211,17 +228,25 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
       // (visibility of Cb_s: the barrier after scoring)
     }
 
+    TSTAMP(1);
     int cur = 0, Bcur = 1;
     for (int t = 0; t < K; ++t) {
       // row s at + s * Dp; lanes past the padded row end read the row START (finite z, zero coefficients)
       const uint16_t *tab_t = tab + (size_t)t * S * Dp + (d0 < Dp ? d0 : 0);
       uint32_t bet[NB];
+      {
+        const uint32_t bv = beta4[cur * 64 + (lane < Bcur ? lane : 0)]; // one LDS round trip, then cross-lane reads
 #pragma unroll
-      for (int b = 0; b < NB; ++b) bet[b] = __builtin_amdgcn_readfirstlane(beta4[cur * 64 + (b < Bcur ? b : 0)]);
+        for (int b = 0; b < NB; ++b) bet[b] = (uint32_t)__builtin_amdgcn_readlane((int)bv, b);
+      }
 
       const int N = S * Bcur;
       // ---------------- scoring: S x Bcur candidates (beam_search_coder.py:80-84) ----------------
+#ifdef IREC_ABLATE_SCORING
+      if (false) {
+#else
       if (active) {
+#endif
         const int s_per_stripe = (S + NSW - 1) / NSW;
         const int nchunks = (s_per_stripe + SPC - 1) / SPC;
         // proposal rows (4 x uint16: dlog(r) + 10006 c of my dims) are fetched one chunk ahead
@@ -233,7 +258,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
           if (s0 < S) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)s0 * Dp);
         }
         for (int ch = 0; ch < nchunks; ++ch) {
-          float acc[RW];
+          float acc[ACC_ROOM];
 #pragma unroll
           for (int p = 0; p < RW; ++p) acc[p] = 0.f;
           uint2 alp[SPC];
@@ -275,15 +300,23 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
               }
             }
           }
-          const float tot = reduce_scatter<RW>(acc, lane);
-          const int p = RW == 64 ? lane : (lane >> 1);
-          const int cc = p / NB, b = p - cc * NB;
-          const int s = (ch * SPC + cc) * NSW + sw;
-          if (cc < SPC && s < S && b < Bcur && (RW == 64 || (lane & 1) == 0))
-            part_s[((size_t)g * SP + s) * NB + b] = tot;
+          if constexpr (RSN) {
+            const float tot = reduce_scatter_n<NB>(acc, lane);
+            const int s = ch * NSW + sw;
+            if (rs_b >= 0 && (lane & 1) == 0 && s < S && rs_b < Bcur) part_s[((size_t)g * SP + s) * NB + rs_b] = tot;
+          } else {
+            const float tot = reduce_scatter<RW>(acc, lane);
+            const int p = RW == 64 ? lane : (lane >> 1);
+            const int cc = p / NB, b = p - cc * NB;
+            const int s = (ch * SPC + cc) * NSW + sw;
+            if (cc < SPC && s < S && b < Bcur && (RW == 64 || (lane & 1) == 0))
+              part_s[((size_t)g * SP + s) * NB + b] = tot;
+          }
         }
       }
+      TSTAMP(2);
       tsync();
+      TSTAMP(3);
       // ---------------- combine dim groups in order, add C_b, build sort keys ----------------
       {
         // keys are written over group 0 of the partials: two phases with a barrier in between because
@@ -309,7 +342,15 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
         }
       }
       const int Bnew = B < N ? B : N;
+      TSTAMP(4);
+#ifdef IREC_ABLATE_SELECT
+      tsync();
+      if (tid < Bnew) { sel_s[tid] = tid % S; sel_b[tid] = tid % Bcur; }
+      tsync();
+#else
       select_topB_sync<NT>(key_s, N, Bnew, Bcur, sm, tid, tsync); // first barrier inside orders the key_s writes
+#endif
+      TSTAMP(5);
       // ---------------- new hashes / back-pointers (beam_search_coder.py:94-95) ----------------
       if (tid < Bnew) {
         const int32_t sp_ = sel_s[tid], bp_ = sel_b[tid];
@@ -321,7 +362,11 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
       // ---------------- gather the surviving beams (beam_search_coder.py:92-93), prepare the next step ----------------
       const bool last = (t == K - 1);
       __builtin_amdgcn_s_setprio(2); // serial phase: ahead of the other team's scoring waves
+#ifdef IREC_ABLATE_UPDATE
+      if (false) {
+#else
       if (active) {
+#endif
         const float sa_t[4] = {sa[0], sa[1], sa[2], sa[3]};   // this step's sample scale
         const float *bold = beams_g + ((size_t)cur * NB) * FAST_MAX_DIM + d0;
         float *bnew = beams_g + ((size_t)(cur ^ 1) * NB) * FAST_MAX_DIM + d0;
@@ -336,7 +381,10 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
         float cacc[32];
 #pragma unroll
         for (int j = 0; j < 32; ++j) cacc[j] = 0.f;
-        constexpr int UB = NB <= 10 ? NB : (NB + 1) / 2;      // beams per load batch
+        constexpr int UB = NB;                                // all beams' loads in one batch (G's registers are free)
+        // lane j fetches the selection of new beam j and the offset of its parent: two LDS round trips for all beams
+        const int32_t v_sp = sel_s[lane < Bnew ? lane : 0], v_bp = sel_b[lane < Bnew ? lane : 0];
+        const uint32_t v_bo = beta4[cur * 64 + v_bp];
 #pragma unroll
         for (int j0 = 0; j0 < NB; j0 += UB) {
           // ---- issue the batch's global reads (proposal rows, old beams) back to back ----
@@ -350,9 +398,9 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
             obv4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             bet_old[u] = 0u;
             if (j < NB && j < Bnew) { // wave-uniform
-              const int32_t sp_ = __builtin_amdgcn_readfirstlane(sel_s[j]);
-              const int32_t bp_ = __builtin_amdgcn_readfirstlane(sel_b[j]);
-              bet_old[u] = __builtin_amdgcn_readfirstlane(beta4[cur * 64 + bp_]);
+              const int32_t sp_ = __builtin_amdgcn_readlane(v_sp, j);
+              const int32_t bp_ = __builtin_amdgcn_readlane(v_bp, j);
+              bet_old[u] = (uint32_t)__builtin_amdgcn_readlane((int)v_bo, j);
               apv[u] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sp_ * Dp);
               if (t) obv4[u] = *reinterpret_cast<const float4 *>(bold + (size_t)bp_ * FAST_MAX_DIM);
             }
@@ -390,13 +438,20 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
           __builtin_amdgcn_sched_barrier(0);
         }
         if (!last) {
-          const float ctot = reduce_scatter<32>(cacc, lane);  // lane l holds beam (l >> 1)
-          const int j = lane >> 1;
-          if (sw == 0 && (lane & 1) == 0 && j < Bnew) cpart_s[g * 32 + j] = ctot;
+          if constexpr (RSN) {
+            const float ctot = reduce_scatter_n<NB>(cacc, lane);
+            if (sw == 0 && (lane & 1) == 0 && rs_b >= 0 && rs_b < Bnew) cpart_s[g * 32 + rs_b] = ctot;
+          } else {
+            const float ctot = reduce_scatter<32>(cacc, lane);  // lane l holds beam (l >> 1)
+            const int j = lane >> 1;
+            if (sw == 0 && (lane & 1) == 0 && j < Bnew) cpart_s[g * 32 + j] = ctot;
+          }
         }
       }
+      TSTAMP(6);
       tsync();
       __builtin_amdgcn_s_setprio(0);
+      TSTAMP(7);
       if (!last && tid < Bnew) {
         float cb = cpart_s[tid];
         for (int gg = 1; gg < NG; ++gg) cb = cb + cpart_s[gg * 32 + tid];
@@ -415,7 +470,12 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
         j = v & 63;
       }
     }
+    TSTAMP(8);
   }
+#ifdef IREC_TEAM_STAMPS
+  if (A.dbg && lane == 0)
+    for (int k = 0; k < 12; ++k) A.dbg[((size_t)blockIdx.x * 8 + wave_wg) * 16 + k] = st_acc[k];
+#endif
 }
 
 // ======================================================================================================

@@ -18,7 +18,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ
   name=$(echo $set | tr ' ' '_' | cut -c1-40)
   timeout 900 rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/prof_$TAG/pmc_$name -- python bench.py --steps 2 --warmup 1 --latents $L --no-cpu-baseline > gpurun_out/prof_$TAG/pmc_$name.log 2>&1
   f=$(find gpurun_out/prof_$TAG/pmc_$name -name "*counter_collection.csv" | head -1)
-  [ -n "$f" ] && python scripts/pmc_summary.py "$f" encode_fast | tee gpurun_out/prof_$TAG/pmc_$name.summary
+  [ -n "$f" ] && python scripts/pmc_summary.py "$f" ${KERNEL:-encode_team} | tee gpurun_out/prof_$TAG/pmc_$name.summary
 done
 fi
 # keep only the small summaries

@@ -1,9 +1,10 @@
 #!/bin/bash
-# Diagnostic: per-phase cycle shares of the fast encoders (in-kernel s_memtime stamps; not a timing run).
+# Diagnostic: per-wave phase shares of the team encoder (csrc/variants/stamps.so = -DIREC_TEAM_STAMPS build; not a timing run).
 set -u
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-for v in table fused; do
-  echo "== $v"
-  IREC_STAMPS=1 IREC_VARIANT=$v timeout 300 python scripts/run_variant.py 2>&1 | grep -E "stamps|ms" | tail -6
-done | tee gpurun_out/stamps.log
+C=relative-entropy-coding_amd/csrc
+cp $C/libirec_hip.so /tmp/full.so
+cp $C/variants/stamps.so $C/libirec_hip.so
+IREC_STAMPS=1 LATENTS=${LATENTS:-2048} timeout 300 python scripts/run_variant.py 2>&1 | tail -16 | tee gpurun_out/stamps.log
+cp /tmp/full.so $C/libirec_hip.so
