@@ -19,15 +19,16 @@ __device__ __forceinline__ int64_t src_index(const EncArgs &A, int64_t base, int
 // Diagnostic phase stamps (only when EncArgs.dbg != nullptr; the values never reach an output of the coder).
 __device__ __forceinline__ unsigned long long stamp_now() { return __builtin_amdgcn_s_memtime(); }
 
-// Small per-workgroup LDS state shared by the encoders.
-struct SmallLds {
+// Small per-workgroup (or per-team) LDS state shared by the encoders; MB = most beams the kernel serves.
+template <int MB>
+struct SmallLdsT {
   union {                           // the two selection paths never run at the same time
     unsigned long long wb[16];      // per-wave maxima of the scan-based selection, double buffered
     unsigned long long cand[64];    // compacted (key, flat) survivors of the threshold selection
   };
-  int32_t sel_s[64], sel_b[64];     // selected (sample, beam) per new beam
-  int32_t hsum[2][64];              // running int32 sum of simple_hash per beam, double buffered
-  uint32_t beta4[2][64];            // 4 * dlog(hash) per beam, double buffered
+  int32_t sel_s[MB], sel_b[MB];     // selected (sample, beam) per new beam
+  int32_t hsum[2][MB];              // running int32 sum of simple_hash per beam, double buffered
+  uint32_t beta4[2][MB];            // 4 * dlog(hash) per beam, double buffered
   int32_t misc[8];                  // [0] block id, [1] K, [7] selection path flag
   union {                           // KL partials are consumed before the first C_b partial is written
     double gpart[4];                // per dim-group KL partial sums
@@ -35,6 +36,7 @@ struct SmallLds {
   };
   float Cb[32];                     // C_b of the live beams
 };
+using SmallLds = SmallLdsT<64>;
 constexpr size_t SMALL_LDS_BYTES = (sizeof(SmallLds) + 15) & ~(size_t)15;
 
 // Block-wide top-Bnew selection over key[0..N) (uint32 sort keys, 0 = taken / empty), NT threads.
@@ -47,8 +49,8 @@ constexpr size_t SMALL_LDS_BYTES = (sizeof(SmallLds) + 15) & ~(size_t)15;
 //  - otherwise: all waves scan the keys, one barrier per selected beam (element f owned by thread f % NT).
 // `sync` is the barrier of the NT threads that run the selection together (the whole workgroup, or one team of it) and
 // `tid` the thread's index among them.
-template <int NT, class Sync>
-__device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew, int Bcur, SmallLds *sm, const int tid, Sync &&sync,
+template <int NT, class SM, class Sync>
+__device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew, int Bcur, SM *sm, const int tid, Sync &&sync,
                                                  unsigned long long *dbg = nullptr) {
   constexpr int NWV = NT / 64;
   int32_t *sel_s = sm->sel_s, *sel_b = sm->sel_b;

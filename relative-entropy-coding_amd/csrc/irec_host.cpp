@@ -353,6 +353,7 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
     }
     if (!pl.table) { pl.n_tab = 0; pl.tab_bytes = 0; }
     pl.team = pl.table && !(p->flags & IREC_FLAG_ONE_TABLE) && irec::team_lds_for(B, S) != (size_t)-1;
+    if (pl.team) pl.grid_cap = irec::team_count() * (ctx->n_cu > 0 ? ctx->n_cu : 256); // one scratch slab per team
   }
   if (pl.fast) {
     if (!pl.team && irec::fast_waves_for(B, S, pl.table) == 8) pl.grid_cap /= 2; // big-LDS configurations: one 8-wave workgroup per CU
@@ -439,19 +440,20 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
       A.tab[q] = tab; A.tab_dim[q] = pl.tab_dim[q];
     }
     if (pl.team) { // grid_cap counts teams (= scratch slabs): two per workgroup, one workgroup per CU
-      const int tgrid = (int)std::min<int64_t>((n_blocks + 1) / 2, pl.grid_cap / 2);
+      const int tgrid = (int)std::min<int64_t>((n_blocks + irec::team_count() - 1) / irec::team_count(), pl.grid_cap / irec::team_count());
       HIP_TRY(irec::launch_encode_team(A, tgrid, st));
       if (ctx->d_dbg) { // diagnostic build (-DIREC_TEAM_STAMPS) only: per-wave phase cycles, wave 0 of a team vs the others
-        std::vector<unsigned long long> h((size_t)tgrid * 8 * 16);
+        const int nwv = irec::team_count() * 4;
+        std::vector<unsigned long long> h((size_t)tgrid * nwv * 16);
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(h.data(), ctx->d_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         static const char *nm[9] = {"fetch", "prologue", "scoring", "wait-score", "combine", "select", "update", "wait-update", "epilogue"};
         double w0[9] = {0}, wo[9] = {0}, t0 = 0, to = 0;
-        for (int w = 0; w < tgrid * 8; ++w)
+        for (int w = 0; w < tgrid * nwv; ++w)
           for (int k = 0; k < 9; ++k) { const double v = (double)h[(size_t)w * 16 + k]; if ((w & 3) == 0) { w0[k] += v; t0 += v; } else { wo[k] += v; to += v; } }
         fprintf(stderr, "[irec team stamps] share of wave time, wave 0 of a team | waves 1-3:\n");
         for (int k = 0; k < 9; ++k) fprintf(stderr, "  %-12s %5.1f%% | %5.1f%%\n", nm[k], 100 * w0[k] / t0, 100 * wo[k] / to);
-        fprintf(stderr, "  cycles per wave: %.0f | %.0f\n", t0 / (tgrid * 2), to / (tgrid * 6));
+        fprintf(stderr, "  cycles per wave: %.0f | %.0f\n", t0 / (tgrid * nwv / 4), to / (tgrid * nwv * 3 / 4));
         return IREC_OK;
       }
     } else HIP_TRY(irec::launch_encode_fast(A, true, grid, st));

@@ -18,6 +18,7 @@
 //     team's serial phases (top-B, beam update) overlap the other team's scoring.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "irec_device.h"
 #include "irec_kernels.h"
@@ -27,13 +28,15 @@ namespace irec {
 
 constexpr int TEAM_NW = 4;                       // waves per team
 constexpr int TEAM_NT = TEAM_NW * 64;            // threads per team
-constexpr int TEAMS = 2;                         // teams per workgroup
+constexpr int TEAM_MB = 32;                      // beams a team serves at most (sizes its small LDS arrays)
+using TeamLds = SmallLdsT<TEAM_MB>;
+constexpr size_t TEAM_SMALL_BYTES = (sizeof(TeamLds) + 15) & ~(size_t)15;
 constexpr uint32_t T3_FLOATS = 3u * IREC_PM1;    // three copies of lut2
 constexpr size_t T3_BYTES = ((size_t)T3_FLOATS * 4 + 15) & ~(size_t)15;
 
 __host__ __device__ inline size_t team_part_bytes(int NB, int S) { return (((size_t)4 * S * NB * 4) + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t team_lds_one(int NB, int S) { return team_part_bytes(NB, S) + SMALL_LDS_BYTES + 16; }
-__host__ __device__ inline size_t team_lds_total(int NB, int S) { return T3_BYTES + (size_t)TEAMS * team_lds_one(NB, S); }
+__host__ __device__ inline size_t team_lds_one(int NB, int S) { return team_part_bytes(NB, S) + TEAM_SMALL_BYTES + 16; }
+__host__ __device__ inline size_t team_lds_total(int NB, int S, int teams) { return T3_BYTES + (size_t)teams * team_lds_one(NB, S); }
 
 // Barrier of the 4 waves of one team: a monotonic LDS counter.  LDS operations of one wave execute in program order and
 // the LDS serves one instruction at a time, so a wave's earlier writes are in place before its add lands; the fences
@@ -41,8 +44,9 @@ __host__ __device__ inline size_t team_lds_total(int NB, int S) { return T3_BYTE
 struct TeamBarrier {
   uint32_t *cnt;
   uint32_t epoch;
+  uint32_t n_waves;
   __device__ __forceinline__ void operator()() {
-    epoch += (uint32_t)TEAM_NW;
+    epoch += n_waves;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     for (;;) {
@@ -62,26 +66,34 @@ struct TeamBarrier {
 #endif
 
 // LDS carve (bytes): lut2 x 3 [120080] | team 0: part [4][S][NB] f32 (sort keys overwrite group 0) | SmallLds | barrier | team 1: same
-template <int NB>
-__global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs A) {
+// BS = beam stripes: with BS == 2 a team has 8 waves, wave w serves dim group / sample stripe (w & 3) and the beams
+// [NBW * (w >> 2), + NBW), NBW = NB / BS: half the G registers per lane (128-VGPR budget, 16 waves per CU).
+template <int NB, int TEAMS, int BS>
+__global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(EncArgs A) {
   using Cfg = FastCfg<NB, true>;
-  constexpr int NT = TEAM_NT, NW = TEAM_NW;
-  // accumulators reduced together: 6 samples x 10 beams through the 64-wide reduce-scatter, or ONE sample x 20 beams
-  // through the 20-value one (22 exchange+add pairs per sample instead of 31, and 12 registers fewer)
-  constexpr bool RSN = NB == 20;
-  constexpr int RW = RSN ? NB : Cfg::RW, SPC = RSN ? 1 : Cfg::SPC;
-  constexpr int ACC_ROOM = RSN ? rsn_room(NB) : RW;
+  constexpr int NW = TEAM_NW;                    // waves per beam stripe (dim groups x sample stripes)
+  constexpr int NWT = TEAM_NW * BS, NT = 64 * NWT; // waves / threads per team
+  constexpr int NBW = NB / BS;                   // beams per wave
+  static_assert(NB % BS == 0, "beam stripes must divide the beam count");
+  // accumulators reduced together: 6 samples x 10 beams through the 64-wide reduce-scatter, or 20 values (one sample x
+  // 20 beams, two samples x 10 beams) through the 20-value one (22 exchange+add pairs instead of 31, 12 registers fewer)
+  constexpr bool RSN = NBW * (20 / NBW) == 20 && (NB == 20);
+  constexpr int RW = RSN ? 20 : Cfg::RW, SPC = RSN ? 20 / NBW : Cfg::SPC;
+  constexpr int ACC_ROOM = RSN ? rsn_room(20) : RW;
+  static_assert(RSN || BS == 1, "beam stripes are only built for the 20-beam encoder");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int S = A.S, B = A.B;
   const int lane = threadIdx.x & 63;
   const int wave_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform by construction
-  const int team = wave_wg >> 2, wave = wave_wg & 3;
-  const int tid = (int)threadIdx.x & (NT - 1);                                  // index inside the team
+  const int team = wave_wg / NWT, wave_t = wave_wg % NWT;
+  const int wave = wave_t & 3, bs = wave_t >> 2;                                // quad position, beam stripe
+  const int b_lo = bs * NBW;                                                    // first beam of my stripe
+  const int tid = (int)threadIdx.x - team * NT;                                 // index inside the team
   char *tbase = smem + T3_BYTES + (size_t)team * team_lds_one(NB, S);
   float *part_s = reinterpret_cast<float *>(tbase);                             // [4][S][NB] per-group partial scores
   uint32_t *key_s = reinterpret_cast<uint32_t *>(tbase);                        // [S*NB] sort keys over group 0
-  SmallLds *sm = reinterpret_cast<SmallLds *>(tbase + team_part_bytes(NB, S));
-  uint32_t *bar_word = reinterpret_cast<uint32_t *>(tbase + team_part_bytes(NB, S) + SMALL_LDS_BYTES);
+  TeamLds *sm = reinterpret_cast<TeamLds *>(tbase + team_part_bytes(NB, S));
+  uint32_t *bar_word = reinterpret_cast<uint32_t *>(tbase + team_part_bytes(NB, S) + TEAM_SMALL_BYTES);
   double *gpart = sm->gpart;
   int32_t *sel_s = sm->sel_s, *sel_b = sm->sel_b;
   int32_t *hsum = &sm->hsum[0][0];
@@ -91,7 +103,8 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
   float *Cb_s = sm->Cb;
   const uint16_t *dlog_s = A.dlog4r;                                            // [10006] 4*dlog(j+1), global (L2)
   const int SP = S;                                                             // one scoring pass per step
-  const int rs_b = RSN ? rsn_owner<NB>(lane) : 0;                               // beam whose total reduce_scatter_n leaves here
+  const int rs_p = RSN ? rsn_owner<20>(lane) : 0;                               // accumulator whose total reduce_scatter_n<20> leaves here
+  const int rs_c = rsn_owner<NBW>(lane);                                        // same for the NBW C_b partials of the update
 
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap(); // see lds_abs_f32
   {
@@ -103,7 +116,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
     if (tid == 0) *bar_word = 0u;
   }
   __syncthreads(); // the only workgroup-wide barrier: from here on the teams never wait for each other
-  TeamBarrier tsync{bar_word, 0u};
+  TeamBarrier tsync{bar_word, 0u, (uint32_t)NWT};
 
   char *slab = A.ws + ((size_t)blockIdx.x * TEAMS + team) * A.ws_per_wg;
   int32_t *bp = reinterpret_cast<int32_t *>(slab);                                            // [max_K][NB]
@@ -151,18 +164,18 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
       c[i] = 0.f;
       ix[i] = valid[i] ? src_index(A, base, pos, d) : src_index(A, base, pos, 0);
       float st3[3] = {0.f, 1.f, 1.f};
-      if (valid[i] && active && sw == 0) { // one wave per dim group does the float64 KL and publishes the statistics
+      if (valid[i] && active && sw == 0 && bs == 0) { // one wave per dim group does the float64 KL and publishes the statistics
         const float mq_ = A.q_loc[ix[i]], sq_ = A.q_scale[ix[i]], mp_ = A.p_loc[ix[i]], sp_ = A.p_scale[ix[i]];
         klacc = klacc + kl_dim(mq_, sq_, mp_, sp_);
         st3[0] = mq_ - mp_; st3[1] = sq_ * sq_; st3[2] = sp_ * sp_;
       }
-      if (active && sw == 0) {
+      if (active && sw == 0 && bs == 0) {
         stats_g[d0 + i] = st3[0]; stats_g[FAST_MAX_DIM + d0 + i] = st3[1]; stats_g[2 * FAST_MAX_DIM + d0 + i] = st3[2];
       }
     }
     {
       const double gs = wave_tree_sum(klacc);
-      if (sw == 0 && active && lane == 0) gpart[g] = gs;
+      if (sw == 0 && bs == 0 && active && lane == 0) gpart[g] = gs;
       tsync();
       if (tid == 0) {
         double tot = gpart[0];
@@ -178,7 +191,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
     const int K = misc[1];
     if (K > A.max_K || K > IREC_MAX_PARTITIONS_DEV) continue;
     if (K == 0) { // nothing to code: sample = p.loc
-      if (active && sw == 0) {
+      if (active && sw == 0 && bs == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           if (valid[i]) A.out_sample[ix[i]] = 0.f + A.p_loc[ix[i]];
@@ -187,7 +200,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
     }
 
     float sa[4], cH[4];
-    float G[NB][4];
+    float G[NBW][4];
     auto step_consts = [&](int t_next, float (&m)[4], float (&cA)[4], float (&cBv)[4]) {
       const float rho = A.rho[K - 1 - t_next];
       const float4 q0 = *reinterpret_cast<const float4 *>(stats_g + d0);
@@ -209,16 +222,16 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
       step_consts(0, m, cA, cBv);
       float cacc = 0.f;
 #pragma unroll
-      for (int b = 0; b < NB; ++b)
+      for (int b = 0; b < NBW; ++b)
 #pragma unroll
         for (int i = 0; i < 4; ++i) G[b][i] = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        G[0][i] = beam_G(0.f, m[i], cA[i], cBv[i], sa[i]);
+        if (bs == 0) G[0][i] = beam_G(0.f, m[i], cA[i], cBv[i], sa[i]);
         cacc = beam_C_term(cacc, 0.f, m[i], cA[i], cBv[i]);
       }
       const float cg = wave_tree_sum(cacc);
-      if (active && sw == 0 && lane == 0) cpart_s[g * 32 + 0] = cg;
+      if (active && sw == 0 && bs == 0 && lane == 0) cpart_s[g * 32 + 0] = cg;
       tsync();
       if (tid == 0) {
         float cb = cpart_s[0];
@@ -233,19 +246,20 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
     for (int t = 0; t < K; ++t) {
       // row s at + s * Dp; lanes past the padded row end read the row START (finite z, zero coefficients)
       const uint16_t *tab_t = tab + (size_t)t * S * Dp + (d0 < Dp ? d0 : 0);
-      uint32_t bet[NB];
+      uint32_t bet[NBW];
       {
-        const uint32_t bv = beta4[cur * 64 + (lane < Bcur ? lane : 0)]; // one LDS round trip, then cross-lane reads
+        const uint32_t bv = beta4[cur * TEAM_MB + (lane < Bcur ? lane : 0)]; // one LDS round trip, then cross-lane reads
 #pragma unroll
-        for (int b = 0; b < NB; ++b) bet[b] = (uint32_t)__builtin_amdgcn_readlane((int)bv, b);
+        for (int b = 0; b < NBW; ++b) bet[b] = (uint32_t)__builtin_amdgcn_readlane((int)bv, b_lo + b);
       }
+      const int nlive = Bcur - b_lo < 0 ? 0 : (Bcur - b_lo < NBW ? Bcur - b_lo : NBW);   // live beams of my stripe
 
       const int N = S * Bcur;
       // ---------------- scoring: S x Bcur candidates (beam_search_coder.py:80-84) ----------------
 #ifdef IREC_ABLATE_SCORING
       if (false) {
 #else
-      if (active) {
+      if (active && nlive > 0) {
 #endif
         const int s_per_stripe = (S + NSW - 1) / NSW;
         const int nchunks = (s_per_stripe + SPC - 1) / SPC;
@@ -275,25 +289,25 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
               const uint2 ap = alp[cc];
               // byte address of entry alpha' in copy 0 (the table starts at LDS address 0)
               const uint32_t al[4] = {(ap.x & 0xFFFFu) << 2, (ap.x >> 16) << 2, (ap.y & 0xFFFFu) << 2, (ap.y >> 16) << 2};
-              if (Bcur == NB) {
-                // steady state: all NB beams alive -> branch-free; the NB gathers of one dim are issued back to back
+              if (nlive == NBW) {
+                // steady state: all my beams alive -> branch-free; the NBW gathers of one dim are issued back to back
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                  float z[NB];
+                  float z[NBW];
 #pragma unroll
-                  for (int b = 0; b < NB; ++b) z[b] = lds_abs_f32(al[i] + bet[b]); // 4*(dlog r + 10006 c + dlog h): no wrap
+                  for (int b = 0; b < NBW; ++b) z[b] = lds_abs_f32(al[i] + bet[b]); // 4*(dlog r + 10006 c + dlog h): no wrap
 #pragma unroll
-                  for (int b = 0; b < NB; ++b) acc[cc * NB + b] = proposal_term(acc[cc * NB + b], z[b], cH[i], G[b][i]);
-                  __builtin_amdgcn_sched_barrier(0); // one dim's NB gathers in flight at a time (VGPR budget)
+                  for (int b = 0; b < NBW; ++b) acc[cc * NBW + b] = proposal_term(acc[cc * NBW + b], z[b], cH[i], G[b][i]);
+                  __builtin_amdgcn_sched_barrier(0); // one dim's NBW gathers in flight at a time (VGPR budget)
                 }
               } else {
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                  if (b < Bcur) { // wave-uniform
+                for (int b = 0; b < NBW; ++b) {
+                  if (b < nlive) { // wave-uniform
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                       const float z = lds_abs_f32(al[i] + bet[b]);
-                      acc[cc * NB + b] = proposal_term(acc[cc * NB + b], z, cH[i], G[b][i]);
+                      acc[cc * NBW + b] = proposal_term(acc[cc * NBW + b], z, cH[i], G[b][i]);
                     }
                   }
                 }
@@ -301,9 +315,10 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
             }
           }
           if constexpr (RSN) {
-            const float tot = reduce_scatter_n<NB>(acc, lane);
-            const int s = ch * NSW + sw;
-            if (rs_b >= 0 && (lane & 1) == 0 && s < S && rs_b < Bcur) part_s[((size_t)g * SP + s) * NB + rs_b] = tot;
+            const float tot = reduce_scatter_n<20>(acc, lane);
+            const int cc = rs_p / NBW, b = rs_p - cc * NBW;   // rs_p < 0: unused slot
+            const int s = (ch * SPC + cc) * NSW + sw;
+            if (rs_p >= 0 && (lane & 1) == 0 && s < S && b < nlive) part_s[((size_t)g * SP + s) * NB + b_lo + b] = tot;
           } else {
             const float tot = reduce_scatter<RW>(acc, lane);
             const int p = RW == 64 ? lane : (lane >> 1);
@@ -354,9 +369,9 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
       // ---------------- new hashes / back-pointers (beam_search_coder.py:94-95) ----------------
       if (tid < Bnew) {
         const int32_t sp_ = sel_s[tid], bp_ = sel_b[tid];
-        const int32_t nh = (int32_t)((uint32_t)hsum[cur * 64 + bp_] + (uint32_t)sp_ * (uint32_t)(69 + t));
-        hsum[(cur ^ 1) * 64 + tid] = nh;
-        beta4[(cur ^ 1) * 64 + tid] = dlog_s[hash_from_sum(nh) - 1u];
+        const int32_t nh = (int32_t)((uint32_t)hsum[cur * TEAM_MB + bp_] + (uint32_t)sp_ * (uint32_t)(69 + t));
+        hsum[(cur ^ 1) * TEAM_MB + tid] = nh;
+        beta4[(cur ^ 1) * TEAM_MB + tid] = dlog_s[hash_from_sum(nh) - 1u];
         bp[(size_t)t * NB + tid] = (sp_ << 6) | bp_;
       }
       // ---------------- gather the surviving beams (beam_search_coder.py:92-93), prepare the next step ----------------
@@ -372,32 +387,32 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
         float *bnew = beams_g + ((size_t)(cur ^ 1) * NB) * FAST_MAX_DIM + d0;
         // G is dead from the end of scoring until it is rebuilt below: every entry is redefined here
 #pragma unroll
-        for (int j = 0; j < NB; ++j)
+        for (int j = 0; j < NBW; ++j)
 #pragma unroll
           for (int i = 0; i < 4; ++i) G[j][i] = 0.f;
         float m[4], cA[4], cBv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { m[i] = 0.f; cA[i] = 0.f; cBv[i] = 0.f; }
-        float cacc[32];
+        float cacc[RSN ? rsn_room(NBW) : 32];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) cacc[j] = 0.f;
-        constexpr int UB = NB;                                // all beams' loads in one batch (G's registers are free)
+        for (int j = 0; j < (RSN ? rsn_room(NBW) : 32); ++j) cacc[j] = 0.f;
+        constexpr int UB = NBW;                               // all my beams' loads in one batch (G's registers are free)
         // lane j fetches the selection of new beam j and the offset of its parent: two LDS round trips for all beams
         const int32_t v_sp = sel_s[lane < Bnew ? lane : 0], v_bp = sel_b[lane < Bnew ? lane : 0];
-        const uint32_t v_bo = beta4[cur * 64 + v_bp];
+        const uint32_t v_bo = beta4[cur * TEAM_MB + v_bp];
 #pragma unroll
-        for (int j0 = 0; j0 < NB; j0 += UB) {
+        for (int j0 = 0; j0 < NBW; j0 += UB) {
           // ---- issue the batch's global reads (proposal rows, old beams) back to back ----
           uint2 apv[UB];
           float4 obv4[UB];
           uint32_t bet_old[UB];
 #pragma unroll
           for (int u = 0; u < UB; ++u) {
-            const int j = j0 + u;
+            const int jj = j0 + u, j = b_lo + jj;  // jj: slot in my stripe, j: new beam
             apv[u] = make_uint2(0u, 0u);
             obv4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             bet_old[u] = 0u;
-            if (j < NB && j < Bnew) { // wave-uniform
+            if (jj < NBW && j < Bnew) { // wave-uniform
               const int32_t sp_ = __builtin_amdgcn_readlane(v_sp, j);
               const int32_t bp_ = __builtin_amdgcn_readlane(v_bp, j);
               bet_old[u] = (uint32_t)__builtin_amdgcn_readlane((int)v_bo, j);
@@ -409,8 +424,8 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
           // ---- new beams, their G and C terms ----
 #pragma unroll
           for (int u = 0; u < UB; ++u) {
-            const int j = j0 + u;
-            if (j < NB && j < Bnew) { // wave-uniform
+            const int jj = j0 + u, j = b_lo + jj;
+            if (jj < NBW && j < Bnew) { // wave-uniform
               const uint32_t al[4] = {(apv[u].x & 0xFFFFu) << 2, (apv[u].x >> 16) << 2, (apv[u].y & 0xFFFFu) << 2, (apv[u].y >> 16) << 2};
               const float obv[4] = {obv4[u].x, obv4[u].y, obv4[u].z, obv4[u].w};
               float nb[4];
@@ -429,8 +444,8 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
                 if (sw == 0) *reinterpret_cast<float4 *>(bnew + (size_t)j * FAST_MAX_DIM) = make_float4(nb[0], nb[1], nb[2], nb[3]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                  G[j][i] = beam_G(nb[i], m[i], cA[i], cBv[i], sa[i]);
-                  cacc[j] = beam_C_term(cacc[j], nb[i], m[i], cA[i], cBv[i]);
+                  G[jj][i] = beam_G(nb[i], m[i], cA[i], cBv[i], sa[i]);
+                  cacc[jj] = beam_C_term(cacc[jj], nb[i], m[i], cA[i], cBv[i]);
                 }
               }
             }
@@ -439,8 +454,8 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
         }
         if (!last) {
           if constexpr (RSN) {
-            const float ctot = reduce_scatter_n<NB>(cacc, lane);
-            if (sw == 0 && (lane & 1) == 0 && rs_b >= 0 && rs_b < Bnew) cpart_s[g * 32 + rs_b] = ctot;
+            const float ctot = reduce_scatter_n<NBW>(cacc, lane);
+            if (sw == 0 && (lane & 1) == 0 && rs_c >= 0 && b_lo + rs_c < Bnew) cpart_s[g * 32 + b_lo + rs_c] = ctot;
           } else {
             const float ctot = reduce_scatter<32>(cacc, lane);  // lane l holds beam (l >> 1)
             const int j = lane >> 1;
@@ -474,7 +489,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_team_kernel(EncArgs
   }
 #ifdef IREC_TEAM_STAMPS
   if (A.dbg && lane == 0)
-    for (int k = 0; k < 12; ++k) A.dbg[((size_t)blockIdx.x * 8 + wave_wg) * 16 + k] = st_acc[k];
+    for (int k = 0; k < 12; ++k) A.dbg[((size_t)blockIdx.x * (TEAMS * 4) + wave_wg) * 16 + k] = st_acc[k];
 #endif
 }
 
@@ -570,28 +585,42 @@ __global__ __launch_bounds__(256) void alpha_choice_kernel(int64_t seed, int32_t
 // ======================================================================================================
 //  launchers
 // ======================================================================================================
+// teams per workgroup / beam stripes per team.  Default 2 x 1 (8 waves per CU).  Diagnostic overrides through the
+// environment: IREC_TEAMS=3 (three 4-wave teams, 168 VGPRs) and IREC_TEAMS=2x2 (two 8-wave beam-striped teams, 128 VGPRs).
+static int team_cfg() {
+  static const int n = [] {
+    const char *e = getenv("IREC_TEAMS");
+    if (e && e[0] == '3') return 3;
+    if (e && e[0] == '2' && e[1] == 'x' && e[2] == '2') return 22;
+    return 2;
+  }();
+  return n;
+}
+int team_count() { return team_cfg() == 3 ? 3 : 2; }
+
 size_t team_lds_for(int B, int S) {
   const int nb = fast_nb_for(B);
   if (nb != 10 && nb != 20) return (size_t)-1;           // the 32-beam build does not fit the register budget of a team
   if ((int64_t)S * nb > 1024) return (size_t)-1;         // one scoring pass, keys over group 0 of the partials
-  const size_t b = team_lds_total(nb, S);
+  const size_t b = team_lds_total(nb, S, team_count());
   return b <= FAST_LDS_LIMIT ? b : (size_t)-1;
 }
 
-template <int NB>
+template <int NB, int TEAMS, int BS>
 static hipError_t launch_team_t(const EncArgs &A, int grid, hipStream_t st) {
-  const size_t lds = team_lds_total(NB, A.S);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_team_kernel<NB>),
+  const size_t lds = team_lds_total(NB, A.S, TEAMS);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_team_kernel<NB, TEAMS, BS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((encode_team_kernel<NB>), dim3(grid), dim3(TEAMS * TEAM_NT), lds, st, A);
+  hipLaunchKernelGGL((encode_team_kernel<NB, TEAMS, BS>), dim3(grid), dim3(TEAMS * BS * TEAM_NT), lds, st, A);
   return hipGetLastError();
 }
 
 hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
+  const int cfg = team_cfg();
   switch (fast_nb_for(A.B)) {
-    case 10: return launch_team_t<10>(A, grid, st);
-    case 20: return launch_team_t<20>(A, grid, st);
+    case 10: return cfg == 3 ? launch_team_t<10, 3, 1>(A, grid, st) : launch_team_t<10, 2, 1>(A, grid, st);
+    case 20: return cfg == 3 ? launch_team_t<20, 3, 1>(A, grid, st) : cfg == 22 ? launch_team_t<20, 2, 2>(A, grid, st) : launch_team_t<20, 2, 1>(A, grid, st);
     default: return hipErrorInvalidValue;
   }
 }
