@@ -259,7 +259,56 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 #ifdef IREC_ABLATE_SCORING
       if (false) {
 #else
-      if (active && nlive > 0) {
+      if (RSN && SPC == 1 && active && nlive == NBW) {
+        // Steady state, software pipelined by dim slot: the NBW gathers of the NEXT slot (or of the next sample's first
+        // slot) are issued before the current slot's values are consumed, so the wave always has look-ups in flight --
+        // also under the fma chain and the reduce-scatter.  A wave can have at most 15 LDS operations outstanding, so
+        // by the time the next slot's 20 are issued the current slot's have all landed.  Empty volatile asm statements
+        // pin the order (pure arithmetic would otherwise drift across the scheduling barriers).
+        const int n_mine = (S - sw + NSW - 1) / NSW;              // my samples: sw, sw + NSW, ...
+        uint2 ap_nxt = make_uint2(0u, 0u);
+        uint32_t al[4];
+        {
+          const uint2 ap = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sw * Dp);
+          al[0] = (ap.x & 0xFFFFu) << 2; al[1] = (ap.x >> 16) << 2; al[2] = (ap.y & 0xFFFFu) << 2; al[3] = (ap.y >> 16) << 2;
+          if (NSW + sw < S) ap_nxt = *reinterpret_cast<const uint2 *>(tab_t + (size_t)(NSW + sw) * Dp);
+        }
+        float zA[NBW], zB[NBW];
+#define IREC_ISSUE(Z, AD) do { _Pragma("unroll") for (int b = 0; b < NBW; ++b) Z[b] = lds_abs_f32((AD) + bet[b]); \
+                               __builtin_amdgcn_sched_barrier(0); } while (0)
+#define IREC_CONSUME(Z, I) do { _Pragma("unroll") for (int b = 0; b < NBW; ++b) asm volatile("" : "+v"(Z[b])); \
+                                _Pragma("unroll") for (int b = 0; b < NBW; ++b) acc[b] = proposal_term(acc[b], Z[b], cH[I], G[b][I]); \
+                                _Pragma("unroll") for (int b = 0; b < NBW; ++b) asm volatile("" : "+v"(acc[b])); \
+                                __builtin_amdgcn_sched_barrier(0); } while (0)
+        IREC_ISSUE(zA, al[0]);
+        for (int ch = 0; ch < n_mine; ++ch) {
+          float acc[ACC_ROOM];
+#pragma unroll
+          for (int p = 0; p < RW; ++p) acc[p] = 0.f;
+          IREC_ISSUE(zB, al[1]);
+          IREC_CONSUME(zA, 0);
+          IREC_ISSUE(zA, al[2]);
+          IREC_CONSUME(zB, 1);
+          IREC_ISSUE(zB, al[3]);
+          IREC_CONSUME(zA, 2);
+          // next sample's row (zero = entry 0: a valid address, its values are dropped after the last sample)
+          al[0] = (ap_nxt.x & 0xFFFFu) << 2; al[1] = (ap_nxt.x >> 16) << 2; al[2] = (ap_nxt.y & 0xFFFFu) << 2; al[3] = (ap_nxt.y >> 16) << 2;
+          {
+            const int sn = (ch + 2) * NSW + sw;
+            ap_nxt = make_uint2(0u, 0u);
+            if (sn < S) ap_nxt = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sn * Dp);
+          }
+          IREC_ISSUE(zA, al[0]);
+          IREC_CONSUME(zB, 3);
+          const float tot = reduce_scatter_n<20>(acc, lane);
+          const int s = ch * NSW + sw;
+          if (rs_p >= 0 && (lane & 1) == 0) part_s[((size_t)g * SP + s) * NB + b_lo + rs_p] = tot;
+        }
+#pragma unroll
+        for (int b = 0; b < NBW; ++b) asm volatile("" : "+v"(zA[b])); // drain the look-ups issued past the last sample
+#undef IREC_ISSUE
+#undef IREC_CONSUME
+      } else if (active && nlive > 0) {
 #endif
         const int s_per_stripe = (S + NSW - 1) / NSW;
         const int nchunks = (s_per_stripe + SPC - 1) / SPC;
@@ -396,7 +445,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         float cacc[RSN ? rsn_room(NBW) : 32];
 #pragma unroll
         for (int j = 0; j < (RSN ? rsn_room(NBW) : 32); ++j) cacc[j] = 0.f;
-        constexpr int UB = NBW;                               // all my beams' loads in one batch (G's registers are free)
+        constexpr int UB = TEAMS >= 3 ? 5 : NBW;              // beams per load batch: all at once (G's registers are free) unless registers are short
         // lane j fetches the selection of new beam j and the offset of its parent: two LDS round trips for all beams
         const int32_t v_sp = sel_s[lane < Bnew ? lane : 0], v_bp = sel_b[lane < Bnew ? lane : 0];
         const uint32_t v_bo = beta4[cur * TEAM_MB + v_bp];
@@ -591,12 +640,13 @@ static int team_cfg() {
   static const int n = [] {
     const char *e = getenv("IREC_TEAMS");
     if (e && e[0] == '3') return 3;
+    if (e && e[0] == '1') return 1;
     if (e && e[0] == '2' && e[1] == 'x' && e[2] == '2') return 22;
     return 2;
   }();
   return n;
 }
-int team_count() { return team_cfg() == 3 ? 3 : 2; }
+int team_count() { return team_cfg() == 3 ? 3 : team_cfg() == 1 ? 1 : 2; }
 
 size_t team_lds_for(int B, int S) {
   const int nb = fast_nb_for(B);
@@ -620,7 +670,7 @@ hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
   const int cfg = team_cfg();
   switch (fast_nb_for(A.B)) {
     case 10: return cfg == 3 ? launch_team_t<10, 3, 1>(A, grid, st) : launch_team_t<10, 2, 1>(A, grid, st);
-    case 20: return cfg == 3 ? launch_team_t<20, 3, 1>(A, grid, st) : cfg == 22 ? launch_team_t<20, 2, 2>(A, grid, st) : launch_team_t<20, 2, 1>(A, grid, st);
+    case 20: return cfg == 1 ? launch_team_t<20, 1, 1>(A, grid, st) : cfg == 3 ? launch_team_t<20, 3, 1>(A, grid, st) : cfg == 22 ? launch_team_t<20, 2, 2>(A, grid, st) : launch_team_t<20, 2, 1>(A, grid, st);
     default: return hipErrorInvalidValue;
   }
 }
