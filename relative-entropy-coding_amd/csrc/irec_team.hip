@@ -387,15 +387,25 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         // key f = s * Bcur + b and partial (s, b) = s * NB + b only coincide when Bcur == NB
         constexpr int MK = (1024 + NT - 1) / NT;
         uint32_t mykey[MK];
+        {
+          // every partial of my candidates is fetched before the first is used: one LDS latency instead of 4 per key
+          float pr[MK][4], cbv[MK];
+          const int gstride = SP * NB;
 #pragma unroll
-        for (int q = 0; q < MK; ++q) {
-          const int f = q * NT + tid;
-          mykey[q] = 0u;
-          if (f < N) {
-            const int s = f / Bcur, b = f - s * Bcur;
-            float sc = part_s[((size_t)0 * SP + s) * NB + b];
-            for (int gg = 1; gg < NG; ++gg) sc = sc + part_s[((size_t)gg * SP + s) * NB + b];
-            mykey[q] = score_key(sc + Cb_s[b]);
+          for (int q = 0; q < MK; ++q) {
+            const int f = q * NT + tid, fs = f < N ? f : 0;
+            const int s = Bcur == NB ? fs / NB : fs / Bcur, b = fs - s * Bcur;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) pr[q][gg] = part_s[(gg < NG ? gg : 0) * gstride + s * NB + b];
+            cbv[q] = Cb_s[b];
+          }
+#pragma unroll
+          for (int q = 0; q < MK; ++q) {
+            float sc = pr[q][0];
+            if (NG > 1) sc = sc + pr[q][1];
+            if (NG > 2) sc = sc + pr[q][2];
+            if (NG > 3) sc = sc + pr[q][3];
+            mykey[q] = q * NT + tid < N ? score_key(sc + cbv[q]) : 0u;
           }
         }
         tsync();
@@ -471,16 +481,27 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           }
           if (j0 == 0 && !last) step_consts(t + 1, m, cA, cBv); // next step's constants, under the loads' latency
           // ---- new beams, their G and C terms ----
+          // look-ups of YB beams are issued back to back, then consumed: UB / YB LDS latencies per batch instead of UB
+          constexpr int YB = 5;
+          float zy[YB][4];
 #pragma unroll
           for (int u = 0; u < UB; ++u) {
+            if (u % YB == 0) {
+#pragma unroll
+              for (int v = 0; v < YB; ++v) {
+                const int uu = u + v < UB ? u + v : UB - 1;
+                const uint32_t al[4] = {(apv[uu].x & 0xFFFFu) << 2, (apv[uu].x >> 16) << 2, (apv[uu].y & 0xFFFFu) << 2, (apv[uu].y >> 16) << 2};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) zy[v][i] = lds_abs_f32(al[i] + bet_old[uu]); // entry 0 for beams that do not exist
+              }
+            }
             const int jj = j0 + u, j = b_lo + jj;
             if (jj < NBW && j < Bnew) { // wave-uniform
-              const uint32_t al[4] = {(apv[u].x & 0xFFFFu) << 2, (apv[u].x >> 16) << 2, (apv[u].y & 0xFFFFu) << 2, (apv[u].y >> 16) << 2};
               const float obv[4] = {obv4[u].x, obv4[u].y, obv4[u].z, obv4[u].w};
               float nb[4];
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
-                const float y = sa_t[i] * lds_abs_f32(al[i] + bet_old[u]); // dist.quantile(.), :48-49
+                const float y = sa_t[i] * zy[u % YB][i];                    // dist.quantile(.), :48-49
                 nb[i] = obv[i] + y;                                         // combined_samples[best_ind_aux, best_ind_beam], :81,92-93
               }
               if (last) {
