@@ -273,18 +273,23 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           al[0] = (ap.x & 0xFFFFu) << 2; al[1] = (ap.x >> 16) << 2; al[2] = (ap.y & 0xFFFFu) << 2; al[3] = (ap.y >> 16) << 2;
           if (NSW + sw < S) ap_nxt = *reinterpret_cast<const uint2 *>(tab_t + (size_t)(NSW + sw) * Dp);
         }
-        float zA[NBW], zB[NBW];
-#define IREC_ISSUE(Z, AD) do { _Pragma("unroll") for (int b = 0; b < NBW; ++b) Z[b] = lds_abs_f32((AD) + bet[b]); \
+        // values travel in register pairs so that the two fma of two beams stay one v_pk_fma_f32 each
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        constexpr int NP = NBW / 2;
+        f2 zA[NP], zB[NP];
+#define IREC_ISSUE(Z, AD) do { _Pragma("unroll") for (int k = 0; k < NP; ++k) { Z[k].x = lds_abs_f32((AD) + bet[2 * k]); Z[k].y = lds_abs_f32((AD) + bet[2 * k + 1]); } \
                                __builtin_amdgcn_sched_barrier(0); } while (0)
-#define IREC_CONSUME(Z, I) do { _Pragma("unroll") for (int b = 0; b < NBW; ++b) asm volatile("" : "+v"(Z[b])); \
-                                _Pragma("unroll") for (int b = 0; b < NBW; ++b) acc[b] = proposal_term(acc[b], Z[b], cH[I], G[b][I]); \
-                                _Pragma("unroll") for (int b = 0; b < NBW; ++b) asm volatile("" : "+v"(acc[b])); \
+#define IREC_CONSUME(Z, I) do { _Pragma("unroll") for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(Z[k])); \
+                                _Pragma("unroll") for (int k = 0; k < NP; ++k) { \
+                                  const f2 h2 = {cH[I], cH[I]}, g2 = {G[2 * k][I], G[2 * k + 1][I]}; \
+                                  acc2[k] = __builtin_elementwise_fma(__builtin_elementwise_fma(h2, Z[k], g2), Z[k], acc2[k]); } \
+                                _Pragma("unroll") for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(acc2[k])); \
                                 __builtin_amdgcn_sched_barrier(0); } while (0)
         IREC_ISSUE(zA, al[0]);
         for (int ch = 0; ch < n_mine; ++ch) {
-          float acc[ACC_ROOM];
+          f2 acc2[NP];
 #pragma unroll
-          for (int p = 0; p < RW; ++p) acc[p] = 0.f;
+          for (int k = 0; k < NP; ++k) acc2[k] = (f2){0.f, 0.f};
           IREC_ISSUE(zB, al[1]);
           IREC_CONSUME(zA, 0);
           IREC_ISSUE(zA, al[2]);
@@ -300,12 +305,15 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           }
           IREC_ISSUE(zA, al[0]);
           IREC_CONSUME(zB, 3);
+          float acc[ACC_ROOM];
+#pragma unroll
+          for (int k = 0; k < NP; ++k) { acc[2 * k] = acc2[k].x; acc[2 * k + 1] = acc2[k].y; }
           const float tot = reduce_scatter_n<20>(acc, lane);
           const int s = ch * NSW + sw;
           if (rs_p >= 0 && (lane & 1) == 0) part_s[((size_t)g * SP + s) * NB + b_lo + rs_p] = tot;
         }
 #pragma unroll
-        for (int b = 0; b < NBW; ++b) asm volatile("" : "+v"(zA[b])); // drain the look-ups issued past the last sample
+        for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(zA[k])); // drain the look-ups issued past the last sample
 #undef IREC_ISSUE
 #undef IREC_CONSUME
       } else if (active && nlive > 0) {
