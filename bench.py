@@ -183,10 +183,15 @@ def main():
                    "parallelism": f"latents sharded over {world} GPU(s), no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": algo_bytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": algo_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "encode_team_kernel<20>", "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes},
+                     "kernel": "encode_team_kernel<20,2,1>", "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes},
         "secondary": {"proposal_evals_per_s": evals / (kernel_ms * 1e-3),
                       "evals_per_clk_per_cu": evals / (kernel_ms * 1e-3) / (N_CU * clk_ghz * 1e9),
-                      "lds_gather_frac_of_128B_per_clk": 4 * evals / (kernel_ms * 1e-3) / (N_CU * 128 * clk_ghz * 1e9),
+                      # the ceiling that actually binds: random 4-byte LDS look-ups per clock per CU, measured by
+                      # scripts/microbench/gather_rates.hip (profiles/r01j): 8.9 for one table copy, 13.4 with the
+                      # 2-choice bank assignment over three copies that the encoder uses (8 waves per CU)
+                      "lds_gather_roofline": {"achieved": evals / (kernel_ms * 1e-3) / (N_CU * clk_ghz * 1e9), "peak": 13.4,
+                                              "unit": "look-ups/clk/CU at 2.4 GHz",
+                                              "frac": evals / (kernel_ms * 1e-3) / (N_CU * clk_ghz * 1e9) / 13.4},
                       "mean_K": float(Kh.mean()), "code_nats_per_latent": float(gathered.mean().item())},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
