@@ -81,6 +81,23 @@ irec_status irec_build_lut(float *lut10007);
  * Host memory. */
 irec_status irec_tf_shuffle_perm(int64_t seed, int64_t n, int64_t *perm);
 
+/* ---- importance sampler (config 1 plumbing; the reference runs it on the CPU, and so does this: host memory) ---------
+ * encode_gaussian_importance_sample with alpha = inf (rec/coding/importance_sampling.py:9-79): standardise the target
+ * w.r.t. the coder, draw n_samples = ceil(exp(coding_bits * log 2)) proposals x[s] ~ N(0,1)^n from the stream of
+ * tf.random.set_seed(seed); tfd.Normal(0,1).sample(n_samples) (:37,50-53), weight them by
+ * sum_d [log N(x; t', s') - log N(x; 0, 1)] (:57-58) and return the index of the largest weight (first one on ties,
+ * tf.argmax :64) and p_scale * x[index] + p_loc (:73-76).  n = number of dims of the (flattened) distributions. */
+irec_status irec_importance_encode(const float *t_loc, const float *t_scale, const float *p_loc, const float *p_scale,
+                                   int64_t n, double coding_bits, int64_t seed, int64_t *out_index, float *out_sample);
+/* decode_gaussian_importance_sample (importance_sampling.py:82-103): sample `index` of the same stream. */
+irec_status irec_importance_decode(const float *p_loc, const float *p_scale, int64_t n, int64_t index, int64_t seed,
+                                   float *out_sample);
+/* n_samples of the call above (float32 arithmetic as in importance_sampling.py:50), or -1 if it does not fit int32. */
+int64_t irec_importance_n_samples(double coding_bits);
+/* out[e] = element e of tf.random.normal([count]) after tf.random.set_seed(seed) -- the stream behind
+ * tfd.Normal.sample.  Host memory; test hook. */
+irec_status irec_tf_random_normal(int64_t seed, int64_t count, float *out);
+
 /* out[e] = element e of tf.random.uniform([n], 1, 10007, seed=seed, dtype=int32) after tf.random.set_seed(seed)
  * -- beam_search_coder.py:38-43.  Host memory; test hook for the in-kernel Philox stream. */
 irec_status irec_philox_uniform_int(int64_t seed, int64_t n, int32_t *out);

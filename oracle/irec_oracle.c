@@ -577,3 +577,80 @@ void irec_oracle_decode_block(int mode, int S, int D, const float *mp, const flo
 }
 
 int irec_oracle_cpu_has_fma(void) { return __builtin_cpu_supports("fma"); }
+
+/* ------------------------------------------------------------------------------------------------
+ * Importance sampler (config 1 plumbing): rec/coding/importance_sampling.py.
+ * tf.random.set_seed(seed) (:37) then tfd.Normal(0,1).sample(num_samples) (:53) = tf.random.normal(shape, seed=None):
+ * op seed = first randint of random.Random(global seed), CPU kernel = Box-Muller on consecutive uint32
+ * pairs of the Philox stream, four outputs per Philox block.  libm float functions stand in for Eigen's.
+ * ---------------------------------------------------------------------------------------------- */
+static float oracle_uint32_to_float(uint32_t x) {
+  uint32_t val = (127u << 23) | (x & 0x7fffffu);
+  float r; memcpy(&r, &val, 4);
+  return r - 1.0f;
+}
+
+void irec_oracle_tf_random_normal(int64_t seed, int64_t count, float *out) {
+  uint64_t s1, s2;
+  tf_seed_pair(seed, irec_oracle_py_first_randint31(seed), &s1, &s2);
+  for (int64_t g = 0; 4 * g < count; ++g) {
+    uint32_t x[4];
+    for (int k = 0; k < 4; ++k) x[k] = philox_stream_u32(s1, s2, (uint64_t)(4 * g + k));
+    float f[4];
+    for (int h = 0; h < 2; ++h) { /* BoxMullerFloat(x[2h], x[2h+1], &f[2h], &f[2h+1]) */
+      const float epsilon = 1.0e-7f;
+      float u1 = oracle_uint32_to_float(x[2 * h]);
+      if (u1 < epsilon) u1 = epsilon;
+      const float v1 = (float)(2.0f * M_PI * oracle_uint32_to_float(x[2 * h + 1]));
+      const float u2 = sqrtf(-2.0f * logf(u1));
+      f[2 * h] = sinf(v1) * u2;
+      f[2 * h + 1] = cosf(v1) * u2;
+    }
+    for (int k = 0; k < 4 && 4 * g + k < count; ++k) out[4 * g + k] = f[k];
+  }
+}
+
+int64_t irec_oracle_importance_n_samples(double coding_bits) { /* :50, float32 tensors */
+  const float nf = ceilf(expf((float)coding_bits * logf(2.0f)));
+  return (nf >= 1.0f && nf < 2147483648.0f) ? (int64_t)nf : -1;
+}
+
+/* encode_gaussian_importance_sample, alpha = inf (:9-79).  Literal shape: all samples first (:53), then the weights.
+ * The reduction order of reduce_sum (:57-58) is not reproducible; canonical: float64 sum in dim order, rounded once. */
+int64_t irec_oracle_importance_encode(const float *t_loc, const float *t_scale, const float *p_loc, const float *p_scale,
+                                      int64_t n, double coding_bits, int64_t seed, float *out_sample) {
+  const int64_t S = irec_oracle_importance_n_samples(coding_bits);
+  if (S < 1 || n < 1) return -1;
+  float *samples = (float *)malloc(sizeof(float) * (size_t)(S * n));
+  if (!samples) return -1;
+  irec_oracle_tf_random_normal(seed, S * n, samples);             /* proposal.sample(num_samples): N(0,1) * 1 + 0 */
+  const float hl2pi = (float)(0.5 * log(2.0 * M_PI));              /* 0.5 * np.log(2 * np.pi) as a float32 constant */
+  int64_t best = 0; float best_w = 0.f;
+  for (int64_t s = 0; s < S; ++s) {
+    double acc = 0.0;
+    for (int64_t d = 0; d < n; ++d) {
+      const float tl = (t_loc[d] - p_loc[d]) / p_scale[d];          /* :40 */
+      const float ts = t_scale[d] / p_scale[d];                     /* :41 */
+      const float x = samples[s * n + d];
+      const float a = x / ts - tl / ts;                             /* Normal._log_prob: squared_difference(x/s, loc/s) */
+      const float lt = -0.5f * (a * a) - (hl2pi + logf(ts));
+      const float b = x / 1.0f - 0.0f / 1.0f;
+      const float lp = -0.5f * (b * b) - (hl2pi + logf(1.0f));
+      acc += (double)(lt - lp);                                     /* :57 */
+    }
+    const float w = (float)acc;
+    if (s == 0 || w > best_w) { best_w = w; best = s; }             /* tf.argmax (:64): first maximum */
+  }
+  for (int64_t d = 0; d < n; ++d) out_sample[d] = p_scale[d] * samples[best * n + d] + p_loc[d]; /* :73-76 */
+  free(samples);
+  return best;
+}
+
+/* decode_gaussian_importance_sample (:82-103) */
+void irec_oracle_importance_decode(const float *p_loc, const float *p_scale, int64_t n, int64_t index, int64_t seed,
+                                   float *out_sample) {
+  float *samples = (float *)malloc(sizeof(float) * (size_t)((index + 1) * n));
+  irec_oracle_tf_random_normal(seed, (index + 1) * n, samples);    /* proposal.sample(index + 1) */
+  for (int64_t d = 0; d < n; ++d) out_sample[d] = p_scale[d] * samples[index * n + d] + p_loc[d];
+  free(samples);
+}

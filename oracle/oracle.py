@@ -68,6 +68,12 @@ def lib():
         L.irec_oracle_encode_block.restype = ctypes.c_int32
         L.irec_oracle_decode_block.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, f32p, f32p, i32p,
                                                ctypes.c_int32, ctypes.c_int64, f32p]
+        L.irec_oracle_tf_random_normal.argtypes = [ctypes.c_int64, ctypes.c_int64, f32p]
+        L.irec_oracle_importance_n_samples.argtypes = [ctypes.c_double]
+        L.irec_oracle_importance_n_samples.restype = ctypes.c_int64
+        L.irec_oracle_importance_encode.argtypes = [f32p, f32p, f32p, f32p, ctypes.c_int64, ctypes.c_double, ctypes.c_int64, f32p]
+        L.irec_oracle_importance_encode.restype = ctypes.c_int64
+        L.irec_oracle_importance_decode.argtypes = [f32p, f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, f32p]
         _lib = L
     return _lib
 
@@ -224,3 +230,31 @@ def synthetic_latent(image_id, n, rng_base=1234):
     mq = mp + sp * rng.normal(0.0, 0.2, n)
     sq = np.exp(lsp - np.abs(rng.normal(0.0, 0.05, n)))
     return tuple(a.astype(np.float32) for a in (mq, sq, mp, sp))
+
+
+# ---- importance sampler (config 1 plumbing; rec/coding/importance_sampling.py) ---------------------------------------
+def tf_random_normal(seed, count):
+    o = np.zeros(count, dtype=np.float32)
+    lib().irec_oracle_tf_random_normal(int(seed), int(count), _p(o, ctypes.c_float))
+    return o
+
+
+def importance_n_samples(coding_bits):
+    return int(lib().irec_oracle_importance_n_samples(float(coding_bits)))
+
+
+def importance_encode(t_loc, t_scale, p_loc, p_scale, coding_bits, seed):
+    tl, ts, pl, ps = (_f32(a).reshape(-1) for a in (t_loc, t_scale, p_loc, p_scale))
+    out = np.zeros_like(tl)
+    idx = lib().irec_oracle_importance_encode(_p(tl, ctypes.c_float), _p(ts, ctypes.c_float), _p(pl, ctypes.c_float),
+                                              _p(ps, ctypes.c_float), tl.size, float(coding_bits), int(seed),
+                                              _p(out, ctypes.c_float))
+    return int(idx), out.reshape(np.shape(t_loc))
+
+
+def importance_decode(p_loc, p_scale, index, seed):
+    pl, ps = (_f32(a).reshape(-1) for a in (p_loc, p_scale))
+    out = np.zeros_like(pl)
+    lib().irec_oracle_importance_decode(_p(pl, ctypes.c_float), _p(ps, ctypes.c_float), pl.size, int(index), int(seed),
+                                        _p(out, ctypes.c_float))
+    return out.reshape(np.shape(p_loc))

@@ -185,6 +185,44 @@ int64_t py_first_randint31(int64_t seed) {
   return (int64_t)r;
 }
 
+// ---- tf.random.normal on the host: Box-Muller on consecutive uint32 pairs of the Philox stream ----
+// random_distributions.h: Uint32ToFloat keeps 23 mantissa bits, BoxMullerFloat clamps u1 at 1e-7.
+inline float u32_to_unit_float(uint32_t x) {
+  const uint32_t bits = (127u << 23) | (x & 0x7fffffu);
+  float f;
+  std::memcpy(&f, &bits, 4);
+  return f - 1.0f;
+}
+inline void box_muller(uint32_t x0, uint32_t x1, float &f0, float &f1) {
+  float u1 = u32_to_unit_float(x0);
+  if (u1 < 1.0e-7f) u1 = 1.0e-7f;
+  const float v1 = (float)(2.0 * 3.14159265358979323846 * (double)u32_to_unit_float(x1));
+  const float u2 = std::sqrt(-2.0f * std::log(u1));
+  f0 = std::sin(v1) * u2;
+  f1 = std::cos(v1) * u2;
+}
+// stream of tf.random.set_seed(seed); tf.random.normal(shape, seed=None): element e <- output (e & 3) of Philox block e >> 2
+struct TfNormalStream {
+  Philox gen;
+  uint64_t have = ~0ull;
+  float f[4];
+  explicit TfNormalStream(int64_t seed) : gen(0, 0) {
+    uint64_t s1, s2;
+    tf_seed_pair(seed, py_first_randint31(seed), s1, s2);
+    gen = Philox(s1, s2);
+  }
+  float element(uint64_t e) {
+    if ((e >> 2) != have) {
+      uint32_t o[4];
+      gen.block(e >> 2, o);
+      box_muller(o[0], o[1], f[0], f[1]);
+      box_muller(o[2], o[3], f[2], f[3]);
+      have = e >> 2;
+    }
+    return f[e & 3];
+  }
+};
+
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 size_t round_up_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
@@ -241,6 +279,63 @@ irec_status irec_philox_uniform_int(int64_t seed, int64_t n, int32_t *out) {
   tf_seed_pair(seed, seed, s1, s2);
   const Philox gen(s1, s2);
   for (int64_t e = 0; e < n; ++e) out[e] = 1 + (int32_t)(gen.element((uint64_t)e) % (uint32_t)(IREC_BIG_PRIME - 1));
+  return IREC_OK;
+}
+
+int64_t irec_importance_n_samples(double coding_bits) {
+  const float n = std::ceil(std::exp((float)coding_bits * std::log(2.0f))); // float32 throughout, importance_sampling.py:50
+  if (!(n >= 1.0f) || !(n < 2147483648.0f)) return -1;
+  return (int64_t)n;
+}
+
+irec_status irec_tf_random_normal(int64_t seed, int64_t count, float *out) {
+  if (count < 0 || (count > 0 && !out)) return fail(IREC_E_INVALID, "irec_tf_random_normal: bad arguments");
+  TfNormalStream st(seed);
+  for (int64_t e = 0; e < count; ++e) out[e] = st.element((uint64_t)e);
+  return IREC_OK;
+}
+
+irec_status irec_importance_encode(const float *t_loc, const float *t_scale, const float *p_loc, const float *p_scale,
+                                   int64_t n, double coding_bits, int64_t seed, int64_t *out_index, float *out_sample) {
+  if (!t_loc || !t_scale || !p_loc || !p_scale || !out_index || !out_sample || n < 1)
+    return fail(IREC_E_INVALID, "irec_importance_encode: bad arguments");
+  const int64_t S = irec_importance_n_samples(coding_bits);
+  if (S < 1) return fail(IREC_E_INVALID, "irec_importance_encode: coding_bits %g gives no valid sample count", coding_bits);
+  // standardise the target w.r.t. the coding distribution (:40-41); per-dim constants of Normal.log_prob (TFP 0.9)
+  const float half_log_2pi = (float)(0.5 * std::log(2.0 * 3.14159265358979323846));
+  std::vector<float> tl(n), ts(n), ln_t(n);
+  for (int64_t d = 0; d < n; ++d) {
+    tl[d] = (t_loc[d] - p_loc[d]) / p_scale[d];
+    ts[d] = t_scale[d] / p_scale[d];
+    ln_t[d] = half_log_2pi + std::log(ts[d]);
+  }
+  TfNormalStream st(seed);
+  float best = 0.f;
+  int64_t best_s = -1;
+  for (int64_t s = 0; s < S; ++s) {
+    double acc = 0.0; // canonical reduction: float32 terms, summed in float64 in dim order, rounded to float32 once
+    for (int64_t d = 0; d < n; ++d) {
+      const float x = st.element((uint64_t)(s * n + d));
+      const float dt = x / ts[d] - tl[d] / ts[d];
+      const float lp_t = -0.5f * (dt * dt) - ln_t[d];
+      const float dp = x / 1.0f - 0.0f / 1.0f;
+      const float lp_p = -0.5f * (dp * dp) - (half_log_2pi + 0.0f);
+      acc += (double)(lp_t - lp_p);
+    }
+    const float w = (float)acc;
+    if (best_s < 0 || w > best) { best = w; best_s = s; } // tf.argmax: first maximum
+  }
+  *out_index = best_s;
+  for (int64_t d = 0; d < n; ++d) out_sample[d] = p_scale[d] * st.element((uint64_t)(best_s * n + d)) + p_loc[d];
+  return IREC_OK;
+}
+
+irec_status irec_importance_decode(const float *p_loc, const float *p_scale, int64_t n, int64_t index, int64_t seed,
+                                   float *out_sample) {
+  if (!p_loc || !p_scale || !out_sample || n < 1 || index < 0)
+    return fail(IREC_E_INVALID, "irec_importance_decode: bad arguments");
+  TfNormalStream st(seed);
+  for (int64_t d = 0; d < n; ++d) out_sample[d] = p_scale[d] * st.element((uint64_t)(index * n + d)) + p_loc[d];
   return IREC_OK;
 }
 

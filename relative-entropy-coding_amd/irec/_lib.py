@@ -41,6 +41,10 @@ SIGNATURES = {
     "irec_build_lut": (ctypes.c_int, [_vp]),
     "irec_tf_shuffle_perm": (ctypes.c_int, [_i64, _i64, _vp]),
     "irec_philox_uniform_int": (ctypes.c_int, [_i64, _i64, _vp]),
+    "irec_importance_encode": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, ctypes.c_double, _i64, ctypes.POINTER(_i64), _vp]),
+    "irec_importance_decode": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
+    "irec_importance_n_samples": (_i64, [ctypes.c_double]),
+    "irec_tf_random_normal": (ctypes.c_int, [_i64, _i64, _vp]),
     "irec_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
     "irec_destroy": (None, [_vp]),
     "irec_encode_workspace_bytes": (ctypes.c_size_t, [_vp, _PP, _i32, _i32]),

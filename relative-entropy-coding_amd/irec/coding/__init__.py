@@ -2,3 +2,4 @@
 from .utils import CodingError  # noqa: F401
 from .coder import Coder, GaussianCoder  # noqa: F401
 from .beam_search_coder import BeamSearchCoder  # noqa: F401
+from .samplers import Sampler, ImportanceSampler  # noqa: F401
