@@ -27,6 +27,7 @@ struct SmallLdsT {
     unsigned long long cand[64];    // compacted (key, flat) survivors of the threshold selection
   };
   int32_t sel_s[MB], sel_b[MB];     // selected (sample, beam) per new beam
+  uint32_t sel_bo[MB];              // 4 * dlog(hash) of the selected parent beam (team encoder)
   int32_t hsum[2][MB];              // running int32 sum of simple_hash per beam, double buffered
   uint32_t beta4[2][MB];            // 4 * dlog(hash) per beam, double buffered
   int32_t misc[8];                  // [0] block id, [1] K, [7] selection path flag
@@ -49,9 +50,12 @@ constexpr size_t SMALL_LDS_BYTES = (sizeof(SmallLds) + 15) & ~(size_t)15;
 //  - otherwise: all waves scan the keys, one barrier per selected beam (element f owned by thread f % NT).
 // `sync` is the barrier of the NT threads that run the selection together (the whole workgroup, or one team of it) and
 // `tid` the thread's index among them.
-template <int NT, class SM, class Sync>
+// `post(j, s, b)` is called by the thread that has just recorded new beam j = candidate (sample s, parent beam b),
+// before the barrier that publishes the selection.
+struct NoPost { __device__ __forceinline__ void operator()(int, int32_t, int32_t) const {} };
+template <int NT, class SM, class Sync, class Post = NoPost>
 __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew, int Bcur, SM *sm, const int tid, Sync &&sync,
-                                                 unsigned long long *dbg = nullptr) {
+                                                 unsigned long long *dbg = nullptr, Post &&post = Post()) {
   constexpr int NWV = NT / 64;
   int32_t *sel_s = sm->sel_s, *sel_b = sm->sel_b;
   unsigned long long t0 = dbg ? stamp_now() : 0ull;
@@ -100,8 +104,11 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
           rank += (ok_ > mk || (ok_ == mk && of_ < mf)) ? 1u : 0u;
         }
         if (tid < (int)C && rank < (uint32_t)Bnew) {
-          sel_s[rank] = (int32_t)(mf / (uint32_t)Bcur); // best_ind_aux  (beam_search_coder.py:89)
-          sel_b[rank] = (int32_t)(mf % (uint32_t)Bcur); // best_ind_beam (beam_search_coder.py:88)
+          const int32_t s_ = (int32_t)(mf / (uint32_t)Bcur); // best_ind_aux  (beam_search_coder.py:89)
+          const int32_t b_ = (int32_t)(mf % (uint32_t)Bcur); // best_ind_beam (beam_search_coder.py:88)
+          sel_s[rank] = s_;
+          sel_b[rank] = b_;
+          post((int)rank, s_, b_);
         }
         sm->misc[7] = 1;
       } else {
@@ -134,8 +141,10 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
     const uint32_t fstar = 0xFFFFFFFFu - (uint32_t)g;
     if ((uint32_t)tid == fstar % (uint32_t)NT) key[fstar] = 0u;
     if (tid == 0) {
-      sel_s[it] = (int32_t)(fstar / (uint32_t)Bcur);
-      sel_b[it] = (int32_t)(fstar % (uint32_t)Bcur);
+      const int32_t s_ = (int32_t)(fstar / (uint32_t)Bcur), b_ = (int32_t)(fstar % (uint32_t)Bcur);
+      sel_s[it] = s_;
+      sel_b[it] = b_;
+      post(it, s_, b_);
     }
   }
   sync();

@@ -35,7 +35,8 @@ constexpr uint32_t T3_FLOATS = 3u * IREC_PM1;    // three copies of lut2
 constexpr size_t T3_BYTES = ((size_t)T3_FLOATS * 4 + 15) & ~(size_t)15;
 
 __host__ __device__ inline size_t team_part_bytes(int NB, int S) { return (((size_t)4 * S * NB * 4) + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t team_lds_one(int NB, int S) { return team_part_bytes(NB, S) + TEAM_SMALL_BYTES + 16; }
+__host__ __device__ inline size_t team_key_bytes(int NB, int S) { return (((size_t)S * NB * 4) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t team_lds_one(int NB, int S) { return team_part_bytes(NB, S) + team_key_bytes(NB, S) + TEAM_SMALL_BYTES + 16; }
 __host__ __device__ inline size_t team_lds_total(int NB, int S, int teams) { return T3_BYTES + (size_t)teams * team_lds_one(NB, S); }
 
 // Barrier of the 4 waves of one team: a monotonic LDS counter.  LDS operations of one wave execute in program order and
@@ -65,7 +66,7 @@ struct TeamBarrier {
 #define TSTAMP(slot) do { } while (0)
 #endif
 
-// LDS carve (bytes): lut2 x 3 [120080] | team 0: part [4][S][NB] f32 (sort keys overwrite group 0) | SmallLds | barrier | team 1: same
+// LDS carve (bytes): lut2 x 3 [120080] | team 0: part [4][S][NB] f32 | sort keys [S*NB] | TeamLds | barrier | team 1: same
 // BS = beam stripes: with BS == 2 a team has 8 waves, wave w serves dim group / sample stripe (w & 3) and the beams
 // [NBW * (w >> 2), + NBW), NBW = NB / BS: half the G registers per lane (128-VGPR budget, 16 waves per CU).
 template <int NB, int TEAMS, int BS>
@@ -91,16 +92,15 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   const int tid = (int)threadIdx.x - team * NT;                                 // index inside the team
   char *tbase = smem + T3_BYTES + (size_t)team * team_lds_one(NB, S);
   float *part_s = reinterpret_cast<float *>(tbase);                             // [4][S][NB] per-group partial scores
-  uint32_t *key_s = reinterpret_cast<uint32_t *>(tbase);                        // [S*NB] sort keys over group 0
-  TeamLds *sm = reinterpret_cast<TeamLds *>(tbase + team_part_bytes(NB, S));
-  uint32_t *bar_word = reinterpret_cast<uint32_t *>(tbase + team_part_bytes(NB, S) + TEAM_SMALL_BYTES);
+  uint32_t *key_s = reinterpret_cast<uint32_t *>(tbase + team_part_bytes(NB, S)); // [S*NB] sort keys
+  TeamLds *sm = reinterpret_cast<TeamLds *>(tbase + team_part_bytes(NB, S) + team_key_bytes(NB, S));
+  uint32_t *bar_word = reinterpret_cast<uint32_t *>(tbase + team_part_bytes(NB, S) + team_key_bytes(NB, S) + TEAM_SMALL_BYTES);
   double *gpart = sm->gpart;
   int32_t *sel_s = sm->sel_s, *sel_b = sm->sel_b;
   int32_t *hsum = &sm->hsum[0][0];
   uint32_t *beta4 = &sm->beta4[0][0];
   int32_t *misc = sm->misc;
   float *cpart_s = &sm->cpart[0][0];
-  float *Cb_s = sm->Cb;
   const uint16_t *dlog_s = A.dlog4r;                                            // [10006] 4*dlog(j+1), global (L2)
   const int SP = S;                                                             // one scoring pass per step
   const int rs_p = RSN ? rsn_owner<20>(lane) : 0;                               // accumulator whose total reduce_scatter_n<20> leaves here
@@ -232,13 +232,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
       }
       const float cg = wave_tree_sum(cacc);
       if (active && sw == 0 && bs == 0 && lane == 0) cpart_s[g * 32 + 0] = cg;
-      tsync();
-      if (tid == 0) {
-        float cb = cpart_s[0];
-        for (int gg = 1; gg < NG; ++gg) cb = cb + cpart_s[gg * 32];
-        Cb_s[0] = cb;
-      }
-      // (visibility of Cb_s: the barrier after scoring)
+      // (visibility of the C_b partials: the barrier after scoring)
     }
 
     TSTAMP(1);
@@ -391,13 +385,11 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
       TSTAMP(3);
       // ---------------- combine dim groups in order, add C_b, build sort keys ----------------
       {
-        // keys are written over group 0 of the partials: two phases with a barrier in between because
-        // key f = s * Bcur + b and partial (s, b) = s * NB + b only coincide when Bcur == NB
         constexpr int MK = (1024 + NT - 1) / NT;
-        uint32_t mykey[MK];
         {
-          // every partial of my candidates is fetched before the first is used: one LDS latency instead of 4 per key
-          float pr[MK][4], cbv[MK];
+          // every partial of my candidates (and of their beams' C_b) is fetched before the first is used: one LDS
+          // latency instead of 4 per key
+          float pr[MK][4], cbv[MK][4];
           const int gstride = SP * NB;
 #pragma unroll
           for (int q = 0; q < MK; ++q) {
@@ -405,7 +397,8 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
             const int s = Bcur == NB ? fs / NB : fs / Bcur, b = fs - s * Bcur;
 #pragma unroll
             for (int gg = 0; gg < 4; ++gg) pr[q][gg] = part_s[(gg < NG ? gg : 0) * gstride + s * NB + b];
-            cbv[q] = Cb_s[b];
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) cbv[q][gg] = cpart_s[(gg < NG ? gg : 0) * 32 + b];
           }
 #pragma unroll
           for (int q = 0; q < MK; ++q) {
@@ -413,34 +406,33 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
             if (NG > 1) sc = sc + pr[q][1];
             if (NG > 2) sc = sc + pr[q][2];
             if (NG > 3) sc = sc + pr[q][3];
-            mykey[q] = q * NT + tid < N ? score_key(sc + cbv[q]) : 0u;
+            float cb = cbv[q][0];                       // C_b: its dim-group partials in order, as the scores'
+            if (NG > 1) cb = cb + cbv[q][1];
+            if (NG > 2) cb = cb + cbv[q][2];
+            if (NG > 3) cb = cb + cbv[q][3];
+            if (q * NT + tid < N) key_s[q * NT + tid] = score_key(sc + cb);
           }
-        }
-        tsync();
-#pragma unroll
-        for (int q = 0; q < MK; ++q) {
-          const int f = q * NT + tid;
-          if (f < N) key_s[f] = mykey[q];
         }
       }
       const int Bnew = B < N ? B : N;
       TSTAMP(4);
 #ifdef IREC_ABLATE_SELECT
       tsync();
-      if (tid < Bnew) { sel_s[tid] = tid % S; sel_b[tid] = tid % Bcur; }
+      if (tid < Bnew) { sel_s[tid] = tid % S; sel_b[tid] = tid % Bcur; sm->sel_bo[tid] = beta4[cur * TEAM_MB + tid % Bcur];
+                        hsum[(cur ^ 1) * TEAM_MB + tid] = 0; beta4[(cur ^ 1) * TEAM_MB + tid] = 0u; }
       tsync();
 #else
-      select_topB_sync<NT>(key_s, N, Bnew, Bcur, sm, tid, tsync); // first barrier inside orders the key_s writes
+      // top-B (beam_search_coder.py:85-89); the thread that records new beam j also extends its hash / back-pointer
+      // (:94-95) and notes its parent's table offset, so one barrier publishes everything the update needs
+      select_topB_sync<NT>(key_s, N, Bnew, Bcur, sm, tid, tsync, nullptr, [&](int j, int32_t sp_, int32_t bp_) {
+        const int32_t nh = (int32_t)((uint32_t)hsum[cur * TEAM_MB + bp_] + (uint32_t)sp_ * (uint32_t)(69 + t));
+        hsum[(cur ^ 1) * TEAM_MB + j] = nh;
+        beta4[(cur ^ 1) * TEAM_MB + j] = dlog_s[hash_from_sum(nh) - 1u];
+        sm->sel_bo[j] = beta4[cur * TEAM_MB + bp_];
+        bp[(size_t)t * NB + j] = (sp_ << 6) | bp_;
+      });
 #endif
       TSTAMP(5);
-      // ---------------- new hashes / back-pointers (beam_search_coder.py:94-95) ----------------
-      if (tid < Bnew) {
-        const int32_t sp_ = sel_s[tid], bp_ = sel_b[tid];
-        const int32_t nh = (int32_t)((uint32_t)hsum[cur * TEAM_MB + bp_] + (uint32_t)sp_ * (uint32_t)(69 + t));
-        hsum[(cur ^ 1) * TEAM_MB + tid] = nh;
-        beta4[(cur ^ 1) * TEAM_MB + tid] = dlog_s[hash_from_sum(nh) - 1u];
-        bp[(size_t)t * NB + tid] = (sp_ << 6) | bp_;
-      }
       // ---------------- gather the surviving beams (beam_search_coder.py:92-93), prepare the next step ----------------
       const bool last = (t == K - 1);
       __builtin_amdgcn_s_setprio(2); // serial phase: ahead of the other team's scoring waves
@@ -463,10 +455,10 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         float cacc[RSN ? rsn_room(NBW) : 32];
 #pragma unroll
         for (int j = 0; j < (RSN ? rsn_room(NBW) : 32); ++j) cacc[j] = 0.f;
-        constexpr int UB = TEAMS >= 3 ? 5 : NBW;              // beams per load batch: all at once (G's registers are free) unless registers are short
+        constexpr int UB = (TEAMS >= 3 || BS >= 2) ? 5 : NBW;              // beams per load batch: all at once (G's registers are free) unless registers are short
         // lane j fetches the selection of new beam j and the offset of its parent: two LDS round trips for all beams
         const int32_t v_sp = sel_s[lane < Bnew ? lane : 0], v_bp = sel_b[lane < Bnew ? lane : 0];
-        const uint32_t v_bo = beta4[cur * TEAM_MB + v_bp];
+        const uint32_t v_bo = sm->sel_bo[lane < Bnew ? lane : 0];
 #pragma unroll
         for (int j0 = 0; j0 < NBW; j0 += UB) {
           // ---- issue the batch's global reads (proposal rows, old beams) back to back ----
@@ -542,14 +534,8 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         }
       }
       TSTAMP(6);
-      tsync();
       __builtin_amdgcn_s_setprio(0);
-      TSTAMP(7);
-      if (!last && tid < Bnew) {
-        float cb = cpart_s[tid];
-        for (int gg = 1; gg < NG; ++gg) cb = cb + cpart_s[gg * 32 + tid];
-        Cb_s[tid] = cb; // read after the next scoring barrier
-      }
+      // no barrier here: the new C_b partials, hashes and beams are first read behind the next step's barriers
       cur ^= 1;
       Bcur = Bnew;
     }
