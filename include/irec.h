@@ -161,8 +161,10 @@ int64_t irec_rec_unpack_bits(const uint8_t *bytes, int64_t n_bytes, uint8_t *out
 /* ---- test hooks (device pointers) ---------------------------------------------------------------------------- */
 /* r[s*D + d] of get_pseudo_random_sample's int32 draw, generated by the in-kernel Philox stream.  out: int32 [n]. */
 irec_status irec_device_uniform_int(irec_context *ctx, int64_t seed, int64_t n, int32_t *out, void *hip_stream);
-/* in: float [64 lanes][width], width in {64, 32}; out[lane] = sum over lanes of in[.][lane*width/64] in the canonical
- * 64-lane reduction tree of the score kernels. */
+/* in: float [64 lanes][width]; out: float [128].  width in {64, 32}: out[lane] = sum over lanes of
+ * in[.][lane*width/64] in the canonical 64-lane reduction tree of the score kernels.  width in {20, 10}
+ * (the arbitrary-width reduce-scatter of the team encoder): out[lane] = such a total of column out[64 + lane] (a column
+ * index as a float, or -1 if the lane ends up with an unused slot); every column is owned by two lanes. */
 irec_status irec_test_reduce_scatter(irec_context *ctx, const float *in, float *out, int32_t width, void *hip_stream);
 /* tf.argsort(scores, DESCENDING)[:n_select] split into (index // n_beams_cur, index % n_beams_cur) -- the top-B step of
  * beam_search_coder.py:85-89 in isolation.  scores: float [n]; scratch_keys: uint32 [n]; out_sel: int32 [n_select][2]. */

@@ -799,7 +799,7 @@ __global__ __launch_bounds__(256) void select_test_kernel(const float *scores, i
   if (threadIdx.x < Bnew) { sel[2 * threadIdx.x] = sm.sel_s[threadIdx.x]; sel[2 * threadIdx.x + 1] = sm.sel_b[threadIdx.x]; }
 }
 
-// in: [64 lanes][width] floats; out[lane] = canonical-tree total of column (lane >> shift)
+// in: [64 lanes][width] floats; out[lane] = canonical-tree total of column (lane >> shift); out has 128 floats
 __global__ void reduce_scatter_test_kernel(const float *in, float *out, int width) {
   const int lane = threadIdx.x & 63;
   if (width == 64) {
@@ -807,11 +807,23 @@ __global__ void reduce_scatter_test_kernel(const float *in, float *out, int widt
 #pragma unroll
     for (int j = 0; j < 64; ++j) v[j] = in[lane * 64 + j];
     out[lane] = reduce_scatter<64>(v, lane);
-  } else {
+  } else if (width == 32) {
     float v[32];
 #pragma unroll
     for (int j = 0; j < 32; ++j) v[j] = in[lane * 32 + j];
     out[lane] = reduce_scatter<32>(v, lane);
+  } else if (width == 20) { // arbitrary-width form: out[lane] = total, out[64 + lane] = column this lane owns (or -1)
+    float v[rsn_room(20)];
+#pragma unroll
+    for (int j = 0; j < 20; ++j) v[j] = in[lane * 20 + j];
+    out[lane] = reduce_scatter_n<20>(v, lane);
+    out[64 + lane] = (float)rsn_owner<20>(lane);
+  } else {
+    float v[rsn_room(10)];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) v[j] = in[lane * 10 + j];
+    out[lane] = reduce_scatter_n<10>(v, lane);
+    out[64 + lane] = (float)rsn_owner<10>(lane);
   }
 }
 

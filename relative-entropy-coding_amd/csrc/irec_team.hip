@@ -274,9 +274,12 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 #define IREC_ISSUE(Z, AD) do { _Pragma("unroll") for (int k = 0; k < NP; ++k) { Z[k].x = lds_abs_f32((AD) + bet[2 * k]); Z[k].y = lds_abs_f32((AD) + bet[2 * k + 1]); } \
                                __builtin_amdgcn_sched_barrier(0); } while (0)
 #define IREC_CONSUME(Z, I) do { _Pragma("unroll") for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(Z[k])); \
+                                f2 t2_[NP]; \
                                 _Pragma("unroll") for (int k = 0; k < NP; ++k) { \
                                   const f2 h2 = {cH[I], cH[I]}, g2 = {G[2 * k][I], G[2 * k + 1][I]}; \
-                                  acc2[k] = __builtin_elementwise_fma(__builtin_elementwise_fma(h2, Z[k], g2), Z[k], acc2[k]); } \
+                                  t2_[k] = __builtin_elementwise_fma(h2, Z[k], g2); } /* inner fma of every pair first: */ \
+                                _Pragma("unroll") for (int k = 0; k < NP; ++k) /* no dependent back-to-back issue */ \
+                                  acc2[k] = __builtin_elementwise_fma(t2_[k], Z[k], acc2[k]); \
                                 _Pragma("unroll") for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(acc2[k])); \
                                 __builtin_amdgcn_sched_barrier(0); } while (0)
         IREC_ISSUE(zA, al[0]);

@@ -200,7 +200,7 @@ class Engine:
 
     def test_reduce_scatter(self, x):
         width = x.shape[1]
-        out = torch.empty(64, dtype=torch.float32, device=self.device)
+        out = torch.zeros(128, dtype=torch.float32, device=self.device)
         _lib.check(self.lib.irec_test_reduce_scatter(self.ctx, _ptr(x), _ptr(out), int(width), self._stream()),
                    "irec_test_reduce_scatter")
         return out

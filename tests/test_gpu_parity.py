@@ -52,6 +52,28 @@ def test_reduce_scatter_is_the_canonical_tree(engine, width):
         assert got[lane] == part[0], (lane, got[lane], part[0])
 
 
+@pytest.mark.parametrize("width", [20, 10])
+def test_arbitrary_width_reduce_scatter_is_the_canonical_tree(engine, width):
+    """The team encoder's 20-/10-value reduce-scatter: every column's total comes out of the same tree (lanes paired at
+    distance 32, 16, 8, 4, 2, 1); the trailing all-reduce stages leave each column's total in 2 (4) neighbouring lanes."""
+    rng = np.random.default_rng(100 + width)
+    x = (rng.standard_normal((64, width)) * np.exp(rng.uniform(-3, 3, (64, width)))).astype(np.float32)
+    out = engine.test_reduce_scatter(torch.from_numpy(x).cuda()).cpu().numpy()
+    tot, owner = out[:64], out[64:].astype(np.int64)
+    for col in range(width):
+        part = x[:, col].copy()
+        step = 32
+        while step >= 1:
+            part[:step] = part[:step] + part[step:2 * step]
+            step >>= 1
+        lanes = np.nonzero(owner == col)[0]
+        # 20 -> 10 -> 5 -> 3 -> 2 -> 1 leaves one all-reduce stage (2 owners); 10 -> 5 -> 3 -> 2 -> 1 -> 1 two (4 owners)
+        n_own = 2 if width == 20 else 4
+        assert len(lanes) == n_own and (lanes >> (n_own // 2)).min() == (lanes >> (n_own // 2)).max(), (col, lanes)
+        assert (tot[lanes] == part[0]).all(), (col, tot[lanes], part[0])
+    assert ((owner >= -1) & (owner < width)).all()
+
+
 def _ref_select(scores, n_select, bcur):
     # tf.argsort(DESCENDING) == top_k: value descending, ties -> lower index; NaN after every number
     keyed = sorted(range(len(scores)), key=lambda i: (np.isnan(scores[i]), -scores[i] if not np.isnan(scores[i]) else 0.0, i))
