@@ -78,10 +78,10 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   static_assert(NB % BS == 0, "beam stripes must divide the beam count");
   // accumulators reduced together: 6 samples x 10 beams through the 64-wide reduce-scatter, or 20 values (one sample x
   // 20 beams, two samples x 10 beams) through the 20-value one (22 exchange+add pairs instead of 31, 12 registers fewer)
-  constexpr bool RSN = NBW * (20 / NBW) == 20 && (NB == 20);
+  constexpr bool RSN = NBW * (20 / NBW) == 20;  // NBW in {10, 20}
   constexpr int RW = RSN ? 20 : Cfg::RW, SPC = RSN ? 20 / NBW : Cfg::SPC;
   constexpr int ACC_ROOM = RSN ? rsn_room(20) : RW;
-  static_assert(RSN || BS == 1, "beam stripes are only built for the 20-beam encoder");
+  static_assert(RSN, "the team encoder is built for 10 or 20 beams per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int S = A.S, B = A.B;
   const int lane = threadIdx.x & 63;
@@ -253,64 +253,80 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 #ifdef IREC_ABLATE_SCORING
       if (false) {
 #else
-      if (RSN && SPC == 1 && active && nlive == NBW) {
-        // Steady state, software pipelined by dim slot: the NBW gathers of the NEXT slot (or of the next sample's first
-        // slot) are issued before the current slot's values are consumed, so the wave always has look-ups in flight --
-        // also under the fma chain and the reduce-scatter.  A wave can have at most 15 LDS operations outstanding, so
-        // by the time the next slot's 20 are issued the current slot's have all landed.  Empty volatile asm statements
-        // pin the order (pure arithmetic would otherwise drift across the scheduling barriers).
+      if (RSN && active && nlive == NBW) {
+        // Steady state, software pipelined by dim slot: the NBW gathers of the NEXT slot (of this sample, of the chunk's
+        // next sample, or of the next chunk's first sample) are issued before the current slot's values are consumed, so
+        // the wave always has look-ups in flight -- also under the fma chain and the reduce-scatter.  A wave can have at
+        // most 15 LDS operations outstanding, so by the time the next slot's are issued the current slot's have landed
+        // (or the compiler's wait counts see to it).  Empty volatile asm statements pin the order (pure arithmetic would
+        // otherwise drift across the scheduling barriers).  A chunk is SPC samples (20 accumulators, one reduce-scatter).
         const int n_mine = (S - sw + NSW - 1) / NSW;              // my samples: sw, sw + NSW, ...
-        uint2 ap_nxt = make_uint2(0u, 0u);
-        uint32_t al[4];
-        {
-          const uint2 ap = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sw * Dp);
-          al[0] = (ap.x & 0xFFFFu) << 2; al[1] = (ap.x >> 16) << 2; al[2] = (ap.y & 0xFFFFu) << 2; al[3] = (ap.y >> 16) << 2;
-          if (NSW + sw < S) ap_nxt = *reinterpret_cast<const uint2 *>(tab_t + (size_t)(NSW + sw) * Dp);
+        const int n_chunks = (n_mine + SPC - 1) / SPC;
+        auto row = [&](int m) {                                     // proposal row of my m-th sample; zero row past the end:
+          uint2 r = make_uint2(0u, 0u);                             // entry 0 is a valid address, its results are dropped
+          if (m < n_mine) r = *reinterpret_cast<const uint2 *>(tab_t + (size_t)(m * NSW + sw) * Dp);
+          return r;
+        };
+        uint2 ap_nxt[SPC];
+        uint32_t al[SPC][4];
+#pragma unroll
+        for (int cc = 0; cc < SPC; ++cc) {
+          const uint2 ap = row(cc);
+          al[cc][0] = (ap.x & 0xFFFFu) << 2; al[cc][1] = (ap.x >> 16) << 2; al[cc][2] = (ap.y & 0xFFFFu) << 2; al[cc][3] = (ap.y >> 16) << 2;
+          ap_nxt[cc] = row(SPC + cc);
         }
         // values travel in register pairs so that the two fma of two beams stay one v_pk_fma_f32 each
         typedef float f2 __attribute__((ext_vector_type(2)));
         constexpr int NP = NBW / 2;
-        f2 zA[NP], zB[NP];
+        constexpr int NQ = 4 * SPC;                                 // dim slots per chunk (even: buffers alternate cleanly)
+        static_assert(NBW % 2 == 0, "beams are processed in pairs");
+        f2 zz[2][NP];
 #define IREC_ISSUE(Z, AD) do { _Pragma("unroll") for (int k = 0; k < NP; ++k) { Z[k].x = lds_abs_f32((AD) + bet[2 * k]); Z[k].y = lds_abs_f32((AD) + bet[2 * k + 1]); } \
                                __builtin_amdgcn_sched_barrier(0); } while (0)
-#define IREC_CONSUME(Z, I) do { _Pragma("unroll") for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(Z[k])); \
+#define IREC_CONSUME(Z, I, ACC) do { _Pragma("unroll") for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(Z[k])); \
                                 f2 t2_[NP]; \
                                 _Pragma("unroll") for (int k = 0; k < NP; ++k) { \
                                   const f2 h2 = {cH[I], cH[I]}, g2 = {G[2 * k][I], G[2 * k + 1][I]}; \
                                   t2_[k] = __builtin_elementwise_fma(h2, Z[k], g2); } /* inner fma of every pair first: */ \
                                 _Pragma("unroll") for (int k = 0; k < NP; ++k) /* no dependent back-to-back issue */ \
-                                  acc2[k] = __builtin_elementwise_fma(t2_[k], Z[k], acc2[k]); \
-                                _Pragma("unroll") for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(acc2[k])); \
+                                  ACC[k] = __builtin_elementwise_fma(t2_[k], Z[k], ACC[k]); \
+                                _Pragma("unroll") for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(ACC[k])); \
                                 __builtin_amdgcn_sched_barrier(0); } while (0)
-        IREC_ISSUE(zA, al[0]);
-        for (int ch = 0; ch < n_mine; ++ch) {
-          f2 acc2[NP];
+        IREC_ISSUE(zz[0], al[0][0]);
+        for (int ch = 0; ch < n_chunks; ++ch) {
+          f2 acc2[SPC][NP];
 #pragma unroll
-          for (int k = 0; k < NP; ++k) acc2[k] = (f2){0.f, 0.f};
-          IREC_ISSUE(zB, al[1]);
-          IREC_CONSUME(zA, 0);
-          IREC_ISSUE(zA, al[2]);
-          IREC_CONSUME(zB, 1);
-          IREC_ISSUE(zB, al[3]);
-          IREC_CONSUME(zA, 2);
-          // next sample's row (zero = entry 0: a valid address, its values are dropped after the last sample)
-          al[0] = (ap_nxt.x & 0xFFFFu) << 2; al[1] = (ap_nxt.x >> 16) << 2; al[2] = (ap_nxt.y & 0xFFFFu) << 2; al[3] = (ap_nxt.y >> 16) << 2;
-          {
-            const int sn = (ch + 2) * NSW + sw;
-            ap_nxt = make_uint2(0u, 0u);
-            if (sn < S) ap_nxt = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sn * Dp);
+          for (int cc = 0; cc < SPC; ++cc)
+#pragma unroll
+            for (int k = 0; k < NP; ++k) acc2[cc][k] = (f2){0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            if (q + 1 < NQ) {
+              IREC_ISSUE(zz[(q + 1) & 1], al[(q + 1) >> 2][(q + 1) & 3]);
+            } else {
+              // next chunk's rows
+#pragma unroll
+              for (int cc = 0; cc < SPC; ++cc) {
+                al[cc][0] = (ap_nxt[cc].x & 0xFFFFu) << 2; al[cc][1] = (ap_nxt[cc].x >> 16) << 2;
+                al[cc][2] = (ap_nxt[cc].y & 0xFFFFu) << 2; al[cc][3] = (ap_nxt[cc].y >> 16) << 2;
+                ap_nxt[cc] = row((ch + 2) * SPC + cc);
+              }
+              IREC_ISSUE(zz[0], al[0][0]);
+            }
+            IREC_CONSUME(zz[q & 1], q & 3, acc2[q >> 2]);
           }
-          IREC_ISSUE(zA, al[0]);
-          IREC_CONSUME(zB, 3);
           float acc[ACC_ROOM];
 #pragma unroll
-          for (int k = 0; k < NP; ++k) { acc[2 * k] = acc2[k].x; acc[2 * k + 1] = acc2[k].y; }
+          for (int cc = 0; cc < SPC; ++cc)
+#pragma unroll
+            for (int k = 0; k < NP; ++k) { acc[cc * NBW + 2 * k] = acc2[cc][k].x; acc[cc * NBW + 2 * k + 1] = acc2[cc][k].y; }
           const float tot = reduce_scatter_n<20>(acc, lane);
-          const int s = ch * NSW + sw;
-          if (rs_p >= 0 && (lane & 1) == 0) part_s[((size_t)g * SP + s) * NB + b_lo + rs_p] = tot;
+          const int cc = rs_p / NBW, b = rs_p - cc * NBW;          // rs_p < 0: unused slot
+          const int m = ch * SPC + cc;                              // my m-th sample
+          if (rs_p >= 0 && (lane & 1) == 0 && m < n_mine) part_s[((size_t)g * SP + m * NSW + sw) * NB + b_lo + b] = tot;
         }
 #pragma unroll
-        for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(zA[k])); // drain the look-ups issued past the last sample
+        for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(zz[0][k])); // drain the look-ups issued past the last sample
 #undef IREC_ISSUE
 #undef IREC_CONSUME
       } else if (active && nlive > 0) {
