@@ -71,17 +71,15 @@ struct TeamBarrier {
 // [NBW * (w >> 2), + NBW), NBW = NB / BS: half the G registers per lane (128-VGPR budget, 16 waves per CU).
 template <int NB, int TEAMS, int BS>
 __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(EncArgs A) {
-  using Cfg = FastCfg<NB, true>;
   constexpr int NW = TEAM_NW;                    // waves per beam stripe (dim groups x sample stripes)
   constexpr int NWT = TEAM_NW * BS, NT = 64 * NWT; // waves / threads per team
   constexpr int NBW = NB / BS;                   // beams per wave
   static_assert(NB % BS == 0, "beam stripes must divide the beam count");
-  // accumulators reduced together: 6 samples x 10 beams through the 64-wide reduce-scatter, or 20 values (one sample x
-  // 20 beams, two samples x 10 beams) through the 20-value one (22 exchange+add pairs instead of 31, 12 registers fewer)
-  constexpr bool RSN = NBW * (20 / NBW) == 20;  // NBW in {10, 20}
-  constexpr int RW = RSN ? 20 : Cfg::RW, SPC = RSN ? 20 / NBW : Cfg::SPC;
-  constexpr int ACC_ROOM = RSN ? rsn_room(20) : RW;
-  static_assert(RSN, "the team encoder is built for 10 or 20 beams per wave");
+  // 20 accumulators are reduced together (one sample x 20 beams, or two samples x 10 beams) by the 20-value
+  // reduce-scatter: 22 exchange+add pairs instead of the 31 of a zero-padded 32-wide one, and 12 registers fewer
+  static_assert(NBW == 10 || NBW == 20, "the team encoder is built for 10 or 20 beams per wave");
+  constexpr int RW = 20, SPC = 20 / NBW;
+  constexpr int ACC_ROOM = rsn_room(20);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int S = A.S, B = A.B;
   const int lane = threadIdx.x & 63;
@@ -103,7 +101,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   float *cpart_s = &sm->cpart[0][0];
   const uint16_t *dlog_s = A.dlog4r;                                            // [10006] 4*dlog(j+1), global (L2)
   const int SP = S;                                                             // one scoring pass per step
-  const int rs_p = RSN ? rsn_owner<20>(lane) : 0;                               // accumulator whose total reduce_scatter_n<20> leaves here
+  const int rs_p = rsn_owner<20>(lane);                                         // accumulator whose total reduce_scatter_n<20> leaves here
   const int rs_c = rsn_owner<NBW>(lane);                                        // same for the NBW C_b partials of the update
 
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap(); // see lds_abs_f32
@@ -253,7 +251,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 #ifdef IREC_ABLATE_SCORING
       if (false) {
 #else
-      if (RSN && active && nlive == NBW) {
+      if (active && nlive == NBW) {
         // Steady state, software pipelined by dim slot: the NBW gathers of the NEXT slot (of this sample, of the chunk's
         // next sample, or of the next chunk's first sample) are issued before the current slot's values are consumed, so
         // the wave always has look-ups in flight -- also under the fma chain and the reduce-scatter.  A wave can have at
@@ -384,19 +382,10 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
               }
             }
           }
-          if constexpr (RSN) {
-            const float tot = reduce_scatter_n<20>(acc, lane);
-            const int cc = rs_p / NBW, b = rs_p - cc * NBW;   // rs_p < 0: unused slot
-            const int s = (ch * SPC + cc) * NSW + sw;
-            if (rs_p >= 0 && (lane & 1) == 0 && s < S && b < nlive) part_s[((size_t)g * SP + s) * NB + b_lo + b] = tot;
-          } else {
-            const float tot = reduce_scatter<RW>(acc, lane);
-            const int p = RW == 64 ? lane : (lane >> 1);
-            const int cc = p / NB, b = p - cc * NB;
-            const int s = (ch * SPC + cc) * NSW + sw;
-            if (cc < SPC && s < S && b < Bcur && (RW == 64 || (lane & 1) == 0))
-              part_s[((size_t)g * SP + s) * NB + b] = tot;
-          }
+          const float tot = reduce_scatter_n<20>(acc, lane);
+          const int cc = rs_p / NBW, b = rs_p - cc * NBW;   // rs_p < 0: unused slot
+          const int s = (ch * SPC + cc) * NSW + sw;
+          if (rs_p >= 0 && (lane & 1) == 0 && s < S && b < nlive) part_s[((size_t)g * SP + s) * NB + b_lo + b] = tot;
         }
       }
       TSTAMP(2);
@@ -471,9 +460,9 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         float m[4], cA[4], cBv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { m[i] = 0.f; cA[i] = 0.f; cBv[i] = 0.f; }
-        float cacc[RSN ? rsn_room(NBW) : 32];
+        float cacc[rsn_room(NBW)];
 #pragma unroll
-        for (int j = 0; j < (RSN ? rsn_room(NBW) : 32); ++j) cacc[j] = 0.f;
+        for (int j = 0; j < rsn_room(NBW); ++j) cacc[j] = 0.f;
         constexpr int UB = (TEAMS >= 3 || BS >= 2) ? 5 : NBW;              // beams per load batch: all at once (G's registers are free) unless registers are short
         // lane j fetches the selection of new beam j and the offset of its parent: two LDS round trips for all beams
         const int32_t v_sp = sel_s[lane < Bnew ? lane : 0], v_bp = sel_b[lane < Bnew ? lane : 0];
@@ -542,14 +531,8 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           __builtin_amdgcn_sched_barrier(0);
         }
         if (!last) {
-          if constexpr (RSN) {
-            const float ctot = reduce_scatter_n<NBW>(cacc, lane);
-            if (sw == 0 && (lane & 1) == 0 && rs_c >= 0 && b_lo + rs_c < Bnew) cpart_s[g * 32 + b_lo + rs_c] = ctot;
-          } else {
-            const float ctot = reduce_scatter<32>(cacc, lane);  // lane l holds beam (l >> 1)
-            const int j = lane >> 1;
-            if (sw == 0 && (lane & 1) == 0 && j < Bnew) cpart_s[g * 32 + j] = ctot;
-          }
+          const float ctot = reduce_scatter_n<NBW>(cacc, lane);
+          if (sw == 0 && (lane & 1) == 0 && rs_c >= 0 && b_lo + rs_c < Bnew) cpart_s[g * 32 + b_lo + rs_c] = ctot;
         }
       }
       TSTAMP(6);
