@@ -153,17 +153,18 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
     // ---- my 4 dims (split == gather through perm) and the block's KL ----
     float c[4];
     bool valid[4];
-    int64_t ix[4];
     double klacc = 0.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int d = d0 + i;
       valid[i] = d < D;
       c[i] = 0.f;
-      ix[i] = valid[i] ? src_index(A, base, pos, d) : src_index(A, base, pos, 0);
+      // (the element's index is looked up again when the sample is written: four 64-bit indices per lane are not worth
+      // holding, or spilling, across the whole step loop)
+      const int64_t ixi = valid[i] ? src_index(A, base, pos, d) : src_index(A, base, pos, 0);
       float st3[3] = {0.f, 1.f, 1.f};
       if (valid[i] && active && sw == 0 && bs == 0) { // one wave per dim group does the float64 KL and publishes the statistics
-        const float mq_ = A.q_loc[ix[i]], sq_ = A.q_scale[ix[i]], mp_ = A.p_loc[ix[i]], sp_ = A.p_scale[ix[i]];
+        const float mq_ = A.q_loc[ixi], sq_ = A.q_scale[ixi], mp_ = A.p_loc[ixi], sp_ = A.p_scale[ixi];
         klacc = klacc + kl_dim(mq_, sq_, mp_, sp_);
         st3[0] = mq_ - mp_; st3[1] = sq_ * sq_; st3[2] = sp_ * sp_;
       }
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
       if (active && sw == 0 && bs == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          if (valid[i]) A.out_sample[ix[i]] = 0.f + A.p_loc[ix[i]];
+          if (valid[i]) { const int64_t ixo = src_index(A, base, pos, d0 + i); A.out_sample[ixo] = 0.f + A.p_loc[ixo]; }
       }
       continue;
     }
@@ -516,7 +517,10 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
                 if (j == 0 && sw == 0) {
 #pragma unroll
                   for (int i = 0; i < 4; ++i)
-                    if (valid[i]) A.out_sample[ix[i]] = nb[i] + A.p_loc[ix[i]]; // beams[0] + coding_dist.loc, :122
+                    if (valid[i]) { // beams[0] + coding_dist.loc, :122
+                      const int64_t ixo = src_index(A, base, pos, d0 + i);
+                      A.out_sample[ixo] = nb[i] + A.p_loc[ixo];
+                    }
                 }
               } else {
                 if (sw == 0) *reinterpret_cast<float4 *>(bnew + (size_t)j * FAST_MAX_DIM) = make_float4(nb[0], nb[1], nb[2], nb[3]);
