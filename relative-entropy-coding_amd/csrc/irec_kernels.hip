@@ -9,9 +9,12 @@
 //   BeamSearchCoder.decode_block            rec/coding/beam_search_coder.py:124-148
 //   Coder.split / merge (as gather/scatter) rec/coding/coder.py:38-122
 //
-// Two encoders share one arithmetic specification:
-//   encode_fast_kernel<NB,NW>  D <= 1024, B <= 32: one persistent workgroup per block, beams live in VGPRs
-//                              (lane owns 4 dims), quantile LUT + discrete-log table in LDS, Philox fused in.
+// All encoders share one arithmetic specification; the default one is encode_team_kernel (irec_team.hip).
+// Here:
+//   encode_fast_kernel<NB,NW,TABLE>  D <= 1024, B <= 32: one persistent workgroup per block, G of every beam in VGPRs
+//                              (lane owns 4 dims), ONE copy of the quantile table in LDS; proposals from the per-call
+//                              table (TABLE) or from the Philox stream fused into the kernel.  Serves B > 20, large S*B,
+//                              calls without dim hints, and IREC_FLAG_ONE_TABLE / IREC_FLAG_FUSED_PHILOX.
 //   encode_generic_kernel      any D, B <= 64: beams in a global scratch slab; correctness fallback.
 //
 // Compiled with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (no implicit fma: see irec_device.h).
