@@ -78,8 +78,9 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   // 20 accumulators are reduced together (one sample x 20 beams, or two samples x 10 beams) by the 20-value
   // reduce-scatter: 22 exchange+add pairs instead of the 31 of a zero-padded 32-wide one, and 12 registers fewer
   static_assert(NBW == 10 || NBW == 20, "the team encoder is built for 10 or 20 beams per wave");
-  constexpr int RW = 20, SPC = 20 / NBW;
-  constexpr int ACC_ROOM = rsn_room(20);
+  constexpr int SPC = BS >= 2 ? 1 : 20 / NBW;   // samples per chunk (beam-striped builds: one, to fit 128 VGPRs)
+  constexpr int RW = NBW * SPC;                  // accumulators reduced together
+  constexpr int ACC_ROOM = rsn_room(RW);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int S = A.S, B = A.B;
   const int lane = threadIdx.x & 63;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   float *cpart_s = &sm->cpart[0][0];
   const uint16_t *dlog_s = A.dlog4r;                                            // [10006] 4*dlog(j+1), global (L2)
   const int SP = S;                                                             // one scoring pass per step
-  const int rs_p = rsn_owner<20>(lane);                                         // accumulator whose total reduce_scatter_n<20> leaves here
+  const int rs_p = rsn_owner<RW>(lane);                                         // accumulator whose total reduce_scatter_n<20> leaves here
   const int rs_c = rsn_owner<NBW>(lane);                                        // same for the NBW C_b partials of the update
 
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap(); // see lds_abs_f32
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           for (int cc = 0; cc < SPC; ++cc)
 #pragma unroll
             for (int k = 0; k < NP; ++k) { acc[cc * NBW + 2 * k] = acc2[cc][k].x; acc[cc * NBW + 2 * k + 1] = acc2[cc][k].y; }
-          const float tot = reduce_scatter_n<20>(acc, lane);
+          const float tot = reduce_scatter_n<RW>(acc, lane);
           const int cc = rs_p / NBW, b = rs_p - cc * NBW;          // rs_p < 0: unused slot
           const int m = ch * SPC + cc;                              // my m-th sample
           if (rs_p >= 0 && (lane & 1) == 0 && m < n_mine) part_s[((size_t)g * SP + m * NSW + sw) * NB + b_lo + b] = tot;
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
               }
             }
           }
-          const float tot = reduce_scatter_n<20>(acc, lane);
+          const float tot = reduce_scatter_n<RW>(acc, lane);
           const int cc = rs_p / NBW, b = rs_p - cc * NBW;   // rs_p < 0: unused slot
           const int s = (ch * SPC + cc) * NSW + sw;
           if (rs_p >= 0 && (lane & 1) == 0 && s < S && b < nlive) part_s[((size_t)g * SP + s) * NB + b_lo + b] = tot;
