@@ -23,7 +23,7 @@ __device__ __forceinline__ unsigned long long stamp_now() { return __builtin_amd
 template <int MB>
 struct SmallLdsT {
   union {                           // the two selection paths never run at the same time
-    unsigned long long wb[16];      // per-wave maxima of the scan-based selection, double buffered
+    unsigned long long wb[32];      // per-wave maxima of the scan-based selection, double buffered (<= 16 waves)
     unsigned long long cand[64];    // compacted (key, flat) survivors of the threshold selection
   };
   int32_t sel_s[MB], sel_b[MB];     // selected (sample, beam) per new beam

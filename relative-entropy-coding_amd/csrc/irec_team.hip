@@ -34,10 +34,23 @@ constexpr size_t TEAM_SMALL_BYTES = (sizeof(TeamLds) + 15) & ~(size_t)15;
 constexpr uint32_t T3_FLOATS = 3u * IREC_PM1;    // three copies of lut2
 constexpr size_t T3_BYTES = ((size_t)T3_FLOATS * 4 + 15) & ~(size_t)15;
 
-__host__ __device__ inline size_t team_part_bytes(int NB, int S) { return (((size_t)4 * S * NB * 4) + 15) & ~(size_t)15; }
+// Sample passes.  The per-group partial scores of SP samples sit in LDS at a time ([4][SP][NB] f32); a step scores S in
+// ceil(S / SP) passes, each followed by the group combine into the sort keys ([S*NB] u32, all of them resident).  Every
+// BASELINE configuration with B <= 20 takes one pass; the 30-beam stress configuration (S = 148) takes four of 37.
 __host__ __device__ inline size_t team_key_bytes(int NB, int S) { return (((size_t)S * NB * 4) + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t team_lds_one(int NB, int S) { return team_part_bytes(NB, S) + team_key_bytes(NB, S) + TEAM_SMALL_BYTES + 16; }
-__host__ __device__ inline size_t team_lds_total(int NB, int S, int teams) { return T3_BYTES + (size_t)teams * team_lds_one(NB, S); }
+__host__ __device__ inline int team_s_pass(int NB, int S, int teams, int cmax) {
+  const long long avail = (long long)((FAST_LDS_LIMIT - T3_BYTES) / (size_t)teams) - (long long)team_key_bytes(NB, S) -
+                          (long long)TEAM_SMALL_BYTES - 32;
+  long long fit = avail / (4LL * NB * 4);           // samples whose partials fit
+  if (fit > cmax / NB) fit = cmax / NB;             // and whose candidates one combine round covers
+  if (fit < 1) return 0;
+  if (fit >= S) return S;
+  const int n_pass = (int)((S + fit - 1) / fit);
+  return (S + n_pass - 1) / n_pass;                 // balanced passes
+}
+__host__ __device__ inline size_t team_part_bytes(int NB, int SP) { return (((size_t)4 * SP * NB * 4) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t team_lds_one(int NB, int S, int SP) { return team_part_bytes(NB, SP) + team_key_bytes(NB, S) + TEAM_SMALL_BYTES + 16; }
+__host__ __device__ inline size_t team_lds_total(int NB, int S, int SP, int teams) { return T3_BYTES + (size_t)teams * team_lds_one(NB, S, SP); }
 
 // Barrier of the 4 waves of one team: a monotonic LDS counter.  LDS operations of one wave execute in program order and
 // the LDS serves one instruction at a time, so a wave's earlier writes are in place before its add lands; the fences
@@ -78,6 +91,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   // 20 accumulators are reduced together (one sample x 20 beams, or two samples x 10 beams) by the 20-value
   // reduce-scatter: 22 exchange+add pairs instead of the 31 of a zero-padded 32-wide one, and 12 registers fewer
   static_assert(NBW == 10 || NBW == 20, "the team encoder is built for 10 or 20 beams per wave");
+  constexpr int CMAX = TEAMS == 1 ? 2048 : 1024;    // candidates one combine round covers (host: SP * NB <= CMAX)
   constexpr int SPC = BS >= 2 ? 1 : 20 / NBW;   // samples per chunk (beam-striped builds: one, to fit 128 VGPRs)
   constexpr int RW = NBW * SPC;                  // accumulators reduced together
   constexpr int ACC_ROOM = rsn_room(RW);
@@ -89,11 +103,14 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   const int wave = wave_t & 3, bs = wave_t >> 2;                                // quad position, beam stripe
   const int b_lo = bs * NBW;                                                    // first beam of my stripe
   const int tid = (int)threadIdx.x - team * NT;                                 // index inside the team
-  char *tbase = smem + T3_BYTES + (size_t)team * team_lds_one(NB, S);
-  float *part_s = reinterpret_cast<float *>(tbase);                             // [4][S][NB] per-group partial scores
-  uint32_t *key_s = reinterpret_cast<uint32_t *>(tbase + team_part_bytes(NB, S)); // [S*NB] sort keys
-  TeamLds *sm = reinterpret_cast<TeamLds *>(tbase + team_part_bytes(NB, S) + team_key_bytes(NB, S));
-  uint32_t *bar_word = reinterpret_cast<uint32_t *>(tbase + team_part_bytes(NB, S) + team_key_bytes(NB, S) + TEAM_SMALL_BYTES);
+  // samples scored per pass: only the single-team builds take more than one pass (the host checked that the others fit
+  // S in one -- then the pass loop below folds away)
+  const int SP = TEAMS == 1 ? team_s_pass(NB, S, TEAMS, CMAX) : S;
+  char *tbase = smem + T3_BYTES + (size_t)team * team_lds_one(NB, S, SP);
+  float *part_s = reinterpret_cast<float *>(tbase);                             // [4][SP][NB] per-group partial scores
+  uint32_t *key_s = reinterpret_cast<uint32_t *>(tbase + team_part_bytes(NB, SP)); // [S*NB] sort keys
+  TeamLds *sm = reinterpret_cast<TeamLds *>(tbase + team_part_bytes(NB, SP) + team_key_bytes(NB, S));
+  uint32_t *bar_word = reinterpret_cast<uint32_t *>(tbase + team_part_bytes(NB, SP) + team_key_bytes(NB, S) + TEAM_SMALL_BYTES);
   double *gpart = sm->gpart;
   int32_t *sel_s = sm->sel_s, *sel_b = sm->sel_b;
   int32_t *hsum = &sm->hsum[0][0];
@@ -101,7 +118,6 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   int32_t *misc = sm->misc;
   float *cpart_s = &sm->cpart[0][0];
   const uint16_t *dlog_s = A.dlog4r;                                            // [10006] 4*dlog(j+1), global (L2)
-  const int SP = S;                                                             // one scoring pass per step
   const int rs_p = rsn_owner<RW>(lane);                                         // accumulator whose total reduce_scatter_n<20> leaves here
   const int rs_c = rsn_owner<NBW>(lane);                                        // same for the NBW C_b partials of the update
 
@@ -249,7 +265,10 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
       const int nlive = Bcur - b_lo < 0 ? 0 : (Bcur - b_lo < NBW ? Bcur - b_lo : NBW);   // live beams of my stripe
 
       const int N = S * Bcur;
-      // ---------------- scoring: S x Bcur candidates (beam_search_coder.py:80-84) ----------------
+      for (int s_base = 0; s_base < S; s_base += SP) {
+      const int s_end = s_base + SP < S ? s_base + SP : S;
+      const int Sp = s_end - s_base;                                // samples of this pass
+      // ---------------- scoring: samples [s_base, s_end) x Bcur candidates (beam_search_coder.py:80-84) ----------------
 #ifdef IREC_ABLATE_SCORING
       if (false) {
 #else
@@ -260,11 +279,11 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         // most 15 LDS operations outstanding, so by the time the next slot's are issued the current slot's have landed
         // (or the compiler's wait counts see to it).  Empty volatile asm statements pin the order (pure arithmetic would
         // otherwise drift across the scheduling barriers).  A chunk is SPC samples (20 accumulators, one reduce-scatter).
-        const int n_mine = (S - sw + NSW - 1) / NSW;              // my samples: sw, sw + NSW, ...
+        const int n_mine = Sp > sw ? (Sp - sw + NSW - 1) / NSW : 0; // my samples of the pass: s_base + sw, + NSW, ...
         const int n_chunks = (n_mine + SPC - 1) / SPC;
         auto row = [&](int m) {                                     // proposal row of my m-th sample; zero row past the end:
           uint2 r = make_uint2(0u, 0u);                             // entry 0 is a valid address, its results are dropped
-          if (m < n_mine) r = *reinterpret_cast<const uint2 *>(tab_t + (size_t)(m * NSW + sw) * Dp);
+          if (m < n_mine) r = *reinterpret_cast<const uint2 *>(tab_t + (size_t)(s_base + m * NSW + sw) * Dp);
           return r;
         };
         uint2 ap_nxt[SPC];
@@ -331,15 +350,15 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 #undef IREC_CONSUME
       } else if (active && nlive > 0) {
 #endif
-        const int s_per_stripe = (S + NSW - 1) / NSW;
+        const int s_per_stripe = (Sp + NSW - 1) / NSW;
         const int nchunks = (s_per_stripe + SPC - 1) / SPC;
         // proposal rows (4 x uint16: dlog(r) + 10006 c of my dims) are fetched one chunk ahead
         uint2 alp_next[SPC];
 #pragma unroll
         for (int cc = 0; cc < SPC; ++cc) {
-          const int s0 = cc * NSW + sw;
+          const int s0 = cc * NSW + sw;   // sample index inside the pass
           alp_next[cc] = make_uint2(0u, 0u);
-          if (s0 < S) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)s0 * Dp);
+          if (s0 < Sp) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)(s_base + s0) * Dp);
         }
         for (int ch = 0; ch < nchunks; ++ch) {
           float acc[ACC_ROOM];
@@ -350,12 +369,12 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           for (int cc = 0; cc < SPC; ++cc) {
             alp[cc] = alp_next[cc];
             const int sn = ((ch + 1) * SPC + cc) * NSW + sw;
-            if (sn < S) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sn * Dp);
+            if (sn < Sp) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)(s_base + sn) * Dp);
           }
 #pragma unroll
           for (int cc = 0; cc < SPC; ++cc) {
-            const int s = (ch * SPC + cc) * NSW + sw;
-            if (s < S) { // wave-uniform
+            const int s = (ch * SPC + cc) * NSW + sw;   // sample index inside the pass
+            if (s < Sp) { // wave-uniform
               const uint2 ap = alp[cc];
               // byte address of entry alpha' in copy 0 (the table starts at LDS address 0)
               const uint32_t al[4] = {(ap.x & 0xFFFFu) << 2, (ap.x >> 16) << 2, (ap.y & 0xFFFFu) << 2, (ap.y >> 16) << 2};
@@ -387,7 +406,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           const float tot = reduce_scatter_n<RW>(acc, lane);
           const int cc = rs_p / NBW, b = rs_p - cc * NBW;   // rs_p < 0: unused slot
           const int s = (ch * SPC + cc) * NSW + sw;
-          if (rs_p >= 0 && (lane & 1) == 0 && s < S && b < nlive) part_s[((size_t)g * SP + s) * NB + b_lo + b] = tot;
+          if (rs_p >= 0 && (lane & 1) == 0 && s < Sp && b < nlive) part_s[((size_t)g * SP + s) * NB + b_lo + b] = tot;
         }
       }
       TSTAMP(2);
@@ -395,7 +414,8 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
       TSTAMP(3);
       // ---------------- combine dim groups in order, add C_b, build sort keys ----------------
       {
-        constexpr int MK = (1024 + NT - 1) / NT;
+        constexpr int MK = (CMAX + NT - 1) / NT;
+        const int Np = Sp * Bcur, f_base = s_base * Bcur; // this pass's candidates: flat indices f_base + [0, Np)
         {
           // every partial of my candidates (and of their beams' C_b) is fetched before the first is used: one LDS
           // latency instead of 4 per key
@@ -403,8 +423,8 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           const int gstride = SP * NB;
 #pragma unroll
           for (int q = 0; q < MK; ++q) {
-            const int f = q * NT + tid, fs = f < N ? f : 0;
-            const int s = Bcur == NB ? fs / NB : fs / Bcur, b = fs - s * Bcur;
+            const int f = q * NT + tid, fs = f < Np ? f : 0;
+            const int s = Bcur == NB ? fs / NB : fs / Bcur, b = fs - s * Bcur;   // s: sample index inside the pass
 #pragma unroll
             for (int gg = 0; gg < 4; ++gg) pr[q][gg] = part_s[(gg < NG ? gg : 0) * gstride + s * NB + b];
 #pragma unroll
@@ -420,10 +440,12 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
             if (NG > 1) cb = cb + cbv[q][1];
             if (NG > 2) cb = cb + cbv[q][2];
             if (NG > 3) cb = cb + cbv[q][3];
-            if (q * NT + tid < N) key_s[q * NT + tid] = score_key(sc + cb);
+            if (q * NT + tid < Np) key_s[f_base + q * NT + tid] = score_key(sc + cb);
           }
         }
       }
+      if (s_end < S) tsync(); // the next pass overwrites the partials
+      } // sample passes
       const int Bnew = B < N ? B : N;
       TSTAMP(4);
 #ifdef IREC_ABLATE_SELECT
@@ -668,19 +690,33 @@ static int team_cfg() {
   }();
   return n;
 }
-int team_count() { return team_cfg() == 3 ? 3 : team_cfg() == 1 ? 1 : 2; }
+// shape of the workgroup that serves B beams: beams per build, teams per workgroup, beam stripes per team
+struct TeamShape { int nb, teams, bs; };
+static TeamShape team_shape(int B) {
+  const int cfg = team_cfg();
+  if (B <= 10) return TeamShape{10, cfg == 3 ? 3 : 2, 1};
+  if (B <= 20) return cfg == 1 ? TeamShape{20, 1, 1} : cfg == 3 ? TeamShape{20, 3, 1} : cfg == 22 ? TeamShape{20, 2, 2} : TeamShape{20, 2, 1};
+  if (B <= 30) return TeamShape{30, 1, 3};   // one 12-wave team: three stripes of 10 beams (the B = 30 stress configuration)
+  return TeamShape{0, 0, 0};
+}
+int team_count_for(int B) { return team_shape(B).teams; }
+int team_waves_for(int B) { const TeamShape sh = team_shape(B); return sh.teams * sh.bs * TEAM_NW; }
 
 size_t team_lds_for(int B, int S) {
-  const int nb = fast_nb_for(B);
-  if (nb != 10 && nb != 20) return (size_t)-1;           // the 32-beam build does not fit the register budget of a team
-  if ((int64_t)S * nb > 1024) return (size_t)-1;         // one scoring pass, keys over group 0 of the partials
-  const size_t b = team_lds_total(nb, S, team_count());
+  const TeamShape sh = team_shape(B);
+  if (!sh.nb) return (size_t)-1;
+  if ((int64_t)S * sh.nb >= (1 << 24)) return (size_t)-1;
+  const int sp = team_s_pass(sh.nb, S, sh.teams, sh.teams == 1 ? 2048 : 1024);
+  if (sp < 1 || (sp < S && (sp < 16 || sh.teams > 1))) return (size_t)-1;   // does not fit (multi-team builds: in one pass),
+                                                                             // or only in slivers: the one-table encoder takes it
+  const size_t b = team_lds_total(sh.nb, S, sp, sh.teams);
   return b <= FAST_LDS_LIMIT ? b : (size_t)-1;
 }
 
 template <int NB, int TEAMS, int BS>
 static hipError_t launch_team_t(const EncArgs &A, int grid, hipStream_t st) {
-  const size_t lds = team_lds_total(NB, A.S, TEAMS);
+  const int sp = TEAMS == 1 ? team_s_pass(NB, A.S, TEAMS, 2048) : A.S;
+  const size_t lds = team_lds_total(NB, A.S, sp, TEAMS);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_team_kernel<NB, TEAMS, BS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -689,10 +725,16 @@ static hipError_t launch_team_t(const EncArgs &A, int grid, hipStream_t st) {
 }
 
 hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
-  const int cfg = team_cfg();
-  switch (fast_nb_for(A.B)) {
-    case 10: return cfg == 3 ? launch_team_t<10, 3, 1>(A, grid, st) : launch_team_t<10, 2, 1>(A, grid, st);
-    case 20: return cfg == 1 ? launch_team_t<20, 1, 1>(A, grid, st) : cfg == 3 ? launch_team_t<20, 3, 1>(A, grid, st) : cfg == 22 ? launch_team_t<20, 2, 2>(A, grid, st) : launch_team_t<20, 2, 1>(A, grid, st);
+  const TeamShape sh = team_shape(A.B);
+  const int key = sh.nb * 100 + sh.teams * 10 + sh.bs;
+  switch (key) {
+    case 1021: return launch_team_t<10, 2, 1>(A, grid, st);
+    case 1031: return launch_team_t<10, 3, 1>(A, grid, st);
+    case 2011: return launch_team_t<20, 1, 1>(A, grid, st);
+    case 2021: return launch_team_t<20, 2, 1>(A, grid, st);
+    case 2031: return launch_team_t<20, 3, 1>(A, grid, st);
+    case 2022: return launch_team_t<20, 2, 2>(A, grid, st);
+    case 3013: return launch_team_t<30, 1, 3>(A, grid, st);
     default: return hipErrorInvalidValue;
   }
 }
