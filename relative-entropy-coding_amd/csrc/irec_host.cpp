@@ -448,7 +448,7 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
     }
     if (!pl.table) { pl.n_tab = 0; pl.tab_bytes = 0; }
     pl.team = pl.table && !(p->flags & IREC_FLAG_ONE_TABLE) && irec::team_lds_for(B, S) != (size_t)-1;
-    if (pl.team) pl.grid_cap = irec::team_count_for(B) * (ctx->n_cu > 0 ? ctx->n_cu : 256); // one scratch slab per team
+    if (pl.team) pl.grid_cap = irec::team_count_for(B, S) * (ctx->n_cu > 0 ? ctx->n_cu : 256); // one scratch slab per team
   }
   if (pl.fast) {
     if (!pl.team && irec::fast_waves_for(B, S, pl.table) == 8) pl.grid_cap /= 2; // big-LDS configurations: one 8-wave workgroup per CU
@@ -535,11 +535,11 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
       A.tab[q] = tab; A.tab_dim[q] = pl.tab_dim[q];
     }
     if (pl.team) { // grid_cap counts teams (= scratch slabs): two per workgroup, one workgroup per CU
-      const int n_teams = irec::team_count_for(p->n_beams);
+      const int n_teams = irec::team_count_for(p->n_beams, p->n_samples);
       const int tgrid = (int)std::min<int64_t>((n_blocks + n_teams - 1) / n_teams, pl.grid_cap / n_teams);
       HIP_TRY(irec::launch_encode_team(A, tgrid, st));
       if (ctx->d_dbg) { // diagnostic build (-DIREC_TEAM_STAMPS) only: per-wave phase cycles, wave 0 of a team vs the others
-        const int nwv = irec::team_waves_for(p->n_beams);
+        const int nwv = irec::team_waves_for(p->n_beams, p->n_samples);
         std::vector<unsigned long long> h((size_t)tgrid * nwv * 16);
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(h.data(), ctx->d_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));

@@ -678,13 +678,15 @@ __global__ __launch_bounds__(256) void alpha_choice_kernel(int64_t seed, int32_t
 // ======================================================================================================
 //  launchers
 // ======================================================================================================
-// teams per workgroup / beam stripes per team.  Default 2 x 1 (8 waves per CU).  Diagnostic overrides through the
-// environment: IREC_TEAMS=3 (three 4-wave teams, 168 VGPRs) and IREC_TEAMS=2x2 (two 8-wave beam-striped teams, 128 VGPRs).
+// teams per workgroup / beam stripes per team.  Defaults: B <= 10: 3 x 1 where the LDS allows (else 2 x 1); B <= 20: 2 x 1
+// (8 waves per CU); B <= 30: 1 x 3.  Diagnostic overrides for B <= 20 through the environment: IREC_TEAMS=1, =2 (two teams
+// also for B <= 10), =3 (three 4-wave teams, 168 VGPRs), =2x2 (two 8-wave beam-striped teams, 128 VGPRs).
 static int team_cfg() {
   static const int n = [] {
     const char *e = getenv("IREC_TEAMS");
     if (e && e[0] == '3') return 3;
     if (e && e[0] == '1') return 1;
+    if (e && e[0] == '2' && e[1] != 'x') return 20;   // exactly two teams, also where three would be the default
     if (e && e[0] == '2' && e[1] == 'x' && e[2] == '2') return 22;
     return 2;
   }();
@@ -692,18 +694,19 @@ static int team_cfg() {
 }
 // shape of the workgroup that serves B beams: beams per build, teams per workgroup, beam stripes per team
 struct TeamShape { int nb, teams, bs; };
-static TeamShape team_shape(int B) {
+static TeamShape team_shape(int B, int S) {
   const int cfg = team_cfg();
-  if (B <= 10) return TeamShape{10, cfg == 3 ? 3 : 2, 1};
+  // 10 beams: G is 40 registers per lane, three teams fit the register file (168 VGPRs) and, for small S, the LDS: +9 %
+  if (B <= 10) return TeamShape{10, (cfg == 3 || (cfg == 2 && team_s_pass(10, S, 3, 1024) == S)) ? 3 : 2, 1};
   if (B <= 20) return cfg == 1 ? TeamShape{20, 1, 1} : cfg == 3 ? TeamShape{20, 3, 1} : cfg == 22 ? TeamShape{20, 2, 2} : TeamShape{20, 2, 1};
   if (B <= 30) return TeamShape{30, 1, 3};   // one 12-wave team: three stripes of 10 beams (the B = 30 stress configuration)
   return TeamShape{0, 0, 0};
 }
-int team_count_for(int B) { return team_shape(B).teams; }
-int team_waves_for(int B) { const TeamShape sh = team_shape(B); return sh.teams * sh.bs * TEAM_NW; }
+int team_count_for(int B, int S) { return team_shape(B, S).teams; }
+int team_waves_for(int B, int S) { const TeamShape sh = team_shape(B, S); return sh.teams * sh.bs * TEAM_NW; }
 
 size_t team_lds_for(int B, int S) {
-  const TeamShape sh = team_shape(B);
+  const TeamShape sh = team_shape(B, S);
   if (!sh.nb) return (size_t)-1;
   if ((int64_t)S * sh.nb >= (1 << 24)) return (size_t)-1;
   const int sp = team_s_pass(sh.nb, S, sh.teams, sh.teams == 1 ? 2048 : 1024);
@@ -725,7 +728,7 @@ static hipError_t launch_team_t(const EncArgs &A, int grid, hipStream_t st) {
 }
 
 hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
-  const TeamShape sh = team_shape(A.B);
+  const TeamShape sh = team_shape(A.B, A.S);
   const int key = sh.nb * 100 + sh.teams * 10 + sh.bs;
   switch (key) {
     case 1021: return launch_team_t<10, 2, 1>(A, grid, st);
