@@ -452,7 +452,7 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
   }
   if (pl.fast) {
     if (!pl.team && irec::fast_waves_for(B, S, pl.table) == 8) pl.grid_cap /= 2; // big-LDS configurations: one 8-wave workgroup per CU
-    pl.ws_per_wg = round_up_sz(irec::fast_ws_for(B, max_K), 256);
+    pl.ws_per_wg = round_up_sz(irec::fast_ws_for(B, max_K) + (pl.team ? irec::team_ws_extra_for(B, S) : 0), 256);
   } else {
     pl.ws_per_wg = round_up_sz((size_t)10 * pl.dpad * 4 + (size_t)2 * B * pl.dpad * 4 +
                                    (size_t)(max_K > 0 ? max_K : 1) * B * 4 + (size_t)S * B * 4, 256);

@@ -54,7 +54,8 @@ hipError_t launch_alpha_table(int64_t seed, int32_t S, int32_t D, int32_t K_tab,
                               hipStream_t st);
 // two-teams-per-CU encoder over three table copies (irec_team.hip)
 int team_count_for(int B, int S);           // teams per workgroup (= scratch slabs per workgroup) of the build that serves B beams
-int team_waves_for(int B, int S);           // waves per workgroup of that build
+int team_waves_for(int B, int S);
+size_t team_ws_extra_for(int B, int S); // extra scratch-slab bytes of that build           // waves per workgroup of that build
 size_t team_lds_for(int B, int S);   // LDS bytes of one workgroup, or (size_t)-1 when the configuration is not served
 hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st);
 hipError_t launch_alpha_choice(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *dlog4r, uint16_t *tab,

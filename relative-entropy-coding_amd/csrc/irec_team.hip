@@ -38,9 +38,16 @@ constexpr size_t T3_BYTES = ((size_t)T3_FLOATS * 4 + 15) & ~(size_t)15;
 // ceil(S / SP) passes, each followed by the group combine into the sort keys ([S*NB] u32, all of them resident).  Every
 // BASELINE configuration with B <= 20 takes one pass; the 30-beam stress configuration (S = 148) takes four of 37.
 __host__ __device__ inline size_t team_key_bytes(int NB, int S) { return (((size_t)S * NB * 4) + 15) & ~(size_t)15; }
-__host__ __device__ inline int team_s_pass(int NB, int S, int teams, int cmax) {
+// Keys in LDS unless they alone would leave room for fewer than 16 samples of partials (single-team builds only: 12 090
+// candidates of B = 30, S = 403 are 48 KB); then they live in the team's scratch slab (L2) and the selection scans them there.
+__host__ __device__ inline bool team_keys_in_lds(int NB, int S, int teams) {
   const long long avail = (long long)((FAST_LDS_LIMIT - T3_BYTES) / (size_t)teams) - (long long)team_key_bytes(NB, S) -
                           (long long)TEAM_SMALL_BYTES - 32;
+  return teams > 1 || avail / (4LL * NB * 4) >= (S < 16 ? S : 16);
+}
+__host__ __device__ inline int team_s_pass(int NB, int S, int teams, int cmax) {
+  const long long avail = (long long)((FAST_LDS_LIMIT - T3_BYTES) / (size_t)teams) -
+                          (team_keys_in_lds(NB, S, teams) ? (long long)team_key_bytes(NB, S) : 0) - (long long)TEAM_SMALL_BYTES - 32;
   long long fit = avail / (4LL * NB * 4);           // samples whose partials fit
   if (fit > cmax / NB) fit = cmax / NB;             // and whose candidates one combine round covers
   if (fit < 1) return 0;
@@ -49,8 +56,10 @@ __host__ __device__ inline int team_s_pass(int NB, int S, int teams, int cmax) {
   return (S + n_pass - 1) / n_pass;                 // balanced passes
 }
 __host__ __device__ inline size_t team_part_bytes(int NB, int SP) { return (((size_t)4 * SP * NB * 4) + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t team_lds_one(int NB, int S, int SP) { return team_part_bytes(NB, SP) + team_key_bytes(NB, S) + TEAM_SMALL_BYTES + 16; }
-__host__ __device__ inline size_t team_lds_total(int NB, int S, int SP, int teams) { return T3_BYTES + (size_t)teams * team_lds_one(NB, S, SP); }
+__host__ __device__ inline size_t team_lds_one(int NB, int S, int SP, int teams) {
+  return team_part_bytes(NB, SP) + (team_keys_in_lds(NB, S, teams) ? team_key_bytes(NB, S) : 0) + TEAM_SMALL_BYTES + 16;
+}
+__host__ __device__ inline size_t team_lds_total(int NB, int S, int SP, int teams) { return T3_BYTES + (size_t)teams * team_lds_one(NB, S, SP, teams); }
 
 // Barrier of the 4 waves of one team: a monotonic LDS counter.  LDS operations of one wave execute in program order and
 // the LDS serves one instruction at a time, so a wave's earlier writes are in place before its add lands; the fences
@@ -106,11 +115,12 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   // samples scored per pass: only the single-team builds take more than one pass (the host checked that the others fit
   // S in one -- then the pass loop below folds away)
   const int SP = TEAMS == 1 ? team_s_pass(NB, S, TEAMS, CMAX) : S;
-  char *tbase = smem + T3_BYTES + (size_t)team * team_lds_one(NB, S, SP);
+  const bool keys_lds = TEAMS > 1 || team_keys_in_lds(NB, S, TEAMS);            // (compile-time true for the multi-team builds)
+  const size_t key_lds_bytes = keys_lds ? team_key_bytes(NB, S) : 0;
+  char *tbase = smem + T3_BYTES + (size_t)team * team_lds_one(NB, S, SP, TEAMS);
   float *part_s = reinterpret_cast<float *>(tbase);                             // [4][SP][NB] per-group partial scores
-  uint32_t *key_s = reinterpret_cast<uint32_t *>(tbase + team_part_bytes(NB, SP)); // [S*NB] sort keys
-  TeamLds *sm = reinterpret_cast<TeamLds *>(tbase + team_part_bytes(NB, SP) + team_key_bytes(NB, S));
-  uint32_t *bar_word = reinterpret_cast<uint32_t *>(tbase + team_part_bytes(NB, SP) + team_key_bytes(NB, S) + TEAM_SMALL_BYTES);
+  TeamLds *sm = reinterpret_cast<TeamLds *>(tbase + team_part_bytes(NB, SP) + key_lds_bytes);
+  uint32_t *bar_word = reinterpret_cast<uint32_t *>(tbase + team_part_bytes(NB, SP) + key_lds_bytes + TEAM_SMALL_BYTES);
   double *gpart = sm->gpart;
   int32_t *sel_s = sm->sel_s, *sel_b = sm->sel_b;
   int32_t *hsum = &sm->hsum[0][0];
@@ -134,8 +144,11 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   TeamBarrier tsync{bar_word, 0u, (uint32_t)NWT};
 
   char *slab = A.ws + ((size_t)blockIdx.x * TEAMS + team) * A.ws_per_wg;
+  const size_t key_glb_bytes = keys_lds ? 0 : ((team_key_bytes(NB, S) + 255) & ~(size_t)255);   // sort keys at the slab's end
+  uint32_t *key_s = keys_lds ? reinterpret_cast<uint32_t *>(tbase + team_part_bytes(NB, SP))     // [S*NB] sort keys
+                             : reinterpret_cast<uint32_t *>(slab + A.ws_per_wg - key_glb_bytes);
   int32_t *bp = reinterpret_cast<int32_t *>(slab);                                            // [max_K][NB]
-  float *beams_g = reinterpret_cast<float *>(slab + A.ws_per_wg - (size_t)2 * NB * FAST_MAX_DIM * 4); // [2][NB][1024]
+  float *beams_g = reinterpret_cast<float *>(slab + A.ws_per_wg - key_glb_bytes - (size_t)2 * NB * FAST_MAX_DIM * 4); // [2][NB][1024]
   float *stats_g = beams_g - 3 * FAST_MAX_DIM;  // [3][1024]: mq - mp, sq^2, sp^2 of the block, coalesced
 
 #ifdef IREC_TEAM_STAMPS
@@ -704,6 +717,10 @@ static TeamShape team_shape(int B, int S) {
 }
 int team_count_for(int B, int S) { return team_shape(B, S).teams; }
 int team_waves_for(int B, int S) { const TeamShape sh = team_shape(B, S); return sh.teams * sh.bs * TEAM_NW; }
+size_t team_ws_extra_for(int B, int S) { // scratch-slab bytes on top of fast_ws_for(): the sort keys when they do not fit the LDS
+  const TeamShape sh = team_shape(B, S);
+  return (sh.nb && !team_keys_in_lds(sh.nb, S, sh.teams)) ? ((team_key_bytes(sh.nb, S) + 255) & ~(size_t)255) : 0;
+}
 
 size_t team_lds_for(int B, int S) {
   const TeamShape sh = team_shape(B, S);
