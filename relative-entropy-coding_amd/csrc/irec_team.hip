@@ -711,7 +711,15 @@ static TeamShape team_shape(int B, int S) {
   const int cfg = team_cfg();
   // 10 beams: G is 40 registers per lane, three teams fit the register file (168 VGPRs) and, for small S, the LDS: +9 %
   if (B <= 10) return TeamShape{10, (cfg == 3 || (cfg == 2 && team_s_pass(10, S, 3, 1024) == S)) ? 3 : 2, 1};
-  if (B <= 20) return cfg == 1 ? TeamShape{20, 1, 1} : cfg == 3 ? TeamShape{20, 3, 1} : cfg == 22 ? TeamShape{20, 2, 2} : TeamShape{20, 2, 1};
+  if (B <= 20) {
+    if (cfg == 1) return TeamShape{20, 1, 1};
+    if (cfg == 3) return TeamShape{20, 3, 1};
+    if (cfg == 22) return TeamShape{20, 2, 2};
+    // more samples than two teams can hold in one pass (e.g. Omega = 5: S = 148): one 8-wave team with two beam stripes
+    // and sample passes
+    if (B > 10 && team_s_pass(20, S, 2, 1024) != S) return TeamShape{20, 1, 2};
+    return TeamShape{20, 2, 1};
+  }
   if (B <= 30) return TeamShape{30, 1, 3};   // one 12-wave team: three stripes of 10 beams (the B = 30 stress configuration)
   return TeamShape{0, 0, 0};
 }
@@ -754,6 +762,7 @@ hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
     case 2021: return launch_team_t<20, 2, 1>(A, grid, st);
     case 2031: return launch_team_t<20, 3, 1>(A, grid, st);
     case 2022: return launch_team_t<20, 2, 2>(A, grid, st);
+    case 2012: return launch_team_t<20, 1, 2>(A, grid, st);
     case 3013: return launch_team_t<30, 1, 3>(A, grid, st);
     default: return hipErrorInvalidValue;
   }
