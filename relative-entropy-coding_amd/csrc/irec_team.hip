@@ -99,7 +99,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   static_assert(NB % BS == 0, "beam stripes must divide the beam count");
   // 20 accumulators are reduced together (one sample x 20 beams, or two samples x 10 beams) by the 20-value
   // reduce-scatter: 22 exchange+add pairs instead of the 31 of a zero-padded 32-wide one, and 12 registers fewer
-  static_assert(NBW == 10 || NBW == 20, "the team encoder is built for 10 or 20 beams per wave");
+  static_assert(NBW == 10 || NBW == 16 || NBW == 20, "the team encoder is built for 10, 16 or 20 beams per wave");
   constexpr int CMAX = TEAMS == 1 ? 2048 : 1024;    // candidates one combine round covers (host: SP * NB <= CMAX)
   constexpr int SPC = BS >= 2 ? 1 : 20 / NBW;   // samples per chunk (beam-striped builds: one, to fit 128 VGPRs)
   constexpr int RW = NBW * SPC;                  // accumulators reduced together
@@ -721,6 +721,7 @@ static TeamShape team_shape(int B, int S) {
     return TeamShape{20, 2, 1};
   }
   if (B <= 30) return TeamShape{30, 1, 3};   // one 12-wave team: three stripes of 10 beams (the B = 30 stress configuration)
+  if (B <= 32) return TeamShape{32, 1, 2};   // one 8-wave team: two stripes of 16 beams
   return TeamShape{0, 0, 0};
 }
 int team_count_for(int B, int S) { return team_shape(B, S).teams; }
@@ -764,6 +765,7 @@ hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
     case 2022: return launch_team_t<20, 2, 2>(A, grid, st);
     case 2012: return launch_team_t<20, 1, 2>(A, grid, st);
     case 3013: return launch_team_t<30, 1, 3>(A, grid, st);
+    case 3212: return launch_team_t<32, 1, 2>(A, grid, st);
     default: return hipErrorInvalidValue;
   }
 }
