@@ -1,4 +1,5 @@
-// irec_team.hip -- the default gfx950 encoder: two independent 4-wave TEAMS per workgroup, one workgroup per CU.
+// irec_team.hip -- the default gfx950 encoder: independent TEAMS of waves inside one workgroup per CU, all of them looking
+// up ONE shared set of three quantile-table copies in LDS.
 //
 // Hot path (reference file:line): BeamSearchCoder.encode_block rec/coding/beam_search_coder.py:53-122, as in
 // irec_kernels.hip; the arithmetic specification and therefore every emitted bit are the same.
@@ -7,15 +8,18 @@
 // reaches the LDS (scripts/microbench/gather_rates.hip):
 //   * a random 4-byte gather costs a 32-lane group as many LDS cycles as the busiest of the 32 banks has distinct
 //     addresses (3.5 on average) -- the 8.9 look-ups/clk/CU ceiling the one-table encoders sit under;
-//   * here the table is stored THREE times back to back (120 KB, shared by both teams of the CU).  Entry
+//   * here the table is stored THREE times back to back (120 KB, shared by every team of the CU).  Entry
 //     e = alpha' + beta with alpha' = dlog r + 10006 c, c in {0, 1}, beta = dlog hash never leaves the three copies, so
 //     the address is ONE add (no "mod 10006"), and bank(e) = (dlog r + 22 c + beta) mod 32: the copy bit c moves a
 //     lane by 22 banks whatever the beam.  c is chosen once per call for every (step, sample, 32-lane group, dim
 //     slot) by alpha_choice_kernel -- an exact min-max assignment on two 16-rings of banks -- and travels inside the
 //     proposal table the block kernel streams anyway.  Busiest bank: 2.15 addresses instead of 3.5.
-//   * one workgroup of 8 waves owns the CU; its two teams code two blocks independently (own block counter pulls, own
-//     LDS scratch, own scratch slab) and synchronise with team barriers (an LDS counter), never with s_barrier, so one
-//     team's serial phases (top-B, beam update) overlap the other team's scoring.
+//   * one workgroup owns the CU; its teams code blocks independently (own block counter pulls, own LDS scratch, own
+//     scratch slab) and synchronise with team barriers (an LDS counter), never with s_barrier, so one team's serial
+//     phases (top-B, beam update) overlap the other teams' scoring.
+// Shapes (team_shape() at the end of the file): B <= 10: three 4-wave teams (two if the LDS is short); B <= 20: two 4-wave
+// teams -- the BASELINE workload; 20 < B <= 32, or B <= 20 with more samples than one scoring pass holds: ONE team whose
+// waves split the beams into stripes (12 waves x 10 beams, 8 x 16, 8 x 10) and that scores the samples in passes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
