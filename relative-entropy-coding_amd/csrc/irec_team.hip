@@ -187,6 +187,10 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
     // ---- my 4 dims (split == gather through perm) and the block's KL ----
     float c[4];
     bool valid[4];
+    // the wave that reads a dim group's statistics keeps them in registers; only the other waves of the group (sample /
+    // beam stripes of short blocks and of the striped builds) re-read them from the slab every step
+    float own_dmu[4], own_vq[4], own_vp[4];
+    const bool own_stats = active && sw == 0 && bs == 0;
     double klacc = 0.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -202,7 +206,8 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         klacc = klacc + kl_dim(mq_, sq_, mp_, sp_);
         st3[0] = mq_ - mp_; st3[1] = sq_ * sq_; st3[2] = sp_ * sp_;
       }
-      if (active && sw == 0 && bs == 0) {
+      own_dmu[i] = st3[0]; own_vq[i] = st3[1]; own_vp[i] = st3[2];
+      if (own_stats && (NSW > 1 || BS > 1)) { // somebody else needs them
         stats_g[d0 + i] = st3[0]; stats_g[FAST_MAX_DIM + d0 + i] = st3[1]; stats_g[2 * FAST_MAX_DIM + d0 + i] = st3[2];
       }
     }
@@ -236,10 +241,18 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
     float G[NBW][4];
     auto step_consts = [&](int t_next, float (&m)[4], float (&cA)[4], float (&cBv)[4]) {
       const float rho = A.rho[K - 1 - t_next];
-      const float4 q0 = *reinterpret_cast<const float4 *>(stats_g + d0);
-      const float4 q1 = *reinterpret_cast<const float4 *>(stats_g + FAST_MAX_DIM + d0);
-      const float4 q2 = *reinterpret_cast<const float4 *>(stats_g + 2 * FAST_MAX_DIM + d0);
-      const float dmu_[4] = {q0.x, q0.y, q0.z, q0.w}, vq_[4] = {q1.x, q1.y, q1.z, q1.w}, vp_[4] = {q2.x, q2.y, q2.z, q2.w};
+      float dmu_[4], vq_[4], vp_[4];
+      if (own_stats) { // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { dmu_[i] = own_dmu[i]; vq_[i] = own_vq[i]; vp_[i] = own_vp[i]; }
+      } else {
+        const float4 q0 = *reinterpret_cast<const float4 *>(stats_g + d0);
+        const float4 q1 = *reinterpret_cast<const float4 *>(stats_g + FAST_MAX_DIM + d0);
+        const float4 q2 = *reinterpret_cast<const float4 *>(stats_g + 2 * FAST_MAX_DIM + d0);
+        dmu_[0] = q0.x; dmu_[1] = q0.y; dmu_[2] = q0.z; dmu_[3] = q0.w;
+        vq_[0] = q1.x; vq_[1] = q1.y; vq_[2] = q1.z; vq_[3] = q1.w;
+        vp_[0] = q2.x; vp_[1] = q2.y; vp_[2] = q2.z; vp_[3] = q2.w;
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const StepConst sc = step_constants(rho, dmu_[i], vq_[i], vp_[i], c[i]);
