@@ -58,8 +58,10 @@ typedef struct {
 
 #define IREC_FLAG_FORCE_GENERIC 1 /* use the generic (any D, any B) kernel even where the fast kernels apply   */
 #define IREC_FLAG_FUSED_PHILOX 2  /* keep the Philox draw fused in the block kernel even when table_dims is set */
-#define IREC_FLAG_ONE_TABLE 4     /* with table_dims: the one-table-copy encoder (one workgroup per block) instead of  */
-                                  /* the default two-teams-per-CU encoder over three table copies; same outputs      */
+#define IREC_FLAG_ONE_TABLE 4     /* with table_dims: always the one-table-copy encoder (one workgroup per block)      */
+#define IREC_FLAG_TEAM 8          /* with table_dims: always the teams-per-CU encoder over three table copies.         */
+                                  /* Neither flag: the team encoder for calls of >= 64 blocks, the one-table encoder   */
+                                  /* (cheaper per-call set-up) below; same outputs, bit for bit                        */
 
 typedef struct irec_context irec_context;
 

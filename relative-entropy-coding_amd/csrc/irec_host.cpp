@@ -504,10 +504,14 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   if (max_K < 0 || max_K > IREC_MAX_PARTITIONS) return fail(IREC_E_INVALID, "irec_beam_encode: max_K %d out of range", max_K);
   if (max_K > 0 && !out_indices) return fail(IREC_E_INVALID, "irec_beam_encode: null out_indices");
   if (max_block_dim < 1 || max_block_dim > (1 << 22)) return fail(IREC_E_INVALID, "irec_beam_encode: max_block_dim %d out of range", max_block_dim);
-  const Plan pl = make_plan(ctx, p, max_block_dim, max_K);
+  Plan pl = make_plan(ctx, p, max_block_dim, max_K);
   const size_t need = 256 + pl.tab_bytes + (size_t)pl.grid_cap * pl.ws_per_wg;
   if (!workspace || workspace_bytes < need)
     return fail(IREC_E_WORKSPACE, "irec_beam_encode: workspace %zu bytes < required %zu", workspace_bytes, need);
+  // small calls (a single image's res-block: 9 blocks) are latency-bound: the one-table encoder's set-up (a 6 us proposal
+  // table, 40 KB of LDS to fill) beats the team encoder's (38 us per table for the bank assignment, 120 KB); the scratch
+  // sized for the team plan covers both
+  if (pl.team && !(p->flags & IREC_FLAG_TEAM) && n_blocks < 64) pl.team = false;
   if (((uintptr_t)workspace & 255) != 0) return fail(IREC_E_WORKSPACE, "irec_beam_encode: workspace must be 256-byte aligned");
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)hip_stream;

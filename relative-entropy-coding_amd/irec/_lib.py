@@ -13,6 +13,7 @@ IREC_E_WORKSPACE = -4
 IREC_FLAG_FORCE_GENERIC = 1
 IREC_FLAG_FUSED_PHILOX = 2
 IREC_FLAG_ONE_TABLE = 4
+IREC_FLAG_TEAM = 8
 BIG_PRIME = 10007
 MAX_BEAMS = 64
 MAX_PARTITIONS = 65536

@@ -25,6 +25,7 @@ class BeamSearchCoder(GaussianCoder):
         self.force_generic = False   # debugging / testing knob: IREC_FLAG_FORCE_GENERIC
         self.fused_philox = False    # debugging / testing knob: IREC_FLAG_FUSED_PHILOX
         self.one_table = False       # debugging / testing knob: IREC_FLAG_ONE_TABLE
+        self.team = False            # debugging / testing knob: IREC_FLAG_TEAM (the team encoder also for small calls)
         self._max_K_hint = 32
 
     # ---- small host-side mirrors ---------------------------------------------------------------------------------
@@ -49,7 +50,8 @@ class BeamSearchCoder(GaussianCoder):
             raise CodingError(f"n_samples = {self.n_samples} < 1")
         flags = (_lib.IREC_FLAG_FORCE_GENERIC if self.force_generic else 0) | \
                 (_lib.IREC_FLAG_FUSED_PHILOX if self.fused_philox else 0) | \
-                (_lib.IREC_FLAG_ONE_TABLE if self.one_table else 0)
+                (_lib.IREC_FLAG_ONE_TABLE if self.one_table else 0) | \
+                (_lib.IREC_FLAG_TEAM if self.team else 0)
         return get_engine().params(self.kl_per_partition, self.n_samples, self.n_beams, flags)
 
     @staticmethod

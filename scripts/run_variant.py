@@ -9,7 +9,7 @@ L = int(os.environ.get("LATENTS", "1024"))
 B = int(os.environ.get("BEAMS", "20")); omega = float(os.environ.get("OMEGA", "3.0")); eps1 = float(os.environ.get("EPS1", "1.2"))
 eng = irec.get_engine()
 S = int(np.exp(omega * eps1))
-flags = {"table": 0, "fused": 2, "generic": 1}[variant]
+flags = {"table": 8, "auto": 0, "one_table": 4, "fused": 2, "generic": 1}[variant]
 params = eng.params(omega, S, B, flags)
 q = bench.synthetic_batch(L, eng.device, 0)
 lay = eng.layout(L, bench.N_DIMS, bench.BLOCK_SIZE, bench.SEED)

@@ -55,7 +55,7 @@ for case in range(n_cases):
     for variant in ("table", "one_table", "fused", "generic"):
         c = irec.BeamSearchCoder(kl_per_partition=omega, n_beams=B, extra_samples=eps1)
         c.n_samples = S
-        c.force_generic = variant == "generic"; c.fused_philox = variant == "fused"; c.one_table = variant == "one_table"
+        c.force_generic = variant == "generic"; c.fused_philox = variant == "fused"; c.one_table = variant == "one_table"; c.team = variant == "table"
         idx, sample = c.encode(q, p, seed=seed, batched=True)
         sh = sample.cpu().numpy()
         ok = all([int(i) for i in idx[n]] == refs[n][0] and np.array_equal(sh[n], refs[n][1]) for n in range(len(tens)))

@@ -17,8 +17,9 @@ def _normal(loc, scale, device="cuda"):
                                       validate_args=False)
 
 
-# two teams per CU over three table copies (default) / one-table proposal-table kernel / Philox-fused kernel / fallback
-VARIANTS = ["table", "one_table", "fused", "generic"]
+# teams per CU over three table copies (forced also for small calls) / the default choice between that and the one-table
+# encoder by call size / one-table proposal-table kernel / Philox-fused kernel / fallback
+VARIANTS = ["table", "auto", "one_table", "fused", "generic"]
 
 
 def _coder(omega, B, eps1, block_size=None, variant="table"):
@@ -27,6 +28,7 @@ def _coder(omega, B, eps1, block_size=None, variant="table"):
     c.force_generic = variant == "generic"
     c.fused_philox = variant == "fused"
     c.one_table = variant == "one_table"
+    c.team = variant == "table"
     return c
 
 
@@ -312,7 +314,7 @@ def test_high_kl_block_many_partitions(engine, oracle):
     assert len(ridx) > 64 and [int(i) for i in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
 
 
-@pytest.mark.parametrize("flags", [0, 4, 2], ids=["table", "one_table", "fused"])
+@pytest.mark.parametrize("flags", [8, 0, 4, 2], ids=["table", "auto", "one_table", "fused"])
 def test_full_size_properties(engine, oracle, flags):
     """BASELINE config 2 at bench size: properties that need no oracle run (round trip, ranges), plus a sampled
     subset of blocks checked against the oracle."""
