@@ -7,33 +7,103 @@ already resident in HBM, with B=20, Omega=3, 1+eps=1.2 (S=36): BASELINE.json con
 GPU, every rank codes its own batch (weak scaling, no data-path collective); the only collective is the final RCCL
 all_gather of the per-latent code lengths.
 
-Prints ONE JSON line on rank 0.
+Launching.  `python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N ranks itself: the parent
+touches no GPU, spawns N children of this file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set,
+relays rank 0's JSON line and exits non-zero if any child fails.  Under `python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N` the environment is already there; `--gpus` must equal WORLD_SIZE.
+IREC_DIST_BACKEND=gloo (test rigs with fewer GPUs than ranks) shares devices round-robin and exchanges on the host.
+
+Prints ONE JSON line on rank 0.  Every figure in it is measured by this run or read from `profiles/` of the same
+source hash (roofline.traffic; null when the committed PMC profile is from other kernel sources).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "relative-entropy-coding_amd")):
+PKG = os.path.join(ROOT, "relative-entropy-coding_amd")
+for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-N_CU, LANES = 256, 64
+LDS_HW_LOOKUPS = 32.0     # ds_read_b32: 128 B/clk/CU = 32 four-byte look-ups per clock per CU (MI355X_MICROARCH.md §LDS)
+LDS_2CHOICE_LOOKUPS = 13.4  # measured ceiling of random look-ups with the 2-choice bank assignment (profiles/r01j)
 TENSOR_SHAPE = (16, 16, 32)
 N_DIMS = 8192
 BLOCK_SIZE = 1000
 OMEGA, EPS1, BEAMS, SEED = 3.0, 1.2, 20, 42
+KERNEL_SOURCES = ("irec_team.hip", "irec_kernels.hip", "irec_fast_common.h", "irec_device.h", "irec_kernels.h",
+                  "irec_host.cpp")
 
 
+def kernel_source_hash():
+    """sha256 (16 hex) over the kernel sources: profiles/traffic.json carries the hash it was measured on."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(PKG, "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+#  launcher: `python bench.py --gpus N` -> N rank processes (the parent never initialises a GPU)
+# ---------------------------------------------------------------------------------------------------------------------
+def launch_ranks(args, argv):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile() as out0_f:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=out0_f if r == 0 else subprocess.DEVNULL))
+        # a rank that dies must not leave the others waiting in a collective: poll, and end the job on the first failure
+        failed = False
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):
+                failed = True
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()      # exactly the PIDs this launcher started
+                break
+            time.sleep(0.05)
+        rcs = [p.wait() for p in procs]
+        out0_f.seek(0)
+        out0 = out0_f.read().decode()
+    if failed or any(rcs):
+        sys.stderr.write(out0)
+        raise SystemExit(f"bench.py: rank exit codes {rcs}")
+    line = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if not line:
+        raise SystemExit("bench.py: rank 0 printed no JSON line")
+    res = json.loads(line[-1])
+    if res.get("n_gpus") != args.gpus or res.get("world_size") != args.gpus:
+        raise SystemExit(f"bench.py: asked for {args.gpus} ranks, the job reports n_gpus={res.get('n_gpus')}")
+    print(line[-1], flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+#  one rank
+# ---------------------------------------------------------------------------------------------------------------------
 def synthetic_batch(n_latents, device, rank):
     """SURVEY.md §8d statistics, drawn on the device (torch generator seeded per rank); values differ from the numpy
     fixtures, the distribution does not."""
+    import torch
     g = torch.Generator(device=device)
     g.manual_seed(1234 + rank)
     shape = (n_latents, N_DIMS)
@@ -46,62 +116,113 @@ def synthetic_batch(n_latents, device, rank):
 
 
 def host_cores():
-    """Cores this process may actually run on (cgroup/affinity aware), capped: eager torch on small tensors does not
-    scale past a few dozen threads and oversubscription makes it far slower."""
+    """Cores this process may run on (cgroup / affinity aware)."""
     try:
-        n = len(os.sched_getaffinity(0))
+        return max(1, len(os.sched_getaffinity(0)))
     except AttributeError:
-        n = os.cpu_count() or 1
-    return max(1, min(n, 32))
+        return max(1, os.cpu_count() or 1)
 
 
-def log(*a):
-    print("[bench]", *a, file=sys.stderr, flush=True)
-
-
-def cpu_baselines(q, n_ref, n_opt):
-    """Timed on the host cores of this box, rank 0 only.  (1) reference-shaped torch-eager port of the TF path
-    (oracle/ref_shaped_torch.py, all cores), (2) the C oracle (1 core)."""
+def cpu_baselines(q, n_ref, n_opt_budget_s):
+    """BASELINE.md §3, timed on the host cores of this box, rank 0 at N = 1 only.
+    CPU-ref: reference-shaped torch-eager restatement of the TF path (oracle/ref_shaped_torch.py): 3 warm-ups, then 5
+             repeats of n_ref latents, median.  Thread count: all cores (the protocol's torch.set_num_threads(cpu_count))
+             and 32 are both probed on two latents and the FASTER setting is used -- eager torch on [S,B,1,D] tensors
+             stops scaling at a few dozen threads, and the baseline gets its best case.
+    CPU-opt: the C oracle, OpenMP over blocks, all cores, for about n_opt_budget_s seconds."""
+    import torch
     from oracle import oracle as O
     from oracle import ref_shaped_torch as R
     S = O.n_samples(OMEGA, EPS1)
-    host = [t[:max(n_ref, n_opt)].cpu().numpy() for t in q]
-    torch.set_num_threads(host_cores())
-    log(f"cpu baseline on {host_cores()} threads (affinity {len(os.sched_getaffinity(0))}, cpu_count {os.cpu_count()})")
-    R.encode_tensor(*(h[0] for h in host), SEED, OMEGA, S, BEAMS, BLOCK_SIZE)  # warm-up
-    log("cpu warm-up done")
+    cores = host_cores()
+    n_host = max(n_ref, 64)
+    host = [t[:n_host].cpu().numpy() for t in q]
+
+    def ref(i):
+        return R.encode_tensor(*(h[i % n_host] for h in host), SEED, OMEGA, S, BEAMS, BLOCK_SIZE)
+
+    probe = {}
+    for nt in sorted({cores, min(cores, 32)}):
+        torch.set_num_threads(nt)
+        ref(0)
+        t0 = time.perf_counter()
+        ref(1); ref(2)
+        probe[nt] = 2 / (time.perf_counter() - t0)
+    threads = max(probe, key=probe.get)
+    torch.set_num_threads(threads)
+    log(f"cpu-ref thread probe (latents/s): {probe} -> {threads} threads; affinity {cores}, cpu_count {os.cpu_count()}")
+    for i in range(3):
+        ref(i)
+    reps = []
+    for rep in range(5):
+        t0 = time.perf_counter()
+        for i in range(n_ref):
+            ref(rep * n_ref + i)
+        reps.append(n_ref / (time.perf_counter() - t0))
+    ref_lps = float(np.median(reps))
+    log(f"cpu-ref repeats (latents/s): {[round(r, 2) for r in reps]}")
+
+    # CPU-opt: batches of 2 latents per core until the budget is spent; the first batch is also the parity sample
+    batch = max(16, 2 * cores)
+    done, t_opt, first = 0, 0.0, None
+    while t_opt < n_opt_budget_s and done + batch <= q[0].shape[0]:
+        hb = [t[done:done + batch].cpu().numpy() for t in q]
+        t0 = time.perf_counter()
+        idx, samp, used = O.encode_tensors_omp(*hb, SEED, OMEGA, S, BEAMS, BLOCK_SIZE, n_threads=cores)
+        t_opt += time.perf_counter() - t0
+        if first is None:
+            first = (idx, samp)
+        done += batch
+    return {"ref_lps": ref_lps, "ref_threads": threads, "ref_probe": probe, "ref_reps": reps, "n_ref": n_ref,
+            "opt_lps": done / t_opt, "opt_threads": used, "opt_latents": done, "opt_first": first}
+
+
+def run_rank_launch_only(args):
+    """IREC_BENCH_LAUNCH_ONLY=1 (CPU test rigs, tests/test_bench_launcher.py): everything of the N-rank job except the GPU
+    work -- rendezvous, the code-length exchange of irec/sharding.py over gloo on made-up K, max-over-ranks timing, the
+    JSON line.  Never a measurement: "value" is null."""
+    import torch
+    import torch.distributed as dist
+    from irec import sharding
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    L = 4
+    local = torch.arange(L, dtype=torch.float64) * world + rank          # item i = rank + k * world  ->  value i
     t0 = time.perf_counter()
-    for i in range(n_ref):
-        R.encode_tensor(*(h[i] for h in host), SEED, OMEGA, S, BEAMS, BLOCK_SIZE)
-    t_ref = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    ref_out = [O.encode_tensor(*(h[i] for h in host), SEED, OMEGA, S, BEAMS, block_size=BLOCK_SIZE) for i in range(n_opt)]
-    t_opt = time.perf_counter() - t0
-    return n_ref / t_ref, n_opt / t_opt, ref_out
+    got = sharding.gather_per_item(local, world * L, rank, world, dist if world > 1 else None)
+    mine = time.perf_counter() - t0
+    assert got.tolist() == list(range(world * L)), got
+    times = [mine]
+    if world > 1:
+        tall = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(tall, torch.tensor([mine], dtype=torch.float64))
+        times = [float(t.item()) for t in tall]
+    if rank == 0:
+        print(json.dumps({"metric": "encoded latents/sec", "value": None, "launch_only": True, "n_gpus": world,
+                          "world_size": dist.get_world_size() if world > 1 else 1, "backend": "gloo",
+                          "steps": args.steps, "warmup": args.warmup, "ranks_timed": len(times)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--latents", type=int, default=2048, help="latent tensors per step per GPU")
-    ap.add_argument("--cpu-ref-latents", type=int, default=48)
-    ap.add_argument("--cpu-opt-latents", type=int, default=96)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
+def run_rank(args):
+    if os.environ.get("IREC_BENCH_LAUNCH_ONLY") == "1":
+        return run_rank_launch_only(args)
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
     n_dev = torch.cuda.device_count()
-    dev_index = local_rank % n_dev          # (test rigs may run several ranks on one GPU: IREC_DIST_BACKEND=gloo)
+    backend = os.environ.get("IREC_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm
+    if backend == "nccl" and world > n_dev:
+        raise SystemExit(f"bench.py: {world} ranks but {n_dev} GPU(s) visible (IREC_DIST_BACKEND=gloo shares devices on test rigs)")
+    dev_index = local_rank % n_dev
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    backend = os.environ.get("IREC_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -109,8 +230,11 @@ def main():
             dist.init_process_group(backend="nccl", device_id=device)
         else:
             dist.init_process_group(backend=backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     import irec
+    from irec import sharding
     eng = irec.get_engine(device)
     S = int(np.exp(OMEGA * EPS1))
     params = eng.params(OMEGA, S, BEAMS)
@@ -121,6 +245,7 @@ def main():
     out = (torch.empty(lay.n_blocks, dtype=torch.int32, device=device),
            torch.empty((lay.n_blocks, max_K), dtype=torch.int32, device=device), torch.empty_like(q[0]))
     eng.workspace(params, lay.max_dim, max_K)  # allocate scratch outside the timed region
+    plan = eng.plan(params, lay, max_K)        # the kernels irec_beam_encode launches for exactly this call
 
     coll_dev = device if backend == "nccl" else torch.device("cpu")   # gloo rigs exchange through host tensors
 
@@ -130,18 +255,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    from irec import sharding
-
     def exchange(K):
         # the path's only exchange step: per-latent code length (nats), all ranks <- all ranks (RCCL over xGMI)
         return sharding.gather_per_item(sharding.code_nats_per_tensor(K, lay, S).to(coll_dev), world * L, rank, world, dist)
 
-    log(f"rank {rank}/{world}: {L} latents, {lay.n_blocks} blocks per step")
+    log(f"rank {rank}/{world}: {L} latents, {lay.n_blocks} blocks per step, kernel {plan['kernel']} grid {plan['grid']}")
     for _ in range(max(args.warmup, 1)):
         eng.encode_blocks(params, lay, *q, SEED, max_K, out=out)
         exchange(out[0])
     barrier()
-    log("warm-up done")
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for a, b in ev:
@@ -151,69 +273,112 @@ def main():
     K = out[0]
     gathered = exchange(K)
     barrier()
-    elapsed = time.perf_counter() - t0
+    my_elapsed = time.perf_counter() - t0
+    elapsed = my_elapsed
+    per_rank = [L * args.steps / my_elapsed]
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        tall = [torch.zeros(1, dtype=torch.float64, device=coll_dev) for _ in range(world)]
+        dist.all_gather(tall, torch.tensor([my_elapsed], dtype=torch.float64, device=coll_dev))
+        times = [float(t.item()) for t in tall]
+        elapsed = max(times)                                  # MAX over ranks
+        per_rank = [L * args.steps / t for t in times]
 
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    log(f"timed region {elapsed:.3f} s, kernel {kernel_ms:.2f} ms per step")
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))   # table kernels + block kernel of one call
+    log(f"rank {rank}: timed region {my_elapsed:.3f} s, {kernel_ms:.2f} ms per call (HIP events)")
     Kh = K.cpu().numpy().astype(np.int64)
     dims = lay.block_dim.cpu().numpy().astype(np.int64)
     assert Kh.min() >= 0 and Kh.max() <= max_K, "a block needed more than max_K partitions"
     algo_bytes = int((24 * dims + 4 * Kh).sum())                        # 24 D + 4 K per block
     evals = int((S * dims * (1 + np.maximum(Kh - 1, 0) * BEAMS) * (Kh > 0)).sum())
-    clk_ghz = 2.4
-    # HBM-side traffic per launch from the committed PMC profile (FETCH_SIZE / WRITE_SIZE passes, corrected as
-    # MI355X_MICROARCH.md prescribes: KiB units, FETCH_SIZE x2 for 16 B/lane streams); scaled by the latent count.
-    traffic = None
+    n_cu, clk_ghz = plan["n_cu"], plan["clock_mhz"] / 1e3
+    lookups = evals / (kernel_ms * 1e-3) / (n_cu * clk_ghz * 1e9)       # per clock per CU at the device's max clock
+    # HBM-side traffic per launch: the committed PMC profile (FETCH_SIZE / WRITE_SIZE passes, corrected as
+    # MI355X_MICROARCH.md prescribes) counts only if it was taken on THESE kernel sources
+    src_hash = kernel_source_hash()
+    traffic, traffic_note = None, "no profiles/traffic.json"
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tj):
         tr = json.load(open(tj))
-        traffic = tr["hbm_bytes_per_latent"] * L
+        if tr.get("source_sha16") == src_hash and tr.get("kernel", "").replace(" ", "").endswith(plan["kernel"]):
+            traffic = tr["hbm_bytes_per_latent"] * L
+            traffic_note = tr.get("source", "")
+        else:
+            traffic_note = (f"profiles/traffic.json is for sources {tr.get('source_sha16')} / {tr.get('kernel')}; "
+                            f"this build is {src_hash} / {plan['kernel']}: not reported")
 
     result = {
         "metric": "encoded latents/sec", "value": world * L * args.steps / elapsed, "unit": "latents/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "n_gpus": world, "world_size": dist.get_world_size() if dist is not None else 1,
+        "backend": backend if dist is not None else None, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "RVAE Cifar10-shape latents [16,16,32], beam_search B=20 Omega=3 eps=0.2 (S=36), "
                                "block_size=1000 (configs[1])",
                    "latents_per_step_per_gpu": L, "blocks_per_step_per_gpu": int(lay.n_blocks),
                    "parallelism": f"latents sharded over {world} GPU(s), no data-path collective"},
+        "per_rank_latents_per_s": per_rank,
         "roofline": {"bound": "hbm", "achieved": algo_bytes / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": algo_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "encode_team_kernel<20,2,1>", "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes},
-        "secondary": {"proposal_evals_per_s": evals / (kernel_ms * 1e-3),
-                      "evals_per_clk_per_cu": evals / (kernel_ms * 1e-3) / (N_CU * clk_ghz * 1e9),
-                      # the ceiling that actually binds: random 4-byte LDS look-ups per clock per CU, measured by
-                      # scripts/microbench/gather_rates.hip (profiles/r01j): 8.9 for one table copy, 13.4 with the
-                      # 2-choice bank assignment over three copies that the encoder uses (8 waves per CU)
-                      "lds_gather_roofline": {"achieved": evals / (kernel_ms * 1e-3) / (N_CU * clk_ghz * 1e9), "peak": 13.4,
-                                              "unit": "look-ups/clk/CU at 2.4 GHz",
-                                              "frac": evals / (kernel_ms * 1e-3) / (N_CU * clk_ghz * 1e9) / 13.4},
+                     "traffic_note": traffic_note, "kernel": plan["kernel"], "table_kernel": plan["table_kernel"],
+                     "grid": plan["grid"], "waves_per_wg": plan["waves_per_wg"], "lds_bytes": plan["lds_bytes"],
+                     "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes, "source_sha16": src_hash},
+        "secondary": {"proposal_evals_per_s": evals / (kernel_ms * 1e-3), "n_cu": n_cu, "clock_ghz": clk_ghz,
+                      "lookups_per_clk_per_cu": lookups,
+                      # hardware rate of the instruction the look-ups use (conflict-free ds_read_b32)
+                      "lds_hw": {"achieved": lookups, "peak": LDS_HW_LOOKUPS, "unit": "look-ups/clk/CU",
+                                 "frac": lookups / LDS_HW_LOOKUPS},
+                      # what random addresses allow: scripts/microbench/gather_rates.hip (profiles/r01j), 2-choice bank
+                      # assignment over three table copies, 8 waves per CU
+                      "lds_gather_roofline": {"achieved": lookups, "peak": LDS_2CHOICE_LOOKUPS,
+                                              "unit": "look-ups/clk/CU", "frac": lookups / LDS_2CHOICE_LOOKUPS},
                       "mean_K": float(Kh.mean()), "code_nats_per_latent": float(gathered.mean().item())},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        ref_lps, opt_lps, ref_out = cpu_baselines(q, args.cpu_ref_latents, args.cpu_opt_latents)
-        # parity of the timed outputs against the oracle on the sampled latents
+        from oracle import oracle as O
+        cb = cpu_baselines(q, args.cpu_ref_latents, args.cpu_opt_seconds)
+        # parity of the timed GPU outputs against the oracle on the first CPU-opt batch
         idx_h = out[1].cpu().numpy()
         samp_h = out[2].cpu().numpy()
-        for i, (ridx, rs) in enumerate(ref_out):
+        ridx, rsamp = cb["opt_first"]
+        for i in range(len(ridx)):
             for j in range(lay.blocks_per_tensor):
                 row = lay.natural[i * lay.blocks_per_tensor + j]
-                assert idx_h[row, :Kh[row]].tolist() == ridx[j], f"parity: latent {i} block {j}"
-            assert np.array_equal(samp_h[i], rs), f"parity: latent {i} sample"
-        result["cpu_baseline"] = {"value": ref_lps, "unit": "latents/s", "cores": host_cores(), "kind": "port",
-                                  "sample": f"{args.cpu_ref_latents} latents of the same batch, reference-shaped "
-                                            "torch-eager restatement of the TF path (oracle/ref_shaped_torch.py)"}
-        result["cpu_baseline_c_oracle"] = {"value": opt_lps, "unit": "latents/s", "cores": 1, "kind": "port",
-                                           "sample": f"{args.cpu_opt_latents} latents, oracle/irec_oracle.c canonical mode"}
-        result["parity_checked_latents"] = len(ref_out)
+                assert idx_h[row, :Kh[row]].tolist() == ridx[i][j], f"parity: latent {i} block {j}"
+            assert np.array_equal(samp_h[i], rsamp[i]), f"parity: latent {i} sample"
+        result["cpu_baseline"] = {"value": cb["ref_lps"], "unit": "latents/s", "cores": cb["ref_threads"], "kind": "port",
+                                  "sample": f"median of 5 repeats x {cb['n_ref']} latents of the same batch after 3 warm-ups, "
+                                            "reference-shaped torch-eager restatement of the TF path "
+                                            "(oracle/ref_shaped_torch.py, BASELINE.md §3 CPU-ref)",
+                                  "thread_probe_latents_per_s": {str(k): v for k, v in cb["ref_probe"].items()},
+                                  "repeats": cb["ref_reps"], "host_cores": host_cores()}
+        result["cpu_baseline_opt"] = {"value": cb["opt_lps"], "unit": "latents/s", "cores": cb["opt_threads"], "kind": "port",
+                                      "sample": f"{cb['opt_latents']} latents, oracle/irec_oracle.c canonical mode, OpenMP over "
+                                                "blocks (BASELINE.md §3 CPU-opt)"}
+        result["parity_checked_latents"] = len(ridx)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--latents", type=int, default=2048, help="latent tensors per step per GPU")
+    ap.add_argument("--cpu-ref-latents", type=int, default=20, help="latents per CPU-ref repeat (5 repeats, median)")
+    ap.add_argument("--cpu-opt-seconds", type=float, default=8.0, help="time budget of the CPU-opt (OpenMP oracle) leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            return launch_ranks(args, sys.argv[1:])     # before anything touches a GPU
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}")
+    run_rank(args)
 
 
 if __name__ == "__main__":

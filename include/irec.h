@@ -54,6 +54,10 @@ typedef struct {
                           /* With it the encoder evaluates the shared-seed Philox draw once per call into a     */
                           /* proposal table (same seed for every block, coder.py:444-449) instead of once per   */
                           /* block; a block whose dim is not listed gets out_K = -1.  All zero = no hint.       */
+  int32_t table_steps;    /* partitions the proposal tables cover (0 = IREC_TABLE_STEPS_DEFAULT, clamped to     */
+                          /* [1, min(max_K, IREC_TABLE_STEPS_MAX)]).  Table scratch is O(table_steps * S * D):  */
+                          /* a block with more partitions is coded by the fused-Philox kernel in a second pass  */
+                          /* of the same call -- same outputs, bit for bit.                                     */
 } irec_params;
 
 #define IREC_FLAG_FORCE_GENERIC 1 /* use the generic (any D, any B) kernel even where the fast kernels apply   */
@@ -62,6 +66,32 @@ typedef struct {
 #define IREC_FLAG_TEAM 8          /* with table_dims: always the teams-per-CU encoder over three table copies.         */
                                   /* Neither flag: the team encoder for calls of >= 64 blocks, the one-table encoder   */
                                   /* (cheaper per-call set-up) below; same outputs, bit for bit                        */
+/* Diagnostic workgroup shapes of the team encoder for B <= 20 (bits 8-11 of flags; 0 = the default shape).  Same outputs. */
+#define IREC_FLAG_SHAPE_SHIFT 8
+#define IREC_FLAG_SHAPE_MASK (0xF << IREC_FLAG_SHAPE_SHIFT)
+#define IREC_FLAG_SHAPE_1 (1 << IREC_FLAG_SHAPE_SHIFT)   /* one 4-wave team per CU                                    */
+#define IREC_FLAG_SHAPE_2 (2 << IREC_FLAG_SHAPE_SHIFT)   /* exactly two teams (also where three are the default)      */
+#define IREC_FLAG_SHAPE_3 (3 << IREC_FLAG_SHAPE_SHIFT)   /* three 4-wave teams (168 VGPRs)                            */
+#define IREC_FLAG_SHAPE_2X2 (4 << IREC_FLAG_SHAPE_SHIFT) /* two 8-wave beam-striped teams (128 VGPRs)                 */
+
+#define IREC_TABLE_STEPS_DEFAULT 32
+#define IREC_TABLE_STEPS_MAX 64
+
+/* What irec_beam_encode does for a given call: filled by irec_encode_plan (same decision code as the launch). */
+typedef struct {
+  char kernel[64];         /* block kernel, e.g. "encode_team_kernel<20,2,1>"                                   */
+  char table_kernel[32];   /* "alpha_choice_kernel", "alpha_table_kernel" or "" (Philox fused in the block kernel) */
+  int32_t grid;            /* workgroups of the block kernel                                                    */
+  int32_t waves_per_wg;
+  int32_t teams_per_wg;    /* independent teams inside a workgroup (1 for the one-workgroup-per-block encoders) */
+  int32_t lds_bytes;       /* dynamic LDS of one workgroup                                                      */
+  int32_t table_steps;     /* partitions the proposal tables cover (0 = no tables)                              */
+  int32_t n_tables;
+  int32_t n_cu;            /* compute units of the context's device                                             */
+  int32_t clock_mhz;       /* its maximum engine clock                                                          */
+  int64_t table_bytes;     /* proposal tables inside the workspace                                              */
+  int64_t workspace_bytes; /* = irec_encode_workspace_bytes()                                                   */
+} irec_plan_info;
 
 typedef struct irec_context irec_context;
 
@@ -113,6 +143,11 @@ void irec_destroy(irec_context *ctx);
 
 /* Bytes of device scratch irec_beam_encode needs for blocks of at most max_dim dims and max_K partitions. */
 size_t irec_encode_workspace_bytes(const irec_context *ctx, const irec_params *p, int32_t max_dim, int32_t max_K);
+
+/* The kernels, grid and scratch irec_beam_encode(ctx, p, n_blocks, ..., max_block_dim, ..., max_K, ...) launches.
+ * Host only, no device work; bench.py reports the kernel it measured from this instead of a string literal. */
+irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int64_t n_blocks, int32_t max_block_dim,
+                             int32_t max_K, irec_plan_info *out);
 
 /* ---- device entry points ---------------------------------------------------------------------------------- */
 

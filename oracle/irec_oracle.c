@@ -546,6 +546,47 @@ int32_t irec_oracle_encode_block(int mode, float omega, int S, int B, int D, con
   return K;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * CPU-opt baseline: encode_block over many independent blocks, OpenMP over blocks
+ * (GaussianCoder.encode's loop, coder.py:435-452, is a plain loop over independent blocks; images are
+ * independent too).  Blocks are already permuted and concatenated: block k = elements
+ * [offset[k], offset[k] + dim[k]) of mq/sq/mp/sp/out_sample.  out_indices: [n_blocks][max_K].
+ * Returns the number of threads used.
+ * ---------------------------------------------------------------------------------------------- */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int irec_oracle_encode_blocks_omp(int mode, float omega, int S, int B, int64_t n_blocks, const int32_t *dim,
+                                  const int64_t *offset, const float *mq, const float *sq, const float *mp,
+                                  const float *sp, int64_t seed, int32_t max_K, int32_t *out_K, int32_t *out_indices,
+                                  float *out_sample, int n_threads) {
+  int used = 1;
+  if (n_blocks > 0) { /* builds the function-static LUT before any thread races for it */
+    float s1[1], q1 = 0.0f, one = 1.0f; int32_t i1[1];
+    irec_oracle_encode_block(mode, omega, 2, 1, 1, &q1, &one, &q1, &one, 0, 0, i1, s1, 0, 0);
+  }
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel
+  {
+#pragma omp single
+    used = omp_get_num_threads();
+#pragma omp for schedule(dynamic, 1)
+    for (int64_t k = 0; k < n_blocks; ++k)
+      out_K[k] = irec_oracle_encode_block(mode, omega, S, B, dim[k], mq + offset[k], sq + offset[k], mp + offset[k],
+                                          sp + offset[k], seed, max_K, out_indices + k * (int64_t)max_K,
+                                          out_sample + offset[k], 0, 0);
+  }
+#else
+  (void)n_threads;
+  for (int64_t k = 0; k < n_blocks; ++k)
+    out_K[k] = irec_oracle_encode_block(mode, omega, S, B, dim[k], mq + offset[k], sq + offset[k], mp + offset[k],
+                                        sp + offset[k], seed, max_K, out_indices + k * (int64_t)max_K,
+                                        out_sample + offset[k], 0, 0);
+#endif
+  return used;
+}
+
 /* decode_block (beam_search_coder.py:124-148).  indices in ENCODER order (idx[t] = choice at iteration t);
  * the reference's in-place list reversal (:127) is an implementation detail of its loop direction. */
 void irec_oracle_decode_block(int mode, int S, int D, const float *mp, const float *sp, const int32_t *indices,

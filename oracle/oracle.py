@@ -66,6 +66,10 @@ def lib():
                                                f32p, f32p, f32p, f32p, ctypes.c_int64, ctypes.c_int32, i32p, f32p,
                                                i32p, f32p]
         L.irec_oracle_encode_block.restype = ctypes.c_int32
+        L.irec_oracle_encode_blocks_omp.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                                    i32p, i64p, f32p, f32p, f32p, f32p, ctypes.c_int64, ctypes.c_int32,
+                                                    i32p, i32p, f32p, ctypes.c_int]
+        L.irec_oracle_encode_blocks_omp.restype = ctypes.c_int
         L.irec_oracle_decode_block.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, f32p, f32p, i32p,
                                                ctypes.c_int32, ctypes.c_int64, f32p]
         L.irec_oracle_tf_random_normal.argtypes = [ctypes.c_int64, ctypes.c_int64, f32p]
@@ -199,6 +203,33 @@ def encode_tensor(q_loc, q_scale, p_loc, p_scale, seed, omega, S, B, block_size=
         indices.append(idx)
         out[g] = samp  # merge: inverse permutation (coder.py:111-117)
     return indices, out.reshape(shape)
+
+
+def encode_tensors_omp(q_loc, q_scale, p_loc, p_scale, seed, omega, S, B, block_size, mode=CANONICAL, max_K=64,
+                       n_threads=0):
+    """CPU-opt baseline: GaussianCoder.encode over a batch [N, n] of latent tensors, OpenMP over the
+    N * blocks independent blocks.  Returns (indices[N][blocks][K], sample [N, n], threads used)."""
+    mq, sq, mp, sp = (np.ascontiguousarray(a, dtype=np.float32).reshape(len(a), -1) for a in (q_loc, q_scale, p_loc, p_scale))
+    N, n = mq.shape
+    perm = tf_shuffle_perm(seed, n)
+    blocks = split_blocks(n, block_size)
+    dims = np.tile(np.array([hi - lo for lo, hi in blocks], dtype=np.int32), N)
+    offs = (np.repeat(np.arange(N, dtype=np.int64) * n, len(blocks)) + np.tile(np.array([lo for lo, _ in blocks], dtype=np.int64), N))
+    pm = [np.ascontiguousarray(a[:, perm]).reshape(-1) for a in (mq, sq, mp, sp)]   # split: gather through perm
+    out_K = np.zeros(len(dims), dtype=np.int32)
+    out_idx = np.zeros((len(dims), max_K), dtype=np.int32)
+    out_s = np.zeros(N * n, dtype=np.float32)
+    used = lib().irec_oracle_encode_blocks_omp(mode, float(np.float32(omega)), S, B, len(dims), _p(dims, ctypes.c_int32),
+                                               _p(offs, ctypes.c_int64), *(_p(a, ctypes.c_float) for a in pm), int(seed),
+                                               max_K, _p(out_K, ctypes.c_int32), _p(out_idx, ctypes.c_int32),
+                                               _p(out_s, ctypes.c_float), int(n_threads))
+    if (out_K > max_K).any():
+        raise ValueError(f"K={int(out_K.max())} exceeds max_K={max_K}")
+    sample = np.zeros((N, n), dtype=np.float32)
+    sample[:, perm] = out_s.reshape(N, n)                                             # merge: inverse permutation
+    nb = len(blocks)
+    indices = [[[int(v) for v in out_idx[i * nb + j, :out_K[i * nb + j]]] for j in range(nb)] for i in range(N)]
+    return indices, sample, used
 
 
 def decode_tensor(p_loc, p_scale, indices, seed, S, block_size=None, mode=CANONICAL):

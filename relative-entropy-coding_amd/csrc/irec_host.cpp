@@ -5,6 +5,7 @@
 // and launches the gfx950 kernels of irec_kernels.hip.  Without a HIP device every device entry point fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -35,6 +36,23 @@ irec_status fail(irec_status code, const char *fmt, ...) {
     hipError_t e_ = (expr);                                                                     \
     if (e_ != hipSuccess) return fail(IREC_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
+
+// Entry points select the context's device for their launches and put the caller's current device back on return
+// (a multi-GPU process keeps torch's / its own current device).
+struct DeviceGuard {
+  int prev = -1;
+  bool changed = false;
+  hipError_t enter(int device) {
+    hipError_t e = hipGetDevice(&prev);
+    if (e != hipSuccess) return e;
+    if (prev == device) return hipSuccess;
+    e = hipSetDevice(device);
+    changed = (e == hipSuccess);
+    return e;
+  }
+  ~DeviceGuard() { if (changed) (void)hipSetDevice(prev); }
+};
+#define IREC_ON_DEVICE(dev) DeviceGuard guard_; HIP_TRY(guard_.enter(dev))
 
 // ---- deterministic log, float64, IEEE basic ops only (same operation sequence as the device code) ----
 double det_log(double x) {
@@ -231,6 +249,7 @@ size_t round_up_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
 struct irec_context {
   int device = -1;
   int n_cu = 0;
+  int clock_mhz = 0;
   float *d_lut = nullptr;
   float *d_lut2 = nullptr;
   uint16_t *d_dlog4r = nullptr;
@@ -350,7 +369,7 @@ irec_status irec_create(int device, irec_context **out) {
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(IREC_E_NO_DEVICE, "irec_create: device %d is %s; this build targets gfx950 only", device, prop.gcnArchName);
-  HIP_TRY(hipSetDevice(device));
+  IREC_ON_DEVICE(device);
 
   const int P = IREC_BIG_PRIME;
   std::vector<float> lut(P);
@@ -383,24 +402,32 @@ irec_status irec_create(int device, irec_context **out) {
   irec_context *ctx = new irec_context();
   ctx->device = device;
   ctx->n_cu = prop.multiProcessorCount;
-  HIP_TRY(hipMalloc(&ctx->d_lut, P * sizeof(float)));
-  HIP_TRY(hipMalloc(&ctx->d_lut2, (P - 1) * sizeof(float)));
-  HIP_TRY(hipMalloc(&ctx->d_dlog4r, (P - 1) * sizeof(uint16_t)));
-  HIP_TRY(hipMalloc(&ctx->d_rho, rho.size() * sizeof(float)));
-  HIP_TRY(hipMemcpy(ctx->d_lut, lut.data(), P * sizeof(float), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(ctx->d_lut2, lut2.data(), (P - 1) * sizeof(float), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(ctx->d_dlog4r, dlog4r.data(), (P - 1) * sizeof(uint16_t), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(ctx->d_rho, rho.data(), rho.size() * sizeof(float), hipMemcpyHostToDevice));
-  if (const char *e = std::getenv("IREC_STAMPS"); e && e[0] == '1') {
-    HIP_TRY(hipMalloc(&ctx->d_dbg, 4096 * 16 * sizeof(unsigned long long)));
-  }
+  ctx->clock_mhz = prop.clockRate / 1000;
+  const irec_status st = [&]() -> irec_status { // any failure below frees what was allocated so far
+    HIP_TRY(hipMalloc(&ctx->d_lut, P * sizeof(float)));
+    HIP_TRY(hipMalloc(&ctx->d_lut2, (P - 1) * sizeof(float)));
+    HIP_TRY(hipMalloc(&ctx->d_dlog4r, (P - 1) * sizeof(uint16_t)));
+    HIP_TRY(hipMalloc(&ctx->d_rho, rho.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(ctx->d_lut, lut.data(), P * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_lut2, lut2.data(), (P - 1) * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_dlog4r, dlog4r.data(), (P - 1) * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_rho, rho.data(), rho.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (const char *e = std::getenv("IREC_STAMPS"); e && e[0] == '1') { // diagnostic builds only (scripts/gpu_stamps.sh)
+      HIP_TRY(hipMalloc(&ctx->d_dbg, 4096 * 16 * sizeof(unsigned long long)));
+    }
+    return IREC_OK;
+  }();
+  if (st != IREC_OK) { irec_destroy(ctx); return st; }
   *out = ctx;
   return IREC_OK;
 }
 
 void irec_destroy(irec_context *ctx) {
   if (!ctx) return;
+  DeviceGuard guard_;
+  (void)guard_.enter(ctx->device);
   (void)hipFree(ctx->d_lut); (void)hipFree(ctx->d_lut2); (void)hipFree(ctx->d_dlog4r); (void)hipFree(ctx->d_rho);
+  (void)hipFree(ctx->d_dbg);
   delete ctx;
 }
 
@@ -412,9 +439,13 @@ struct Plan {
   bool fast;         // register-resident fast encoder with the Philox draw fused in
   bool table;        // fast encoder fed by per-call proposal tables (Philox hoisted out of the block kernel)
   bool team;         // table && two-teams-per-CU encoder over three table copies (the default where it applies)
-  int grid_cap;      // resident workgroups (persistent kernels pull blocks from an atomic counter)
+  int shape;         // team-encoder workgroup shape override (IREC_FLAG_SHAPE_*; 0 = default)
+  int grid_cap;      // scratch slabs = resident workgroups / teams (persistent kernels pull blocks from an atomic counter)
+  int one_grid_cap;  // resident workgroups of the one-workgroup-per-block encoder of this plan (small calls of a team plan too)
+  int fast_grid_cap; // resident workgroups of the deferred pass of a table plan (fused-Philox encoder), 0 without tables
   size_t ws_per_wg;
   int dpad;
+  int K_tab;         // partitions the proposal tables cover
   int n_tab;
   int tab_dim[4];
   size_t tab_off[4]; // byte offsets of the proposal tables inside the workspace (after the 256-byte counter block)
@@ -426,38 +457,59 @@ irec_status check_params(const irec_params *p) {
   if (!(p->kl_per_partition > 0.0f)) return fail(IREC_E_INVALID, "kl_per_partition must be > 0");
   if (p->n_samples < 1 || p->n_samples > (1 << 24)) return fail(IREC_E_INVALID, "n_samples %d out of range", p->n_samples);
   if (p->n_beams < 1 || p->n_beams > IREC_MAX_BEAMS) return fail(IREC_E_INVALID, "n_beams %d out of range [1,%d]", p->n_beams, IREC_MAX_BEAMS);
+  if (p->table_steps < 0) return fail(IREC_E_INVALID, "table_steps %d < 0", p->table_steps);
+  if (((p->flags & IREC_FLAG_SHAPE_MASK) >> IREC_FLAG_SHAPE_SHIFT) > 4) return fail(IREC_E_INVALID, "unknown IREC_FLAG_SHAPE_* value");
   return IREC_OK;
 }
 
 Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, int32_t max_K) {
   Plan pl;
   const int B = p->n_beams, S = p->n_samples;
+  const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+  pl.shape = (p->flags & IREC_FLAG_SHAPE_MASK) >> IREC_FLAG_SHAPE_SHIFT;
   pl.dpad = round_up(max_dim > 0 ? max_dim : 1, 256);
   pl.fast = !(p->flags & IREC_FLAG_FORCE_GENERIC) && max_dim <= irec::FAST_MAX_DIM && irec::fast_nb_for(B) != 0 &&
             irec::fast_lds_for(B, S, false) <= irec::FAST_LDS_LIMIT && (int64_t)S * B < (1 << 24);
-  pl.grid_cap = 2 * (ctx->n_cu > 0 ? ctx->n_cu : 256); // measured residency: 2 workgroups per CU for every encoder
+  pl.grid_cap = 2 * n_cu; // measured residency: 2 workgroups per CU for every encoder
   pl.table = false; pl.team = false; pl.n_tab = 0; pl.tab_bytes = 0;
+  // table window: the tables cover the first K_tab partitions; blocks with more go to the fused-Philox second pass
+  const int want = p->table_steps > 0 ? p->table_steps : IREC_TABLE_STEPS_DEFAULT;
+  pl.K_tab = std::max(1, std::min(std::min(want, IREC_TABLE_STEPS_MAX), max_K > 0 ? max_K : 1));
   if (pl.fast && !(p->flags & IREC_FLAG_FUSED_PHILOX) && p->table_dims[0] > 0) {
     pl.table = true;
     for (int q = 0; q < 4 && p->table_dims[q] > 0; ++q) {
       if (p->table_dims[q] > irec::FAST_MAX_DIM) { pl.table = false; break; }
       pl.tab_dim[pl.n_tab] = p->table_dims[q];
       pl.tab_off[pl.n_tab] = pl.tab_bytes;
-      pl.tab_bytes += round_up_sz((size_t)(max_K > 0 ? max_K : 1) * S * round_up(p->table_dims[q], 4) * 2, 256);
+      pl.tab_bytes += round_up_sz((size_t)pl.K_tab * S * round_up(p->table_dims[q], 4) * 2, 256);
       ++pl.n_tab;
     }
     if (!pl.table) { pl.n_tab = 0; pl.tab_bytes = 0; }
-    pl.team = pl.table && !(p->flags & IREC_FLAG_ONE_TABLE) && irec::team_lds_for(B, S) != (size_t)-1;
-    if (pl.team) pl.grid_cap = irec::team_count_for(B, S) * (ctx->n_cu > 0 ? ctx->n_cu : 256); // one scratch slab per team
+    pl.team = pl.table && !(p->flags & IREC_FLAG_ONE_TABLE) && irec::team_lds_for(B, S, pl.shape) != (size_t)-1;
+    if (pl.team) pl.grid_cap = irec::team_count_for(B, S, pl.shape) * n_cu; // one scratch slab per team
   }
+  // resident workgroups of the one-workgroup-per-block encoders: two per CU, one for the big-LDS 8-wave configurations
+  auto one_cap = [&](bool table) { return (irec::fast_waves_for(B, S, table) == 8 ? 1 : 2) * n_cu; };
   if (pl.fast) {
-    if (!pl.team && irec::fast_waves_for(B, S, pl.table) == 8) pl.grid_cap /= 2; // big-LDS configurations: one 8-wave workgroup per CU
-    pl.ws_per_wg = round_up_sz(irec::fast_ws_for(B, max_K) + (pl.team ? irec::team_ws_extra_for(B, S) : 0), 256);
+    pl.one_grid_cap = one_cap(pl.table);
+    pl.fast_grid_cap = pl.table ? one_cap(false) : 0;              // deferred pass of a table plan (fused Philox)
+    if (!pl.team) pl.grid_cap = pl.one_grid_cap;
+    pl.grid_cap = std::max(pl.grid_cap, pl.fast_grid_cap);          // both passes index the same slabs
+    pl.ws_per_wg = round_up_sz(irec::fast_ws_for(B, max_K) + (pl.team ? irec::team_ws_extra_for(B, S, pl.shape) : 0), 256);
   } else {
+    pl.one_grid_cap = pl.grid_cap; pl.fast_grid_cap = 0;
     pl.ws_per_wg = round_up_sz((size_t)10 * pl.dpad * 4 + (size_t)2 * B * pl.dpad * 4 +
                                    (size_t)(max_K > 0 ? max_K : 1) * B * 4 + (size_t)S * B * 4, 256);
   }
+  if (!pl.table) pl.K_tab = 0;
   return pl;
+}
+
+// small calls (a single image's res-block: 9 blocks) are latency-bound: the one-table encoder's set-up (a 6 us proposal
+// table, 40 KB of LDS to fill) beats the team encoder's (38 us per table for the bank assignment, 120 KB); the scratch
+// sized for the team plan covers both
+bool team_for_call(const Plan &pl, const irec_params *p, int64_t n_blocks) {
+  return pl.team && ((p->flags & IREC_FLAG_TEAM) || n_blocks >= 64);
 }
 
 } // namespace
@@ -470,6 +522,46 @@ size_t irec_encode_workspace_bytes(const irec_context *ctx, const irec_params *p
   return 256 + pl.tab_bytes + (size_t)pl.grid_cap * pl.ws_per_wg;
 }
 
+irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int64_t n_blocks, int32_t max_block_dim,
+                             int32_t max_K, irec_plan_info *out) {
+  if (!ctx || !out) return fail(IREC_E_INVALID, "irec_encode_plan: null argument");
+  if (irec_status s = check_params(p)) return s;
+  if (n_blocks < 0 || max_block_dim < 1 || max_K < 0) return fail(IREC_E_INVALID, "irec_encode_plan: bad sizes");
+  const Plan pl = make_plan(ctx, p, max_block_dim, max_K);
+  const bool team = team_for_call(pl, p, n_blocks);
+  std::memset(out, 0, sizeof(*out));
+  const int B = p->n_beams, S = p->n_samples;
+  if (team) {
+    const int n_teams = irec::team_count_for(B, S, pl.shape);
+    std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::team_kernel_name(B, S, pl.shape));
+    std::snprintf(out->table_kernel, sizeof out->table_kernel, "alpha_choice_kernel");
+    out->grid = (int32_t)std::min<int64_t>((n_blocks + n_teams - 1) / n_teams, pl.grid_cap / n_teams);
+    out->waves_per_wg = irec::team_waves_for(B, S, pl.shape);
+    out->teams_per_wg = n_teams;
+    out->lds_bytes = (int32_t)irec::team_lds_for(B, S, pl.shape);
+  } else if (pl.fast) {
+    std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::fast_kernel_name(B, S, pl.table));
+    if (pl.table) std::snprintf(out->table_kernel, sizeof out->table_kernel, "alpha_table_kernel");
+    out->grid = (int32_t)std::min<int64_t>(n_blocks, pl.one_grid_cap);
+    out->waves_per_wg = irec::fast_waves_for(B, S, pl.table);
+    out->teams_per_wg = 1;
+    out->lds_bytes = (int32_t)irec::fast_lds_for(B, S, pl.table);
+  } else {
+    std::snprintf(out->kernel, sizeof out->kernel, "encode_generic_kernel");
+    out->grid = (int32_t)std::min<int64_t>(n_blocks, pl.grid_cap);
+    out->waves_per_wg = 4;
+    out->teams_per_wg = 1;
+    out->lds_bytes = (int32_t)irec::generic_lds_bytes();
+  }
+  out->table_steps = pl.K_tab;
+  out->n_tables = pl.n_tab;
+  out->n_cu = ctx->n_cu;
+  out->clock_mhz = ctx->clock_mhz;
+  out->table_bytes = (int64_t)pl.tab_bytes;
+  out->workspace_bytes = (int64_t)(256 + pl.tab_bytes + (size_t)pl.grid_cap * pl.ws_per_wg);
+  return IREC_OK;
+}
+
 irec_status irec_block_kl(irec_context *ctx, const irec_params *p, int64_t n_blocks, const int64_t *block_base,
                           const int32_t *block_pos, const int32_t *block_dim, const int32_t *perm, const float *q_loc,
                           const float *q_scale, const float *p_loc, const float *p_scale, float *out_kl, int32_t *out_K,
@@ -480,7 +572,7 @@ irec_status irec_block_kl(irec_context *ctx, const irec_params *p, int64_t n_blo
   if (n_blocks == 0) return IREC_OK;
   if (!block_base || !block_pos || !block_dim || !q_loc || !q_scale || !p_loc || !p_scale || !out_K)
     return fail(IREC_E_INVALID, "irec_block_kl: null pointer argument");
-  HIP_TRY(hipSetDevice(ctx->device));
+  IREC_ON_DEVICE(ctx->device);
   irec::EncArgs A{};
   A.block_base = block_base; A.block_pos = block_pos; A.block_dim = block_dim; A.perm = perm;
   A.q_loc = q_loc; A.q_scale = q_scale; A.p_loc = p_loc; A.p_scale = p_scale;
@@ -508,12 +600,9 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   const size_t need = 256 + pl.tab_bytes + (size_t)pl.grid_cap * pl.ws_per_wg;
   if (!workspace || workspace_bytes < need)
     return fail(IREC_E_WORKSPACE, "irec_beam_encode: workspace %zu bytes < required %zu", workspace_bytes, need);
-  // small calls (a single image's res-block: 9 blocks) are latency-bound: the one-table encoder's set-up (a 6 us proposal
-  // table, 40 KB of LDS to fill) beats the team encoder's (38 us per table for the bank assignment, 120 KB); the scratch
-  // sized for the team plan covers both
-  if (pl.team && !(p->flags & IREC_FLAG_TEAM) && n_blocks < 64) pl.team = false;
+  pl.team = team_for_call(pl, p, n_blocks);
   if (((uintptr_t)workspace & 255) != 0) return fail(IREC_E_WORKSPACE, "irec_beam_encode: workspace must be 256-byte aligned");
-  HIP_TRY(hipSetDevice(ctx->device));
+  IREC_ON_DEVICE(ctx->device);
   hipStream_t st = (hipStream_t)hip_stream;
   irec::EncArgs A{};
   A.block_base = block_base; A.block_pos = block_pos; A.block_dim = block_dim; A.perm = perm;
@@ -522,28 +611,44 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   A.omega = p->kl_per_partition; A.S = p->n_samples; A.B = p->n_beams; A.max_K = max_K;
   A.out_K = out_K; A.out_indices = out_indices; A.out_sample = out_sample;
   A.lut = ctx->d_lut; A.lut2 = ctx->d_lut2; A.dlog4r = ctx->d_dlog4r; A.rho = ctx->d_rho;
+  // counter block (256 bytes, zeroed per call): [0] block counter of the first pass, [1] deferred-block count,
+  // [2] block counter of the deferred pass
   A.counter = (unsigned int *)workspace;
+  A.defer_count = (unsigned int *)workspace + 1;
+  A.K_tab = pl.K_tab; A.deferred_pass = 0; A.shape_override = pl.shape;
   A.ws = (char *)workspace + 256 + pl.tab_bytes;
   A.ws_per_wg = pl.ws_per_wg;
   A.max_dim_pad = pl.dpad;
   HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));
-  const int grid = (int)std::min<int64_t>(n_blocks, pl.grid_cap);
+  const int grid = (int)std::min<int64_t>(n_blocks, pl.one_grid_cap);
   A.dbg = ctx->d_dbg;
   if (ctx->d_dbg) HIP_TRY(hipMemsetAsync(ctx->d_dbg, 0, 4096 * 16 * sizeof(unsigned long long), st));
   if (pl.table) {
     for (int q = 0; q < 4; ++q) { A.tab[q] = nullptr; A.tab_dim[q] = -1; }
     for (int q = 0; q < pl.n_tab; ++q) {
       uint16_t *tab = (uint16_t *)((char *)workspace + 256 + pl.tab_off[q]);
-      if (pl.team) HIP_TRY(irec::launch_alpha_choice(seed, p->n_samples, pl.tab_dim[q], max_K > 0 ? max_K : 1, ctx->d_dlog4r, tab, st));
-      else HIP_TRY(irec::launch_alpha_table(seed, p->n_samples, pl.tab_dim[q], max_K > 0 ? max_K : 1, ctx->d_dlog4r, tab, st));
+      if (pl.team) HIP_TRY(irec::launch_alpha_choice(seed, p->n_samples, pl.tab_dim[q], pl.K_tab, ctx->d_dlog4r, tab, st));
+      else HIP_TRY(irec::launch_alpha_table(seed, p->n_samples, pl.tab_dim[q], pl.K_tab, ctx->d_dlog4r, tab, st));
       A.tab[q] = tab; A.tab_dim[q] = pl.tab_dim[q];
     }
+    // second pass (only when the window is shorter than max_K): the fused-Philox encoder codes the blocks whose K lies
+    // beyond the table window; it returns at once when the first pass deferred nothing
+    auto deferred_pass = [&]() -> irec_status {
+      if (pl.K_tab >= max_K) return IREC_OK;
+      irec::EncArgs A2 = A;
+      A2.deferred_pass = 1;
+      A2.counter = (unsigned int *)workspace + 2;
+      for (int q = 0; q < 4; ++q) { A2.tab[q] = nullptr; A2.tab_dim[q] = -1; }
+      HIP_TRY(irec::launch_encode_fast(A2, false, (int)std::min<int64_t>(n_blocks, pl.fast_grid_cap), st));
+      return IREC_OK;
+    };
     if (pl.team) { // grid_cap counts teams (= scratch slabs): two per workgroup, one workgroup per CU
-      const int n_teams = irec::team_count_for(p->n_beams, p->n_samples);
+      const int n_teams = irec::team_count_for(p->n_beams, p->n_samples, pl.shape);
       const int tgrid = (int)std::min<int64_t>((n_blocks + n_teams - 1) / n_teams, pl.grid_cap / n_teams);
       HIP_TRY(irec::launch_encode_team(A, tgrid, st));
+      if (!ctx->d_dbg) { if (irec_status s2 = deferred_pass()) return s2; }
       if (ctx->d_dbg) { // diagnostic build (-DIREC_TEAM_STAMPS) only: per-wave phase cycles, wave 0 of a team vs the others
-        const int nwv = irec::team_waves_for(p->n_beams, p->n_samples);
+        const int nwv = irec::team_waves_for(p->n_beams, p->n_samples, pl.shape);
         std::vector<unsigned long long> h((size_t)tgrid * nwv * 16);
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(h.data(), ctx->d_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -556,7 +661,10 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
         fprintf(stderr, "  cycles per wave: %.0f | %.0f\n", t0 / (tgrid * nwv / 4), to / (tgrid * nwv * 3 / 4));
         return IREC_OK;
       }
-    } else HIP_TRY(irec::launch_encode_fast(A, true, grid, st));
+    } else {
+      HIP_TRY(irec::launch_encode_fast(A, true, grid, st));
+      if (irec_status s2 = deferred_pass()) return s2;
+    }
   } else if (pl.fast) {
     HIP_TRY(irec::launch_encode_fast(A, false, grid, st));
   } else {
@@ -597,7 +705,7 @@ irec_status irec_beam_decode(irec_context *ctx, const irec_params *p, int64_t n_
   if (!block_base || !block_pos || !block_dim || !p_loc || !p_scale || !K || !out_sample || (max_K > 0 && !indices))
     return fail(IREC_E_INVALID, "irec_beam_decode: null pointer argument");
   if (max_K < 0 || max_K > IREC_MAX_PARTITIONS) return fail(IREC_E_INVALID, "irec_beam_decode: max_K %d out of range", max_K);
-  HIP_TRY(hipSetDevice(ctx->device));
+  IREC_ON_DEVICE(ctx->device);
   irec::DecArgs A{};
   A.block_base = block_base; A.block_pos = block_pos; A.block_dim = block_dim; A.perm = perm;
   A.p_loc = p_loc; A.p_scale = p_scale; A.n_blocks = n_blocks; A.seed = seed; A.max_K = max_K; A.K = K;
@@ -610,14 +718,14 @@ irec_status irec_beam_decode(irec_context *ctx, const irec_params *p, int64_t n_
 irec_status irec_device_uniform_int(irec_context *ctx, int64_t seed, int64_t n, int32_t *out, void *hip_stream) {
   if (!ctx || n < 0 || (n > 0 && !out)) return fail(IREC_E_INVALID, "irec_device_uniform_int: bad arguments");
   if (n == 0) return IREC_OK;
-  HIP_TRY(hipSetDevice(ctx->device));
+  IREC_ON_DEVICE(ctx->device);
   HIP_TRY(irec::launch_uniform_int(seed, n, out, (hipStream_t)hip_stream));
   return IREC_OK;
 }
 
 irec_status irec_test_reduce_scatter(irec_context *ctx, const float *in, float *out, int32_t width, void *hip_stream) {
   if (!ctx || !in || !out || (width != 64 && width != 32 && width != 20 && width != 10)) return fail(IREC_E_INVALID, "irec_test_reduce_scatter: bad arguments");
-  HIP_TRY(hipSetDevice(ctx->device));
+  IREC_ON_DEVICE(ctx->device);
   HIP_TRY(irec::launch_reduce_scatter_test(in, out, width, (hipStream_t)hip_stream));
   return IREC_OK;
 }
@@ -627,7 +735,7 @@ irec_status irec_test_select(irec_context *ctx, const float *scores, int32_t n, 
   if (!ctx || !scores || !scratch_keys || !out_sel || n < 1 || n_select < 1 || n_select > n || n_select > IREC_MAX_BEAMS ||
       n_beams_cur < 1)
     return fail(IREC_E_INVALID, "irec_test_select: bad arguments");
-  HIP_TRY(hipSetDevice(ctx->device));
+  IREC_ON_DEVICE(ctx->device);
   HIP_TRY(irec::launch_select_test(scores, n, n_select, n_beams_cur, scratch_keys, out_sel, (hipStream_t)hip_stream));
   return IREC_OK;
 }
@@ -636,7 +744,7 @@ irec_status irec_test_proposal_table(irec_context *ctx, int64_t seed, int32_t n_
                                      uint16_t *out_tab, void *hip_stream) {
   if (!ctx || !out_tab || n_samples < 1 || dim < 1 || dim > irec::FAST_MAX_DIM || n_steps < 1)
     return fail(IREC_E_INVALID, "irec_test_proposal_table: bad arguments");
-  HIP_TRY(hipSetDevice(ctx->device));
+  IREC_ON_DEVICE(ctx->device);
   HIP_TRY(irec::launch_alpha_choice(seed, n_samples, dim, n_steps, ctx->d_dlog4r, out_tab, (hipStream_t)hip_stream));
   return IREC_OK;
 }

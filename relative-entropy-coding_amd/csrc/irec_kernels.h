@@ -29,6 +29,11 @@ struct EncArgs {
   unsigned int *counter; char *ws; size_t ws_per_wg; int32_t max_dim_pad;
   // shared proposal tables (beam-striped encoder): tab[q] serves blocks with block_dim == tab_dim[q]
   const uint16_t *tab[4]; int32_t tab_dim[4];
+  // The tables hold the first K_tab steps only (bounded workspace: O(K_tab * S * D), not O(max_K * S * D)).  A table-fed
+  // kernel leaves a block with K > K_tab uncoded (out_K[blk] = K is written) and bumps *defer_count; the host then runs
+  // the fused-Philox encoder with deferred_pass = 1, which codes exactly the blocks with K_tab < out_K[blk] <= max_K.
+  int32_t K_tab; int32_t deferred_pass; unsigned int *defer_count;
+  int32_t shape_override;   // team-encoder workgroup shape (diagnostics; 0 = default)
   // diagnostics (IREC_STAMPS=1): per-workgroup cycle sums [grid][8]; nullptr in normal runs
   unsigned long long *dbg;
 };
@@ -53,11 +58,14 @@ int fast_waves_for(int B, int S, bool table);
 hipError_t launch_alpha_table(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *dlog4r, uint16_t *tab,
                               hipStream_t st);
 // two-teams-per-CU encoder over three table copies (irec_team.hip)
-int team_count_for(int B, int S);           // teams per workgroup (= scratch slabs per workgroup) of the build that serves B beams
-int team_waves_for(int B, int S);
-size_t team_ws_extra_for(int B, int S); // extra scratch-slab bytes of that build           // waves per workgroup of that build
-size_t team_lds_for(int B, int S);   // LDS bytes of one workgroup, or (size_t)-1 when the configuration is not served
+// (shape_override: 0 = default shape, 1..4 = the diagnostic shapes of IREC_FLAG_SHAPE_*, see team_cfg() in irec_team.hip)
+int team_count_for(int B, int S, int shape_override);   // teams per workgroup (= scratch slabs per workgroup) of the build that serves B beams
+int team_waves_for(int B, int S, int shape_override);   // waves per workgroup of that build
+size_t team_ws_extra_for(int B, int S, int shape_override); // extra scratch-slab bytes of that build
+size_t team_lds_for(int B, int S, int shape_override);  // LDS bytes of one workgroup, or (size_t)-1 when the configuration is not served
 hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st);
+const char *team_kernel_name(int B, int S, int shape_override);   // e.g. "encode_team_kernel<20,2,1>"
+const char *fast_kernel_name(int B, int S, bool table);
 hipError_t launch_alpha_choice(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *dlog4r, uint16_t *tab,
                                hipStream_t st);
 hipError_t launch_decode(const DecArgs &A, int grid, hipStream_t st);

@@ -20,6 +20,7 @@
 // Compiled with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (no implicit fma: see irec_device.h).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "irec_device.h"
 #include "irec_kernels.h"
@@ -350,6 +351,11 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
     __syncthreads();
     const int64_t blk = misc[0];
     if (blk >= A.n_blocks) break; // every wave of every workgroup reaches this
+    if (!TABLE && A.deferred_pass) { // second pass of a windowed-table call: only the blocks the table kernels left
+      if (*A.defer_count == 0u) break;   // (uniform over the grid: nothing was deferred)
+      const int32_t k1 = A.out_K[blk];
+      if (k1 <= A.K_tab || k1 > A.max_K) continue;
+    }
     const int D = A.block_dim[blk];
     const int64_t base = A.block_base[blk];
     const int32_t pos = A.block_pos[blk];
@@ -409,6 +415,10 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
     }
     const int K = misc[1];
     if (K > A.max_K || K > IREC_MAX_PARTITIONS_DEV) continue;
+    if (TABLE && K > A.K_tab) { // beyond the table window: the fused-Philox pass codes it
+      if (tid == 0) atomicAdd(A.defer_count, 1u);
+      continue;
+    }
     if (K == 0) { // nothing to code: sample = p.loc
       if (active && sw == 0) {
 #pragma unroll
@@ -869,6 +879,12 @@ size_t fast_lds_for(int B, int S, bool table) {
   return p.s_pass >= 1 ? p.bytes : (size_t)-1;
 }
 int fast_waves_for(int B, int S, bool table) { const int nb = fast_nb_for(B); return nb ? fast_plan(nb, S, table).nw : 0; }
+const char *fast_kernel_name(int B, int S, bool table) {
+  static thread_local char buf[64];
+  const int nb = fast_nb_for(B);
+  snprintf(buf, sizeof buf, "encode_fast_kernel<%d,%d,%s>", nb, nb ? fast_plan(nb, S, table).nw : 0, table ? "true" : "false");
+  return buf;
+}
 
 size_t fast_ws_for(int B, int max_K) { return fast_ws_bytes(fast_nb_for(B), max_K); }
 size_t fast_ws_bytes_nb(int NB, int max_K) { return fast_ws_bytes(NB, max_K); }

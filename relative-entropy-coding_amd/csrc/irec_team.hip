@@ -22,7 +22,7 @@
 // waves split the beams into stripes (12 waves x 10 beams, 8 x 16, 8 x 10) and that scores the samples in passes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
+#include <stdio.h>
 
 #include "irec_device.h"
 #include "irec_kernels.h"
@@ -228,6 +228,10 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
     }
     const int K = misc[1];
     if (K > A.max_K || K > IREC_MAX_PARTITIONS_DEV) continue;
+    if (K > A.K_tab) { // beyond the table window: the fused-Philox pass codes it
+      if (tid == 0) atomicAdd(A.defer_count, 1u);
+      continue;
+    }
     if (K == 0) { // nothing to code: sample = p.loc
       if (active && sw == 0 && bs == 0) {
 #pragma unroll
@@ -709,23 +713,22 @@ __global__ __launch_bounds__(256) void alpha_choice_kernel(int64_t seed, int32_t
 //  launchers
 // ======================================================================================================
 // teams per workgroup / beam stripes per team.  Defaults: B <= 10: 3 x 1 where the LDS allows (else 2 x 1); B <= 20: 2 x 1
-// (8 waves per CU); B <= 30: 1 x 3.  Diagnostic overrides for B <= 20 through the environment: IREC_TEAMS=1, =2 (two teams
-// also for B <= 10), =3 (three 4-wave teams, 168 VGPRs), =2x2 (two 8-wave beam-striped teams, 128 VGPRs).
-static int team_cfg() {
-  static const int n = [] {
-    const char *e = getenv("IREC_TEAMS");
-    if (e && e[0] == '3') return 3;
-    if (e && e[0] == '1') return 1;
-    if (e && e[0] == '2' && e[1] != 'x') return 20;   // exactly two teams, also where three would be the default
-    if (e && e[0] == '2' && e[1] == 'x' && e[2] == '2') return 22;
-    return 2;
-  }();
-  return n;
+// (8 waves per CU); B <= 30: 1 x 3.  Diagnostic overrides for B <= 20 travel in irec_params.flags (IREC_FLAG_SHAPE_*, no
+// environment variable is read on the product path): cfg 1 = one team, 20 = exactly two teams (also where three would be
+// the default), 3 = three 4-wave teams (168 VGPRs), 22 = two 8-wave beam-striped teams (128 VGPRs).
+static int team_cfg(int shape_override) {
+  switch (shape_override) {
+    case 1: return 1;
+    case 2: return 20;
+    case 3: return 3;
+    case 4: return 22;
+    default: return 2;
+  }
 }
 // shape of the workgroup that serves B beams: beams per build, teams per workgroup, beam stripes per team
 struct TeamShape { int nb, teams, bs; };
-static TeamShape team_shape(int B, int S) {
-  const int cfg = team_cfg();
+static TeamShape team_shape(int B, int S, int ovr) {
+  const int cfg = team_cfg(ovr);
   // 10 beams: G is 40 registers per lane, three teams fit the register file (168 VGPRs) and, for small S, the LDS: +9 %
   if (B <= 10) return TeamShape{10, (cfg == 3 || (cfg == 2 && team_s_pass(10, S, 3, 1024) == S)) ? 3 : 2, 1};
   if (B <= 20) {
@@ -741,15 +744,21 @@ static TeamShape team_shape(int B, int S) {
   if (B <= 32) return TeamShape{32, 1, 2};   // one 8-wave team: two stripes of 16 beams
   return TeamShape{0, 0, 0};
 }
-int team_count_for(int B, int S) { return team_shape(B, S).teams; }
-int team_waves_for(int B, int S) { const TeamShape sh = team_shape(B, S); return sh.teams * sh.bs * TEAM_NW; }
-size_t team_ws_extra_for(int B, int S) { // scratch-slab bytes on top of fast_ws_for(): the sort keys when they do not fit the LDS
-  const TeamShape sh = team_shape(B, S);
+int team_count_for(int B, int S, int ovr) { return team_shape(B, S, ovr).teams; }
+int team_waves_for(int B, int S, int ovr) { const TeamShape sh = team_shape(B, S, ovr); return sh.teams * sh.bs * TEAM_NW; }
+size_t team_ws_extra_for(int B, int S, int ovr) { // scratch-slab bytes on top of fast_ws_for(): the sort keys when they do not fit the LDS
+  const TeamShape sh = team_shape(B, S, ovr);
   return (sh.nb && !team_keys_in_lds(sh.nb, S, sh.teams)) ? ((team_key_bytes(sh.nb, S) + 255) & ~(size_t)255) : 0;
 }
+const char *team_kernel_name(int B, int S, int ovr) {
+  static thread_local char buf[64];
+  const TeamShape sh = team_shape(B, S, ovr);
+  snprintf(buf, sizeof buf, "encode_team_kernel<%d,%d,%d>", sh.nb, sh.teams, sh.bs);
+  return buf;
+}
 
-size_t team_lds_for(int B, int S) {
-  const TeamShape sh = team_shape(B, S);
+size_t team_lds_for(int B, int S, int ovr) {
+  const TeamShape sh = team_shape(B, S, ovr);
   if (!sh.nb) return (size_t)-1;
   if ((int64_t)S * sh.nb >= (1 << 24)) return (size_t)-1;
   const int sp = team_s_pass(sh.nb, S, sh.teams, sh.teams == 1 ? 2048 : 1024);
@@ -771,7 +780,7 @@ static hipError_t launch_team_t(const EncArgs &A, int grid, hipStream_t st) {
 }
 
 hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
-  const TeamShape sh = team_shape(A.B, A.S);
+  const TeamShape sh = team_shape(A.B, A.S, A.shape_override);
   const int key = sh.nb * 100 + sh.teams * 10 + sh.bs;
   switch (key) {
     case 1021: return launch_team_t<10, 2, 1>(A, grid, st);

@@ -2,8 +2,11 @@
 import ctypes
 import os
 
+from .errors import IrecLibraryError  # noqa: F401  (re-exported: irec._lib.IrecLibraryError)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libirec_hip.so")
+# IREC_LIB_PATH: load a diagnostic build (csrc/variants/*.so) by path instead of copying it over the product library
+LIB_PATH = os.environ.get("IREC_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "csrc", "libirec_hip.so")
 
 IREC_OK = 0
 IREC_E_INVALID = -1
@@ -14,6 +17,10 @@ IREC_FLAG_FORCE_GENERIC = 1
 IREC_FLAG_FUSED_PHILOX = 2
 IREC_FLAG_ONE_TABLE = 4
 IREC_FLAG_TEAM = 8
+IREC_FLAG_SHAPE_SHIFT = 8          # diagnostic workgroup shapes of the team encoder (include/irec.h)
+IREC_FLAG_SHAPE = {"default": 0, "1": 1 << 8, "2": 2 << 8, "3": 3 << 8, "2x2": 4 << 8}
+IREC_TABLE_STEPS_DEFAULT = 32
+IREC_TABLE_STEPS_MAX = 64
 BIG_PRIME = 10007
 MAX_BEAMS = 64
 MAX_PARTITIONS = 65536
@@ -21,11 +28,19 @@ MAX_PARTITIONS = 65536
 
 class IrecParams(ctypes.Structure):
     _fields_ = [("kl_per_partition", ctypes.c_float), ("n_samples", ctypes.c_int32), ("n_beams", ctypes.c_int32),
-                ("flags", ctypes.c_int32), ("table_dims", ctypes.c_int32 * 4)]
+                ("flags", ctypes.c_int32), ("table_dims", ctypes.c_int32 * 4), ("table_steps", ctypes.c_int32)]
 
 
-class IrecLibraryError(RuntimeError):
-    pass
+class IrecPlanInfo(ctypes.Structure):
+    """irec_plan_info of include/irec.h."""
+    _fields_ = [("kernel", ctypes.c_char * 64), ("table_kernel", ctypes.c_char * 32), ("grid", ctypes.c_int32),
+                ("waves_per_wg", ctypes.c_int32), ("teams_per_wg", ctypes.c_int32), ("lds_bytes", ctypes.c_int32),
+                ("table_steps", ctypes.c_int32), ("n_tables", ctypes.c_int32), ("n_cu", ctypes.c_int32),
+                ("clock_mhz", ctypes.c_int32), ("table_bytes", ctypes.c_int64), ("workspace_bytes", ctypes.c_int64)]
+
+    def as_dict(self):
+        return {name: (getattr(self, name).decode() if isinstance(getattr(self, name), bytes) else int(getattr(self, name)))
+                for name, _ in self._fields_}
 
 
 _vp = ctypes.c_void_p
@@ -49,6 +64,7 @@ SIGNATURES = {
     "irec_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
     "irec_destroy": (None, [_vp]),
     "irec_encode_workspace_bytes": (ctypes.c_size_t, [_vp, _PP, _i32, _i32]),
+    "irec_encode_plan": (ctypes.c_int, [_vp, _PP, _i64, _i32, _i32, ctypes.POINTER(IrecPlanInfo)]),
     "irec_block_kl": (ctypes.c_int, [_vp, _PP, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "irec_beam_encode": (ctypes.c_int, [_vp, _PP, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32,
                                         _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),

@@ -13,6 +13,66 @@ from .. import _lib
 from ..engine import get_engine
 
 
+class MorePartitionsNeeded(CodingError):
+    """A block has K = ceil(KL / Omega) > max_K: it was NOT coded; encode again with max_K >= need."""
+
+    def __init__(self, need):
+        super().__init__(f"a block needs {need} partitions: encode again with max_K >= {need}")
+        self.need = need
+
+
+class PendingCode:
+    """Result of one asynchronous encode call: everything stays on the device until the host asks.
+    K [n_blocks] int32, idx [n_blocks, max_K] int32 (rows in layout order), sample (input shape)."""
+
+    def __init__(self, coder, lay, K, idx, sample, max_K):
+        self.coder, self.lay, self.K, self.idx, self.sample, self.max_K = coder, lay, K, idx, sample, max_K
+
+    def _lists(self, K_host, idx_host):
+        if (K_host < 0).any():
+            raise CodingError("a block exceeded the engine's dimension bound")
+        need = int(K_host.max()) if K_host.size else 0
+        self.coder._max_K_hint = max(self.coder._max_K_hint, need)
+        if need > _lib.MAX_PARTITIONS:
+            raise CodingError(f"KL divergence needs {need} partitions; this build supports {_lib.MAX_PARTITIONS}")
+        if need > self.max_K:
+            raise MorePartitionsNeeded(need)
+        lay, per_tensor = self.lay, []
+        bpt = lay.blocks_per_tensor
+        for i in range(lay.n_tensors):
+            blocks = []
+            for j in range(bpt):
+                row = lay.natural[i * bpt + j]
+                blocks.append([int(v) for v in idx_host[row, :K_host[row]]])
+            per_tensor.append(blocks)
+        return per_tensor
+
+    def to_lists(self):
+        """Indices per tensor per block (host lists): ONE device-to-host copy (K and the index rows together)."""
+        both = torch.cat([self.K[:, None], self.idx], dim=1).cpu().numpy()
+        return self._lists(both[:, 0], both[:, 1:])
+
+    @staticmethod
+    def gather(pendings):
+        """Indices of many calls (e.g. the 24 residual blocks of a model pass) with ONE device-to-host copy in all."""
+        if not pendings:
+            return []
+        width = max(p.idx.shape[1] for p in pendings)
+        rows = []
+        for p in pendings:
+            r = torch.cat([p.K[:, None], p.idx], dim=1)
+            if r.shape[1] < width + 1:
+                r = torch.nn.functional.pad(r, (0, width + 1 - r.shape[1]))
+            rows.append(r)
+        both = torch.cat(rows, dim=0).cpu().numpy()
+        out, at = [], 0
+        for p in pendings:
+            n = p.K.shape[0]
+            out.append(p._lists(both[at:at + n, 0], both[at:at + n, 1:1 + p.idx.shape[1]]))
+            at += n
+        return out
+
+
 class BeamSearchCoder(GaussianCoder):
     def __init__(self, kl_per_partition, n_beams, extra_samples=1., extrapolate_auxiliary_ratios=True,
                  name="gaussian_encoder", **kwargs):
@@ -26,6 +86,9 @@ class BeamSearchCoder(GaussianCoder):
         self.fused_philox = False    # debugging / testing knob: IREC_FLAG_FUSED_PHILOX
         self.one_table = False       # debugging / testing knob: IREC_FLAG_ONE_TABLE
         self.team = False            # debugging / testing knob: IREC_FLAG_TEAM (the team encoder also for small calls)
+        self.team_shape = "default"  # diagnostics: IREC_FLAG_SHAPE_* workgroup shape of the team encoder
+        self.table_steps = 0         # partitions the per-call proposal tables cover (0 = library default, 32); blocks
+                                     # with more are coded by the fused-Philox kernel in a second pass of the same call
         self._max_K_hint = 32
 
     # ---- small host-side mirrors ---------------------------------------------------------------------------------
@@ -51,8 +114,9 @@ class BeamSearchCoder(GaussianCoder):
         flags = (_lib.IREC_FLAG_FORCE_GENERIC if self.force_generic else 0) | \
                 (_lib.IREC_FLAG_FUSED_PHILOX if self.fused_philox else 0) | \
                 (_lib.IREC_FLAG_ONE_TABLE if self.one_table else 0) | \
-                (_lib.IREC_FLAG_TEAM if self.team else 0)
-        return get_engine().params(self.kl_per_partition, self.n_samples, self.n_beams, flags)
+                (_lib.IREC_FLAG_TEAM if self.team else 0) | _lib.IREC_FLAG_SHAPE[self.team_shape]
+        return get_engine().params(self.kl_per_partition, self.n_samples, self.n_beams, flags,
+                                   table_steps=self.table_steps)
 
     @staticmethod
     def _dev(t, device):
@@ -63,9 +127,10 @@ class BeamSearchCoder(GaussianCoder):
         t = torch.as_tensor(tensor)
         return get_engine(t.device if t.device.type == "cuda" else None)
 
-    def encode_tensors(self, q_loc, q_scale, p_loc, p_scale, seed, block_size):
-        """Batched core of encode / encode_block: leading dim = independent latent tensors.
-        Returns (indices per tensor per block, sample tensor on the input's device)."""
+    def encode_tensors_device(self, q_loc, q_scale, p_loc, p_scale, seed, block_size, max_K=None):
+        """Asynchronous core of encode: launches the encoder on the current stream and returns a `PendingCode` -- K,
+        indices and sample still on the device, NO host synchronisation.  The caller reads the indices when it needs
+        them (`PendingCode.to_lists`, one device-to-host copy; `PendingCode.gather` for many calls at once)."""
         src = torch.as_tensor(q_loc)
         eng = self._engine_for(src)
         params = self._params()
@@ -76,30 +141,20 @@ class BeamSearchCoder(GaussianCoder):
             raise CodingError("All tensor arguments supplied to split must have the same batch dimensions!")
         ql, qs, pl, ps = (self._dev(t, eng.device) for t in (q_loc, q_scale, p_loc, p_scale))
         lay = eng.layout(n_tensors, n, block_size, seed)
-        max_K = self._max_K_hint
-        while True:
-            K, idx, sample = eng.encode_blocks(params, lay, ql, qs, pl, ps, seed, max_K)
-            K_host = K.cpu().numpy()
-            if (K_host < 0).any():
-                raise CodingError("a block exceeded the engine's dimension bound")
-            need = int(K_host.max()) if K_host.size else 0
-            if need <= max_K:
-                break
-            if need > _lib.MAX_PARTITIONS:
-                raise CodingError(f"KL divergence needs {need} partitions; this build supports {_lib.MAX_PARTITIONS}")
-            max_K = need
-            self._max_K_hint = max(self._max_K_hint, need)
-        idx_host = idx.cpu().numpy()
-        per_tensor = []
-        bpt = lay.blocks_per_tensor
-        for i in range(n_tensors):
-            blocks = []
-            for j in range(bpt):
-                row = lay.natural[i * bpt + j]
-                blocks.append([int(v) for v in idx_host[row, :K_host[row]]])
-            per_tensor.append(blocks)
-        return per_tensor, sample.reshape(src.shape).to(src.device)
+        max_K = self._max_K_hint if max_K is None else int(max_K)
+        K, idx, sample = eng.encode_blocks(params, lay, ql, qs, pl, ps, seed, max_K)
+        return PendingCode(self, lay, K, idx, sample.reshape(src.shape).to(src.device), max_K)
 
+    def encode_tensors(self, q_loc, q_scale, p_loc, p_scale, seed, block_size):
+        """Batched core of encode / encode_block: leading dim = independent latent tensors.
+        Returns (indices per tensor per block, sample tensor on the input's device)."""
+        max_K = None
+        while True:
+            pending = self.encode_tensors_device(q_loc, q_scale, p_loc, p_scale, seed, block_size, max_K)
+            try:
+                return pending.to_lists(), pending.sample
+            except MorePartitionsNeeded as e:     # a block's KL asks for more partitions than the index buffer holds
+                max_K = e.need
     def decode_tensors(self, p_loc, p_scale, indices, seed, block_size):
         src = torch.as_tensor(p_loc)
         eng = self._engine_for(src)
@@ -148,13 +203,20 @@ class BeamSearchCoder(GaussianCoder):
         return out.reshape(loc.shape)
 
     def encode(self, target_dist, coding_dist, seed, **kwargs):
-        """GaussianCoder.encode, coder.py:412-457.  Extension: a leading batch dim N > 1 encodes N independent latent
-        tensors in one launch when `batched=True` is passed (the reference rejects N != 1, beam_search_coder.py:54-55)."""
+        """GaussianCoder.encode, coder.py:412-457.  Extensions (the reference rejects N != 1, beam_search_coder.py:54-55):
+        `batched=True`: a leading batch dim N > 1 encodes N independent latent tensors in one launch;
+        `defer=True`: returns (PendingCode, sample) without any host synchronisation -- the model shims use it to keep
+        the 24 sequential residual blocks of an image on the device and read all indices once at the end."""
         batched = kwargs.pop("batched", False)
-        if self.block_size is None and not batched:
+        defer = kwargs.pop("defer", False)
+        if self.block_size is None and not batched and not defer:
             return self.encode_block(target_dist, coding_dist, seed, **kwargs)
         if target_dist.loc.shape[0] != 1 and not batched:
             raise CodingError("For encoding, batch size must be 1.")
+        if defer:
+            pending = self.encode_tensors_device(target_dist.loc, target_dist.scale, coding_dist.loc, coding_dist.scale,
+                                                 seed, self.block_size, kwargs.pop("max_K", None))
+            return pending, pending.sample
         idx, sample = self.encode_tensors(target_dist.loc, target_dist.scale, coding_dist.loc, coding_dist.scale,
                                           seed, self.block_size)
         if self.block_size is None:

@@ -1,2 +1,3 @@
-class CodingError(Exception):
-    """Base exception for errors occurring in irec.coding (reference: rec/coding/utils.py:6)."""
+"""rec/coding/utils.py: CodingError (:6) and stateless_gumbel_sample (:9-12, as the host entry point behind
+ImportanceSampler's alpha < inf branch)."""
+from ..errors import CodingError  # noqa: F401

@@ -88,7 +88,7 @@ class Engine:
         _lib.check(self.lib.irec_create(self.index, ctypes.byref(ctx)), "irec_create")
         self.ctx = ctx
         self._layouts = {}
-        self._ws = None
+        self._ws = {}      # one scratch buffer per HIP stream: calls on different streams never share counters / slabs
 
     def __del__(self):
         try:
@@ -110,26 +110,41 @@ class Engine:
         return lay
 
     def workspace(self, params, max_dim, max_K):
+        """Scratch of the CURRENT torch stream (the C ABI is re-entrant; the scratch is what two concurrent calls must
+        not share: block counter, proposal tables, beam slabs)."""
         need = self.lib.irec_encode_workspace_bytes(self.ctx, ctypes.byref(params), int(max_dim), int(max_K))
         if need == 0:
             raise _lib.IrecLibraryError("irec_encode_workspace_bytes rejected the parameters: " +
                                         self.lib.irec_last_error().decode())
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws, need
+        key = int(torch.cuda.current_stream(self.device).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            if ws is None and len(self._ws) >= 16:
+                self._ws.clear()       # streams come and go: drop the lot rather than grow without bound
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws, need
+
+    def plan(self, params, lay, max_K):
+        """What irec_beam_encode launches for this call (kernel names, grid, LDS, table window): irec_encode_plan."""
+        params = self.with_table_dims(params, lay)
+        info = _lib.IrecPlanInfo()
+        _lib.check(self.lib.irec_encode_plan(self.ctx, ctypes.byref(params), lay.n_blocks, lay.max_dim, int(max_K),
+                                             ctypes.byref(info)), "irec_encode_plan")
+        return info.as_dict()
 
     @staticmethod
-    def params(kl_per_partition, n_samples, n_beams, flags=0, table_dims=()):
+    def params(kl_per_partition, n_samples, n_beams, flags=0, table_dims=(), table_steps=0):
         dims = list(table_dims)[:4] if len(table_dims) <= 4 else []
         dims = dims + [0] * (4 - len(dims))
         return _lib.IrecParams(float(np.float32(kl_per_partition)), int(n_samples), int(n_beams), int(flags),
-                               (ctypes.c_int32 * 4)(*dims))
+                               (ctypes.c_int32 * 4)(*dims), int(table_steps))
 
     @staticmethod
     def with_table_dims(params, lay):
         """Copy of `params` carrying the layout's distinct block dims (enables the per-call proposal tables)."""
         return Engine.params(params.kl_per_partition, params.n_samples, params.n_beams, params.flags,
-                             lay.distinct_dims)
+                             lay.distinct_dims, params.table_steps)
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

@@ -16,6 +16,21 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "both_suites: host-only test that runs in the CPU suite (-m 'not gpu') AND, as a "
+                                       "second item marked gpu, in the driver's -m gpu run on the GPU box")
+
+
+@pytest.fixture
+def suite(request):
+    """'cpu' or 'gpubox' -- which of the two items of a both_suites test this is."""
+    return getattr(request, "param", "cpu")
+
+
+def pytest_generate_tests(metafunc):
+    # The golden-vector tests of the wire format, the C-ABI symbol check and the importance-sampler tests need no GPU, but
+    # the driver only records what `-m gpu` ran on the GPU box: give each of them a second, gpu-marked item.
+    if metafunc.definition.get_closest_marker("both_suites") and "suite" in metafunc.fixturenames:
+        metafunc.parametrize("suite", ["cpu", pytest.param("gpubox", marks=pytest.mark.gpu)], indirect=True)
 
 
 def golden_files(kind=None):

@@ -11,6 +11,9 @@ import torch
 
 from conftest import ROOT
 
+pytestmark = [pytest.mark.both_suites, pytest.mark.usefixtures("suite")]   # also run (as gpu-marked items) by the driver on the GPU box
+
+
 
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "irec.h")).read()

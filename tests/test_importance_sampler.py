@@ -13,6 +13,9 @@ import torch
 import irec
 from irec.coding import CodingError, ImportanceSampler
 
+pytestmark = [pytest.mark.both_suites, pytest.mark.usefixtures("suite")]   # also run (as gpu-marked items) by the driver on the GPU box
+
+
 
 def _normal(loc, scale):
     return torch.distributions.Normal(torch.as_tensor(loc), torch.as_tensor(scale), validate_args=False)

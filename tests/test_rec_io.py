@@ -10,6 +10,9 @@ import pytest
 
 from conftest import GOLDEN_DIR
 
+pytestmark = [pytest.mark.both_suites, pytest.mark.usefixtures("suite")]   # also run (as gpu-marked items) by the driver on the GPU box
+
+
 
 def _ac_cases():
     g = np.load(os.path.join(GOLDEN_DIR, "rec_ac_vectors.npz"))
