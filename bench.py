@@ -126,9 +126,10 @@ def host_cores():
 def cpu_baselines(q, n_ref, n_opt_budget_s):
     """BASELINE.md §3, timed on the host cores of this box, rank 0 at N = 1 only.
     CPU-ref: reference-shaped torch-eager restatement of the TF path (oracle/ref_shaped_torch.py): 3 warm-ups, then 5
-             repeats of n_ref latents, median.  Thread count: all cores (the protocol's torch.set_num_threads(cpu_count))
-             and 32 are both probed on two latents and the FASTER setting is used -- eager torch on [S,B,1,D] tensors
-             stops scaling at a few dozen threads, and the baseline gets its best case.
+             repeats of n_ref latents, median.  Thread count: 16, 32 and 64 (capped at the core count) are probed on two
+             latents each and the FASTEST setting is used -- eager torch on [S,B,1,D] tensors stops scaling at a few dozen
+             threads (the protocol's torch.set_num_threads(cpu_count) = 256 on the GPU box runs at 0.005 latents/s), and
+             the baseline gets its best case.
     CPU-opt: the C oracle, OpenMP over blocks, all cores, for about n_opt_budget_s seconds."""
     import torch
     from oracle import oracle as O
@@ -142,7 +143,9 @@ def cpu_baselines(q, n_ref, n_opt_budget_s):
         return R.encode_tensor(*(h[i % n_host] for h in host), SEED, OMEGA, S, BEAMS, BLOCK_SIZE)
 
     probe = {}
-    for nt in sorted({cores, min(cores, 32)}):
+    # (measured once on the 256-thread GPU box, profiles/r02a/bench_default.err: 256 threads -> 0.005 latents/s against 3.9
+    # at 32 -- every eager op then pays a 256-way fork/join; the probe stops at 64 so that the bench finishes in minutes)
+    for nt in sorted({min(cores, 16), min(cores, 32), min(cores, 64)}):
         torch.set_num_threads(nt)
         ref(0)
         t0 = time.perf_counter()

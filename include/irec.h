@@ -114,13 +114,18 @@ irec_status irec_build_lut(float *lut10007);
 irec_status irec_tf_shuffle_perm(int64_t seed, int64_t n, int64_t *perm);
 
 /* ---- importance sampler (config 1 plumbing; the reference runs it on the CPU, and so does this: host memory) ---------
- * encode_gaussian_importance_sample with alpha = inf (rec/coding/importance_sampling.py:9-79): standardise the target
- * w.r.t. the coder, draw n_samples = ceil(exp(coding_bits * log 2)) proposals x[s] ~ N(0,1)^n from the stream of
- * tf.random.set_seed(seed); tfd.Normal(0,1).sample(n_samples) (:37,50-53), weight them by
- * sum_d [log N(x; t', s') - log N(x; 0, 1)] (:57-58) and return the index of the largest weight (first one on ties,
- * tf.argmax :64) and p_scale * x[index] + p_loc (:73-76).  n = number of dims of the (flattened) distributions. */
+ * encode_gaussian_importance_sample (rec/coding/importance_sampling.py:9-79): standardise the target w.r.t. the coder,
+ * draw n_samples = ceil(exp(coding_bits * log 2)) proposals x[s] ~ N(0,1)^n from the stream of tf.random.set_seed(seed);
+ * tfd.Normal(0,1).sample(n_samples) (:37,50-53), weight them by w[s] = sum_d [log N(x; t', s') - log N(x; 0, 1)] (:57-58).
+ *   alpha = inf : index = argmax_s w[s] (first one on ties, tf.argmax :64)
+ *   1 <= alpha  : index = argmax_s alpha * w[s] + g[s], g = stateless_gumbel_sample([n_samples], seed + 1) (:67-71;
+ *                 rec/coding/utils.py:9-12 puts a stateless NORMAL draw inside -log(-log(.)), so g is NaN for most s and
+ *                 tf.argmax skips those: reproduced as written)
+ *   alpha < 1   : error (:33-34)
+ * Returns the index and p_scale * x[index] + p_loc (:73-76).  n = number of dims of the (flattened) distributions. */
 irec_status irec_importance_encode(const float *t_loc, const float *t_scale, const float *p_loc, const float *p_scale,
-                                   int64_t n, double coding_bits, int64_t seed, int64_t *out_index, float *out_sample);
+                                   int64_t n, double coding_bits, double alpha, int64_t seed, int64_t *out_index,
+                                   float *out_sample);
 /* decode_gaussian_importance_sample (importance_sampling.py:82-103): sample `index` of the same stream. */
 irec_status irec_importance_decode(const float *p_loc, const float *p_scale, int64_t n, int64_t index, int64_t seed,
                                    float *out_sample);
@@ -129,6 +134,9 @@ int64_t irec_importance_n_samples(double coding_bits);
 /* out[e] = element e of tf.random.normal([count]) after tf.random.set_seed(seed) -- the stream behind
  * tfd.Normal.sample.  Host memory; test hook. */
 irec_status irec_tf_random_normal(int64_t seed, int64_t count, float *out);
+/* out[e] = element e of tf.random.stateless_normal([count], seed=[seed0, seed1]) -- the draw inside
+ * stateless_gumbel_sample (rec/coding/utils.py:9-12).  Host memory; test hook. */
+irec_status irec_tf_stateless_normal(int64_t seed0, int64_t seed1, int64_t count, float *out);
 
 /* out[e] = element e of tf.random.uniform([n], 1, 10007, seed=seed, dtype=int32) after tf.random.set_seed(seed)
  * -- beam_search_coder.py:38-43.  Host memory; test hook for the in-kernel Philox stream. */

@@ -656,17 +656,48 @@ int64_t irec_oracle_importance_n_samples(double coding_bits) { /* :50, float32 t
   return (nf >= 1.0f && nf < 2147483648.0f) ? (int64_t)nf : -1;
 }
 
-/* encode_gaussian_importance_sample, alpha = inf (:9-79).  Literal shape: all samples first (:53), then the weights.
- * The reduction order of reduce_sum (:57-58) is not reproducible; canonical: float64 sum in dim order, rounded once. */
+/* tf.random.stateless_normal([count], seed=[seed0, seed1]) (rec/coding/utils.py:11): stateless_random_ops.cc GenerateKey
+ * = one Philox block with key (0x3ec8f720, 0x02461e29) over counter (seed0 lo, hi, seed1 lo, hi); words 0-1 of the result are
+ * the stream's key, words 2-3 its upper counter half; then the Box-Muller fill of tf.random.normal.  [TF-src, unpinned] */
+void irec_oracle_tf_stateless_normal(int64_t seed0, int64_t seed1, int64_t count, float *out) {
+  const uint32_t k0[2] = {0x3ec8f720u, 0x02461e29u};
+  const uint32_t c0[4] = {(uint32_t)(uint64_t)seed0, (uint32_t)((uint64_t)seed0 >> 32), (uint32_t)(uint64_t)seed1,
+                          (uint32_t)((uint64_t)seed1 >> 32)};
+  uint32_t mix[4];
+  irec_oracle_philox4x32(k0, c0, mix);
+  const uint32_t key[2] = {mix[0], mix[1]};
+  for (int64_t g = 0; 4 * g < count; ++g) {
+    const uint32_t ctr[4] = {(uint32_t)(uint64_t)g, (uint32_t)((uint64_t)g >> 32), mix[2], mix[3]};
+    uint32_t x[4];
+    irec_oracle_philox4x32(key, ctr, x);
+    float f[4];
+    for (int h = 0; h < 2; ++h) {
+      const float epsilon = 1.0e-7f;
+      float u1 = oracle_uint32_to_float(x[2 * h]);
+      if (u1 < epsilon) u1 = epsilon;
+      const float v1 = (float)(2.0f * M_PI * oracle_uint32_to_float(x[2 * h + 1]));
+      const float u2 = sqrtf(-2.0f * logf(u1));
+      f[2 * h] = sinf(v1) * u2;
+      f[2 * h + 1] = cosf(v1) * u2;
+    }
+    for (int k = 0; k < 4 && 4 * g + k < count; ++k) out[4 * g + k] = f[k];
+  }
+}
+
+/* encode_gaussian_importance_sample (:9-79).  Literal shape: all samples first (:53), then the weights, then (alpha < inf)
+ * the Gumbel perturbation (:67-71) and the argmax.  The reduction order of reduce_sum (:57-58) is not reproducible;
+ * canonical: float64 sum in dim order, rounded once.  alpha < 1 returns -2 (the reference raises CodingError, :33-34). */
+#include <float.h>
 int64_t irec_oracle_importance_encode(const float *t_loc, const float *t_scale, const float *p_loc, const float *p_scale,
-                                      int64_t n, double coding_bits, int64_t seed, float *out_sample) {
+                                      int64_t n, double coding_bits, double alpha, int64_t seed, float *out_sample) {
   const int64_t S = irec_oracle_importance_n_samples(coding_bits);
+  if (!(alpha >= 1.0)) return -2;
   if (S < 1 || n < 1) return -1;
   float *samples = (float *)malloc(sizeof(float) * (size_t)(S * n));
-  if (!samples) return -1;
+  float *w = (float *)malloc(sizeof(float) * (size_t)S);
+  if (!samples || !w) return -1;
   irec_oracle_tf_random_normal(seed, S * n, samples);             /* proposal.sample(num_samples): N(0,1) * 1 + 0 */
   const float hl2pi = (float)(0.5 * log(2.0 * M_PI));              /* 0.5 * np.log(2 * np.pi) as a float32 constant */
-  int64_t best = 0; float best_w = 0.f;
   for (int64_t s = 0; s < S; ++s) {
     double acc = 0.0;
     for (int64_t d = 0; d < n; ++d) {
@@ -679,11 +710,19 @@ int64_t irec_oracle_importance_encode(const float *t_loc, const float *t_scale, 
       const float lp = -0.5f * (b * b) - (hl2pi + logf(1.0f));
       acc += (double)(lt - lp);                                     /* :57 */
     }
-    const float w = (float)acc;
-    if (s == 0 || w > best_w) { best_w = w; best = s; }             /* tf.argmax (:64): first maximum */
+    w[s] = (float)acc;
   }
+  if (!isinf(alpha)) {                                              /* :67-71 */
+    float *g = (float *)malloc(sizeof(float) * (size_t)S);
+    irec_oracle_tf_stateless_normal(seed + 1, seed + 2, S, g);     /* stateless_gumbel_sample(shape, seed + 1): [seed, seed + 1] of ITS seed */
+    for (int64_t s = 0; s < S; ++s) w[s] = (float)alpha * w[s] + (-logf(-logf(g[s])));
+    free(g);
+  }
+  int64_t best = 0; float best_w = -FLT_MAX;                        /* Eigen ArgMaxTupleReducer: (0, lowest()), strict > */
+  for (int64_t s = 0; s < S; ++s)
+    if (w[s] > best_w) { best_w = w[s]; best = s; }                 /* tf.argmax: first maximum, NaN never selected */
   for (int64_t d = 0; d < n; ++d) out_sample[d] = p_scale[d] * samples[best * n + d] + p_loc[d]; /* :73-76 */
-  free(samples);
+  free(samples); free(w);
   return best;
 }
 

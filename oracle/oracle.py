@@ -75,7 +75,9 @@ def lib():
         L.irec_oracle_tf_random_normal.argtypes = [ctypes.c_int64, ctypes.c_int64, f32p]
         L.irec_oracle_importance_n_samples.argtypes = [ctypes.c_double]
         L.irec_oracle_importance_n_samples.restype = ctypes.c_int64
-        L.irec_oracle_importance_encode.argtypes = [f32p, f32p, f32p, f32p, ctypes.c_int64, ctypes.c_double, ctypes.c_int64, f32p]
+        L.irec_oracle_tf_stateless_normal.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, f32p]
+        L.irec_oracle_importance_encode.argtypes = [f32p, f32p, f32p, f32p, ctypes.c_int64, ctypes.c_double, ctypes.c_double,
+                                                    ctypes.c_int64, f32p]
         L.irec_oracle_importance_encode.restype = ctypes.c_int64
         L.irec_oracle_importance_decode.argtypes = [f32p, f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, f32p]
         _lib = L
@@ -274,11 +276,17 @@ def importance_n_samples(coding_bits):
     return int(lib().irec_oracle_importance_n_samples(float(coding_bits)))
 
 
-def importance_encode(t_loc, t_scale, p_loc, p_scale, coding_bits, seed):
+def tf_stateless_normal(seed0, seed1, count):
+    o = np.zeros(count, dtype=np.float32)
+    lib().irec_oracle_tf_stateless_normal(int(seed0), int(seed1), int(count), _p(o, ctypes.c_float))
+    return o
+
+
+def importance_encode(t_loc, t_scale, p_loc, p_scale, coding_bits, seed, alpha=float("inf")):
     tl, ts, pl, ps = (_f32(a).reshape(-1) for a in (t_loc, t_scale, p_loc, p_scale))
     out = np.zeros_like(tl)
     idx = lib().irec_oracle_importance_encode(_p(tl, ctypes.c_float), _p(ts, ctypes.c_float), _p(pl, ctypes.c_float),
-                                              _p(ps, ctypes.c_float), tl.size, float(coding_bits), int(seed),
+                                              _p(ps, ctypes.c_float), tl.size, float(coding_bits), float(alpha), int(seed),
                                               _p(out, ctypes.c_float))
     return int(idx), out.reshape(np.shape(t_loc))
 

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -241,6 +242,32 @@ struct TfNormalStream {
   }
 };
 
+// stream of tf.random.stateless_normal(shape, seed=[seed0, seed1]) (rec/coding/utils.py:9-12): stateless_random_ops.cc
+// GenerateKey scrambles the seed pair with one Philox block under the fixed key (0x3ec8f720, 0x02461e29) and counter
+// (seed0 lo, seed0 hi, seed1 lo, seed1 hi); the result's words 0-1 become the key, words 2-3 the upper counter half; the
+// fill is the stateful kernel's (Box-Muller on consecutive uint32 pairs, four outputs per Philox block, no skip).
+struct TfStatelessNormalStream {
+  Philox gen;
+  uint64_t have = ~0ull;
+  float f[4];
+  TfStatelessNormalStream(int64_t seed0, int64_t seed1) : gen(0, 0) {
+    const Philox scramble(((uint64_t)0x02461e29u << 32) | 0x3ec8f720u, (uint64_t)seed1);
+    uint32_t mix[4];
+    scramble.block((uint64_t)seed0, mix);
+    gen = Philox(((uint64_t)mix[1] << 32) | mix[0], ((uint64_t)mix[3] << 32) | mix[2]);
+  }
+  float element(uint64_t e) {
+    if ((e >> 2) != have) {
+      uint32_t o[4];
+      gen.block(e >> 2, o);
+      box_muller(o[0], o[1], f[0], f[1]);
+      box_muller(o[2], o[3], f[2], f[3]);
+      have = e >> 2;
+    }
+    return f[e & 3];
+  }
+};
+
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
 size_t round_up_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
@@ -314,10 +341,19 @@ irec_status irec_tf_random_normal(int64_t seed, int64_t count, float *out) {
   return IREC_OK;
 }
 
+irec_status irec_tf_stateless_normal(int64_t seed0, int64_t seed1, int64_t count, float *out) {
+  if (count < 0 || (count > 0 && !out)) return fail(IREC_E_INVALID, "irec_tf_stateless_normal: bad arguments");
+  TfStatelessNormalStream st(seed0, seed1);
+  for (int64_t e = 0; e < count; ++e) out[e] = st.element((uint64_t)e);
+  return IREC_OK;
+}
+
 irec_status irec_importance_encode(const float *t_loc, const float *t_scale, const float *p_loc, const float *p_scale,
-                                   int64_t n, double coding_bits, int64_t seed, int64_t *out_index, float *out_sample) {
+                                   int64_t n, double coding_bits, double alpha, int64_t seed, int64_t *out_index,
+                                   float *out_sample) {
   if (!t_loc || !t_scale || !p_loc || !p_scale || !out_index || !out_sample || n < 1)
     return fail(IREC_E_INVALID, "irec_importance_encode: bad arguments");
+  if (!(alpha >= 1.0)) return fail(IREC_E_INVALID, "Alpha must be in the range [1, inf), but %g was given!", alpha); // :33-34
   const int64_t S = irec_importance_n_samples(coding_bits);
   if (S < 1) return fail(IREC_E_INVALID, "irec_importance_encode: coding_bits %g gives no valid sample count", coding_bits);
   // standardise the target w.r.t. the coding distribution (:40-41); per-dim constants of Normal.log_prob (TFP 0.9)
@@ -329,8 +365,13 @@ irec_status irec_importance_encode(const float *t_loc, const float *t_scale, con
     ln_t[d] = half_log_2pi + std::log(ts[d]);
   }
   TfNormalStream st(seed);
-  float best = 0.f;
-  int64_t best_s = -1;
+  // alpha < inf: Gumbel-max over alpha * w + g (:67-71), g = stateless_gumbel_sample([S], seed + 1) =
+  // -log(-log(stateless_normal([S], [seed + 1, seed + 2]))) (rec/coding/utils.py:9-12 -- a NORMAL draw inside the double
+  // log, as the reference has it: g is NaN wherever the draw is outside (0, 1]; tf.argmax never selects a NaN).
+  const bool gumbel = !std::isinf(alpha);
+  TfStatelessNormalStream gst(seed + 1, seed + 2);
+  float best = -FLT_MAX;   // Eigen's ArgMaxTupleReducer: accumulator starts at (0, lowest()) and moves on a strict ">"
+  int64_t best_s = 0;
   for (int64_t s = 0; s < S; ++s) {
     double acc = 0.0; // canonical reduction: float32 terms, summed in float64 in dim order, rounded to float32 once
     for (int64_t d = 0; d < n; ++d) {
@@ -341,8 +382,9 @@ irec_status irec_importance_encode(const float *t_loc, const float *t_scale, con
       const float lp_p = -0.5f * (dp * dp) - (half_log_2pi + 0.0f);
       acc += (double)(lp_t - lp_p);
     }
-    const float w = (float)acc;
-    if (best_s < 0 || w > best) { best = w; best_s = s; } // tf.argmax: first maximum
+    float w = (float)acc;
+    if (gumbel) w = (float)alpha * w + (-std::log(-std::log(gst.element((uint64_t)s))));
+    if (w > best) { best = w; best_s = s; } // tf.argmax: first maximum; a NaN never compares greater
   }
   *out_index = best_s;
   for (int64_t d = 0; d < n; ++d) out_sample[d] = p_scale[d] * st.element((uint64_t)(best_s * n + d)) + p_loc[d];

@@ -57,7 +57,9 @@ SIGNATURES = {
     "irec_build_lut": (ctypes.c_int, [_vp]),
     "irec_tf_shuffle_perm": (ctypes.c_int, [_i64, _i64, _vp]),
     "irec_philox_uniform_int": (ctypes.c_int, [_i64, _i64, _vp]),
-    "irec_importance_encode": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, ctypes.c_double, _i64, ctypes.POINTER(_i64), _vp]),
+    "irec_importance_encode": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, ctypes.c_double, ctypes.c_double, _i64,
+                                              ctypes.POINTER(_i64), _vp]),
+    "irec_tf_stateless_normal": (ctypes.c_int, [_i64, _i64, _i64, _vp]),
     "irec_importance_decode": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
     "irec_importance_n_samples": (_i64, [ctypes.c_double]),
     "irec_tf_random_normal": (ctypes.c_int, [_i64, _i64, _vp]),

@@ -65,11 +65,16 @@ class PendingCode:
                 r = torch.nn.functional.pad(r, (0, width + 1 - r.shape[1]))
             rows.append(r)
         both = torch.cat(rows, dim=0).cpu().numpy()
-        out, at = [], 0
+        out, at, retry = [], 0, None
         for p in pendings:
             n = p.K.shape[0]
-            out.append(p._lists(both[at:at + n, 0], both[at:at + n, 1:1 + p.idx.shape[1]]))
+            try:
+                out.append(p._lists(both[at:at + n, 0], both[at:at + n, 1:1 + p.idx.shape[1]]))
+            except MorePartitionsNeeded as e:     # keep going: every coder's hint is raised before the caller codes again
+                retry = e if retry is None or e.need > retry.need else retry
             at += n
+        if retry is not None:
+            raise retry
         return out
 
 

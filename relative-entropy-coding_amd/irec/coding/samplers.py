@@ -4,12 +4,14 @@
 on the CPU -- e^KL standard-normal proposals from TensorFlow's global Philox stream, an argmax over their importance
 weights (importance_sampling.py:9-103) -- and so does this mirror: it calls the host-side entry points
 `irec_importance_encode / _decode` of libirec_hip.so (include/irec.h), which need no GPU.  It is not on the
-`sampler='beam_search'` hot path and no device kernel is involved.  Only `alpha = inf` (the reference's default, the
-setting its models use: resnet_vae.py:126-131) is built; the rejection sampler is out of scope.
+`sampler='beam_search'` hot path and no device kernel is involved.  Both branches are built: `alpha = inf` (the
+reference's default, the setting its models use: resnet_vae.py:126-131) takes the argmax of the importance weights,
+`1 <= alpha < inf` the Gumbel-max of importance_sampling.py:67-71 over `stateless_gumbel_sample`
+(rec/coding/utils.py:9-12).  The rejection sampler is out of scope.
 """
 import abc
 import ctypes
-import math
+import math  # noqa: F401
 
 import numpy as np
 import torch
@@ -58,11 +60,8 @@ class ImportanceSampler(Sampler):
         self.coding_bits = coding_bits
 
     def _check_alpha(self):
-        if self.alpha < 1.:   # importance_sampling.py:33-34
+        if not self.alpha >= 1.:   # importance_sampling.py:33-34
             raise CodingError(f"Alpha must be in the range [1, inf), but {self.alpha} was given!")
-        if not math.isinf(self.alpha):
-            raise CodingError("only alpha = inf (argmax of the importance weights) is built; the Gumbel-max branch "
-                              "(importance_sampling.py:67-71) needs tf.random.stateless_normal")
 
     def n_samples(self):
         """ceil(exp(coding_bits * log 2)) in float32 (importance_sampling.py:50)."""
@@ -79,7 +78,8 @@ class ImportanceSampler(Sampler):
         out = np.empty_like(pl)
         idx = ctypes.c_int64(-1)
         _lib.check(_lib.load().irec_importance_encode(_ptr(tl), _ptr(ts), _ptr(pl), _ptr(ps), pl.size,
-                                                      float(self.coding_bits), int(seed), ctypes.byref(idx), _ptr(out)),
+                                                      float(self.coding_bits), float(self.alpha), int(seed),
+                                                      ctypes.byref(idx), _ptr(out)),
                    "irec_importance_encode")
         return int(idx.value), torch.from_numpy(out).reshape(loc.shape).to(loc.device)
 

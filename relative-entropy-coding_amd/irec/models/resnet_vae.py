@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..coding import BeamSearchCoder
+from ..coding.beam_search_coder import MorePartitionsNeeded, PendingCode
 
 
 class ModelError(Exception):
@@ -168,27 +169,53 @@ class BidirectionalResNetVAE(nn.Module):
 
     @torch.no_grad()
     def compress(self, image, seed, update_sampler=False):
-        """resnet_vae.py:803-836.  image: [1, 3, H, W] in [-0.5, 0.5].  Returns (block_indices, reconstruction)."""
+        """resnet_vae.py:803-836.  image: [N, 3, H, W] in [-0.5, 0.5].  Returns (block_indices, reconstruction).
+
+        N = 1 (the reference's only case): block_indices[res_block][coder_block] = list of indices, as the reference returns.
+        N > 1 (extension): the N images go through every residual block together -- one coder launch per residual block
+        for all of them -- and block_indices[image][res_block][coder_block].
+        Nothing is copied to the host until the last residual block has been coded: each block's `coder.encode(...,
+        defer=True)` leaves its K / index rows on the device and hands the merged sample straight to the next block's
+        convolutions; ONE device-to-host copy then fetches all indices of all blocks and images."""
         batch_size, _, height, width = image.shape
-        with deterministic_transforms():
-            tensor = self.first_infer_conv(image)
-            for resnet_block in list(self.residual_blocks)[::-1]:             # inference pass, reverse order (:811-813)
-                tensor = resnet_block(tensor, inference_pass=True)
-            tensor = self.generative_base(batch_size=batch_size, width=width, height=height)
-            block_indices = []
-            for resnet_block in self.residual_blocks:                         # strictly sequential (:821-826)
-                indices, tensor = resnet_block(tensor, inference_pass=False,
-                                               encoder_args={"seed": seed, "update_sampler": update_sampler})
-                block_indices.append(indices)
-            return block_indices, self._finish(tensor)
+        for _attempt in range(6):
+            with deterministic_transforms():
+                tensor = self.first_infer_conv(image)
+                for resnet_block in list(self.residual_blocks)[::-1]:         # inference pass, reverse order (:811-813)
+                    tensor = resnet_block(tensor, inference_pass=True)
+                tensor = self.generative_base(batch_size=batch_size, width=width, height=height)
+                pendings = []
+                for resnet_block in self.residual_blocks:                     # strictly sequential (:821-826)
+                    pending, tensor = resnet_block(tensor, inference_pass=False,
+                                                   encoder_args={"seed": seed, "update_sampler": update_sampler,
+                                                                 "batched": True, "defer": True})
+                    pendings.append(pending)
+                reconstruction = self._finish(tensor)
+            try:
+                per_block = PendingCode.gather(pendings)     # [res_block][image][coder_block]; the only host sync
+                break
+            except MorePartitionsNeeded:
+                continue   # some block's KL needs more index slots than the coders' hint: the hints are raised, code again
+        else:
+            raise MorePartitionsNeeded(max(b.coder._max_K_hint for b in self.residual_blocks) + 1)
+        flat = [blk.coder.block_size is None for blk in self.residual_blocks]   # no block_size: one index list per tensor
+        per_block = [[img[0] if flat[r] else img for img in blk] for r, blk in enumerate(per_block)]
+        if batch_size == 1:
+            return [blk[0] for blk in per_block], reconstruction
+        return [[blk[i] for blk in per_block] for i in range(batch_size)], reconstruction
 
     @torch.no_grad()
     def decompress(self, block_indices, seed, image_shape):
         """The generative pass driven by the stored indices.  (The reference's own decompress, resnet_vae.py:844-860,
-        is an unfinished stub; this is the pass its decoder_args plumbing implies.)"""
+        is an unfinished stub; this is the pass its decoder_args plumbing implies.)  image_shape[0] = N > 1 takes the
+        batched form of `compress`'s block_indices."""
         batch_size, _, height, width = image_shape
         with deterministic_transforms():
             tensor = self.generative_base(batch_size=batch_size, width=width, height=height)
-            for resnet_block, indices in zip(self.residual_blocks, block_indices):
-                tensor = resnet_block(tensor, inference_pass=False, decoder_args={"seed": seed, "indices": indices})
+            for r, resnet_block in enumerate(self.residual_blocks):
+                if batch_size == 1:
+                    args = {"seed": seed, "indices": block_indices[r]}
+                else:
+                    args = {"seed": seed, "indices": [block_indices[i][r] for i in range(batch_size)], "batched": True}
+                tensor = resnet_block(tensor, inference_pass=False, decoder_args=args)
             return self._finish(tensor)

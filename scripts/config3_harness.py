@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[2] end to end on this rank's GPU: 300 Cifar10-shaped images through the 24-block RVAE shim
+(random-init weights: no checkpoint exists), image i -> rank i mod G, per-GPU share compressed as ONE batch
+(38 images: one coder launch per residual block), .rec written / read back / compared per image, bits gathered.
+Also times single-image compression (N = 1: the reference's only mode).  Diagnostic; prints one JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "relative-entropy-coding_amd")]
+
+
+def build_model(device, blocks=24):
+    from irec.models import BidirectionalResNetVAE
+    torch.manual_seed(0)
+    m = BidirectionalResNetVAE(num_res_blocks=blocks, sampler="beam_search",
+                               sampler_args={"n_beams": 20, "extra_samples": 1.2}, coder_args={"block_size": 1000},
+                               deterministic_filters=160, stochastic_filters=32, kl_per_partition=3.)
+    with torch.no_grad():   # keep posteriors near priors so that K ~ 6..10 per 1000-dim block, as on trained models' latents
+        for b in m.residual_blocks:
+            for head in (b.gen_posterior_loc_head, b.gen_posterior_log_scale_head, b.infer_posterior_loc_head,
+                         b.infer_posterior_log_scale_head, b.prior_loc_head, b.prior_log_scale_head):
+                head.weight.mul_(0.25)
+        m._generative_base.normal_(0, 0.5)
+    return m.to(device).eval()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=300)
+    ap.add_argument("--blocks", type=int, default=24)
+    ap.add_argument("--singles", type=int, default=8, help="images timed one at a time (N = 1)")
+    args = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend=os.environ.get("IREC_DIST_BACKEND", "nccl"))
+    from irec import harness, sharding
+    model = build_model(device, args.blocks)
+    g = torch.Generator().manual_seed(7)
+    images = torch.rand(args.images, 3, 32, 32, generator=g) - 0.5
+    out_dir = tempfile.mkdtemp(prefix=f"irec_cfg3_r{rank}_")
+    share = len(sharding.shard_indices(args.images, rank, world))
+    harness.compress_sharded(model, images[:2 * world], 42, 1000, out_dir, rank, world, dist)       # warm-up (MIOpen, tables)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rows, all_bits, all_nats = harness.compress_sharded(model, images, 42, 1000, out_dir, rank, world, dist)
+    torch.cuda.synchronize()
+    t_batch = time.perf_counter() - t0
+    t_model = 0.0
+    for _ in range(3):   # model.compress alone on the share (no file I/O)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        model.compress(images[torch.as_tensor(sharding.shard_indices(args.images, rank, world))].to(device), seed=42)
+        torch.cuda.synchronize(); t_model = time.perf_counter() - t1
+    singles = []
+    for i in range(args.singles):
+        x = images[i:i + 1].to(device)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        model.compress(x, seed=42)
+        torch.cuda.synchronize(); singles.append(time.perf_counter() - t1)
+    if rank == 0:
+        ok = [r for r in rows if "error" not in r]
+        print(json.dumps({
+            "config": f"{args.images} images 32x32, {args.blocks}-block RVAE shim, B=20 Omega=3 eps=0.2, {world} rank(s)",
+            "images_this_rank": share, "all_indices_recovered": all(r["indices_recovered"] for r in ok), "errors": len(rows) - len(ok),
+            "share_seconds_incl_rec_io": t_batch, "images_per_s_incl_rec_io": share / t_batch,
+            "model_compress_seconds_share": t_model, "images_per_s_model_compress": share / t_model,
+            "latents_per_s_model_compress": share * args.blocks / t_model,
+            "single_image_ms": [round(1e3 * s, 2) for s in singles], "single_image_ms_median": 1e3 * sorted(singles)[len(singles) // 2],
+            "mean_bits_per_image": float(all_bits.mean()), "mean_code_bpd": float(all_bits.mean()) / (32 * 32 * 3),
+            "mean_code_nats": float(all_nats.mean()), "gathered_items": int(all_bits.numel())}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

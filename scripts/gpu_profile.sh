@@ -3,8 +3,8 @@
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-L=${LATENTS:-1024}
-TAG=${TAG:-r01}
+L=${LATENTS:-2048}
+TAG=${TAG:-r02}
 echo "== quick parity"; timeout 600 python -m pytest tests -x -q -m gpu -k "golden or full_size or reduce_scatter" 2>&1 | tail -3
 echo "== bench"; timeout 600 python bench.py --steps 5 --warmup 2 --latents $L --no-cpu-baseline 2>&1 | tail -4 | tee gpurun_out/bench_$TAG.log
 echo "== kernel trace"
@@ -24,3 +24,4 @@ fi
 # keep only the small summaries
 find gpurun_out/prof_$TAG -name "*.csv" -size +2M -delete
 du -sh gpurun_out/prof_$TAG
+python scripts/make_traffic_json.py gpurun_out/prof_$TAG $L ${KERNEL:-encode_team} > gpurun_out/prof_$TAG/traffic.json 2>&1 || true

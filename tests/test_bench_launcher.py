@@ -1,0 +1,66 @@
+"""bench.py --gpus N must START N ranks (round-1 verdict: the flag used to be parsed and ignored).
+
+CPU: the launcher, the rendezvous, the code-length exchange and the JSON contract with IREC_BENCH_LAUNCH_ONLY=1 (gloo,
+no GPU work).  GPU box (one MI355X): the real bench with two ranks sharing the device over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra, timeout=600):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_launcher_starts_n_ranks_cpu_rig(n):
+    r = _run(["--gpus", str(n), "--steps", "2", "--warmup", "1"], {"IREC_BENCH_LAUNCH_ONLY": "1"}, timeout=180)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                    # ONE JSON line, from rank 0
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == n and res["world_size"] == n and res["ranks_timed"] == n
+    assert res["steps"] == 2 and res["warmup"] == 1
+
+
+def test_world_size_mismatch_is_an_error():
+    r = _run(["--gpus", "2"], {"IREC_BENCH_LAUNCH_ONLY": "1", "WORLD_SIZE": "3", "RANK": "0"}, timeout=60)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_a_failing_rank_fails_the_job():
+    # without the launch-only switch and without a GPU every rank exits non-zero ("no CPU fallback"): the launcher must
+    # report failure instead of relaying a line
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], {}, timeout=180)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_over_gloo():
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--latents", "128", "--no-cpu-baseline"],
+             {"IREC_DIST_BACKEND": "gloo"}, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["world_size"] == 2 and res["backend"] == "gloo"
+    assert len(res["per_rank_latents_per_s"]) == 2 and res["value"] > 0
+    assert res["roofline"]["kernel"].startswith("encode_") and res["scaling"] == "weak"
+
+
+@pytest.mark.gpu
+def test_single_rank_line_is_self_describing():
+    r = _run(["--steps", "2", "--warmup", "1", "--latents", "256", "--no-cpu-baseline"], {}, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 1 and res["roofline"]["kernel"] == "encode_team_kernel<20,2,1>"
+    assert res["roofline"]["bound"] == "hbm" and 0 < res["roofline"]["frac"] < 1
+    assert res["secondary"]["lds_hw"]["peak"] == 32.0 and res["secondary"]["n_cu"] == 256

@@ -407,3 +407,117 @@ def test_config4_kodak_shapes_full_size(engine, oracle):
 def test_config5_stress_full_size(engine, oracle):
     # BASELINE configs[4]: ImageNet32 RVAE latents, B = 30, Omega = 5 (S = 148): 4440 candidates per step
     _full_size_check(engine, oracle, 96, 8192, 1000, 5.0, 1.0, 30, n_oracle_blocks=6, gen_seed=63)
+
+
+# ---- round 2: bounded proposal tables, plan export, per-stream scratch ------------------------------------------------
+def test_table_window_mixed_partition_counts_fit_256mb(engine, oracle):
+    """Blocks with K = 7..8 and blocks with K ~ 3000 in ONE call at S = 403 (Omega = 5, eps = 0.2): the proposal tables
+    cover 32 steps whatever max_K is, the high-K blocks take the fused-Philox second pass, the scratch stays under
+    256 MB and every output is the oracle's, bit for bit."""
+    n, bs, omega, eps1, B = 1064, 1000, 5.0, 1.2, 20
+    S = oracle.n_samples(omega, eps1)
+    assert S == 403
+    lat = [list(oracle.synthetic_latent(900 + i, n)) for i in range(3)]
+    perm = oracle.tf_shuffle_perm(42, n)
+    tail = perm[1000:]                                     # the 64-dim tail block of every tensor
+    for i, l in enumerate(lat):
+        if i != 1:                                         # tensors 0 and 2: a tail block ~ 235 nats/dim -> K ~ 3000
+            l[0][tail] = (l[2][tail] + 21.7 * l[3][tail]).astype(np.float32)
+    q = [np.stack([l[j] for l in lat]) for j in range(4)]
+    c = _coder(omega, B, eps1, block_size=bs, variant="table")
+    idx, sample = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)
+    Ks = [[len(b) for b in t] for t in idx]
+    assert max(Ks[0]) > 2500 and max(Ks[1]) <= 32 and max(Ks[2]) > 2500, Ks
+    for i in range(3):
+        ridx, rs = oracle.encode_tensor(q[0][i], q[1][i], q[2][i], q[3][i], 42, omega, S, B, block_size=bs) \
+            if max(Ks[i]) <= 32 else (None, None)
+        if ridx is None:   # the oracle's per-tensor wrapper caps max_K at 4096: fine here
+            ridx, rs = oracle.encode_tensor(q[0][i], q[1][i], q[2][i], q[3][i], 42, omega, S, B, block_size=bs)
+        assert idx[i] == ridx, i
+        assert np.array_equal(sample[i].cpu().numpy(), rs), i
+    lay = engine.layout(3, n, bs, 42)
+    plan = engine.plan(c._params(), lay, max(max(k) for k in Ks))
+    assert plan["table_steps"] == 32 and plan["workspace_bytes"] < 256 * 2 ** 20, plan
+    # round trip through the decoder
+    rec = c.decode(_normal(q[2], q[3]), idx, seed=42, batched=True)
+    assert torch.equal(rec, sample)
+
+
+@pytest.mark.parametrize("steps", [1, 4, 7])
+def test_short_table_window_is_bit_exact(engine, oracle, steps):
+    """table_steps below the blocks' K: everything goes through the second pass, or is split between the passes."""
+    q = [np.stack([oracle.synthetic_latent(40 + i, 8192)[j] for i in range(8)]) for j in range(4)]
+    for variant in ("table", "one_table"):
+        c = _coder(3.0, 20, 1.2, block_size=1000, variant=variant)
+        c.table_steps = steps
+        idx, sample = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)
+        for i in (0, 5):
+            ridx, rs = oracle.encode_tensor(q[0][i], q[1][i], q[2][i], q[3][i], 42, 3.0, 36, 20, block_size=1000)
+            assert idx[i] == ridx and np.array_equal(sample[i].cpu().numpy(), rs), (variant, steps, i)
+
+
+def test_plan_names_the_kernels_that_run(engine, oracle):
+    import irec
+    S = 36
+    big = engine.layout(64, 8192, 1000, 42)
+    small = engine.layout(1, 8192, 1000, 42)
+    p = engine.params(3.0, S, 20)
+    assert engine.plan(p, big, 32)["kernel"] == "encode_team_kernel<20,2,1>"
+    assert engine.plan(p, big, 32)["table_kernel"] == "alpha_choice_kernel"
+    assert engine.plan(p, small, 32)["kernel"].startswith("encode_fast_kernel<20,")       # < 64 blocks: one-table set-up
+    assert engine.plan(engine.params(3.0, S, 20, irec._lib.IREC_FLAG_FUSED_PHILOX), big, 32)["table_kernel"] == ""
+    assert engine.plan(engine.params(3.0, 20, 10), big, 32)["kernel"] == "encode_team_kernel<10,3,1>"
+    assert engine.plan(engine.params(5.0, 148, 30), big, 32)["kernel"] == "encode_team_kernel<30,1,3>"
+    assert engine.plan(engine.params(3.0, S, 40), big, 32)["kernel"] == "encode_generic_kernel"
+    info = engine.plan(p, big, 32)
+    assert info["n_cu"] == 256 and info["clock_mhz"] > 1000 and info["lds_bytes"] <= 160 * 1024
+
+
+def test_two_streams_encode_concurrently(engine, oracle):
+    """One scratch buffer per stream: two encodes in flight at once on different streams do not share block counters,
+    tables or slabs."""
+    qa = [np.stack([oracle.synthetic_latent(70 + i, 8192)[j] for i in range(16)]) for j in range(4)]
+    qb = [np.stack([oracle.synthetic_latent(90 + i, 8192)[j] for i in range(16)]) for j in range(4)]
+    c = _coder(3.0, 20, 1.2, block_size=1000, variant="table")
+    ta = [torch.as_tensor(a, device="cuda") for a in qa]
+    tb = [torch.as_tensor(a, device="cuda") for a in qb]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    pend = []
+    for rep in range(3):
+        with torch.cuda.stream(s1):
+            pa = c.encode_tensors_device(*ta, 42, 1000)
+        with torch.cuda.stream(s2):
+            pb = c.encode_tensors_device(*tb, 42, 1000)
+        pend.append((pa, pb))
+    torch.cuda.synchronize()
+    assert len(engine._ws) >= 2
+    for pa, pb in pend:
+        la, lb = pa.to_lists(), pb.to_lists()
+        for i in (0, 9):
+            ra, rsa = oracle.encode_tensor(qa[0][i], qa[1][i], qa[2][i], qa[3][i], 42, 3.0, 36, 20, block_size=1000)
+            rb, rsb = oracle.encode_tensor(qb[0][i], qb[1][i], qb[2][i], qb[3][i], 42, 3.0, 36, 20, block_size=1000)
+            assert la[i] == ra and lb[i] == rb
+            assert np.array_equal(pa.sample[i].cpu().numpy(), rsa) and np.array_equal(pb.sample[i].cpu().numpy(), rsb)
+
+
+@pytest.mark.parametrize("shape", ["1", "2", "3", "2x2"])
+def test_diagnostic_team_shapes_are_bit_exact(engine, oracle, shape):
+    q = [np.stack([oracle.synthetic_latent(20 + i, 8192)[j] for i in range(8)]) for j in range(4)]
+    c = _coder(3.0, 20, 1.2, block_size=1000, variant="table")
+    c.team_shape = shape
+    idx, sample = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)
+    ridx, rs = oracle.encode_tensor(q[0][3], q[1][3], q[2][3], q[3][3], 42, 3.0, 36, 20, block_size=1000)
+    assert idx[3] == ridx and np.array_equal(sample[3].cpu().numpy(), rs)
+
+
+def test_library_errors_are_coding_errors(engine):
+    import irec
+    c = irec.BeamSearchCoder(kl_per_partition=3., n_beams=100, extra_samples=1.)
+    with pytest.raises(irec.CodingError):
+        c.encode(_normal(np.zeros((1, 4), np.float32), np.ones((1, 4), np.float32)),
+                 _normal(np.zeros((1, 4), np.float32), np.ones((1, 4), np.float32)), seed=1)
+    assert issubclass(irec._lib.IrecLibraryError, irec.CodingError)
+    st = irec._lib.load().irec_beam_encode(engine.ctx, None, 1, *([None] * 3), 4, *([None] * 5), 1, 4, *([None] * 4), 0, None)
+    with pytest.raises(irec.CodingError):
+        irec._lib.check(st, "irec_beam_encode(null params)")

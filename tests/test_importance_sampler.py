@@ -88,6 +88,62 @@ def test_importance_sampler_shapes_and_errors():
     with pytest.raises(CodingError):
         ImportanceSampler(coding_bits=5, alpha=0.5).coded_sample(t, p, seed=9)      # importance_sampling.py:33-34
     with pytest.raises(CodingError):
-        ImportanceSampler(coding_bits=5, alpha=2.0).coded_sample(t, p, seed=9)      # Gumbel-max branch not built
+        ImportanceSampler(coding_bits=5, alpha=float("nan")).coded_sample(t, p, seed=9)
     with pytest.raises(irec._lib.IrecLibraryError):
         ImportanceSampler(coding_bits=40).coded_sample(t, p, seed=9)                # 2^40 proposals: refused
+
+
+# ---- Gumbel-max branch (importance_sampling.py:67-71, rec/coding/utils.py:9-12) ---------------------------------------------
+def test_stateless_normal_stream_key_scramble(oracle):
+    """tf.random.stateless_normal(seed=[s0, s1]): one Philox block under the fixed key over the seed pair gives the stream's
+    key and upper counter half (stateless_random_ops.cc GenerateKey); product == oracle, and the layout is re-derived here."""
+    import ctypes
+    for s0, s1 in [(1, 2), (43, 44), (2 ** 31, 2 ** 31 + 1), (123456789012, 5)]:
+        got = np.empty(11, np.float32)
+        irec._lib.check(irec._lib.load().irec_tf_stateless_normal(s0, s1, 11, got.ctypes.data_as(ctypes.c_void_p)), "stateless")
+        assert np.array_equal(got, oracle.tf_stateless_normal(s0, s1, 11))
+        mix = oracle.philox4x32([0x3ec8f720, 0x02461e29], [s0 & 0xFFFFFFFF, s0 >> 32, s1 & 0xFFFFFFFF, s1 >> 32])
+        x = oracle.philox4x32([mix[0], mix[1]], [1, 0, mix[2], mix[3]]).astype(np.uint64)      # block 1 -> elements 4..7
+        u = (x & 0x7fffff).astype(np.float64) / 2.0 ** 23
+        r = math.sqrt(-2.0 * math.log(max(u[0], 1e-7)))
+        assert abs(got[4] - math.sin(2 * math.pi * u[1]) * r) < 2e-6 and abs(got[5] - math.cos(2 * math.pi * u[1]) * r) < 2e-6
+    z = oracle.tf_stateless_normal(7, 8, 40000).astype(np.float64)
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02
+
+
+def test_stateless_gumbel_sample_as_written():
+    from irec.coding.utils import stateless_gumbel_sample
+    g = stateless_gumbel_sample((4, 5), 10)
+    assert g.shape == (4, 5) and g.dtype == np.float32
+    # a normal draw lies in (0, 1] about a third of the time; everywhere else the double log is NaN (reference quirk kept)
+    g = stateless_gumbel_sample((4000,), 3)
+    assert 0.25 < np.isfinite(g).mean() < 0.45
+
+
+@pytest.mark.parametrize("n,bits,seed,alpha", [(1, 6.0, 1, 1.0), (5, 8.0, 42, 1.0), (16, 9.0, 7, 2.5), (64, 7.0, 5, 1.0),
+                                               (3, 10.0, 11, 30.0)])
+def test_gumbel_max_branch_matches_oracle(oracle, n, bits, seed, alpha):
+    rng = np.random.default_rng(1000 * n + seed)
+    p_loc = rng.standard_normal(n).astype(np.float32)
+    p_scale = np.exp(rng.normal(0, 0.25, n)).astype(np.float32)
+    t_loc = (p_loc + p_scale * rng.normal(0, 0.5, n)).astype(np.float32)
+    t_scale = (p_scale * np.exp(-np.abs(rng.normal(0, 0.3, n)))).astype(np.float32)
+    sampler = ImportanceSampler(coding_bits=bits, alpha=alpha)
+    S = sampler.n_samples()
+    idx, sample = sampler.coded_sample(_normal(t_loc, t_scale), _normal(p_loc, p_scale), seed)
+    ridx, rsample = oracle.importance_encode(t_loc, t_scale, p_loc, p_scale, bits, seed, alpha=alpha)
+    assert idx == ridx and 0 <= idx < S and np.array_equal(sample.numpy(), rsample)
+    assert torch.equal(sampler.decode_sample(_normal(p_loc, p_scale), idx, seed), sample)     # the decoder ignores alpha
+    # float64 recomputation: the winner maximises alpha * w + g among the proposals whose perturbation is finite
+    x = oracle.tf_random_normal(seed, S * n).astype(np.float64).reshape(S, n)
+    tl = (t_loc.astype(np.float64) - p_loc) / p_scale
+    ts = t_scale.astype(np.float64) / p_scale
+    w = (-0.5 * ((x - tl) / ts) ** 2 - np.log(ts) + 0.5 * x ** 2).sum(axis=1)
+    z = oracle.tf_stateless_normal(seed + 1, seed + 2, S).astype(np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        pert = alpha * w - np.log(-np.log(z))
+    finite = np.isfinite(pert) | (pert == np.inf)
+    assert finite[idx] and pert[idx] >= np.nanmax(np.where(finite, pert, -np.inf)) - 1e-3 * max(1.0, abs(pert[idx]))
+    # with a large alpha the perturbation cannot overturn a clear winner among the finite ones; alpha = inf ignores it
+    i_inf, _ = ImportanceSampler(coding_bits=bits).coded_sample(_normal(t_loc, t_scale), _normal(p_loc, p_scale), seed)
+    assert i_inf == int(np.argmax(w)) or abs(w[i_inf] - w.max()) < 1e-3

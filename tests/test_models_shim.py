@@ -61,8 +61,9 @@ def test_compress_decompress_round_trip_and_in_situ_parity(engine, oracle):
     assert len(block_indices) == 3 and all(len(bi) == 3 for bi in block_indices)      # 2048 dims -> 1000 + 1000 + 48
     assert recon.shape == image.shape and torch.isfinite(recon).all()
     assert len(seen) == 3
-    for ql, qs, pl, ps, (idx, sample) in seen:                                         # NHWC, batch 1, as in the reference
+    for ql, qs, pl, ps, (pending, sample) in seen:                                     # NHWC, batch 1, as in the reference
         assert ql.shape == (1, 16, 16, 8)
+        idx = pending.to_lists()[0]                                                    # compress defers the host copy
         ridx, rs = oracle.encode_tensor(ql.cpu().numpy(), qs.cpu().numpy(), pl.cpu().numpy(), ps.cpu().numpy(), 42, 3.0,
                                         36, 20, block_size=1000)
         assert idx == ridx
@@ -103,3 +104,45 @@ def test_lossy_two_level_compress_file_decompress(engine, tmp_path):
     assert torch.equal(recon2, recon)
     import os
     assert os.path.getsize(path) < 4000          # a few hundred indices, arithmetic coded
+
+
+@pytest.mark.gpu
+def test_batched_compress_equals_one_by_one_and_writes_rec(engine, oracle, tmp_path):
+    """N images through every residual block together == the N = 1 path image by image (indices and reconstruction),
+    each block's hand-off still the oracle's; the harness writes one .rec per image, reads it back and gathers the bits
+    (compression_performance.py:350-375)."""
+    import irec
+    from irec import harness
+    m = _model("cuda", blocks=4)
+    torch.manual_seed(5)
+    images = torch.rand(5, 3, 32, 32, device="cuda") - 0.5
+    seen = []
+    blk = m.residual_blocks[2]
+    orig = blk.coder.encode
+
+    def spy(target_dist, coding_dist, seed, **kw):
+        out = orig(target_dist, coding_dist, seed, **kw)
+        seen.append((target_dist.loc.clone(), target_dist.scale.clone(), coding_dist.loc.clone(), coding_dist.scale.clone(), out))
+        return out
+    blk.coder.encode = spy
+    bi_batch, recon_batch = m.compress(images, seed=42)
+    del blk.coder.encode
+    assert len(bi_batch) == 5 and len(bi_batch[0]) == 4 and len(bi_batch[0][0]) == 3
+    ql, qs, pl, ps, (pending, sample) = seen[0]
+    assert ql.shape == (5, 16, 16, 8)
+    lists = pending.to_lists()
+    for i in (0, 3):                                                                   # in-situ oracle parity inside the batch
+        ridx, rs = oracle.encode_tensor(ql[i].cpu().numpy(), qs[i].cpu().numpy(), pl[i].cpu().numpy(), ps[i].cpu().numpy(),
+                                        42, 3.0, 36, 20, block_size=1000)
+        assert lists[i] == ridx and np.array_equal(sample[i].cpu().numpy(), rs)
+    for i in range(5):
+        bi_one, recon_one = m.compress(images[i:i + 1], seed=42)
+        assert bi_one == bi_batch[i]
+        assert torch.allclose(recon_one[0], recon_batch[i], atol=1e-5, rtol=0)   # convolutions at batch 1 vs 5 may pick other kernels
+    assert torch.allclose(m.decompress(bi_batch, seed=42, image_shape=images.shape), recon_batch, atol=1e-5, rtol=0)
+    rows, all_bits, all_nats = harness.compress_sharded(m, images.cpu(), 42, 1000, str(tmp_path), batch=3)
+    assert len(rows) == 5 and all(r["indices_recovered"] for r in rows)
+    assert all_bits.tolist() == [r["comp_codelength"] for r in rows] and all(b > 0 for b in all_bits.tolist())
+    s, shape, bs, bi_file = irec.io.read_compressed_code(str(tmp_path / "img_00003.rec"))
+    assert (s, shape, bs) == (42, (32, 32, 3), 1000) and bi_file == bi_batch[3]
+    assert rows[3]["n_indices"] == sum(len(ix) for b in bi_batch[3] for ix in b)

@@ -1,0 +1,122 @@
+"""Consumes tests/golden/tf_*.npz -- vectors harvested from the REAL TensorFlow 2.1 / TFP 0.9 / reference stack by
+scripts/make_tf_vectors.py on a machine that has them -- and checks the oracle (LITERAL mode first: it restates the TF
+ops one to one) and, on the GPU box, the HIP path against them.
+
+The files cannot be produced in the build image (no TF wheel for this Python, no network).  While they are absent every
+test here SKIPS with that reason, and the parity status of the hot path stays "unpinned" (DESIGN.md §7): these tests are
+the place where a TF-pinned vector, once committed, starts failing anything that mis-restates TensorFlow."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR
+
+PRIM = os.path.join(GOLDEN_DIR, "tf_primitives.npz")
+ENC = os.path.join(GOLDEN_DIR, "tf_encode_blocks.npz")
+WHY = ("%s not committed: run scripts/make_tf_vectors.py where TensorFlow 2.1.0 + TFP 0.9.0 + the reference exist "
+       "(hot-path parity stays UNPINNED against real TensorFlow until then)")
+
+pytestmark = [pytest.mark.both_suites, pytest.mark.usefixtures("suite")]
+
+
+def _prim():
+    if not os.path.exists(PRIM):
+        pytest.skip(WHY % "tests/golden/tf_primitives.npz")
+    return np.load(PRIM)
+
+
+def _enc():
+    if not os.path.exists(ENC):
+        pytest.skip(WHY % "tests/golden/tf_encode_blocks.npz")
+    return np.load(ENC)
+
+
+def test_harvest_script_is_importable_without_tensorflow():
+    """The script must at least parse here (it is the deliverable a TF machine runs)."""
+    import ast
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "scripts", "make_tf_vectors.py")).read()
+    ast.parse(src)
+    assert "tf.random.uniform" in src and "tf.random.shuffle" in src and "encode_block" in src and "quantile" in src
+
+
+def test_tf_uniform_int_stream(oracle):
+    g = _prim()
+    n = 0
+    for key in g.files:
+        if key.startswith("uniform_"):
+            seed_s, shape = key[len("uniform_"):].rsplit("_", 1)
+            seed = sum(int(p) for p in seed_s.split("+"))
+            S, D = (int(v) for v in shape.split("x"))
+            assert np.array_equal(g[key].reshape(-1), oracle.uniform_int(seed, S * D)), key
+            n += 1
+    assert n >= 20
+
+
+def test_tf_shuffle(oracle):
+    g = _prim()
+    for key in g.files:
+        if key.startswith("shuffle_"):
+            _, seed, n = key.split("_")
+            assert np.array_equal(g[key], oracle.tf_shuffle_perm(int(seed), int(n))), key
+
+
+def test_tfp_quantile_table(oracle):
+    g = _prim()
+    lut = oracle.build_lut()
+    assert np.array_equal(g["quantile"], lut[1:]), "Normal(0,1).quantile(k/10007) differs from the oracle's LUT"
+
+
+def test_tf_argsort_tie_rule(oracle):
+    g = _prim()
+    v = g["argsort_ties_in"]
+    mine = sorted(range(len(v)), key=lambda i: (-float(v[i]), i))       # value descending, ties to the lower index
+    assert g["argsort_ties"].tolist() == mine
+
+
+def test_tf_random_normal_stream(oracle):
+    g = _prim()
+    for key in g.files:
+        if key.startswith("normal_"):
+            _, seed, n = key.split("_")
+            want = g[key].reshape(-1)
+            got = oracle.tf_random_normal(int(seed), want.size)
+            assert np.allclose(got, want, rtol=0, atol=2e-7), key       # Box-Muller through Eigen's sin/cos/log: last-bit slack
+
+
+def test_tf_kl_and_partition_count(oracle):
+    g = _prim()
+    kl = oracle.block_kl(g["grid_loc"], g["grid_scale"], g["grid_loc2"], g["grid_scale2"], mode=oracle.LITERAL)
+    assert abs(kl - float(g["kl_sum"])) <= 1e-5 * abs(float(g["kl_sum"]))
+
+
+def test_tf_encode_block_indices_oracle(oracle):
+    g = _enc()
+    for name in g["names"]:
+        name = str(name)
+        f = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        S = int(f["n_samples"])
+        for mode in (oracle.LITERAL, oracle.CANONICAL):
+            idx, sample = oracle.encode_block(f["q_loc"], f["q_scale"], f["p_loc"], f["p_scale"], int(f["seed"]),
+                                              float(f["kl_per_partition"]), S, int(f["n_beams"]), mode=mode)
+            assert idx == g[f"{name}_indices"].tolist(), (name, mode)
+        assert np.allclose(sample, g[f"{name}_sample"], rtol=0, atol=1e-5), name          # north_star: 1e-5 on reconstructions
+        assert np.allclose(g[f"{name}_decoded"], g[f"{name}_sample"], rtol=0, atol=1e-5), name
+
+
+@pytest.mark.gpu
+def test_tf_encode_block_indices_hip(engine):
+    import irec
+    import torch
+    g = _enc()
+    for name in g["names"]:
+        name = str(name)
+        f = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        c = irec.BeamSearchCoder(kl_per_partition=float(f["kl_per_partition"]), n_beams=int(f["n_beams"]),
+                                 extra_samples=float(f["extra_samples"]))
+        q = torch.distributions.Normal(torch.as_tensor(f["q_loc"][None]).cuda(), torch.as_tensor(f["q_scale"][None]).cuda(), validate_args=False)
+        p = torch.distributions.Normal(torch.as_tensor(f["p_loc"][None]).cuda(), torch.as_tensor(f["p_scale"][None]).cuda(), validate_args=False)
+        idx, sample = c.encode(q, p, seed=int(f["seed"]))
+        assert [int(i) for i in idx] == g[f"{name}_indices"].tolist(), name
+        assert np.allclose(sample.cpu().numpy().reshape(-1), g[f"{name}_sample"], rtol=0, atol=1e-5), name
