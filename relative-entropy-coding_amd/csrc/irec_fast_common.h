@@ -306,10 +306,11 @@ struct FastCfg {
   static_assert(SPC >= 1, "NB too large");
 };
 
-// Scratch slab of one workgroup (bytes): bp int32 [max_K][NB] | stats float [3][1024] | beams float [2][NB][1024]
+// Scratch slab of one workgroup (bytes): bp int32 [max_K][NB] | parked float [2][1024] | stats float [3][1024] | beams float [2][NB][1024]
+// (parked: cumulative variance and sample scale of the three-team builds, which cannot hold them across the scoring loop)
 __host__ __device__ inline size_t fast_ws_bytes(int NB, int max_K) {
   const size_t bp = (((size_t)(max_K > 0 ? max_K : 1) * NB * 4) + 255) & ~(size_t)255;
-  return bp + (size_t)3 * FAST_MAX_DIM * 4 + (size_t)2 * NB * FAST_MAX_DIM * 4;
+  return bp + (size_t)5 * FAST_MAX_DIM * 4 + (size_t)2 * NB * FAST_MAX_DIM * 4;
 }
 
 } // namespace irec

@@ -28,6 +28,9 @@
 #include "irec_kernels.h"
 #include "irec_fast_common.h"
 
+#ifndef IREC_UB3
+#define IREC_UB3 5   // beams per load batch of the update in the register-short builds
+#endif
 namespace irec {
 
 constexpr int TEAM_NW = 4;                       // waves per team
@@ -49,9 +52,14 @@ __host__ __device__ inline bool team_keys_in_lds(int NB, int S, int teams) {
                           (long long)TEAM_SMALL_BYTES - 32;
   return teams > 1 || avail / (4LL * NB * 4) >= (S < 16 ? S : 16);
 }
+// Three 20-beam teams only fit the 160 KB next to the table copies if the sort keys are written over group 0 of the partial
+// scores (key f = s * Bcur + b lands on partial s * NB + b: the same word when Bcur == NB, which every step but the first
+// has; otherwise a barrier separates the partial reads from the key writes).
+__host__ __device__ inline bool team_keys_alias(int NB, int teams) { return teams >= 3 && NB == 20; }
 __host__ __device__ inline int team_s_pass(int NB, int S, int teams, int cmax) {
   const long long avail = (long long)((FAST_LDS_LIMIT - T3_BYTES) / (size_t)teams) -
-                          (team_keys_in_lds(NB, S, teams) ? (long long)team_key_bytes(NB, S) : 0) - (long long)TEAM_SMALL_BYTES - 32;
+                          ((team_keys_in_lds(NB, S, teams) && !team_keys_alias(NB, teams)) ? (long long)team_key_bytes(NB, S) : 0) -
+                          (long long)TEAM_SMALL_BYTES - 32;
   long long fit = avail / (4LL * NB * 4);           // samples whose partials fit
   if (fit > cmax / NB) fit = cmax / NB;             // and whose candidates one combine round covers
   if (fit < 1) return 0;
@@ -61,7 +69,8 @@ __host__ __device__ inline int team_s_pass(int NB, int S, int teams, int cmax) {
 }
 __host__ __device__ inline size_t team_part_bytes(int NB, int SP) { return (((size_t)4 * SP * NB * 4) + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t team_lds_one(int NB, int S, int SP, int teams) {
-  return team_part_bytes(NB, SP) + (team_keys_in_lds(NB, S, teams) ? team_key_bytes(NB, S) : 0) + TEAM_SMALL_BYTES + 16;
+  return team_part_bytes(NB, SP) + ((team_keys_in_lds(NB, S, teams) && !team_keys_alias(NB, teams)) ? team_key_bytes(NB, S) : 0) +
+         TEAM_SMALL_BYTES + 16;
 }
 __host__ __device__ inline size_t team_lds_total(int NB, int S, int SP, int teams) { return T3_BYTES + (size_t)teams * team_lds_one(NB, S, SP, teams); }
 
@@ -120,7 +129,8 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   // S in one -- then the pass loop below folds away)
   const int SP = TEAMS == 1 ? team_s_pass(NB, S, TEAMS, CMAX) : S;
   const bool keys_lds = TEAMS > 1 || team_keys_in_lds(NB, S, TEAMS);            // (compile-time true for the multi-team builds)
-  const size_t key_lds_bytes = keys_lds ? team_key_bytes(NB, S) : 0;
+  constexpr bool KEYS_ALIAS = TEAMS >= 3 && NB == 20;                          // team_keys_alias()
+  const size_t key_lds_bytes = (keys_lds && !KEYS_ALIAS) ? team_key_bytes(NB, S) : 0;
   char *tbase = smem + T3_BYTES + (size_t)team * team_lds_one(NB, S, SP, TEAMS);
   float *part_s = reinterpret_cast<float *>(tbase);                             // [4][SP][NB] per-group partial scores
   TeamLds *sm = reinterpret_cast<TeamLds *>(tbase + team_part_bytes(NB, SP) + key_lds_bytes);
@@ -149,11 +159,18 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 
   char *slab = A.ws + ((size_t)blockIdx.x * TEAMS + team) * A.ws_per_wg;
   const size_t key_glb_bytes = keys_lds ? 0 : ((team_key_bytes(NB, S) + 255) & ~(size_t)255);   // sort keys at the slab's end
-  uint32_t *key_s = keys_lds ? reinterpret_cast<uint32_t *>(tbase + team_part_bytes(NB, SP))     // [S*NB] sort keys
-                             : reinterpret_cast<uint32_t *>(slab + A.ws_per_wg - key_glb_bytes);
+  uint32_t *key_s = KEYS_ALIAS ? reinterpret_cast<uint32_t *>(tbase)                            // over partial group 0
+                    : keys_lds ? reinterpret_cast<uint32_t *>(tbase + team_part_bytes(NB, SP))     // [S*NB] sort keys
+                               : reinterpret_cast<uint32_t *>(slab + A.ws_per_wg - key_glb_bytes);
   int32_t *bp = reinterpret_cast<int32_t *>(slab);                                            // [max_K][NB]
   float *beams_g = reinterpret_cast<float *>(slab + A.ws_per_wg - key_glb_bytes - (size_t)2 * NB * FAST_MAX_DIM * 4); // [2][NB][1024]
   float *stats_g = beams_g - 3 * FAST_MAX_DIM;  // [3][1024]: mq - mp, sq^2, sp^2 of the block, coalesced
+  float *park_g = stats_g - 2 * FAST_MAX_DIM;   // [2][1024]: c (cumulative variance) and sa of the PARK builds
+  // Three-team builds have 168 VGPRs: the cumulative variance and the sample scale (needed only by the update) are parked
+  // in the slab across the scoring loop instead of being spilled inside it
+  constexpr bool PARK = TEAMS >= 3;
+  constexpr bool LATE_G = false;   // (tried: new beams wait in G's registers and G is formed after the batches -- the
+                                   //  register allocator then shuffles eight registers through scratch per beam: 844 B)
 
 #ifdef IREC_TEAM_STAMPS
   unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -190,7 +207,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
     // the wave that reads a dim group's statistics keeps them in registers; only the other waves of the group (sample /
     // beam stripes of short blocks and of the striped builds) re-read them from the slab every step
     float own_dmu[4], own_vq[4], own_vp[4];
-    const bool own_stats = active && sw == 0 && bs == 0;
+    const bool own_stats = active && sw == 0 && bs == 0 && TEAMS < 3;   // (three-team builds: 168 VGPRs, the slab keeps them)
     double klacc = 0.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -207,7 +224,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         st3[0] = mq_ - mp_; st3[1] = sq_ * sq_; st3[2] = sp_ * sp_;
       }
       own_dmu[i] = st3[0]; own_vq[i] = st3[1]; own_vp[i] = st3[2];
-      if (own_stats && (NSW > 1 || BS > 1)) { // somebody else needs them
+      if (active && sw == 0 && bs == 0 && (NSW > 1 || BS > 1 || TEAMS >= 3)) { // somebody else (or a later step) needs them
         stats_g[d0 + i] = st3[0]; stats_g[FAST_MAX_DIM + d0 + i] = st3[1]; stats_g[2 * FAST_MAX_DIM + d0 + i] = st3[2];
       }
     }
@@ -266,10 +283,26 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         __builtin_amdgcn_sched_barrier(0); // one dim at a time: the division sequences are register hungry
       }
     };
+    auto park = [&]() {     // (waves of the same dim group write the same bits)
+      if (PARK && active) {
+        *reinterpret_cast<float4 *>(park_g + d0) = make_float4(c[0], c[1], c[2], c[3]);
+        *reinterpret_cast<float4 *>(park_g + FAST_MAX_DIM + d0) = make_float4(sa[0], sa[1], sa[2], sa[3]);
+      }
+    };
+    auto unpark = [&]() {
+      if (PARK && active) {
+        asm volatile("" ::: "memory");   // a real reload: the values are dead between park() and here
+        const float4 pc = *reinterpret_cast<const float4 *>(park_g + d0);
+        const float4 ps = *reinterpret_cast<const float4 *>(park_g + FAST_MAX_DIM + d0);
+        c[0] = pc.x; c[1] = pc.y; c[2] = pc.z; c[3] = pc.w;
+        sa[0] = ps.x; sa[1] = ps.y; sa[2] = ps.z; sa[3] = ps.w;
+      }
+    };
     // ---- prologue: step 0 has one (all-zero) beam ----
     {
       float m[4], cA[4], cBv[4];
       step_consts(0, m, cA, cBv);
+      park();
       float cacc = 0.f;
 #pragma unroll
       for (int b = 0; b < NBW; ++b)
@@ -289,7 +322,9 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
     int cur = 0, Bcur = 1;
     for (int t = 0; t < K; ++t) {
       // row s at + s * Dp; lanes past the padded row end read the row START (finite z, zero coefficients)
-      const uint16_t *tab_t = tab + (size_t)t * S * Dp + (d0 < Dp ? d0 : 0);
+      const uint16_t *tab_tu = tab + (size_t)t * S * Dp;             // uniform base of this step's rows
+      const uint32_t tab_lo = (uint32_t)(d0 < Dp ? d0 : 0);          // my quad inside a row (32-bit offsets: one VGPR)
+      const uint16_t *tab_t = tab_tu + tab_lo;
       uint32_t bet[NBW];
       {
         const uint32_t bv = beta4[cur * TEAM_MB + (lane < Bcur ? lane : 0)]; // one LDS round trip, then cross-lane reads
@@ -317,35 +352,46 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         const int n_chunks = (n_mine + SPC - 1) / SPC;
         auto row = [&](int m) {                                     // proposal row of my m-th sample; zero row past the end:
           uint2 r = make_uint2(0u, 0u);                             // entry 0 is a valid address, its results are dropped
-          if (m < n_mine) r = *reinterpret_cast<const uint2 *>(tab_t + (size_t)(s_base + m * NSW + sw) * Dp);
+          if (m < n_mine) r = *reinterpret_cast<const uint2 *>(tab_tu + ((uint32_t)(s_base + m * NSW + sw) * (uint32_t)Dp + tab_lo));
           return r;
         };
-        uint2 ap_nxt[SPC];
-        uint32_t al[SPC][4];
+        // proposal rows stay packed (4 x uint16 per sample in two registers); the byte address of a dim slot's entry in copy 0
+        // is unpacked when its look-ups are issued (one live temporary instead of four registers per sample)
+        uint2 ap_cur[SPC], ap_nxt[SPC];
 #pragma unroll
-        for (int cc = 0; cc < SPC; ++cc) {
-          const uint2 ap = row(cc);
-          al[cc][0] = (ap.x & 0xFFFFu) << 2; al[cc][1] = (ap.x >> 16) << 2; al[cc][2] = (ap.y & 0xFFFFu) << 2; al[cc][3] = (ap.y >> 16) << 2;
-          ap_nxt[cc] = row(SPC + cc);
-        }
+        for (int cc = 0; cc < SPC; ++cc) { ap_cur[cc] = row(cc); ap_nxt[cc] = row(SPC + cc); }
+#define IREC_AL(CC, I) ((((I) & 2) ? (((I) & 1) ? (ap_cur[CC].y >> 16) : (ap_cur[CC].y & 0xFFFFu)) : (((I) & 1) ? (ap_cur[CC].x >> 16) : (ap_cur[CC].x & 0xFFFFu))) << 2)
         // values travel in register pairs so that the two fma of two beams stay one v_pk_fma_f32 each
         typedef float f2 __attribute__((ext_vector_type(2)));
         constexpr int NP = NBW / 2;
         constexpr int NQ = 4 * SPC;                                 // dim slots per chunk (even: buffers alternate cleanly)
         static_assert(NBW % 2 == 0, "beams are processed in pairs");
-        f2 zz[2][NP];
-#define IREC_ISSUE(Z, AD) do { _Pragma("unroll") for (int k = 0; k < NP; ++k) { Z[k].x = lds_abs_f32((AD) + bet[2 * k]); Z[k].y = lds_abs_f32((AD) + bet[2 * k + 1]); } \
+        // Pipeline granule: a whole dim slot (NP beam pairs per look-up buffer), or HALF a slot for the three-team
+        // 20-beam build (5 pairs per buffer: 20 instead of 40 look-up registers -- three waves per SIMD hide what the
+        // shallower pipeline exposes).
+        constexpr int NH = (TEAMS >= 3 && NBW == 20) ? 2 : 1;       // granules per dim slot
+        constexpr int HP = NP / NH;                                 // beam pairs per granule
+        constexpr int NQH = NQ * NH;                                // granules per chunk
+        static_assert(NP % NH == 0 && NQH % 2 == 0, "granules must tile the slots and alternate buffers cleanly");
+        f2 zz[2][HP];
+#define IREC_ISSUE(Z, AD, K0) do { _Pragma("unroll") for (int k = 0; k < HP; ++k) { Z[k].x = lds_abs_f32((AD) + bet[2 * ((K0) + k)]); Z[k].y = lds_abs_f32((AD) + bet[2 * ((K0) + k) + 1]); } \
                                __builtin_amdgcn_sched_barrier(0); } while (0)
-#define IREC_CONSUME(Z, I, ACC) do { _Pragma("unroll") for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(Z[k])); \
-                                f2 t2_[NP]; \
-                                _Pragma("unroll") for (int k = 0; k < NP; ++k) { \
-                                  const f2 h2 = {cH[I], cH[I]}, g2 = {G[2 * k][I], G[2 * k + 1][I]}; \
+#define IREC_CONSUME(Z, I, ACC, K0) do { _Pragma("unroll") for (int k = 0; k < HP; ++k) asm volatile("" : "+v"(Z[k])); \
+                                f2 t2_[HP]; \
+                                _Pragma("unroll") for (int k = 0; k < HP; ++k) { \
+                                  const f2 h2 = {cH[I], cH[I]}, g2 = {G[2 * ((K0) + k)][I], G[2 * ((K0) + k) + 1][I]}; \
                                   t2_[k] = __builtin_elementwise_fma(h2, Z[k], g2); } /* inner fma of every pair first: */ \
-                                _Pragma("unroll") for (int k = 0; k < NP; ++k) /* no dependent back-to-back issue */ \
-                                  ACC[k] = __builtin_elementwise_fma(t2_[k], Z[k], ACC[k]); \
-                                _Pragma("unroll") for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(ACC[k])); \
+                                _Pragma("unroll") for (int k = 0; k < HP; ++k) /* no dependent back-to-back issue */ \
+                                  ACC[(K0) + k] = __builtin_elementwise_fma(t2_[k], Z[k], ACC[(K0) + k]); \
+                                _Pragma("unroll") for (int k = 0; k < HP; ++k) asm volatile("" : "+v"(ACC[(K0) + k])); \
                                 __builtin_amdgcn_sched_barrier(0); } while (0)
-        IREC_ISSUE(zz[0], al[0][0]);
+        if constexpr (PARK) { // every G of the wave in a register HERE: a spilled one is reloaded once per step, not per sample
+#pragma unroll
+          for (int b = 0; b < NBW; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(G[b][i]));
+        }
+        IREC_ISSUE(zz[0], IREC_AL(0, 0), 0);
         for (int ch = 0; ch < n_chunks; ++ch) {
           f2 acc2[SPC][NP];
 #pragma unroll
@@ -353,20 +399,19 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 #pragma unroll
             for (int k = 0; k < NP; ++k) acc2[cc][k] = (f2){0.f, 0.f};
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) {
-            if (q + 1 < NQ) {
-              IREC_ISSUE(zz[(q + 1) & 1], al[(q + 1) >> 2][(q + 1) & 3]);
+          for (int qh = 0; qh < NQH; ++qh) {
+            constexpr int dummy_ = 0; (void)dummy_;
+            const int q = qh / NH, h = qh % NH;                     // dim slot of the chunk, granule of the slot
+            if (qh + 1 < NQH) {
+              const int qn = (qh + 1) / NH, hn = (qh + 1) % NH;
+              IREC_ISSUE(zz[(qh + 1) & 1], IREC_AL(qn >> 2, qn & 3), hn * HP);
             } else {
               // next chunk's rows
 #pragma unroll
-              for (int cc = 0; cc < SPC; ++cc) {
-                al[cc][0] = (ap_nxt[cc].x & 0xFFFFu) << 2; al[cc][1] = (ap_nxt[cc].x >> 16) << 2;
-                al[cc][2] = (ap_nxt[cc].y & 0xFFFFu) << 2; al[cc][3] = (ap_nxt[cc].y >> 16) << 2;
-                ap_nxt[cc] = row((ch + 2) * SPC + cc);
-              }
-              IREC_ISSUE(zz[0], al[0][0]);
+              for (int cc = 0; cc < SPC; ++cc) { ap_cur[cc] = ap_nxt[cc]; ap_nxt[cc] = row((ch + 2) * SPC + cc); }
+              IREC_ISSUE(zz[0], IREC_AL(0, 0), 0);
             }
-            IREC_CONSUME(zz[q & 1], q & 3, acc2[q >> 2]);
+            IREC_CONSUME(zz[qh & 1], q & 3, acc2[q >> 2], h * HP);
           }
           float acc[ACC_ROOM];
 #pragma unroll
@@ -379,9 +424,10 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           if (rs_p >= 0 && (lane & 1) == 0 && m < n_mine) part_s[((size_t)g * SP + m * NSW + sw) * NB + b_lo + b] = tot;
         }
 #pragma unroll
-        for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(zz[0][k])); // drain the look-ups issued past the last sample
+        for (int k = 0; k < HP; ++k) asm volatile("" : "+v"(zz[0][k])); // drain the look-ups issued past the last sample
 #undef IREC_ISSUE
 #undef IREC_CONSUME
+#undef IREC_AL
       } else if (active && nlive > 0) {
 #endif
         const int s_per_stripe = (Sp + NSW - 1) / NSW;
@@ -464,6 +510,13 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 #pragma unroll
             for (int gg = 0; gg < 4; ++gg) cbv[q][gg] = cpart_s[(gg < NG ? gg : 0) * 32 + b];
           }
+          if (KEYS_ALIAS && Bcur != NB) { // key f and partial f belong to different candidates: all reads before any write
+#pragma unroll
+            for (int q = 0; q < MK; ++q)
+#pragma unroll
+              for (int gg = 0; gg < 4; ++gg) asm volatile("" : "+v"(pr[q][gg]));
+            tsync();
+          }
 #pragma unroll
           for (int q = 0; q < MK; ++q) {
             float sc = pr[q][0];
@@ -507,6 +560,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 #else
       if (active) {
 #endif
+        unpark();
         const float sa_t[4] = {sa[0], sa[1], sa[2], sa[3]};   // this step's sample scale
         const float *bold = beams_g + ((size_t)cur * NB) * FAST_MAX_DIM + d0;
         float *bnew = beams_g + ((size_t)(cur ^ 1) * NB) * FAST_MAX_DIM + d0;
@@ -521,7 +575,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         float cacc[rsn_room(NBW)];
 #pragma unroll
         for (int j = 0; j < rsn_room(NBW); ++j) cacc[j] = 0.f;
-        constexpr int UB = (TEAMS >= 3 || BS >= 2) ? 5 : NBW;              // beams per load batch: all at once (G's registers are free) unless registers are short
+        constexpr int UB = (TEAMS >= 3 || BS >= 2) ? IREC_UB3 : NBW;              // beams per load batch: all at once (G's registers are free) unless registers are short
         // lane j fetches the selection of new beam j and the offset of its parent: two LDS round trips for all beams
         const int32_t v_sp = sel_s[lane < Bnew ? lane : 0], v_bp = sel_b[lane < Bnew ? lane : 0];
         const uint32_t v_bo = sm->sel_bo[lane < Bnew ? lane : 0];
@@ -545,7 +599,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
               if (t) obv4[u] = *reinterpret_cast<const float4 *>(bold + (size_t)bp_ * FAST_MAX_DIM);
             }
           }
-          if (j0 == 0 && !last) step_consts(t + 1, m, cA, cBv); // next step's constants, under the loads' latency
+          if (j0 == 0 && !last) { step_consts(t + 1, m, cA, cBv); park(); } // next step's constants, under the loads' latency
           // ---- new beams, their G and C terms ----
           // look-ups of YB beams are issued back to back, then consumed: UB / YB LDS latencies per batch instead of UB
           constexpr int YB = 5;
@@ -581,15 +635,38 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
                 }
               } else {
                 if (sw == 0) *reinterpret_cast<float4 *>(bnew + (size_t)j * FAST_MAX_DIM) = make_float4(nb[0], nb[1], nb[2], nb[3]);
+                if constexpr (LATE_G) {
+                  // 168-VGPR builds: the new beam waits in G's own registers; G and the C terms are formed below, once the
+                  // batch temporaries (parent beams, proposal rows, look-ups) are dead -- same operations on the same values
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                  G[jj][i] = beam_G(nb[i], m[i], cA[i], cBv[i], sa[i]);
-                  cacc[jj] = beam_C_term(cacc[jj], nb[i], m[i], cA[i], cBv[i]);
+                  for (int i = 0; i < 4; ++i) G[jj][i] = nb[i];
+                } else {
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) {
+                    G[jj][i] = beam_G(nb[i], m[i], cA[i], cBv[i], sa[i]);
+                    cacc[jj] = beam_C_term(cacc[jj], nb[i], m[i], cA[i], cBv[i]);
+                  }
                 }
               }
             }
           }
           __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (LATE_G) {
+          if (!last) {
+#pragma unroll
+            for (int jj = 0; jj < NBW; ++jj) {
+              if (b_lo + jj < Bnew) { // wave-uniform; beams that do not exist keep G = 0
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  const float nbv = G[jj][i];
+                  G[jj][i] = beam_G(nbv, m[i], cA[i], cBv[i], sa[i]);
+                  cacc[jj] = beam_C_term(cacc[jj], nbv, m[i], cA[i], cBv[i]);
+                }
+              }
+              __builtin_amdgcn_sched_barrier(0); // one beam at a time (the scheduler would interleave all twenty)
+            }
+          }
         }
         if (!last) {
           const float ctot = reduce_scatter_n<NBW>(cacc, lane);
@@ -712,8 +789,8 @@ __global__ __launch_bounds__(256) void alpha_choice_kernel(int64_t seed, int32_t
 // ======================================================================================================
 //  launchers
 // ======================================================================================================
-// teams per workgroup / beam stripes per team.  Defaults: B <= 10: 3 x 1 where the LDS allows (else 2 x 1); B <= 20: 2 x 1
-// (8 waves per CU); B <= 30: 1 x 3.  Diagnostic overrides for B <= 20 travel in irec_params.flags (IREC_FLAG_SHAPE_*, no
+// teams per workgroup / beam stripes per team.  Defaults: B <= 20: 3 x 1 where the LDS allows (else 2 x 1, or 1 x 2 with
+// sample passes); B <= 30: 1 x 3.  Diagnostic overrides for B <= 20 travel in irec_params.flags (IREC_FLAG_SHAPE_*, no
 // environment variable is read on the product path): cfg 1 = one team, 20 = exactly two teams (also where three would be
 // the default), 3 = three 4-wave teams (168 VGPRs), 22 = two 8-wave beam-striped teams (128 VGPRs).
 static int team_cfg(int shape_override) {
@@ -733,11 +810,15 @@ static TeamShape team_shape(int B, int S, int ovr) {
   if (B <= 10) return TeamShape{10, (cfg == 3 || (cfg == 2 && team_s_pass(10, S, 3, 1024) == S)) ? 3 : 2, 1};
   if (B <= 20) {
     if (cfg == 1) return TeamShape{20, 1, 1};
-    if (cfg == 3) return TeamShape{20, 3, 1};
+    if (cfg == 20) return TeamShape{20, 2, 1};
     if (cfg == 22) return TeamShape{20, 2, 2};
+    // three 4-wave teams (168 VGPRs: half-slot look-up pipeline, statistics / variance / scale parked in the slab, sort keys
+    // over the partial scores) wherever their LDS fits next to the table copies -- S <= 38, the BASELINE workload: a third
+    // team scores while another is in a serial phase (r02c: 13.2 ms against 13.7 ms of two teams)
+    if (team_s_pass(20, S, 3, 1024) == S) return TeamShape{20, 3, 1};
     // more samples than two teams can hold in one pass (e.g. Omega = 5: S = 148): one 8-wave team with two beam stripes
     // and sample passes
-    if (B > 10 && team_s_pass(20, S, 2, 1024) != S) return TeamShape{20, 1, 2};
+    if (team_s_pass(20, S, 2, 1024) != S) return TeamShape{20, 1, 2};
     return TeamShape{20, 2, 1};
   }
   if (B <= 30) return TeamShape{30, 1, 3};   // one 12-wave team: three stripes of 10 beams (the B = 30 stress configuration)

@@ -10,11 +10,13 @@ B = int(os.environ.get("BEAMS", "20")); omega = float(os.environ.get("OMEGA", "3
 eng = irec.get_engine()
 S = int(np.exp(omega * eps1))
 flags = {"table": 8, "auto": 0, "one_table": 4, "fused": 2, "generic": 1}[variant]
+flags |= irec._lib.IREC_FLAG_SHAPE[os.environ.get("SHAPE", "default")]   # team-encoder workgroup shape (diagnostics)
 params = eng.params(omega, S, B, flags)
 q = bench.synthetic_batch(L, eng.device, 0)
 lay = eng.layout(L, bench.N_DIMS, bench.BLOCK_SIZE, bench.SEED)
 out = None
-for i in range(3):
+print("plan:", eng.plan(params, lay, 32)["kernel"], flush=True)
+for i in range(int(os.environ.get("REPS", "3"))):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     out = eng.encode_blocks(params, lay, *q, bench.SEED, 32)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0

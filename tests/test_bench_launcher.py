@@ -61,6 +61,6 @@ def test_single_rank_line_is_self_describing():
     r = _run(["--steps", "2", "--warmup", "1", "--latents", "256", "--no-cpu-baseline"], {}, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert res["n_gpus"] == 1 and res["roofline"]["kernel"] == "encode_team_kernel<20,2,1>"
+    assert res["n_gpus"] == 1 and res["roofline"]["kernel"] == "encode_team_kernel<20,3,1>"
     assert res["roofline"]["bound"] == "hbm" and 0 < res["roofline"]["frac"] < 1
     assert res["secondary"]["lds_hw"]["peak"] == 32.0 and res["secondary"]["n_cu"] == 256

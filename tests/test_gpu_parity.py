@@ -462,7 +462,7 @@ def test_plan_names_the_kernels_that_run(engine, oracle):
     big = engine.layout(64, 8192, 1000, 42)
     small = engine.layout(1, 8192, 1000, 42)
     p = engine.params(3.0, S, 20)
-    assert engine.plan(p, big, 32)["kernel"] == "encode_team_kernel<20,2,1>"
+    assert engine.plan(p, big, 32)["kernel"] == "encode_team_kernel<20,3,1>"
     assert engine.plan(p, big, 32)["table_kernel"] == "alpha_choice_kernel"
     assert engine.plan(p, small, 32)["kernel"].startswith("encode_fast_kernel<20,")       # < 64 blocks: one-table set-up
     assert engine.plan(engine.params(3.0, S, 20, irec._lib.IREC_FLAG_FUSED_PHILOX), big, 32)["table_kernel"] == ""
