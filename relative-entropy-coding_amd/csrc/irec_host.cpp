@@ -661,7 +661,7 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   A.ws = (char *)workspace + 256 + pl.tab_bytes;
   A.ws_per_wg = pl.ws_per_wg;
   A.max_dim_pad = pl.dpad;
-  HIP_TRY(hipMemsetAsync(workspace, 0, 256, st));
+  HIP_TRY(irec::launch_zero_counters(workspace, st));
   const int grid = (int)std::min<int64_t>(n_blocks, pl.one_grid_cap);
   A.dbg = ctx->d_dbg;
   if (ctx->d_dbg) HIP_TRY(hipMemsetAsync(ctx->d_dbg, 0, 4096 * 16 * sizeof(unsigned long long), st));

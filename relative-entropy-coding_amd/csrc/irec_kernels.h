@@ -68,6 +68,7 @@ const char *team_kernel_name(int B, int S, int shape_override);   // e.g. "encod
 const char *fast_kernel_name(int B, int S, bool table);
 hipError_t launch_alpha_choice(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *dlog4r, uint16_t *tab,
                                hipStream_t st);
+hipError_t launch_zero_counters(void *p, hipStream_t st);   // 256 bytes
 hipError_t launch_decode(const DecArgs &A, int grid, hipStream_t st);
 hipError_t launch_uniform_int(int64_t seed, int64_t n, int32_t *out, hipStream_t st);
 hipError_t launch_select_test(const float *scores, int N, int Bnew, int Bcur, uint32_t *keys, int32_t *sel, hipStream_t st);

@@ -911,6 +911,15 @@ hipError_t launch_alpha_table(int64_t seed, int32_t S, int32_t D, int32_t K_tab,
   return hipGetLastError();
 }
 
+// zeroes the 256-byte counter block at the head of the workspace.  A kernel, not hipMemsetAsync: the call sequence of
+// irec_beam_encode is then kernels only, which is also what a HIP-graph capture of it records (r02: replaying a capture
+// that held the memset node faulted on the second replay).
+__global__ void zero_counters_kernel(uint32_t *p) { p[threadIdx.x] = 0u; }
+hipError_t launch_zero_counters(void *p, hipStream_t st) {
+  hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<uint32_t *>(p));
+  return hipGetLastError();
+}
+
 hipError_t launch_decode(const DecArgs &A, int grid, hipStream_t st) {
   hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(256), 0, st, A);
   return hipGetLastError();

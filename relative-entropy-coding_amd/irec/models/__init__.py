@@ -1,3 +1,3 @@
 """Host shims of the reference's model call surface around the coder."""
-from .resnet_vae import BidirectionalResidualBlock, BidirectionalResNetVAE, ModelError  # noqa: F401
+from .resnet_vae import BidirectionalResidualBlock, BidirectionalResNetVAE, GraphedCompress, ModelError  # noqa: F401
 from .lossy import Large2LevelVAE  # noqa: F401

@@ -177,20 +177,8 @@ class BidirectionalResNetVAE(nn.Module):
         Nothing is copied to the host until the last residual block has been coded: each block's `coder.encode(...,
         defer=True)` leaves its K / index rows on the device and hands the merged sample straight to the next block's
         convolutions; ONE device-to-host copy then fetches all indices of all blocks and images."""
-        batch_size, _, height, width = image.shape
         for _attempt in range(6):
-            with deterministic_transforms():
-                tensor = self.first_infer_conv(image)
-                for resnet_block in list(self.residual_blocks)[::-1]:         # inference pass, reverse order (:811-813)
-                    tensor = resnet_block(tensor, inference_pass=True)
-                tensor = self.generative_base(batch_size=batch_size, width=width, height=height)
-                pendings = []
-                for resnet_block in self.residual_blocks:                     # strictly sequential (:821-826)
-                    pending, tensor = resnet_block(tensor, inference_pass=False,
-                                                   encoder_args={"seed": seed, "update_sampler": update_sampler,
-                                                                 "batched": True, "defer": True})
-                    pendings.append(pending)
-                reconstruction = self._finish(tensor)
+            pendings, reconstruction = self._compress_device(image, seed, update_sampler)
             try:
                 per_block = PendingCode.gather(pendings)     # [res_block][image][coder_block]; the only host sync
                 break
@@ -198,11 +186,31 @@ class BidirectionalResNetVAE(nn.Module):
                 continue   # some block's KL needs more index slots than the coders' hint: the hints are raised, code again
         else:
             raise MorePartitionsNeeded(max(b.coder._max_K_hint for b in self.residual_blocks) + 1)
+        return self._indices_structure(per_block, image.shape[0]), reconstruction
+
+    def _compress_device(self, image, seed, update_sampler=False):
+        """Everything of `compress` that runs on the device, with no host synchronisation: (PendingCode per residual
+        block, reconstruction).  Capturable in a HIP graph (GraphedCompress)."""
+        batch_size, _, height, width = image.shape
+        with deterministic_transforms():
+            tensor = self.first_infer_conv(image)
+            for resnet_block in list(self.residual_blocks)[::-1]:         # inference pass, reverse order (:811-813)
+                tensor = resnet_block(tensor, inference_pass=True)
+            tensor = self.generative_base(batch_size=batch_size, width=width, height=height)
+            pendings = []
+            for resnet_block in self.residual_blocks:                     # strictly sequential (:821-826)
+                pending, tensor = resnet_block(tensor, inference_pass=False,
+                                               encoder_args={"seed": seed, "update_sampler": update_sampler,
+                                                             "batched": True, "defer": True})
+                pendings.append(pending)
+            return pendings, self._finish(tensor)
+
+    def _indices_structure(self, per_block, batch_size):
         flat = [blk.coder.block_size is None for blk in self.residual_blocks]   # no block_size: one index list per tensor
         per_block = [[img[0] if flat[r] else img for img in blk] for r, blk in enumerate(per_block)]
         if batch_size == 1:
-            return [blk[0] for blk in per_block], reconstruction
-        return [[blk[i] for blk in per_block] for i in range(batch_size)], reconstruction
+            return [blk[0] for blk in per_block]
+        return [[blk[i] for blk in per_block] for i in range(batch_size)]
 
     @torch.no_grad()
     def decompress(self, block_indices, seed, image_shape):
@@ -219,3 +227,45 @@ class BidirectionalResNetVAE(nn.Module):
                     args = {"seed": seed, "indices": [block_indices[i][r] for i in range(batch_size)], "batched": True}
                 tensor = resnet_block(tensor, inference_pass=False, decoder_args=args)
             return self._finish(tensor)
+
+
+class GraphedCompress:
+    """`model.compress` for a fixed image shape and seed as ONE HIP graph: the first call captures the whole device side
+    of the pass -- every convolution, elementwise op and coder launch of the 24 strictly sequential residual blocks --
+    and later calls replay it (one graph launch instead of several hundred kernel launches; the coder's entry points are
+    asynchronous and allocation-free, so they capture like any other kernel).  Inputs are copied into the graph's static
+    image buffer; indices are read back with the usual single device-to-host copy.  Same outputs as `model.compress`.
+    A block that needs more partitions than the captured index buffers hold falls back to the eager path and re-captures."""
+
+    def __init__(self, model, image_shape, seed, update_sampler=False):
+        self.model, self.seed, self.update_sampler = model, seed, update_sampler
+        self.device = next(model.parameters()).device
+        self.static_image = torch.zeros(image_shape, device=self.device)
+        self.graph = None
+
+    @torch.no_grad()
+    def _capture(self):
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):                                  # warm-up on the capture side: caches, scratch, MIOpen
+            for _ in range(2):
+                self.model._compress_device(self.static_image, self.seed, self.update_sampler)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.pendings, self.reconstruction = self.model._compress_device(self.static_image, self.seed,
+                                                                             self.update_sampler)
+
+    @torch.no_grad()
+    def __call__(self, image):
+        self.static_image.copy_(image)
+        if self.graph is None:
+            self._capture()
+        self.graph.replay()
+        try:
+            per_block = PendingCode.gather(self.pendings)
+        except MorePartitionsNeeded:
+            self.graph = None                                          # hints were raised: eager now, re-capture next time
+            return self.model.compress(image, seed=self.seed, update_sampler=self.update_sampler)
+        return self.model._indices_structure(per_block, image.shape[0]), self.reconstruction.clone()

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--images", type=int, default=300)
     ap.add_argument("--blocks", type=int, default=24)
     ap.add_argument("--singles", type=int, default=8, help="images timed one at a time (N = 1)")
+    ap.add_argument("--no-graph", action="store_true", help="skip the HIP-graph single-image leg")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
@@ -67,6 +68,20 @@ def main():
         torch.cuda.synchronize(); t1 = time.perf_counter()
         model.compress(x, seed=42)
         torch.cuda.synchronize(); singles.append(time.perf_counter() - t1)
+    # the same single images through ONE captured HIP graph of the whole pass (GraphedCompress)
+    from irec.models import GraphedCompress
+    graph_equal, graph_ms = None, [0.0]
+    if not args.no_graph:
+        graphed = GraphedCompress(model, (1, 3, 32, 32), seed=42)
+        ref_idx, ref_rec = model.compress(images[0:1].to(device), seed=42)
+        g_idx, g_rec = graphed(images[0:1].to(device))
+        graph_equal = (g_idx == ref_idx) and bool(torch.equal(g_rec, ref_rec))
+        graph_ms = []
+    for i in range(0 if args.no_graph else args.singles):
+        x = images[i:i + 1].to(device)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        graphed(x)
+        torch.cuda.synchronize(); graph_ms.append(time.perf_counter() - t1)
     if rank == 0:
         ok = [r for r in rows if "error" not in r]
         print(json.dumps({
@@ -76,6 +91,8 @@ def main():
             "model_compress_seconds_share": t_model, "images_per_s_model_compress": share / t_model,
             "latents_per_s_model_compress": share * args.blocks / t_model,
             "single_image_ms": [round(1e3 * s, 2) for s in singles], "single_image_ms_median": 1e3 * sorted(singles)[len(singles) // 2],
+            "single_image_graph_ms": [round(1e3 * s, 2) for s in graph_ms], "single_image_graph_ms_median": 1e3 * sorted(graph_ms)[len(graph_ms) // 2],
+            "graph_equals_eager": graph_equal,
             "mean_bits_per_image": float(all_bits.mean()), "mean_code_bpd": float(all_bits.mean()) / (32 * 32 * 3),
             "mean_code_nats": float(all_nats.mean()), "gathered_items": int(all_bits.numel())}), flush=True)
     if dist is not None:

@@ -146,3 +146,20 @@ def test_batched_compress_equals_one_by_one_and_writes_rec(engine, oracle, tmp_p
     s, shape, bs, bi_file = irec.io.read_compressed_code(str(tmp_path / "img_00003.rec"))
     assert (s, shape, bs) == (42, (32, 32, 3), 1000) and bi_file == bi_batch[3]
     assert rows[3]["n_indices"] == sum(len(ix) for b in bi_batch[3] for ix in b)
+
+
+@pytest.mark.gpu
+def test_graphed_compress_replays_the_whole_pass(engine):
+    """The device side of compress (convolutions + 4 sequential coder launches, no host sync) captured as one HIP graph:
+    same indices and reconstruction as the eager pass, for the capture image and for others replayed through it."""
+    from irec.models import GraphedCompress
+    m = _model("cuda", blocks=4)
+    torch.manual_seed(9)
+    images = torch.rand(3, 1, 3, 32, 32, device="cuda") - 0.5
+    graphed = GraphedCompress(m, (1, 3, 32, 32), seed=42)
+    for k in range(3):
+        idx_e, rec_e = m.compress(images[k], seed=42)
+        idx_g, rec_g = graphed(images[k])
+        assert idx_g == idx_e and torch.equal(rec_g, rec_e), k
+    assert graphed.graph is not None
+    assert torch.equal(m.decompress(idx_g, seed=42, image_shape=images[2].shape), rec_g)
