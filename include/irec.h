@@ -66,6 +66,9 @@ typedef struct {
 #define IREC_FLAG_TEAM 8          /* with table_dims: always the teams-per-CU encoder over three table copies.         */
                                   /* Neither flag: the team encoder for calls of >= 64 blocks, the one-table encoder   */
                                   /* (cheaper per-call set-up) below; same outputs, bit for bit                        */
+#define IREC_FLAG_NO_SPLIT 16     /* never the split encoder (several workgroups per block for calls of few blocks)   */
+#define IREC_FLAG_SPLIT_SHIFT 12  /* bits 12-15: workgroups per block of the split encoder, 0 = chosen by the library (diagnostics) */
+#define IREC_FLAG_SPLIT_MASK (0xF << IREC_FLAG_SPLIT_SHIFT)
 /* Diagnostic workgroup shapes of the team encoder for B <= 20 (bits 8-11 of flags; 0 = the default shape).  Same outputs. */
 #define IREC_FLAG_SHAPE_SHIFT 8
 #define IREC_FLAG_SHAPE_MASK (0xF << IREC_FLAG_SHAPE_SHIFT)
@@ -87,6 +90,7 @@ typedef struct {
   int32_t lds_bytes;       /* dynamic LDS of one workgroup                                                      */
   int32_t table_steps;     /* partitions the proposal tables cover (0 = no tables)                              */
   int32_t n_tables;
+  int32_t split;           /* workgroups that share one block (split encoder of small calls), 0 = one block per workgroup */
   int32_t n_cu;            /* compute units of the context's device                                             */
   int32_t clock_mhz;       /* its maximum engine clock                                                          */
   int64_t table_bytes;     /* proposal tables inside the workspace                                              */

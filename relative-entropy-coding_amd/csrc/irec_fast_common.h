@@ -50,9 +50,9 @@ constexpr size_t SMALL_LDS_BYTES = (sizeof(SmallLds) + 15) & ~(size_t)15;
 //  - otherwise: all waves scan the keys, one barrier per selected beam (element f owned by thread f % NT).
 // `sync` is the barrier of the NT threads that run the selection together (the whole workgroup, or one team of it) and
 // `tid` the thread's index among them.
-// `post(j, s, b)` is called by the thread that has just recorded new beam j = candidate (sample s, parent beam b),
-// before the barrier that publishes the selection.
-struct NoPost { __device__ __forceinline__ void operator()(int, int32_t, int32_t) const {} };
+// `post(j, s, b, key)` is called by the thread that has just recorded new beam j = candidate (sample s, parent beam b)
+// with sort key `key`, before the barrier that publishes the selection.
+struct NoPost { __device__ __forceinline__ void operator()(int, int32_t, int32_t, uint32_t) const {} };
 template <int NT, class SM, class Sync, class Post = NoPost>
 __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew, int Bcur, SM *sm, const int tid, Sync &&sync,
                                                  unsigned long long *dbg = nullptr, Post &&post = Post()) {
@@ -108,7 +108,7 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
           const int32_t b_ = (int32_t)(mf % (uint32_t)Bcur); // best_ind_beam (beam_search_coder.py:88)
           sel_s[rank] = s_;
           sel_b[rank] = b_;
-          post((int)rank, s_, b_);
+          post((int)rank, s_, b_, mk);
         }
         sm->misc[7] = 1;
       } else {
@@ -144,7 +144,7 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
       const int32_t s_ = (int32_t)(fstar / (uint32_t)Bcur), b_ = (int32_t)(fstar % (uint32_t)Bcur);
       sel_s[it] = s_;
       sel_b[it] = b_;
-      post(it, s_, b_);
+      post(it, s_, b_, (uint32_t)(g >> 32));
     }
   }
   sync();

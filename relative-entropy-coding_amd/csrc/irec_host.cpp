@@ -547,6 +547,23 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
   return pl;
 }
 
+// Split encoder for calls of so few blocks that most CUs would idle (one image's residual block: 9 blocks): W workgroups
+// per block, each scoring a stripe of the samples (irec_kernels.hip).  All n_blocks * W workgroups must be resident at once
+// (they wait for each other every step), so the grid stays within HALF the CUs -- room for a second such call on another
+// stream -- and W within what the exchange buffers hold.  0 = not split.
+int split_width(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks) {
+  if (!pl.table || (p->flags & IREC_FLAG_NO_SPLIT)) return 0;
+  const int B = p->n_beams, S = p->n_samples, nb = irec::fast_nb_for(B);
+  if (!nb || irec::fast_waves_for(B, S, true) != 4 || (int64_t)S * nb > 1024) return 0;   // aliased-key 4-wave builds only
+  if (n_blocks < 1 || n_blocks > irec::COOP_MAX_BLOCKS) return 0;
+  const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+  int64_t W = (n_cu / 2) / n_blocks;
+  W = std::min<int64_t>(W, S);                                             // at least one sample per workgroup
+  const int want = (p->flags & IREC_FLAG_SPLIT_MASK) >> IREC_FLAG_SPLIT_SHIFT;
+  W = std::min<int64_t>(W, want >= 2 ? want : 12);                         // exchange + merge grow with W; scoring is ~S/W
+  return W >= 2 ? (int)W : 0;
+}
+
 // small calls (a single image's res-block: 9 blocks) are latency-bound: the one-table encoder's set-up (a 6 us proposal
 // table, 40 KB of LDS to fill) beats the team encoder's (38 us per table for the bank assignment, 120 KB); the scratch
 // sized for the team plan covers both
@@ -561,7 +578,7 @@ extern "C" {
 size_t irec_encode_workspace_bytes(const irec_context *ctx, const irec_params *p, int32_t max_dim, int32_t max_K) {
   if (!ctx || check_params(p) != IREC_OK || max_dim < 1 || max_K < 0) return 0;
   const Plan pl = make_plan(ctx, p, max_dim, max_K);
-  return 256 + pl.tab_bytes + (size_t)pl.grid_cap * pl.ws_per_wg;
+  return irec::WS_HEAD_BYTES + pl.tab_bytes + (size_t)pl.grid_cap * pl.ws_per_wg;
 }
 
 irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int64_t n_blocks, int32_t max_block_dim,
@@ -585,6 +602,8 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
     std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::fast_kernel_name(B, S, pl.table));
     if (pl.table) std::snprintf(out->table_kernel, sizeof out->table_kernel, "alpha_table_kernel");
     out->grid = (int32_t)std::min<int64_t>(n_blocks, pl.one_grid_cap);
+    out->split = split_width(ctx, pl, p, n_blocks);
+    if (out->split >= 2) out->grid = (int32_t)(n_blocks * out->split);
     out->waves_per_wg = irec::fast_waves_for(B, S, pl.table);
     out->teams_per_wg = 1;
     out->lds_bytes = (int32_t)irec::fast_lds_for(B, S, pl.table);
@@ -600,7 +619,7 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
   out->n_cu = ctx->n_cu;
   out->clock_mhz = ctx->clock_mhz;
   out->table_bytes = (int64_t)pl.tab_bytes;
-  out->workspace_bytes = (int64_t)(256 + pl.tab_bytes + (size_t)pl.grid_cap * pl.ws_per_wg);
+  out->workspace_bytes = (int64_t)(irec::WS_HEAD_BYTES + pl.tab_bytes + (size_t)pl.grid_cap * pl.ws_per_wg);
   return IREC_OK;
 }
 
@@ -639,7 +658,7 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   if (max_K > 0 && !out_indices) return fail(IREC_E_INVALID, "irec_beam_encode: null out_indices");
   if (max_block_dim < 1 || max_block_dim > (1 << 22)) return fail(IREC_E_INVALID, "irec_beam_encode: max_block_dim %d out of range", max_block_dim);
   Plan pl = make_plan(ctx, p, max_block_dim, max_K);
-  const size_t need = 256 + pl.tab_bytes + (size_t)pl.grid_cap * pl.ws_per_wg;
+  const size_t need = irec::WS_HEAD_BYTES + pl.tab_bytes + (size_t)pl.grid_cap * pl.ws_per_wg;
   if (!workspace || workspace_bytes < need)
     return fail(IREC_E_WORKSPACE, "irec_beam_encode: workspace %zu bytes < required %zu", workspace_bytes, need);
   pl.team = team_for_call(pl, p, n_blocks);
@@ -653,12 +672,15 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   A.omega = p->kl_per_partition; A.S = p->n_samples; A.B = p->n_beams; A.max_K = max_K;
   A.out_K = out_K; A.out_indices = out_indices; A.out_sample = out_sample;
   A.lut = ctx->d_lut; A.lut2 = ctx->d_lut2; A.dlog4r = ctx->d_dlog4r; A.rho = ctx->d_rho;
-  // counter block (256 bytes, zeroed per call): [0] block counter of the first pass, [1] deferred-block count,
-  // [2] block counter of the deferred pass
+  // workspace head: counter block (512 bytes, zeroed per call: [0] block counter of the first pass, [1] deferred-block
+  // count, [2] block counter of the deferred pass, [3] split-encoder error flag, [64..127] its per-block arrival counters),
+  // then the candidate exchange of the split encoder
   A.counter = (unsigned int *)workspace;
   A.defer_count = (unsigned int *)workspace + 1;
   A.K_tab = pl.K_tab; A.deferred_pass = 0; A.shape_override = pl.shape;
-  A.ws = (char *)workspace + 256 + pl.tab_bytes;
+  A.coop_W = 1; A.coop_err = (unsigned int *)workspace + 3; A.coop_arrive = (unsigned int *)workspace + 64;
+  A.coop_xch = (uint32_t *)((char *)workspace + irec::WS_COUNTER_BYTES);
+  A.ws = (char *)workspace + irec::WS_HEAD_BYTES + pl.tab_bytes;
   A.ws_per_wg = pl.ws_per_wg;
   A.max_dim_pad = pl.dpad;
   HIP_TRY(irec::launch_zero_counters(workspace, st));
@@ -668,7 +690,7 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   if (pl.table) {
     for (int q = 0; q < 4; ++q) { A.tab[q] = nullptr; A.tab_dim[q] = -1; }
     for (int q = 0; q < pl.n_tab; ++q) {
-      uint16_t *tab = (uint16_t *)((char *)workspace + 256 + pl.tab_off[q]);
+      uint16_t *tab = (uint16_t *)((char *)workspace + irec::WS_HEAD_BYTES + pl.tab_off[q]);
       if (pl.team) HIP_TRY(irec::launch_alpha_choice(seed, p->n_samples, pl.tab_dim[q], pl.K_tab, ctx->d_dlog4r, tab, st));
       else HIP_TRY(irec::launch_alpha_table(seed, p->n_samples, pl.tab_dim[q], pl.K_tab, ctx->d_dlog4r, tab, st));
       A.tab[q] = tab; A.tab_dim[q] = pl.tab_dim[q];
@@ -678,7 +700,7 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
     auto deferred_pass = [&]() -> irec_status {
       if (pl.K_tab >= max_K) return IREC_OK;
       irec::EncArgs A2 = A;
-      A2.deferred_pass = 1;
+      A2.deferred_pass = 1; A2.coop_W = 1;
       A2.counter = (unsigned int *)workspace + 2;
       for (int q = 0; q < 4; ++q) { A2.tab[q] = nullptr; A2.tab_dim[q] = -1; }
       HIP_TRY(irec::launch_encode_fast(A2, false, (int)std::min<int64_t>(n_blocks, pl.fast_grid_cap), st));
@@ -704,7 +726,11 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
         return IREC_OK;
       }
     } else {
-      HIP_TRY(irec::launch_encode_fast(A, true, grid, st));
+      const int W = split_width(ctx, pl, p, n_blocks);
+      if (W >= 2) {
+        A.coop_W = W;
+        HIP_TRY(irec::launch_encode_fast(A, true, (int)(n_blocks * W), st));
+      } else HIP_TRY(irec::launch_encode_fast(A, true, grid, st));
       if (irec_status s2 = deferred_pass()) return s2;
     }
   } else if (pl.fast) {

@@ -34,6 +34,12 @@ struct EncArgs {
   // the fused-Philox encoder with deferred_pass = 1, which codes exactly the blocks with K_tab < out_K[blk] <= max_K.
   int32_t K_tab; int32_t deferred_pass; unsigned int *defer_count;
   int32_t shape_override;   // team-encoder workgroup shape (diagnostics; 0 = default)
+  // Split encoder (small calls: fewer blocks than CUs).  coop_W > 1: workgroup blockIdx.x serves block blockIdx.x / coop_W
+  // and scores the samples of stripe blockIdx.x % coop_W only; per step the coop_W workgroups of a block publish the sort keys
+  // of their candidates in coop_xch [2][COOP_MAX_BLOCKS][COOP_KEYS] behind the arrival counter coop_arrive[block], read all of
+  // the step's keys back and run the same selection.  *coop_err != 0: a workgroup gave up waiting (partners not resident):
+  // block not coded.
+  int32_t coop_W; unsigned int *coop_arrive; uint32_t *coop_xch; unsigned int *coop_err;
   // diagnostics (IREC_STAMPS=1): per-workgroup cycle sums [grid][8]; nullptr in normal runs
   unsigned long long *dbg;
 };
@@ -68,7 +74,11 @@ const char *team_kernel_name(int B, int S, int shape_override);   // e.g. "encod
 const char *fast_kernel_name(int B, int S, bool table);
 hipError_t launch_alpha_choice(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *dlog4r, uint16_t *tab,
                                hipStream_t st);
-hipError_t launch_zero_counters(void *p, hipStream_t st);   // 256 bytes
+hipError_t launch_zero_counters(void *p, hipStream_t st);   // the 512-byte counter block
+constexpr size_t WS_COUNTER_BYTES = 512;                  // [0,256): block / deferred counters, [256,512): 64 arrival counters
+constexpr int COOP_MAX_BLOCKS = 64, COOP_KEYS = 1024;      // split encoder: blocks per call, sort keys per step (S * NB, aliased-key builds)
+constexpr size_t WS_XCH_BYTES = (size_t)2 * COOP_MAX_BLOCKS * COOP_KEYS * 4;   // key exchange of the split encoder, double buffered
+constexpr size_t WS_HEAD_BYTES = WS_COUNTER_BYTES + WS_XCH_BYTES;
 hipError_t launch_decode(const DecArgs &A, int grid, hipStream_t st);
 hipError_t launch_uniform_int(int64_t seed, int64_t n, int32_t *out, hipStream_t st);
 hipError_t launch_select_test(const float *scores, int N, int Bnew, int Bcur, uint32_t *keys, int32_t *sel, hipStream_t st);

@@ -345,9 +345,15 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
   float *stats_g = beams_g - 3 * FAST_MAX_DIM;  // [3][1024]: mq - mp, sq^2, sp^2 of the block, coalesced
 
   unsigned long long stamp_prev = A.dbg ? stamp_now() : 0ull;
+  // Split mode (A.coop_W > 1, TABLE kernels of 4 waves with aliased keys only): this workgroup serves ONE block together
+  // with coop_W - 1 partners and scores sample stripe coop_w of it; no block counter, one trip through the loop.
+  const int coop_W = TABLE && NW == 4 ? A.coop_W : 1;
+  const int coop_w = coop_W > 1 ? (int)(blockIdx.x % (unsigned)coop_W) : 0;
+  bool coop_done = false;
   for (;;) {
     __syncthreads();
-    if (tid == 0) misc[0] = (int32_t)atomicAdd(A.counter, 1u);
+    if (coop_W > 1) { if (tid == 0) { misc[0] = coop_done ? 0x7FFFFFFF : (int32_t)(blockIdx.x / (unsigned)coop_W); misc[6] = 0; } coop_done = true; }
+    else if (tid == 0) misc[0] = (int32_t)atomicAdd(A.counter, 1u);
     __syncthreads();
     const int64_t blk = misc[0];
     if (blk >= A.n_blocks) break; // every wave of every workgroup reaches this
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
         for (int gg = 1; gg < NG; ++gg) tot = tot + gpart[gg];
         const int32_t K = num_aux((float)tot, A.omega);
         misc[1] = K;
-        A.out_K[blk] = K;
+        if (coop_w == 0) A.out_K[blk] = K;
         hsum[0] = 0;
         beta4[0] = 0u; // hash of the empty path is 1 = g^0
       }
@@ -416,11 +422,11 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
     const int K = misc[1];
     if (K > A.max_K || K > IREC_MAX_PARTITIONS_DEV) continue;
     if (TABLE && K > A.K_tab) { // beyond the table window: the fused-Philox pass codes it
-      if (tid == 0) atomicAdd(A.defer_count, 1u);
+      if (tid == 0 && coop_w == 0) atomicAdd(A.defer_count, 1u);
       continue;
     }
     if (K == 0) { // nothing to code: sample = p.loc
-      if (active && sw == 0) {
+      if (active && sw == 0 && coop_w == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           if (valid[i]) A.out_sample[ix[i]] = 0.f + A.p_loc[ix[i]];
@@ -490,9 +496,13 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
 #pragma unroll
       for (int b = 0; b < NB; ++b) bet[b] = __builtin_amdgcn_readfirstlane(beta4[cur * 64 + (b < Bcur ? b : 0)]);
 
-      const int N = S * Bcur;
-      for (int s_base = 0; s_base < S; s_base += SP) {
-      const int s_end = s_base + SP < S ? s_base + SP : S;
+      // my samples: all of them, or stripe coop_w of the split encoder (contiguous: [s_lo, s_hi))
+      const int S_w = coop_W > 1 ? (S + coop_W - 1) / coop_W : S;
+      const int s_lo = coop_W > 1 ? (coop_w * S_w < S ? coop_w * S_w : S) : 0;
+      const int s_hi = coop_W > 1 ? (s_lo + S_w < S ? s_lo + S_w : S) : S;
+      const int N = (s_hi - s_lo) * Bcur;                       // candidates scored HERE (all of the step's unless split)
+      for (int s_base = s_lo; s_base < s_hi || s_base == s_lo; s_base += SP) {
+      const int s_end = s_base + SP < s_hi ? s_base + SP : s_hi;
       // ---------------- scoring: samples [s_base, s_end) x Bcur candidates (beam_search_coder.py:80-84) ----------------
       if (active) {
         const int s_per_stripe = (s_end - s_base + NSW - 1) / NSW;
@@ -609,10 +619,46 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
         }
         if (s_end < S) __syncthreads(); // the next pass overwrites the partials
       }
+      if (s_end >= s_hi) break;
       } // sample passes
-      const int Bnew = B < N ? B : N;
+      const int Ng = S * Bcur;                                  // candidates of the step over all workgroups
+      const int Bnew = B < Ng ? B : Ng;
       if (A.dbg && tid == 0) { const unsigned long long now_ = stamp_now(); A.dbg[(size_t)blockIdx.x * 16 + 11] += now_ - stamp_prev; } // combine
-      select_topB<NT>(key_s, N, Bnew, Bcur, sm, A.dbg ? A.dbg + (size_t)blockIdx.x * 16 : nullptr); // first barrier inside orders key_s writes
+      if (coop_W > 1) {
+        // ---- split encoder: every workgroup of the block publishes the sort keys of ITS candidates at their global flat
+        // positions, waits for its partners, reads the whole step's keys back and runs the same selection as everybody else.
+        // Hand-off without fences (MI355X_MICROARCH.md, inter-workgroup visibility): every handed-off byte is stored and
+        // loaded `sc1` (relaxed agent-scope atomics: L2-bypassing, never a stale line), the storing waves drain their stores
+        // (s_waitcnt vmcnt(0)) before ONE lane behind the workgroup barrier adds to the block's arrival counter, the polling
+        // lane reads that counter `sc1`, and the payload loads sit behind the next workgroup barrier.
+        uint32_t *xk = A.coop_xch + ((size_t)(t & 1) * COOP_MAX_BLOCKS + (size_t)blk) * COOP_KEYS;
+        __syncthreads();   // (aliased keys: all of them written)
+        for (int f = tid; f < N; f += NT) __hip_atomic_store(&xk[s_lo * Bcur + f], key_s[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+          __hip_atomic_fetch_add(&A.coop_arrive[blk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t want = (uint32_t)coop_W * (uint32_t)(t + 1);
+          const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
+          int32_t bad = 0;
+          while (__hip_atomic_load(&A.coop_arrive[blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            if (__hip_atomic_load(A.coop_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bad = 1; break; }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { // 2 s: the partners are not resident -- give up, loudly
+              __hip_atomic_store(A.coop_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              bad = 1; break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+          }
+          misc[6] = bad;
+        }
+        __syncthreads();
+        if (misc[6]) { // every workgroup of the block sees the flag (it is sticky): nobody waits for anybody any more
+          if (tid == 0 && coop_w == 0) A.out_K[blk] = -2;
+          break;
+        }
+        for (int f = tid; f < Ng; f += NT) key_s[f] = __hip_atomic_load(&xk[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      select_topB<NT>(key_s, Ng, Bnew, Bcur, sm, A.dbg ? A.dbg + (size_t)blockIdx.x * 16 : nullptr); // first barrier inside orders key_s writes
       IREC_STAMP(2);
       // ---------------- new hashes / back-pointers (beam_search_coder.py:94-95) ----------------
       if (tid < Bnew) {
@@ -687,7 +733,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
                 nb[i] = obv[i] + y;                          // combined_samples[best_ind_aux, best_ind_beam], :81,92-93
               }
               if (last) {
-                if (j == 0 && sw == 0) {
+                if (j == 0 && sw == 0 && coop_w == 0) {
 #pragma unroll
                   for (int i = 0; i < 4; ++i)
                     if (valid[i]) A.out_sample[ix[i]] = nb[i] + A.p_loc[ix[i]]; // beams[0] + coding_dist.loc, :122
@@ -723,7 +769,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
     }
     // ---- index path of beam 0 (beam_search_coder.py:118-121) ----
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && coop_w == 0 && !(coop_W > 1 && misc[6])) {
       int j = 0;
       for (int t = K - 1; t >= 0; --t) {
         const int32_t v = __builtin_nontemporal_load(&bp[(size_t)t * NB + j]);
@@ -916,7 +962,7 @@ hipError_t launch_alpha_table(int64_t seed, int32_t S, int32_t D, int32_t K_tab,
 // that held the memset node faulted on the second replay).
 __global__ void zero_counters_kernel(uint32_t *p) { p[threadIdx.x] = 0u; }
 hipError_t launch_zero_counters(void *p, hipStream_t st) {
-  hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<uint32_t *>(p));
+  hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(WS_COUNTER_BYTES / 4), 0, st, reinterpret_cast<uint32_t *>(p));
   return hipGetLastError();
 }
 

@@ -543,7 +543,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 #else
       // top-B (beam_search_coder.py:85-89); the thread that records new beam j also extends its hash / back-pointer
       // (:94-95) and notes its parent's table offset, so one barrier publishes everything the update needs
-      select_topB_sync<NT>(key_s, N, Bnew, Bcur, sm, tid, tsync, nullptr, [&](int j, int32_t sp_, int32_t bp_) {
+      select_topB_sync<NT>(key_s, N, Bnew, Bcur, sm, tid, tsync, nullptr, [&](int j, int32_t sp_, int32_t bp_, uint32_t) {
         const int32_t nh = (int32_t)((uint32_t)hsum[cur * TEAM_MB + bp_] + (uint32_t)sp_ * (uint32_t)(69 + t));
         hsum[(cur ^ 1) * TEAM_MB + j] = nh;
         beta4[(cur ^ 1) * TEAM_MB + j] = dlog_s[hash_from_sum(nh) - 1u];

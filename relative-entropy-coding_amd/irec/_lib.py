@@ -17,6 +17,7 @@ IREC_FLAG_FORCE_GENERIC = 1
 IREC_FLAG_FUSED_PHILOX = 2
 IREC_FLAG_ONE_TABLE = 4
 IREC_FLAG_TEAM = 8
+IREC_FLAG_NO_SPLIT = 16
 IREC_FLAG_SHAPE_SHIFT = 8          # diagnostic workgroup shapes of the team encoder (include/irec.h)
 IREC_FLAG_SHAPE = {"default": 0, "1": 1 << 8, "2": 2 << 8, "3": 3 << 8, "2x2": 4 << 8}
 IREC_TABLE_STEPS_DEFAULT = 32
@@ -35,7 +36,7 @@ class IrecPlanInfo(ctypes.Structure):
     """irec_plan_info of include/irec.h."""
     _fields_ = [("kernel", ctypes.c_char * 64), ("table_kernel", ctypes.c_char * 32), ("grid", ctypes.c_int32),
                 ("waves_per_wg", ctypes.c_int32), ("teams_per_wg", ctypes.c_int32), ("lds_bytes", ctypes.c_int32),
-                ("table_steps", ctypes.c_int32), ("n_tables", ctypes.c_int32), ("n_cu", ctypes.c_int32),
+                ("table_steps", ctypes.c_int32), ("n_tables", ctypes.c_int32), ("split", ctypes.c_int32), ("n_cu", ctypes.c_int32),
                 ("clock_mhz", ctypes.c_int32), ("table_bytes", ctypes.c_int64), ("workspace_bytes", ctypes.c_int64)]
 
     def as_dict(self):

@@ -29,6 +29,9 @@ class PendingCode:
         self.coder, self.lay, self.K, self.idx, self.sample, self.max_K = coder, lay, K, idx, sample, max_K
 
     def _lists(self, K_host, idx_host):
+        if (K_host == -2).any():
+            raise CodingError("the split encoder's cooperating workgroups were not all resident (too many small calls in "
+                              "flight on this device): encode again, or set coder.no_split = True")
         if (K_host < 0).any():
             raise CodingError("a block exceeded the engine's dimension bound")
         need = int(K_host.max()) if K_host.size else 0
@@ -91,6 +94,7 @@ class BeamSearchCoder(GaussianCoder):
         self.fused_philox = False    # debugging / testing knob: IREC_FLAG_FUSED_PHILOX
         self.one_table = False       # debugging / testing knob: IREC_FLAG_ONE_TABLE
         self.team = False            # debugging / testing knob: IREC_FLAG_TEAM (the team encoder also for small calls)
+        self.no_split = False        # debugging / testing knob: IREC_FLAG_NO_SPLIT (one workgroup per block also for small calls)
         self.team_shape = "default"  # diagnostics: IREC_FLAG_SHAPE_* workgroup shape of the team encoder
         self.table_steps = 0         # partitions the per-call proposal tables cover (0 = library default, 32); blocks
                                      # with more are coded by the fused-Philox kernel in a second pass of the same call
@@ -119,7 +123,8 @@ class BeamSearchCoder(GaussianCoder):
         flags = (_lib.IREC_FLAG_FORCE_GENERIC if self.force_generic else 0) | \
                 (_lib.IREC_FLAG_FUSED_PHILOX if self.fused_philox else 0) | \
                 (_lib.IREC_FLAG_ONE_TABLE if self.one_table else 0) | \
-                (_lib.IREC_FLAG_TEAM if self.team else 0) | _lib.IREC_FLAG_SHAPE[self.team_shape]
+                (_lib.IREC_FLAG_TEAM if self.team else 0) | (_lib.IREC_FLAG_NO_SPLIT if self.no_split else 0) | \
+                _lib.IREC_FLAG_SHAPE[self.team_shape]
         return get_engine().params(self.kl_per_partition, self.n_samples, self.n_beams, flags,
                                    table_steps=self.table_steps)
 

@@ -19,7 +19,7 @@ def _normal(loc, scale, device="cuda"):
 
 # teams per CU over three table copies (forced also for small calls) / the default choice between that and the one-table
 # encoder by call size / one-table proposal-table kernel / Philox-fused kernel / fallback
-VARIANTS = ["table", "auto", "one_table", "fused", "generic"]
+VARIANTS = ["table", "auto", "one_table", "one_table_nosplit", "fused", "generic"]
 
 
 def _coder(omega, B, eps1, block_size=None, variant="table"):
@@ -27,7 +27,8 @@ def _coder(omega, B, eps1, block_size=None, variant="table"):
     c = irec.BeamSearchCoder(kl_per_partition=omega, n_beams=B, extra_samples=eps1, block_size=block_size)
     c.force_generic = variant == "generic"
     c.fused_philox = variant == "fused"
-    c.one_table = variant == "one_table"
+    c.one_table = variant in ("one_table", "one_table_nosplit")
+    c.no_split = variant == "one_table_nosplit"     # small calls otherwise take the split encoder (W workgroups per block)
     c.team = variant == "table"
     return c
 
@@ -521,3 +522,32 @@ def test_library_errors_are_coding_errors(engine):
     st = irec._lib.load().irec_beam_encode(engine.ctx, None, 1, *([None] * 3), 4, *([None] * 5), 1, 4, *([None] * 4), 0, None)
     with pytest.raises(irec.CodingError):
         irec._lib.check(st, "irec_beam_encode(null params)")
+
+
+# ---- split encoder: several workgroups share one block of a small call -------------------------------------------------
+@pytest.mark.parametrize("n_tensors,n,bs,omega,eps1,B", [(1, 8192, 1000, 3.0, 1.2, 20), (1, 1000, None, 3.0, 1.2, 20),
+                                                         (3, 2048, 1000, 3.0, 1.0, 10), (1, 777, None, 2.0, 1.0, 7),
+                                                         (2, 4096, 1000, 3.0, 1.2, 11), (1, 64, None, 1.5, 1.0, 20)])
+def test_split_encoder_small_calls(engine, oracle, n_tensors, n, bs, omega, eps1, B):
+    """Calls of few blocks run W workgroups per block (plan['split']), each scoring a stripe of the samples and exchanging
+    its local top-B every step: the merged selection, and therefore every output, is the one-workgroup encoder's and the
+    oracle's, bit for bit -- also with K of several hundred steps' worth of cross-workgroup hand-offs."""
+    S = oracle.n_samples(omega, eps1)
+    q = [np.stack([oracle.synthetic_latent(300 + i, n)[j] for i in range(n_tensors)]) for j in range(4)]
+    if n == 777:
+        q[1] = (q[1] * 0.3).astype(np.float32)            # sharper posterior: K in the hundreds
+    c = _coder(omega, B, eps1, block_size=bs, variant="one_table")
+    lay = engine.layout(n_tensors, n, bs, 42)
+    plan = engine.plan(c._params(), lay, 32)
+    assert plan["split"] >= 2 and plan["grid"] == lay.n_blocks * plan["split"], plan
+    idx, sample = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)
+    c2 = _coder(omega, B, eps1, block_size=bs, variant="one_table_nosplit")
+    assert engine.plan(c2._params(), lay, 32)["split"] == 0
+    idx2, sample2 = c2.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)
+    assert idx == idx2 and torch.equal(sample, sample2)
+    for i in range(n_tensors):
+        ridx, rs = oracle.encode_tensor(q[0][i], q[1][i], q[2][i], q[3][i], 42, omega, S, B, block_size=bs)
+        got = idx[i] if bs is not None else idx[i]
+        assert got == ridx and np.array_equal(sample[i].cpu().numpy(), rs), i
+    if n == 777:
+        assert len(idx[0]) > 100
