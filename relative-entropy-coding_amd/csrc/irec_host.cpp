@@ -594,7 +594,7 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
     const int n_teams = irec::team_count_for(B, S, pl.shape);
     std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::team_kernel_name(B, S, pl.shape));
     std::snprintf(out->table_kernel, sizeof out->table_kernel, "alpha_choice_kernel");
-    out->grid = (int32_t)std::min<int64_t>((n_blocks + n_teams - 1) / n_teams, pl.grid_cap / n_teams);
+    out->grid = (int32_t)std::min<int64_t>(n_blocks, pl.grid_cap / n_teams);
     out->waves_per_wg = irec::team_waves_for(B, S, pl.shape);
     out->teams_per_wg = n_teams;
     out->lds_bytes = (int32_t)irec::team_lds_for(B, S, pl.shape);
@@ -708,7 +708,8 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
     };
     if (pl.team) { // grid_cap counts teams (= scratch slabs): two per workgroup, one workgroup per CU
       const int n_teams = irec::team_count_for(p->n_beams, p->n_samples, pl.shape);
-      const int tgrid = (int)std::min<int64_t>((n_blocks + n_teams - 1) / n_teams, pl.grid_cap / n_teams);
+      // one workgroup per CU as soon as there is a block for it: team k of workgroup w starts on block k * grid + w
+      const int tgrid = (int)std::min<int64_t>(n_blocks, pl.grid_cap / n_teams);
       HIP_TRY(irec::launch_encode_team(A, tgrid, st));
       if (!ctx->d_dbg) { if (irec_status s2 = deferred_pass()) return s2; }
       if (ctx->d_dbg) { // diagnostic build (-DIREC_TEAM_STAMPS) only: per-wave phase cycles, wave 0 of a team vs the others

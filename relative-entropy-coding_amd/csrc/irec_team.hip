@@ -176,9 +176,15 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_prev = __builtin_amdgcn_s_memtime();
 #endif
+  // Block hand-out: the first block of team k of workgroup w is k * gridDim.x + w -- a call of fewer blocks than resident
+  // teams (a mid-size batch: 38 images x 9 blocks) puts ONE block on every CU before any CU gets a second one, instead of
+  // three on the first third of the CUs; later blocks come from the atomic counter, which starts behind the static ones.
+  bool first_block = true;
   for (;;) {
     tsync();
-    if (tid == 0) misc[0] = (int32_t)atomicAdd(A.counter, 1u);
+    if (tid == 0) misc[0] = first_block ? (int32_t)(team * (int)gridDim.x + (int)blockIdx.x)
+                                        : (int32_t)(TEAMS * (int)gridDim.x) + (int32_t)atomicAdd(A.counter, 1u);
+    first_block = false;
     tsync();
     const int64_t blk = misc[0];
     TSTAMP(0);

@@ -10,7 +10,14 @@ echo "== bench"; timeout 600 python bench.py --steps 5 --warmup 2 --latents $L -
 echo "== kernel trace"
 rm -rf gpurun_out/prof_$TAG; mkdir -p gpurun_out/prof_$TAG
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG/trace -- python bench.py --steps 5 --warmup 2 --latents $L --no-cpu-baseline > gpurun_out/prof_$TAG/trace.log 2>&1
-find gpurun_out/prof_$TAG/trace -name "*kernel_stats.csv" | head -1 | xargs -r head -12
+f=$(find gpurun_out/prof_$TAG/trace -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && python - "$f" gpurun_out/prof_$TAG/kernel_stats.csv <<'PY'
+import csv, sys
+rows = list(csv.reader(open(sys.argv[1])))
+out = [rows[0]] + [[r[0][:100]] + r[1:] for r in rows[1:]]
+csv.writer(open(sys.argv[2], "w")).writerows(out)
+for r in out[:6]: print(r)
+PY
 if [ "${PMC:-1}" = "1" ]; then
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
