@@ -168,7 +168,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   float *park_g = stats_g - 2 * FAST_MAX_DIM;   // [2][1024]: c (cumulative variance) and sa of the PARK builds
   // Three-team builds have 168 VGPRs: the cumulative variance and the sample scale (needed only by the update) are parked
   // in the slab across the scoring loop instead of being spilled inside it
-  constexpr bool PARK = TEAMS >= 3;
+  constexpr bool PARK = TEAMS >= 3 && NBW == 20;
   constexpr bool LATE_G = false;   // (tried: new beams wait in G's registers and G is formed after the batches -- the
                                    //  register allocator then shuffles eight registers through scratch per beam: 844 B)
 
@@ -327,9 +327,11 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
     TSTAMP(1);
     int cur = 0, Bcur = 1;
     for (int t = 0; t < K; ++t) {
-      // row s at + s * Dp; lanes past the padded row end read the row START (finite z, zero coefficients)
       const uint16_t *tab_tu = tab + (size_t)t * S * Dp;             // uniform base of this step's rows
-      const uint32_t tab_lo = (uint32_t)(d0 < Dp ? d0 : 0);          // my quad inside a row (32-bit offsets: one VGPR)
+      // my quad inside a row (32-bit offsets: one VGPR).  Lanes past the padded row end (all their dims invalid, zero
+      // coefficients) read the row's LAST quad: finite z, and the same addresses as the last real lane of their 32-lane
+      // group -- the LDS serves identical addresses as one broadcast, so they add no bank conflict to the look-ups
+      const uint32_t tab_lo = (uint32_t)(d0 < Dp ? d0 : Dp - 4);
       const uint16_t *tab_t = tab_tu + tab_lo;
       uint32_t bet[NBW];
       {
