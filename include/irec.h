@@ -67,6 +67,8 @@ typedef struct {
                                   /* Neither flag: the team encoder for calls of >= 64 blocks, the one-table encoder   */
                                   /* (cheaper per-call set-up) below; same outputs, bit for bit                        */
 #define IREC_FLAG_NO_SPLIT 16     /* never the split encoder (several workgroups per block for calls of few blocks)   */
+#define IREC_FLAG_TEST_SPLIT_ORPHAN 32 /* test hook: the partner workgroups of the split encoder leave at once, so workgroup 0  */
+                                  /* of every block must take the 2-second give-up exit (out_K = -2) instead of hanging   */
 #define IREC_FLAG_SPLIT_SHIFT 12  /* bits 12-15: workgroups per block of the split encoder, 0 = chosen by the library (diagnostics) */
 #define IREC_FLAG_SPLIT_MASK (0xF << IREC_FLAG_SPLIT_SHIFT)
 /* Diagnostic workgroup shapes of the team encoder for B <= 20 (bits 8-11 of flags; 0 = the default shape).  Same outputs. */

@@ -730,6 +730,7 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
       const int W = split_width(ctx, pl, p, n_blocks);
       if (W >= 2) {
         A.coop_W = W;
+        A.coop_test_orphan = (p->flags & IREC_FLAG_TEST_SPLIT_ORPHAN) ? 1 : 0;
         HIP_TRY(irec::launch_encode_fast(A, true, (int)(n_blocks * W), st));
       } else HIP_TRY(irec::launch_encode_fast(A, true, grid, st));
       if (irec_status s2 = deferred_pass()) return s2;

@@ -350,6 +350,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
   const int coop_W = TABLE && NW == 4 ? A.coop_W : 1;
   const int coop_w = coop_W > 1 ? (int)(blockIdx.x % (unsigned)coop_W) : 0;
   bool coop_done = false;
+  if (coop_W > 1 && A.coop_test_orphan && coop_w != 0) return;   // test hook: workgroup 0 of each block is left waiting
   for (;;) {
     __syncthreads();
     if (coop_W > 1) { if (tid == 0) { misc[0] = coop_done ? 0x7FFFFFFF : (int32_t)(blockIdx.x / (unsigned)coop_W); misc[6] = 0; } coop_done = true; }

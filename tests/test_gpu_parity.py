@@ -410,6 +410,13 @@ def test_config5_stress_full_size(engine, oracle):
     _full_size_check(engine, oracle, 96, 8192, 1000, 5.0, 1.0, 30, n_oracle_blocks=6, gen_seed=63)
 
 
+def test_config5_stress_s403_full_tensors(engine, oracle):
+    # BASELINE configs[4] at eps = 0.2: S = int(e^6) = 403, B = 30 -> 12 090 candidates per step (sort keys in the slab, six
+    # sample passes): 24 full latent tensors (216 blocks), round trip on every dim + four blocks against the oracle
+    Kh = _full_size_check(engine, oracle, 24, 8192, 1000, 5.0, 1.2, 30, n_oracle_blocks=4, gen_seed=64)
+    assert len(Kh) == 24 * 9
+
+
 # ---- round 2: bounded proposal tables, plan export, per-stream scratch ------------------------------------------------
 def test_table_window_mixed_partition_counts_fit_256mb(engine, oracle):
     """Blocks with K = 7..8 and blocks with K ~ 3000 in ONE call at S = 403 (Omega = 5, eps = 0.2): the proposal tables
@@ -430,10 +437,7 @@ def test_table_window_mixed_partition_counts_fit_256mb(engine, oracle):
     Ks = [[len(b) for b in t] for t in idx]
     assert max(Ks[0]) > 2500 and max(Ks[1]) <= 32 and max(Ks[2]) > 2500, Ks
     for i in range(3):
-        ridx, rs = oracle.encode_tensor(q[0][i], q[1][i], q[2][i], q[3][i], 42, omega, S, B, block_size=bs) \
-            if max(Ks[i]) <= 32 else (None, None)
-        if ridx is None:   # the oracle's per-tensor wrapper caps max_K at 4096: fine here
-            ridx, rs = oracle.encode_tensor(q[0][i], q[1][i], q[2][i], q[3][i], 42, omega, S, B, block_size=bs)
+        ridx, rs = oracle.encode_tensor(q[0][i], q[1][i], q[2][i], q[3][i], 42, omega, S, B, block_size=bs)
         assert idx[i] == ridx, i
         assert np.array_equal(sample[i].cpu().numpy(), rs), i
     lay = engine.layout(3, n, bs, 42)
@@ -551,3 +555,25 @@ def test_split_encoder_small_calls(engine, oracle, n_tensors, n, bs, omega, eps1
         assert got == ridx and np.array_equal(sample[i].cpu().numpy(), rs), i
     if n == 777:
         assert len(idx[0]) > 100
+
+
+def test_split_encoder_gives_up_instead_of_hanging(engine, oracle):
+    """The cooperating workgroups of the split encoder wait for each other every step.  If the partners never arrive (test
+    hook: they leave at once) the waiting workgroup must reach its exit: after 2 s it raises the sticky error flag, the
+    block comes back with out_K = -2 and the Python layer turns that into a CodingError -- no hung GPU."""
+    import time
+    import irec
+    mq, sq, mp, sp = (torch.as_tensor(a[None], device="cuda") for a in oracle.synthetic_latent(77, 1000))
+    lay = engine.layout(1, 1000, None, 42)
+    params = engine.params(3.0, 36, 20, irec._lib.IREC_FLAG_ONE_TABLE | 32)      # 32 = IREC_FLAG_TEST_SPLIT_ORPHAN
+    assert engine.plan(params, lay, 32)["split"] >= 2
+    t0 = time.perf_counter()
+    K, idx, sample = engine.encode_blocks(params, lay, mq, sq, mp, sp, 42, 32)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert int(K.cpu()[0]) == -2 and 1.5 < dt < 10.0, (K.cpu(), dt)
+    # the same call without the hook works, and the engine is usable afterwards
+    c = _coder(3.0, 20, 1.2, variant="one_table")
+    i2, s2 = c.encode(_normal(mq, sq), _normal(mp, sp), seed=42)
+    ridx, rs = oracle.encode_block(mq.cpu().numpy()[0], sq.cpu().numpy()[0], mp.cpu().numpy()[0], sp.cpu().numpy()[0], 42, 3.0, 36, 20)
+    assert [int(v) for v in i2] == ridx and np.array_equal(s2.cpu().numpy()[0], rs)

@@ -94,10 +94,26 @@ def test_lossy_two_level_compress_file_decompress(engine, tmp_path):
     sampler = irec.BeamSearchCoder(kl_per_partition=3., n_beams=10, extra_samples=1., block_size=1000)
     image = torch.rand(128, 192, 3, device="cuda") - 0.5
     path = str(tmp_path / "kodak_crop.rec")
+    seen = []                                     # what each of the two sequential sampler.encode calls was handed, and returned
+    orig = sampler.encode
+
+    def spy(target, coder, seed, **kw):
+        out = orig(target, coder, seed, **kw)
+        seen.append((target.loc.clone(), target.scale.clone(), coder.loc.clone(), coder.scale.clone(), out))
+        return out
+    sampler.encode = spy
     recon = m.compress(path, image, seed=42, sampler=sampler, block_size=1000, max_index=20)
+    del sampler.encode
+    from oracle import oracle as O
+    assert [tuple(t[0].shape) for t in seen] == [(1, 2, 3, 128), (1, 8, 12, 196)]       # level 2 first, then level 1 (:359,394)
+    for ql, qs, pl, ps, (idx, sample) in seen:                                            # in-situ parity with the oracle
+        ridx, rs = O.encode_tensor(ql.cpu().numpy(), qs.cpu().numpy(), pl.cpu().numpy(), ps.cpu().numpy(), 42, 3.0, 20, 10,
+                                   block_size=1000)
+        assert idx == ridx and np.array_equal(sample.cpu().numpy(), rs)
     assert recon.shape == (1, 3, 128, 192) and torch.isfinite(recon).all()
     seed, shape, bs, block_indices = irec.io.read_compressed_code(path)
     assert (seed, shape, bs) == (42, (128, 192, 3), 1000)
+    assert block_indices == [seen[0][4][0], seen[1][4][0]]                               # the file holds what the coder emitted
     assert [len(b) for b in block_indices] == [1, 19]
     assert m.level_1_posterior.loc.shape == (1, 8, 12, 196) and m.level_2_posterior.loc.shape == (1, 2, 3, 128)
     recon2 = m.decompress(path, sampler)
