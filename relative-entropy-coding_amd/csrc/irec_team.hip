@@ -604,7 +604,9 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
               const int32_t bp_ = __builtin_amdgcn_readlane(v_bp, j);
               bet_old[u] = (uint32_t)__builtin_amdgcn_readlane((int)v_bo, j);
               apv[u] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sp_ * Dp);
+#ifndef IREC_ABLATE_SLAB
               if (t) obv4[u] = *reinterpret_cast<const float4 *>(bold + (size_t)bp_ * FAST_MAX_DIM);
+#endif
             }
           }
           if (j0 == 0 && !last) { step_consts(t + 1, m, cA, cBv); park(); } // next step's constants, under the loads' latency
@@ -642,7 +644,9 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
                     }
                 }
               } else {
+#ifndef IREC_ABLATE_SLAB
                 if (sw == 0) *reinterpret_cast<float4 *>(bnew + (size_t)j * FAST_MAX_DIM) = make_float4(nb[0], nb[1], nb[2], nb[3]);
+#endif
                 if constexpr (LATE_G) {
                   // 168-VGPR builds: the new beam waits in G's own registers; G and the C terms are formed below, once the
                   // batch temporaries (parent beams, proposal rows, look-ups) are dead -- same operations on the same values
