@@ -36,6 +36,9 @@ class PendingCode:
             raise CodingError("a block exceeded the engine's dimension bound")
         need = int(K_host.max()) if K_host.size else 0
         self.coder._max_K_hint = max(self.coder._max_K_hint, need)
+        c = self.coder            # table window hint: the largest K of the first read, then a slowly decaying maximum
+        c._K_seen = need if c._K_reads == 0 else max(need, c._K_seen - 1 if c._K_reads % 16 == 0 else c._K_seen)
+        c._K_reads += 1
         if need > _lib.MAX_PARTITIONS:
             raise CodingError(f"KL divergence needs {need} partitions; this build supports {_lib.MAX_PARTITIONS}")
         if need > self.max_K:
@@ -96,9 +99,12 @@ class BeamSearchCoder(GaussianCoder):
         self.team = False            # debugging / testing knob: IREC_FLAG_TEAM (the team encoder also for small calls)
         self.no_split = False        # debugging / testing knob: IREC_FLAG_NO_SPLIT (one workgroup per block also for small calls)
         self.team_shape = "default"  # diagnostics: IREC_FLAG_SHAPE_* workgroup shape of the team encoder
-        self.table_steps = 0         # partitions the per-call proposal tables cover (0 = library default, 32); blocks
-                                     # with more are coded by the fused-Philox kernel in a second pass of the same call
+        self.table_steps = 0         # partitions the per-call proposal tables cover; 0 = sized from the partition counts
+                                     # this coder has seen so far (_K_seen + 4, between 8 and the library default of 32);
+                                     # blocks with more are coded by the fused-Philox kernel in a second pass of the same call
         self._max_K_hint = 32
+        self._K_seen = 28            # largest K read back so far (starts at the default window; shrinks with evidence)
+        self._K_reads = 0
 
     # ---- small host-side mirrors ---------------------------------------------------------------------------------
     def simple_hash(self, matrix):
@@ -125,8 +131,10 @@ class BeamSearchCoder(GaussianCoder):
                 (_lib.IREC_FLAG_ONE_TABLE if self.one_table else 0) | \
                 (_lib.IREC_FLAG_TEAM if self.team else 0) | (_lib.IREC_FLAG_NO_SPLIT if self.no_split else 0) | \
                 _lib.IREC_FLAG_SHAPE[self.team_shape]
-        return get_engine().params(self.kl_per_partition, self.n_samples, self.n_beams, flags,
-                                   table_steps=self.table_steps)
+        steps = self.table_steps
+        if steps == 0:   # running hint: the tables cost set-up time and scratch per step they cover (typical K is ~8)
+            steps = min(_lib.IREC_TABLE_STEPS_DEFAULT, max(8, (self._K_seen + 4 + 3) // 4 * 4))
+        return get_engine().params(self.kl_per_partition, self.n_samples, self.n_beams, flags, table_steps=steps)
 
     @staticmethod
     def _dev(t, device):

@@ -577,3 +577,25 @@ def test_split_encoder_gives_up_instead_of_hanging(engine, oracle):
     i2, s2 = c.encode(_normal(mq, sq), _normal(mp, sp), seed=42)
     ridx, rs = oracle.encode_block(mq.cpu().numpy()[0], sq.cpu().numpy()[0], mp.cpu().numpy()[0], sp.cpu().numpy()[0], 42, 3.0, 36, 20)
     assert [int(v) for v in i2] == ridx and np.array_equal(s2.cpu().numpy()[0], rs)
+
+
+def test_table_window_follows_the_partition_counts(engine, oracle):
+    """The Python coder sizes the proposal tables from the K it has read back (32 steps of table for K ~ 8)."""
+    import irec
+    q = [np.stack([oracle.synthetic_latent(500 + i, 8192)[j] for i in range(8)]) for j in range(4)]
+    c = irec.BeamSearchCoder(kl_per_partition=3., n_beams=20, extra_samples=1.2, block_size=1000)
+    assert c._params().table_steps == 32                                  # nothing seen yet: the library default
+    idx, sample = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)
+    kmax = max(len(b) for t in idx for b in t)
+    assert 8 <= c._params().table_steps <= kmax + 8 and c._params().table_steps < 32
+    idx2, sample2 = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)   # coded with the short window
+    assert idx2 == idx and torch.equal(sample2, sample)
+    ridx, rs = oracle.encode_tensor(q[0][5], q[1][5], q[2][5], q[3][5], 42, 3.0, 36, 20, block_size=1000)
+    assert idx2[5] == ridx and np.array_equal(sample2[5].cpu().numpy(), rs)
+    # a later batch with much larger K than the window: the second pass codes it, same results as a fresh coder
+    q2 = [a.copy() for a in q]
+    q2[1] = (q2[1] * 0.35).astype(np.float32)
+    idx3, sample3 = c.encode(_normal(q2[0], q2[1]), _normal(q2[2], q2[3]), seed=42, batched=True)
+    fresh = irec.BeamSearchCoder(kl_per_partition=3., n_beams=20, extra_samples=1.2, block_size=1000)
+    idx4, sample4 = fresh.encode(_normal(q2[0], q2[1]), _normal(q2[2], q2[3]), seed=42, batched=True)
+    assert idx3 == idx4 and torch.equal(sample3, sample4) and max(len(b) for t in idx3 for b in t) > 20
