@@ -226,9 +226,14 @@ def run_rank(args):
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # (IREC_BENCH_FORCE_DIST=1: test rigs run the collective code path -- process group, barrier, all_gathers over RCCL --
+    #  with a world of ONE rank on the one GPU they have; tests/test_bench_launcher.py)
+    if world > 1 or os.environ.get("IREC_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)
         else:

@@ -64,3 +64,14 @@ def test_single_rank_line_is_self_describing():
     assert res["n_gpus"] == 1 and res["roofline"]["kernel"] == "encode_team_kernel<20,3,1>"
     assert res["roofline"]["bound"] == "hbm" and 0 < res["roofline"]["frac"] < 1
     assert res["secondary"]["lds_hw"]["peak"] == 32.0 and res["secondary"]["n_cu"] == 256
+
+
+@pytest.mark.gpu
+def test_rccl_code_path_with_a_world_of_one():
+    """The collectives of the N-rank job (process group on RCCL, barrier, all_gather_into_tensor of the code lengths,
+    all_gather of the rank times) executed for real over the nccl backend with one rank -- all a 1-GPU box can run."""
+    r = _run(["--steps", "2", "--warmup", "1", "--latents", "128", "--no-cpu-baseline"],
+             {"IREC_BENCH_FORCE_DIST": "1", "IREC_DIST_BACKEND": "nccl"}, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 1 and res["world_size"] == 1 and res["backend"] == "nccl" and res["value"] > 0
