@@ -717,12 +717,13 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
         std::vector<unsigned long long> h((size_t)tgrid * nwv * 16);
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(h.data(), ctx->d_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        static const char *nm[9] = {"fetch", "prologue", "scoring", "wait-score", "combine", "select", "update", "wait-update", "epilogue"};
-        double w0[9] = {0}, wo[9] = {0}, t0 = 0, to = 0;
+        static const char *nm[12] = {"fetch", "prologue", "scoring", "wait-score", "combine", "select", "update-tail", "wait-update", "epilogue",
+                                     "upd:sel+issue+consts", "upd:batches", "-"};
+        double w0[12] = {0}, wo[12] = {0}, t0 = 0, to = 0;
         for (int w = 0; w < tgrid * nwv; ++w)
-          for (int k = 0; k < 9; ++k) { const double v = (double)h[(size_t)w * 16 + k]; if ((w & 3) == 0) { w0[k] += v; t0 += v; } else { wo[k] += v; to += v; } }
+          for (int k = 0; k < 12; ++k) { const double v = (double)h[(size_t)w * 16 + k]; if ((w & 3) == 0) { w0[k] += v; t0 += v; } else { wo[k] += v; to += v; } }
         fprintf(stderr, "[irec team stamps] share of wave time, wave 0 of a team | waves 1-3:\n");
-        for (int k = 0; k < 9; ++k) fprintf(stderr, "  %-12s %5.1f%% | %5.1f%%\n", nm[k], 100 * w0[k] / t0, 100 * wo[k] / to);
+        for (int k = 0; k < 11; ++k) fprintf(stderr, "  %-20s %5.1f%% | %5.1f%%\n", nm[k], 100 * w0[k] / t0, 100 * wo[k] / to);
         fprintf(stderr, "  cycles per wave: %.0f | %.0f\n", t0 / (tgrid * nwv / 4), to / (tgrid * nwv * 3 / 4));
         return IREC_OK;
       }

@@ -610,6 +610,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
             }
           }
           if (j0 == 0 && !last) { step_consts(t + 1, m, cA, cBv); park(); } // next step's constants, under the loads' latency
+          if (j0 == 0) TSTAMP(9);   // (diagnostic build: selection fetch + first load batch issued + step constants)
           // ---- new beams, their G and C terms ----
           // look-ups of YB beams are issued back to back, then consumed: UB / YB LDS latencies per batch instead of UB
           constexpr int YB = 5;
@@ -680,6 +681,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
             }
           }
         }
+        TSTAMP(10);                 // (diagnostic build: the load batches -- new beams, G, C)
         if (!last) {
           const float ctot = reduce_scatter_n<NBW>(cacc, lane);
           if (sw == 0 && (lane & 1) == 0 && rs_c >= 0 && b_lo + rs_c < Bnew) cpart_s[g * 32 + b_lo + rs_c] = ctot;
