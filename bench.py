@@ -2,7 +2,7 @@
 """bench.py -- encoded latents/s of the iREC beam-search encoder on MI355X (BASELINE.json metric).
 
 One "step" = one pass of the hot path (irec_beam_encode: one persistent kernel launch) over one batch of
---latents synthetic RVAE latent tensors [16,16,32] (8192 dims -> 8 blocks of 1000 + 1 of 192 dims each) that are
+--latents (default 8192) synthetic RVAE latent tensors [16,16,32] (8192 dims -> 8 blocks of 1000 + 1 of 192 dims each) that are
 already resident in HBM, with B=20, Omega=3, 1+eps=1.2 (S=36): BASELINE.json configs[1].  Multi-GPU: one process per
 GPU, every rank codes its own batch (weak scaling, no data-path collective); the only collective is the final RCCL
 all_gather of the per-latent code lengths.
@@ -374,7 +374,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--latents", type=int, default=2048, help="latent tensors per step per GPU")
+    ap.add_argument("--latents", type=int, default=8192, help="latent tensors per step per GPU (8192: 73 728 blocks, 53 ms "
+                    "per step -- a timed region of about a second at the driver's 20 steps; 2048 gives 2.5 %% less: set-up "
+                    "and tail of the persistent kernel weigh more)")
     ap.add_argument("--cpu-ref-latents", type=int, default=20, help="latents per CPU-ref repeat (5 repeats, median)")
     ap.add_argument("--cpu-opt-seconds", type=float, default=8.0, help="time budget of the CPU-opt (OpenMP oracle) leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")

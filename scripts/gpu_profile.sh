@@ -3,7 +3,7 @@
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-L=${LATENTS:-2048}
+L=${LATENTS:-8192}
 TAG=${TAG:-r02}
 echo "== quick parity"; timeout 600 python -m pytest tests -x -q -m gpu -k "golden or full_size or reduce_scatter" 2>&1 | tail -3
 echo "== bench"; timeout 600 python bench.py --steps 5 --warmup 2 --latents $L --no-cpu-baseline 2>&1 | tail -4 | tee gpurun_out/bench_$TAG.log
