@@ -15,7 +15,10 @@
  *   - scipy.special.ndtri over the 10006 LUT points,
  *   - CPython's own `random` module for the MT19937 seed plumbing of tf.random.shuffle,
  *   - the reference's test_beam_search case (round trip),
- *   - the literal-vs-canonical cross check below.
+ *   - the literal-vs-canonical cross check below,
+ *   - (round 2) the reference's OWN Python run on every fixture over numpy stubs of its TensorFlow calls (oracle/tfshim,
+ *     tests/golden/make_golden_refpy.py): identical indices -- this pins the control flow restated here to the reference;
+ *     the TensorFlow primitives the stubs take from THIS file remain unpinned.
  *
  * Two arithmetic modes:
  *   IREC_ORACLE_LITERAL   : every TF/TFP op restated one-to-one in float32 in the reference's op order
