@@ -114,6 +114,48 @@ def test_hip_equals_reference_python_on_split_tensor(engine):
     assert np.allclose(dec.cpu().numpy(), REF["tensor_decoded"], rtol=0, atol=1e-5)
 
 
+RAND = np.load(os.path.join(GOLDEN_DIR, "refpy_random_blocks.npz"))
+
+
+def _rand_case(k):
+    mq, sq, mp, sp = RAND[f"b{k}_in"]
+    omega, eps1, B, seed, S = RAND[f"b{k}_meta"]
+    return mq, sq, mp, sp, float(omega), float(eps1), int(B), int(seed), int(S)
+
+
+@pytest.mark.both_suites
+@pytest.mark.usefixtures("suite")
+def test_oracle_equals_reference_python_on_48_random_blocks(oracle):
+    """tests/golden/make_golden_refpy_random.py: six coder settings (S from 4 to 403, B from 7 to 30, S < B included), three
+    statistics regimes, K up to ~100, dims 1..1000 -- what the reference's encode_block returned for each."""
+    n_ok = 0
+    for k in range(int(RAND["n"])):
+        mq, sq, mp, sp, omega, eps1, B, seed, S = _rand_case(k)
+        want = RAND[f"b{k}_indices"].tolist()
+        ci, cs = oracle.encode_block(mq, sq, mp, sp, seed, omega, S, B, mode=oracle.CANONICAL, max_K=4096)
+        li, ls = oracle.encode_block(mq, sq, mp, sp, seed, omega, S, B, mode=oracle.LITERAL, max_K=4096)
+        assert ci == want and li == want, k
+        assert np.allclose(cs, RAND[f"b{k}_sample"], rtol=0, atol=1e-5 * max(1.0, float(np.abs(cs).max()))), k
+        assert np.allclose(RAND[f"b{k}_decoded"], RAND[f"b{k}_sample"], rtol=0, atol=1e-5 * max(1.0, float(np.abs(cs).max()))), k
+        n_ok += 1
+    assert n_ok == 48
+
+
+@pytest.mark.gpu
+def test_hip_equals_reference_python_on_48_random_blocks(engine):
+    import irec
+    import torch
+    for k in range(int(RAND["n"])):
+        mq, sq, mp, sp, omega, eps1, B, seed, S = _rand_case(k)
+        c = irec.BeamSearchCoder(kl_per_partition=omega, n_beams=B, extra_samples=eps1)
+        assert c.n_samples == S
+        N = lambda a, b: torch.distributions.Normal(torch.as_tensor(a[None]).cuda(), torch.as_tensor(b[None]).cuda(), validate_args=False)  # noqa: E731
+        idx, sample = c.encode(N(mq, sq), N(mp, sp), seed=seed)
+        assert [int(i) for i in idx] == RAND[f"b{k}_indices"].tolist(), k
+        got = sample.cpu().numpy().reshape(-1)
+        assert np.allclose(got, RAND[f"b{k}_sample"], rtol=0, atol=1e-5 * max(1.0, float(np.abs(got).max()))), k
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/rec/coding"), reason="live run needs the reference checkout (build container only)")
 def test_reference_python_live_on_fresh_blocks(oracle):
     """The reference's encode_block / decode_block executed NOW (numpy TF stub) on random blocks of the four settings."""
