@@ -179,3 +179,25 @@ def test_graphed_compress_replays_the_whole_pass(engine):
         assert idx_g == idx_e and torch.equal(rec_g, rec_e), k
     assert graphed.graph is not None
     assert torch.equal(m.decompress(idx_g, seed=42, image_shape=images[2].shape), rec_g)
+
+
+@pytest.mark.gpu
+def test_config3_harness_two_ranks_share_images(tmp_path):
+    """scripts/config3_harness.py under torch.distributed.run with two ranks (gloo: both on the one GPU of the test box):
+    image i goes to rank i mod 2, every rank compresses its share as one batch, writes / reads back its .rec files, and the
+    per-image bits of ALL images are gathered on every rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(IREC_DIST_BACKEND="gloo", TMPDIR=str(tmp_path))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(root, "scripts", "config3_harness.py"),
+                        "--images", "10", "--blocks", "3", "--singles", "1", "--no-graph"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["images_this_rank"] == 5 and res["gathered_items"] == 10 and res["all_indices_recovered"] and res["errors"] == 0
+    assert res["mean_bits_per_image"] > 0
