@@ -209,6 +209,21 @@ int64_t irec_rec_pack_bits(const uint8_t *bits, int64_t n_bits, uint8_t *out_byt
 /* bin(int.from_bytes(bytes, 'big'))[3:] -- rec/io/utils.py:158-170.  Returns code bits written or -1. */
 int64_t irec_rec_unpack_bits(const uint8_t *bytes, int64_t n_bytes, uint8_t *out_bits, int64_t cap);
 
+/* Whole .rec files with the default symbol models, one call each (the per-stream Python glue of the reference, utils.py:55-106 and
+ * :150-216, costs more host time per image than the GPU takes to code it).
+ * write_compressed_code(file_path, seed, image_shape, block_size, block_indices, max_index) -- rec/io/utils.py:7-106:
+ *   blocks_per_res [R]; K [sum blocks_per_res] partitions of every coded block, residual block after residual block;
+ *   indices [sum K] their sample indices back to back.  Returns the file's byte count (also when > cap: call again), -1 on error. */
+int64_t irec_rec_encode_file(uint32_t seed, uint32_t block_size, uint32_t max_index, uint32_t height, uint32_t width,
+                             uint32_t channels, int32_t n_res_blocks, const int32_t *blocks_per_res, const int32_t *K,
+                             const int32_t *indices, uint8_t *out, int64_t cap);
+/* read_compressed_code -- rec/io/utils.py:109-216.  header_out[9] = seed, block_size, max_index, height, width, channels,
+ * uses_count_file, uses_index_file, R; sizes_out[3] = R, coded blocks, indices.  IREC_E_WORKSPACE (sizes filled) when an
+ * output array is null or short. */
+irec_status irec_rec_decode_file(const uint8_t *bytes, int64_t n_bytes, uint32_t *header_out, int64_t *sizes_out,
+                                 int32_t *blocks_per_res, int64_t cap_res, int32_t *K, int64_t cap_blocks, int32_t *indices,
+                                 int64_t cap_indices);
+
 /* ---- test hooks (device pointers) ---------------------------------------------------------------------------- */
 /* r[s*D + d] of get_pseudo_random_sample's int32 draw, generated by the in-kernel Philox stream.  out: int32 [n]. */
 irec_status irec_device_uniform_int(irec_context *ctx, int64_t seed, int64_t n, int32_t *out, void *hip_stream);

@@ -154,4 +154,133 @@ int64_t irec_rec_unpack_bits(const uint8_t *bytes, int64_t n_bytes, uint8_t *out
   return n;
 }
 
+// ---- whole .rec files with the default symbol models (rec/io/utils.py:7-106 / :109-216) ------------------------------------
+namespace {
+// one stream: message = values + 1, terminated by 0 (utils.py:58-68); model = count 1 for the terminator, 1 + weight for every
+// other symbol (utils.py:31-35: weight 1000 for indices over max_index + 1 symbols; :41-47: weight 100 for partition counts)
+bool encode_stream(const int32_t *values, int64_t n, int32_t n_values, int64_t weight, std::vector<uint8_t> &out) {
+  std::vector<int64_t> model((size_t)n_values + 1, 1 + weight), msg((size_t)n + 1);
+  model[0] = 1;
+  for (int64_t i = 0; i < n; ++i) {
+    if (values[i] < 0 || values[i] >= n_values) return false;
+    msg[(size_t)i] = (int64_t)values[i] + 1;
+  }
+  msg[(size_t)n] = 0;
+  std::vector<uint8_t> bits((size_t)(64 + 40 * (n + 1)));
+  int64_t nb = 0;
+  irec_status st = irec_ac_encode(model.data(), n_values + 1, msg.data(), n + 1, 32, bits.data(), (int64_t)bits.size(), &nb);
+  if (st != IREC_OK && nb > (int64_t)bits.size()) {
+    bits.resize((size_t)nb);
+    st = irec_ac_encode(model.data(), n_values + 1, msg.data(), n + 1, 32, bits.data(), (int64_t)bits.size(), &nb);
+  }
+  if (st != IREC_OK) return false;
+  out.resize((size_t)((nb + 1 + 7) / 8));
+  return irec_rec_pack_bits(bits.data(), nb, out.data(), (int64_t)out.size()) == (int64_t)out.size();
+}
+bool decode_stream(const uint8_t *bytes, int64_t n_bytes, int32_t n_values, int64_t weight, std::vector<int32_t> &values) {
+  std::vector<int64_t> model((size_t)n_values + 1, 1 + weight);
+  model[0] = 1;
+  std::vector<uint8_t> bits((size_t)(n_bytes * 8 + 8));
+  const int64_t nb = irec_rec_unpack_bits(bytes, n_bytes, bits.data(), (int64_t)bits.size());
+  if (nb < 0) return false;
+  std::vector<int64_t> msg((size_t)(nb * 4 + 64));
+  int64_t nm = 0;
+  irec_status st = irec_ac_decode(model.data(), n_values + 1, bits.data(), nb, 32, msg.data(), (int64_t)msg.size(), &nm);
+  if (st != IREC_OK && nm > (int64_t)msg.size()) {
+    msg.resize((size_t)nm);
+    st = irec_ac_decode(model.data(), n_values + 1, bits.data(), nb, 32, msg.data(), (int64_t)msg.size(), &nm);
+  }
+  if (st != IREC_OK || nm < 1) return false;
+  values.resize((size_t)(nm - 1));
+  for (int64_t i = 0; i + 1 < nm; ++i) values[(size_t)i] = (int32_t)(msg[(size_t)i] - 1);
+  return true;
+}
+void put_u32(std::vector<uint8_t> &o, uint32_t v) { for (int k = 0; k < 4; ++k) o.push_back((uint8_t)(v >> (8 * k))); }
+void put_u16(std::vector<uint8_t> &o, uint16_t v) { o.push_back((uint8_t)v); o.push_back((uint8_t)(v >> 8)); }
+uint32_t get_u32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+uint16_t get_u16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+} // namespace
+
+// write_compressed_code(file_path, seed, image_shape, block_size, block_indices, max_index) with the default models
+// (rec/io/utils.py:7-106), the whole container in one call: static header 'IIIIIHHHH' (:81-90), 4 x R uint32 (:91-95), the R
+// partition-count streams, the R index streams (:97-106).  blocks_per_res [R]; K = partitions of every coded block, residual
+// block after residual block [sum blocks_per_res]; indices = their sample indices back to back [sum K].
+// Returns the file's byte count (also when it exceeds cap: call again), or -1 on invalid input (irec_io_last_error()).
+int64_t irec_rec_encode_file(uint32_t seed, uint32_t block_size, uint32_t max_index, uint32_t height, uint32_t width,
+                             uint32_t channels, int32_t n_res_blocks, const int32_t *blocks_per_res, const int32_t *K,
+                             const int32_t *indices, uint8_t *out, int64_t cap) {
+  if (n_res_blocks < 0 || n_res_blocks > 65535 || (n_res_blocks > 0 && (!blocks_per_res || !K)) || height > 65535 ||
+      width > 65535 || channels > 65535) { io_fail("irec_rec_encode_file: bad arguments"); return -1; }
+  std::vector<std::vector<uint8_t>> cs((size_t)n_res_blocks), xs((size_t)n_res_blocks);
+  std::vector<uint32_t> max_part((size_t)n_res_blocks);
+  int64_t kb = 0, ib = 0;
+  for (int32_t r = 0; r < n_res_blocks; ++r) {
+    const int32_t nb = blocks_per_res[r];
+    if (nb < 1) { io_fail("irec_rec_encode_file: a residual block without coded blocks"); return -1; }
+    int32_t mx = 0; int64_t tot = 0;
+    for (int32_t b = 0; b < nb; ++b) { if (K[kb + b] < 0) { io_fail("irec_rec_encode_file: negative K"); return -1; } mx = K[kb + b] > mx ? K[kb + b] : mx; tot += K[kb + b]; }
+    if (tot > 0 && !indices) { io_fail("irec_rec_encode_file: null indices"); return -1; }
+    max_part[(size_t)r] = (uint32_t)mx;
+    if (!encode_stream(K + kb, nb, mx + 1, 100, cs[(size_t)r])) { io_fail("irec_rec_encode_file: count stream"); return -1; }
+    if (!encode_stream(indices + ib, tot, (int32_t)max_index, 1000, xs[(size_t)r])) {
+      io_fail("irec_rec_encode_file: an index does not fit max_index"); return -1; }   // (the reference overruns its table here)
+    kb += nb; ib += tot;
+  }
+  std::vector<uint8_t> f;
+  put_u32(f, seed); put_u32(f, block_size); put_u32(f, max_index); put_u32(f, height); put_u32(f, width);
+  put_u16(f, (uint16_t)channels); put_u16(f, 0); put_u16(f, 0); put_u16(f, (uint16_t)n_res_blocks);
+  for (int32_t r = 0; r < n_res_blocks; ++r) put_u32(f, (uint32_t)blocks_per_res[r]);
+  for (int32_t r = 0; r < n_res_blocks; ++r) put_u32(f, (uint32_t)cs[(size_t)r].size());
+  for (int32_t r = 0; r < n_res_blocks; ++r) put_u32(f, (uint32_t)xs[(size_t)r].size());
+  for (int32_t r = 0; r < n_res_blocks; ++r) put_u32(f, max_part[(size_t)r]);
+  for (auto &v : cs) f.insert(f.end(), v.begin(), v.end());
+  for (auto &v : xs) f.insert(f.end(), v.begin(), v.end());
+  if (out && cap >= (int64_t)f.size()) std::memcpy(out, f.data(), f.size());
+  return (int64_t)f.size();
+}
+
+// read_compressed_code (rec/io/utils.py:109-216) for files written with the default models.  header_out[9] = seed, block_size,
+// max_index, height, width, channels, uses_count_file, uses_index_file, R.  Two-call protocol: with null / short outputs it
+// returns the sizes in sizes_out[3] = {R, total coded blocks, total indices} and IREC_E_WORKSPACE; with room it fills
+// blocks_per_res [R], K [blocks], indices [total].
+irec_status irec_rec_decode_file(const uint8_t *bytes, int64_t n_bytes, uint32_t *header_out, int64_t *sizes_out,
+                                 int32_t *blocks_per_res, int64_t cap_res, int32_t *K, int64_t cap_blocks, int32_t *indices,
+                                 int64_t cap_indices) {
+  if (!bytes || n_bytes < 28 || !header_out || !sizes_out) return io_fail("irec_rec_decode_file: bad arguments");
+  for (int k = 0; k < 5; ++k) header_out[k] = get_u32(bytes + 4 * k);
+  for (int k = 0; k < 4; ++k) header_out[5 + k] = get_u16(bytes + 20 + 2 * k);
+  const int64_t R = header_out[8];
+  if (header_out[6] || header_out[7]) return io_fail("irec_rec_decode_file: file uses empirical count tables (not the default models)");
+  if (n_bytes < 28 + 16 * R) return io_fail("irec_rec_decode_file: truncated header");
+  const uint8_t *dyn = bytes + 28;
+  int64_t pos = 28 + 16 * R, n_blocks = 0, n_idx = 0;
+  std::vector<std::vector<int32_t>> counts((size_t)R), vals((size_t)R);
+  int64_t off_x = pos;
+  for (int64_t r = 0; r < R; ++r) off_x += get_u32(dyn + 4 * (R + r));
+  for (int64_t r = 0; r < R; ++r) {
+    const int64_t nc = get_u32(dyn + 4 * (R + r)), nx = get_u32(dyn + 4 * (2 * R + r));
+    const int32_t mx = (int32_t)get_u32(dyn + 4 * (3 * R + r));
+    if (pos + nc > n_bytes || off_x + nx > n_bytes) return io_fail("irec_rec_decode_file: truncated streams");
+    if (!decode_stream(bytes + pos, nc, mx + 1, 100, counts[(size_t)r])) return io_fail("irec_rec_decode_file: corrupt count stream");
+    if (!decode_stream(bytes + off_x, nx, (int32_t)header_out[2], 1000, vals[(size_t)r])) return io_fail("irec_rec_decode_file: corrupt index stream");
+    int64_t tot = 0;
+    for (int32_t c : counts[(size_t)r]) tot += c;
+    if ((int64_t)counts[(size_t)r].size() != (int64_t)get_u32(dyn + 4 * r) || tot != (int64_t)vals[(size_t)r].size())
+      return io_fail("irec_rec_decode_file: streams do not match the header");
+    pos += nc; off_x += nx; n_blocks += (int64_t)counts[(size_t)r].size(); n_idx += tot;
+  }
+  sizes_out[0] = R; sizes_out[1] = n_blocks; sizes_out[2] = n_idx;
+  if (!blocks_per_res || !K || (n_idx > 0 && !indices) || cap_res < R || cap_blocks < n_blocks || cap_indices < n_idx) {
+    g_io_error = "irec_rec_decode_file: output buffers too small (sizes returned)";
+    return IREC_E_WORKSPACE;
+  }
+  int64_t kb = 0, ib = 0;
+  for (int64_t r = 0; r < R; ++r) {
+    blocks_per_res[r] = (int32_t)counts[(size_t)r].size();
+    for (int32_t c : counts[(size_t)r]) K[kb++] = c;
+    for (int32_t v : vals[(size_t)r]) indices[ib++] = v;
+  }
+  return IREC_OK;
+}
+
 } // extern "C"

@@ -90,11 +90,69 @@ class RecHeader:
                    list(tail[r:2 * r]), list(tail[2 * r:3 * r]), list(tail[3 * r:]))
 
 
+def _native_encode(seed, image_shape, block_size, block_indices, max_index):
+    """The whole container in one C++ call (irec_rec_encode_file): default symbol models only."""
+    lib = _lib.load()
+    bpr = np.array([len(rb) for rb in block_indices], dtype=np.int32)
+    K = np.array([len(ix) for rb in block_indices for ix in rb], dtype=np.int32)
+    flat = np.array([v for rb in block_indices for ix in rb for v in ix], dtype=np.int32)
+    h, w, c = (int(v) for v in image_shape)
+    cap = 64 + 16 * len(bpr) + 4 * (K.size + flat.size) + 64
+    while True:
+        out = np.empty(cap, dtype=np.uint8)
+        n = lib.irec_rec_encode_file(int(seed), int(block_size), int(max_index), h, w, c, len(bpr), bpr.ctypes.data,
+                                     K.ctypes.data, flat.ctypes.data if flat.size else None, out.ctypes.data, cap)
+        if n < 0:
+            raise ValueError(lib.irec_io_last_error().decode())
+        if n <= cap:
+            return out[:n].tobytes()
+        cap = int(n)
+
+
+def _native_decode(data):
+    lib = _lib.load()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    hdr = np.zeros(9, dtype=np.uint32)
+    sizes = np.zeros(3, dtype=np.int64)
+    st = lib.irec_rec_decode_file(buf.ctypes.data, buf.size, hdr.ctypes.data, sizes.ctypes.data, None, 0, None, 0, None, 0)
+    if st != _lib.IREC_E_WORKSPACE:
+        raise ValueError(lib.irec_io_last_error().decode())
+    bpr = np.zeros(max(int(sizes[0]), 1), dtype=np.int32)
+    K = np.zeros(max(int(sizes[1]), 1), dtype=np.int32)
+    idx = np.zeros(max(int(sizes[2]), 1), dtype=np.int32)
+    st = lib.irec_rec_decode_file(buf.ctypes.data, buf.size, hdr.ctypes.data, sizes.ctypes.data, bpr.ctypes.data, bpr.size,
+                                  K.ctypes.data, K.size, idx.ctypes.data, idx.size)
+    if st != 0:
+        raise ValueError(lib.irec_io_last_error().decode())
+    blocks, kb, ib = [], 0, 0
+    for r in range(int(sizes[0])):
+        rb = []
+        for _ in range(int(bpr[r])):
+            k = int(K[kb]); kb += 1
+            rb.append(idx[ib:ib + k].tolist()); ib += k
+        blocks.append(rb)
+    return int(hdr[0]), (int(hdr[3]), int(hdr[4]), int(hdr[5])), int(hdr[1]), blocks
+
+
 def write_compressed_code(file_path, seed, image_shape, block_size, block_indices, max_index,
                           num_aux_var_counts_file=None, index_counts_file=None):
-    """Same signature as rec/io/utils.py:7.  block_indices[r][k] = sample indices of coded block k of residual block r."""
+    """Same signature as rec/io/utils.py:7.  block_indices[r][k] = sample indices of coded block k of residual block r.
+    With the default symbol models (no count files) the container is assembled natively in one call; the per-stream Python
+    path below is the reference-shaped one (byte-identical, tests/test_rec_io.py) and serves the count-file variants."""
     if len(image_shape) != 3:
         raise ValueError(f"Image shape must be rank 3, but was {image_shape}!")
+    if num_aux_var_counts_file is None and index_counts_file is None and len(block_indices) > 0 and \
+            all(len(rb) > 0 for rb in block_indices):
+        with open(file_path, "wb") as fh:
+            fh.write(_native_encode(seed, image_shape, block_size, block_indices, max_index))
+        return
+    return _write_compressed_code_py(file_path, seed, image_shape, block_size, block_indices, max_index,
+                                     num_aux_var_counts_file, index_counts_file)
+
+
+def _write_compressed_code_py(file_path, seed, image_shape, block_size, block_indices, max_index,
+                              num_aux_var_counts_file=None, index_counts_file=None):
+    """The reference-shaped writer: one ArithmeticCoder call per stream (rec/io/utils.py:7-106)."""
     partition_counts = [[len(ix) for ix in res_block] for res_block in block_indices]
     flat_indices = [np.concatenate([np.asarray(ix, dtype=np.int64).reshape(-1) for ix in res_block])
                     for res_block in block_indices]
@@ -123,6 +181,16 @@ def write_compressed_code(file_path, seed, image_shape, block_size, block_indice
 
 def read_compressed_code(file_path, static_header_size=28, num_aux_var_counts_file=None, index_counts_file=None):
     """Same signature and return value as rec/io/utils.py:109: (seed, image_shape, block_size, block_indices)."""
+    if static_header_size == 28 and num_aux_var_counts_file is None and index_counts_file is None:
+        with open(file_path, "rb") as fh:
+            data = fh.read()
+        if len(data) >= 28 and data[22:26] == b"\x00\x00\x00\x00":     # neither count-file flag set: default models
+            return _native_decode(data)
+    return _read_compressed_code_py(file_path, static_header_size, num_aux_var_counts_file, index_counts_file)
+
+
+def _read_compressed_code_py(file_path, static_header_size=28, num_aux_var_counts_file=None, index_counts_file=None):
+    """The reference-shaped reader (rec/io/utils.py:109-216)."""
     with open(file_path, "rb") as fh:
         hdr = RecHeader.read(fh, static_header_size)
         if hdr.uses_index_file and index_counts_file is None:

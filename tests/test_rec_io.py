@@ -112,3 +112,30 @@ def test_against_live_reference_when_available(tmp_path):
         write_compressed_code(str(my_path), 42, (32, 32, 3), 1000, blocks, 40)
         assert ref_path.read_bytes() == my_path.read_bytes()
         assert U.read_compressed_code(str(my_path))[3] == blocks
+
+
+def test_native_container_equals_the_per_stream_writer(tmp_path):
+    """irec_rec_encode_file / irec_rec_decode_file (the whole container in one C++ call) against the reference-shaped
+    per-stream Python writer / reader, which the golden tests above pin to the real reference: byte-identical files, same
+    decoded structure -- random block structures, empty index lists (K = 0), one-block residual blocks, S up to 403."""
+    from irec.io import utils as U
+    rng = np.random.default_rng(5)
+    for case in range(40):
+        R = int(rng.integers(1, 9))
+        S = int(rng.choice([4, 20, 36, 148, 403]))
+        blocks = []
+        for _ in range(R):
+            nb = int(rng.integers(1, 12))
+            blocks.append([rng.integers(0, S, int(rng.choice([0, 1, 2, 7, 9, 40]))).tolist() for _ in range(nb)])
+        shape = (int(rng.integers(1, 4000)), int(rng.integers(1, 4000)), 3)
+        seed, bs = int(rng.integers(0, 2 ** 32)), int(rng.choice([1000, 64, 4096]))
+        a, b = tmp_path / f"a{case}.rec", tmp_path / f"b{case}.rec"
+        U.write_compressed_code(str(a), seed, shape, bs, blocks, S)                      # native path
+        U._write_compressed_code_py(str(b), seed, shape, bs, blocks, S)                  # reference-shaped path
+        assert a.read_bytes() == b.read_bytes(), case
+        assert U.read_compressed_code(str(a)) == (seed, shape, bs, blocks)               # native reader
+        assert U._read_compressed_code_py(str(a)) == (seed, shape, bs, blocks)
+    with pytest.raises(ValueError):
+        U.write_compressed_code(str(tmp_path / "bad.rec"), 1, (8, 8, 3), 1000, [[[0, 36]]], 36)   # index 36 needs max_index >= 37
+    with pytest.raises(ValueError):
+        U._native_decode(b"\x00" * 26 + b"\x05\x00" + b"\x00" * 12)            # R = 5 but the dynamic header is truncated
