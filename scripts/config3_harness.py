@@ -62,6 +62,20 @@ def main():
         torch.cuda.synchronize(); t1 = time.perf_counter()
         model.compress(images[torch.as_tensor(sharding.shard_indices(args.images, rank, world))].to(device), seed=42)
         torch.cuda.synchronize(); t_model = time.perf_counter() - t1
+    # the share again as ONE captured HIP graph (the whole batched pass: 24 residual blocks x the rank's images)
+    t_graph_share, graph_share_equal = None, None
+    if not args.no_graph:
+        from irec.models import GraphedCompress
+        mine = images[torch.as_tensor(sharding.shard_indices(args.images, rank, world))].to(device)
+        gshare = GraphedCompress(model, tuple(mine.shape), seed=42)
+        ref_idx, _ = model.compress(mine, seed=42)
+        g_idx, _ = gshare(mine)
+        graph_share_equal = g_idx == ref_idx
+        for _ in range(3):
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            gshare(mine)
+            torch.cuda.synchronize(); t_graph_share = time.perf_counter() - t1
+        del gshare
     singles = []
     for i in range(args.singles):
         x = images[i:i + 1].to(device)
@@ -90,6 +104,7 @@ def main():
             "share_seconds_incl_rec_io": t_batch, "images_per_s_incl_rec_io": share / t_batch,
             "model_compress_seconds_share": t_model, "images_per_s_model_compress": share / t_model,
             "latents_per_s_model_compress": share * args.blocks / t_model,
+            "model_compress_seconds_share_graph": t_graph_share, "graph_share_equals_eager": graph_share_equal,
             "single_image_ms": [round(1e3 * s, 2) for s in singles], "single_image_ms_median": 1e3 * sorted(singles)[len(singles) // 2],
             "single_image_graph_ms": [round(1e3 * s, 2) for s in graph_ms], "single_image_graph_ms_median": 1e3 * sorted(graph_ms)[len(graph_ms) // 2],
             "graph_equals_eager": graph_equal,
