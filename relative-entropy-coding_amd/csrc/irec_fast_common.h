@@ -47,7 +47,11 @@ constexpr size_t SMALL_LDS_BYTES = (sizeof(SmallLds) + 15) & ~(size_t)15;
 //      2. compact the candidates >= T (a few dozen) to one per lane through LDS
 //      3. rank them by (key desc, flat asc); rank r < Bnew IS new beam r
 //    ~600 wave instructions and ONE barrier instead of Bnew barrier rounds.
-//  - otherwise: all waves scan the keys, one barrier per selected beam (element f owned by thread f % NT).
+//  - N > 1024 (B = 30 / S = 148, the S = 403 stress case): the same three stages, wave 0 streaming the keys twice
+//    (16-byte reads; LDS, or the L2-resident slab) instead of holding them: lane maxima, then the compaction.  Two barriers
+//    instead of Bnew scan rounds with one each.
+//  - more than 64 candidates at the threshold (a tie storm): all waves scan the keys, one barrier per selected beam
+//    (element f owned by thread f % NT).
 // `sync` is the barrier of the NT threads that run the selection together (the whole workgroup, or one team of it) and
 // `tid` the thread's index among them.
 // `post(j, s, b, key)` is called by the thread that has just recorded new beam j = candidate (sample s, parent beam b)
@@ -119,6 +123,76 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
     }
     sync();
     if (dbg && tid == 0) { const unsigned long long t1 = stamp_now(); dbg[10] += t1 - t0; t0 = t1; } // closing barrier
+    done = sm->misc[7] != 0;
+  }
+  else {
+    if (tid < 64) {
+      __builtin_amdgcn_s_setprio(3);
+      const bool al = (reinterpret_cast<uintptr_t>(key) & 15) == 0;
+      const int n4 = al ? N >> 2 : 0;                        // quads read as uint4, the rest one by one
+      const uint4 *key4 = reinterpret_cast<const uint4 *>(key);
+      uint32_t M = 0u;
+      for (int i = tid; i < n4; i += 64) {
+        const uint4 v = key4[i];
+        const uint32_t a = v.x > v.y ? v.x : v.y, b = v.z > v.w ? v.z : v.w;
+        M = M > a ? M : a;
+        M = M > b ? M : b;
+      }
+      for (int f = (n4 << 2) + tid; f < N; f += 64) M = key[f] > M ? key[f] : M;
+      uint32_t cnt_gt = 0u;
+#pragma unroll
+      for (int l = 0; l < 64; ++l) cnt_gt += (uint32_t)__builtin_amdgcn_readlane((int)M, l) > M ? 1u : 0u;
+      uint32_t T = cnt_gt < (uint32_t)Bnew ? M : 0xFFFFFFFFu;
+      T = 0xFFFFFFFFu - (uint32_t)wave_max_u64((unsigned long long)(0xFFFFFFFFu - T)); // wave min
+      T = T ? T : 1u;                                        // (0 marks a taken / empty key)
+      uint32_t base = 0u;
+      auto put = [&](bool in, uint32_t k, uint32_t flat) {
+        const unsigned long long mask = __ballot(in);
+        if (mask) {                                          // wave-uniform
+          const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+          if (in && pos < 64u) sm->cand[pos] = ((unsigned long long)k << 32) | flat;
+          base += (uint32_t)__popcll(mask);
+        }
+      };
+      for (int i0 = 0; i0 < n4; i0 += 64) {
+        const int i = i0 + tid;
+        const uint4 v = i < n4 ? key4[i] : make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t a = v.x > v.y ? v.x : v.y, b = v.z > v.w ? v.z : v.w;
+        if (__ballot((a > b ? a : b) >= T)) {                // most 256-key rounds hold no survivor at all
+          put(v.x >= T, v.x, (uint32_t)(4 * i));
+          put(v.y >= T, v.y, (uint32_t)(4 * i + 1));
+          put(v.z >= T, v.z, (uint32_t)(4 * i + 2));
+          put(v.w >= T, v.w, (uint32_t)(4 * i + 3));
+        }
+      }
+      for (int f0 = n4 << 2; f0 < N; f0 += 64) {
+        const int f = f0 + tid;
+        const uint32_t k = f < N ? key[f] : 0u;
+        put(k >= T, k, (uint32_t)f);
+      }
+      const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      if (C <= 64u) {
+        const unsigned long long mine = tid < (int)C ? sm->cand[tid] : 0ull;
+        const uint32_t mk = (uint32_t)(mine >> 32), mf = (uint32_t)mine;
+        uint32_t rank = 0u;
+        for (uint32_t l = 0; l < C; ++l) {
+          const uint32_t ok_ = (uint32_t)__builtin_amdgcn_readlane((int)mk, (int)l);
+          const uint32_t of_ = (uint32_t)__builtin_amdgcn_readlane((int)mf, (int)l);
+          rank += (ok_ > mk || (ok_ == mk && of_ < mf)) ? 1u : 0u;
+        }
+        if (tid < (int)C && rank < (uint32_t)Bnew) {
+          const int32_t s_ = (int32_t)(mf / (uint32_t)Bcur), b_ = (int32_t)(mf % (uint32_t)Bcur);
+          sel_s[rank] = s_;
+          sel_b[rank] = b_;
+          post((int)rank, s_, b_, mk);
+        }
+        sm->misc[7] = 1;
+      } else {
+        sm->misc[7] = 0;
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    sync();
     done = sm->misc[7] != 0;
   }
   if (done) return;

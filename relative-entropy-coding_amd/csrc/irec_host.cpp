@@ -684,7 +684,7 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   A.ws_per_wg = pl.ws_per_wg;
   A.max_dim_pad = pl.dpad;
   HIP_TRY(irec::launch_zero_counters(workspace, st));
-  const int grid = (int)std::min<int64_t>(n_blocks, pl.one_grid_cap);
+  int grid = (int)std::min<int64_t>(n_blocks, pl.one_grid_cap);
   A.dbg = ctx->d_dbg;
   if (ctx->d_dbg) HIP_TRY(hipMemsetAsync(ctx->d_dbg, 0, 4096 * 16 * sizeof(unsigned long long), st));
   if (pl.table) {
@@ -733,6 +733,7 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
         A.coop_W = W;
         A.coop_test_orphan = (p->flags & IREC_FLAG_TEST_SPLIT_ORPHAN) ? 1 : 0;
         HIP_TRY(irec::launch_encode_fast(A, true, (int)(n_blocks * W), st));
+        if (ctx->d_dbg) grid = (int)(n_blocks * W);   // (diagnostics below: the stamps of every workgroup)
       } else HIP_TRY(irec::launch_encode_fast(A, true, grid, st));
       if (irec_status s2 = deferred_pass()) return s2;
     }
@@ -756,6 +757,9 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
     }
     fprintf(stderr, "[irec stamps] top-B detail cycles/WG: combine %.0f, wait-for-keys barrier %.0f, wave-0 select %.0f, closing barrier %.0f\n",
             sum[11] / grid, sum[8] / grid, sum[9] / grid, sum[10] / grid);
+    if (sum[12] + sum[13] + sum[14] > 0)
+      fprintf(stderr, "[irec stamps] split exchange cycles/WG: publish %.0f, wait for partners %.0f, read back %.0f\n",
+              sum[12] / grid, sum[13] / grid, sum[14] / grid);
     fprintf(stderr, "[irec stamps] waves/workgroup %d, LDS %zu B\n",
             irec::fast_waves_for(p->n_beams, p->n_samples, pl.table), irec::fast_lds_for(p->n_beams, p->n_samples, pl.table));
     fprintf(stderr, "[irec stamps] %s grid=%d cycles/WG: prologue %.0f (%.1f%%) scoring %.0f (%.1f%%) select %.0f (%.1f%%) update %.0f (%.1f%%)\n",

@@ -587,7 +587,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
         }
       }
       __syncthreads();
-      if (s_base == 0) IREC_STAMP(1);
+      if (s_base == s_lo) IREC_STAMP(1);
       // ---------------- combine dim groups in order, add C_b, build sort keys ----------------
       if (keys_alias) {
         // single pass, keys written over group 0 of the partials: two phases with a barrier in between because
@@ -633,12 +633,17 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
         // (s_waitcnt vmcnt(0)) before ONE lane behind the workgroup barrier adds to the block's arrival counter, the polling
         // lane reads that counter `sc1`, and the payload loads sit behind the next workgroup barrier.
         uint32_t *xk = A.coop_xch + ((size_t)(t & 1) * COOP_MAX_BLOCKS + (size_t)blk) * COOP_KEYS;
+        unsigned long long sub_prev = A.dbg ? stamp_now() : 0ull;   // diagnostics: [12] publish, [13] wait for partners, [14] read back
+        auto sub_stamp = [&](int slot) {
+          if (A.dbg && tid == 0) { const unsigned long long now_ = stamp_now(); A.dbg[(size_t)blockIdx.x * 16 + slot] += now_ - sub_prev; sub_prev = now_; }
+        };
         __syncthreads();   // (aliased keys: all of them written)
         for (int f = tid; f < N; f += NT) __hip_atomic_store(&xk[s_lo * Bcur + f], key_s[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
           __hip_atomic_fetch_add(&A.coop_arrive[blk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          sub_stamp(12);
           const uint32_t want = (uint32_t)coop_W * (uint32_t)(t + 1);
           const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
           int32_t bad = 0;
@@ -651,6 +656,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
             __builtin_amdgcn_s_sleep(2);
           }
           misc[6] = bad;
+          sub_stamp(13);
         }
         __syncthreads();
         if (misc[6]) { // every workgroup of the block sees the flag (it is sticky): nobody waits for anybody any more
@@ -658,6 +664,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
           break;
         }
         for (int f = tid; f < Ng; f += NT) key_s[f] = __hip_atomic_load(&xk[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sub_stamp(14);
       }
       select_topB<NT>(key_s, Ng, Bnew, Bcur, sm, A.dbg ? A.dbg + (size_t)blockIdx.x * 16 : nullptr); // first barrier inside orders key_s writes
       IREC_STAMP(2);

@@ -83,7 +83,9 @@ def _ref_select(scores, n_select, bcur):
     return [(i // bcur, i % bcur) for i in keyed[:n_select]]
 
 
-@pytest.mark.parametrize("case", ["random720", "tiny", "ties_small", "tie_storm", "nan_inf_zero", "n1024", "n4440_scan"])
+@pytest.mark.parametrize("case", ["random720", "tiny", "ties_small", "tie_storm", "nan_inf_zero", "n1024", "n4440_stream",
+                                  "n2960_stream", "n4096_stream", "n1025_stream", "n3000_ties", "n3000_storm", "n2000_front",
+                                  "n2000_nan"])
 def test_top_b_selection(engine, case):
     rng = np.random.default_rng(5)
     if case == "random720":
@@ -100,6 +102,23 @@ def test_top_b_selection(engine, case):
         B, bcur = 30, 10
     elif case == "n1024":
         sc, B, bcur = rng.standard_normal(1024).astype(np.float32), 64, 32
+    # N > 1024: wave 0 streams the keys (16-byte reads + scalar tail) instead of holding them in registers
+    elif case == "n2960_stream":
+        sc, B, bcur = rng.standard_normal(2960).astype(np.float32) * 9, 20, 20
+    elif case == "n4096_stream":
+        sc, B, bcur = rng.standard_normal(4096).astype(np.float32), 32, 32
+    elif case == "n1025_stream":
+        sc, B, bcur = rng.standard_normal(1025).astype(np.float32), 30, 5
+    elif case == "n3000_ties":
+        sc, B, bcur = rng.integers(-40, 40, 3000).astype(np.float32), 30, 30     # ties across the wave boundaries
+    elif case == "n3000_storm":
+        sc, B, bcur = np.full(3000, 1.5, np.float32), 30, 30                      # > 64 survivors -> scan
+    elif case == "n2000_front":
+        sc = rng.standard_normal(2000).astype(np.float32); sc[:40] += 100.0       # all winners in the first rows
+        B, bcur = 30, 20
+    elif case == "n2000_nan":
+        sc = rng.standard_normal(2000).astype(np.float32); sc[::3] = np.nan; sc[1500:] = -np.inf
+        B, bcur = 30, 20
     else:
         sc, B, bcur = rng.standard_normal(4440).astype(np.float32), 30, 30
     got = engine.test_select(torch.from_numpy(sc).cuda(), B, bcur).cpu().numpy().tolist()
