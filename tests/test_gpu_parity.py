@@ -123,6 +123,9 @@ def test_top_b_selection(engine, case):
         sc, B, bcur = rng.standard_normal(4440).astype(np.float32), 30, 30
     got = engine.test_select(torch.from_numpy(sc).cuda(), B, bcur).cpu().numpy().tolist()
     assert [tuple(g) for g in got] == _ref_select(sc.tolist(), B, bcur)
+    if len(sc) > 1024:   # the streamed selection reads 16 bytes at a time only from a 16-byte-aligned key array
+        got = engine.test_select(torch.from_numpy(sc).cuda(), B, bcur, key_offset=1).cpu().numpy().tolist()
+        assert [tuple(g) for g in got] == _ref_select(sc.tolist(), B, bcur)
 
 
 def test_in_kernel_philox_stream(engine, oracle):
