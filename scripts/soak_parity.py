@@ -17,8 +17,11 @@ for case in range(n_cases):
     B = int(rng.choice([1, 2, 7, 10, 11, 20, 21, 30, 32, int(rng.integers(1, 33))]))
     omega = float(rng.choice([1.0, 2.0, 3.0, 4.0, float(rng.uniform(0.7, 5.0))]))
     eps1 = float(rng.choice([1.0, 1.2, 1.5]))
+    if os.environ.get("SOAK_BIG"):   # bias towards more than 1024 candidates per step (streamed top-B, sample passes, keys in the slab)
+        B = int(rng.choice([11, 16, 20, 21, 30, 31, 32])); omega = float(rng.choice([4.0, 5.0, 5.5, 6.0])); eps1 = float(rng.choice([1.0, 1.1, 1.2]))
+        D = int(rng.choice([192, 777, 1000, 1024]))
     S = int(np.exp(omega * eps1))
-    if S * B * D > 6e6:          # keep the oracle fast
+    if S * B * D > (1.3e7 if os.environ.get("SOAK_BIG") else 6e6):          # keep the oracle fast
         continue
     NT = int(rng.choice([1, 2, 3, 5, 8]))   # tensors per call (= blocks per call: both teams of a CU get work)
     def draw():
