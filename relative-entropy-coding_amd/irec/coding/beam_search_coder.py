@@ -4,6 +4,8 @@ the arithmetic runs in the gfx950 kernels behind include/irec.h (no CPU path).
 Distributions are duck-typed exactly as in the reference (only `.loc` and `.scale` are read, coder.py:427-430),
 e.g. torch.distributions.Normal with CPU or cuda (HIP) float32 tensors.
 """
+import gc
+
 import numpy as np
 import torch
 
@@ -43,15 +45,20 @@ class PendingCode:
             raise CodingError(f"KL divergence needs {need} partitions; this build supports {_lib.MAX_PARTITIONS}")
         if need > self.max_K:
             raise MorePartitionsNeeded(need)
-        lay, per_tensor = self.lay, []
+        lay = self.lay
         bpt = lay.blocks_per_tensor
-        for i in range(lay.n_tensors):
-            blocks = []
-            for j in range(bpt):
-                row = lay.natural[i * bpt + j]
-                blocks.append([int(v) for v in idx_host[row, :K_host[row]]])
-            per_tensor.append(blocks)
-        return per_tensor
+        # One C-speed conversion, the per-block lists are slices of it; the cyclic collector is paused meanwhile (a batched
+        # model pass makes tens of thousands of small lists, none of them garbage: generation-2 passes triggered by the
+        # allocation count alone cost more than the conversion).
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            rows, ks = idx_host.tolist(), K_host.tolist()
+            nat = lay.natural.tolist() if hasattr(lay.natural, "tolist") else list(lay.natural)
+            return [[rows[r][:ks[r]] for r in nat[i * bpt:(i + 1) * bpt]] for i in range(lay.n_tensors)]
+        finally:
+            if gc_was_on:
+                gc.enable()
 
     def to_lists(self):
         """Indices per tensor per block (host lists): ONE device-to-host copy (K and the index rows together)."""

@@ -81,8 +81,9 @@ class BidirectionalResidualBlock(nn.Module):
         self.prior_loc_head, self.prior_log_scale_head = conv(d, s), conv(d, s)
         self.gen_posterior_loc_head, self.gen_posterior_log_scale_head = conv(d, s), conv(d, s)
         self.infer_posterior_loc = self.infer_posterior_log_scale = 0.
-        self.gen_posterior_loc = self.gen_posterior_log_scale = 0.
         self.posterior = self.prior = None
+        self._pad = pad
+        self._fused = None   # (parameter versions, inference-side weight / bias, generative-side weight / bias)
         # ---- stuff for compression (resnet_vae.py:118-141) ----
         if sampler == "beam_search":
             self.coder = BeamSearchCoder(kl_per_partition=kl_per_partition, n_beams=sampler_args['n_beams'],
@@ -96,40 +97,64 @@ class BidirectionalResidualBlock(nn.Module):
 
     @property
     def posterior_loc(self):
-        return self.infer_posterior_loc + self.gen_posterior_loc
+        """resnet_vae.py: infer_posterior_loc + gen_posterior_loc (the sum is formed in place in `forward`)."""
+        return _nchw(self.posterior.loc)
 
     @property
     def posterior_scale(self):
-        return torch.exp(self.infer_posterior_log_scale + self.gen_posterior_log_scale)
+        return _nchw(self.posterior.scale)
+
+    def _fused_weights(self):
+        """The convolutions that read the same activation, as ONE convolution each (output channels concatenated):
+        inference side = posterior heads (loc, log-scale) + infer_conv1; generative side = prior heads, posterior heads
+        + gen_conv1.  Ten convolutions per residual block become four -- on a 16x16 latent grid each one is a
+        launch-bound im2col + GEMM pair, and a single image spends more time in them than in the coder.  The compress and
+        the decompress pass both run the SAME generative-side convolution (the decoder drops the posterior channels), so
+        the prior the decoder rebuilds is bit-identical to the one the encoder coded against.  Rebuilt when a parameter
+        changes (tensor version counters)."""
+        heads_i = [self.infer_posterior_loc_head, self.infer_posterior_log_scale_head] + ([] if self.is_last else [self.infer_conv1])
+        heads_g = [self.prior_loc_head, self.prior_log_scale_head, self.gen_posterior_loc_head,
+                   self.gen_posterior_log_scale_head, self.gen_conv1]
+        ver = tuple((p._version, p.device, p.dtype) for m in heads_i + heads_g for p in (m.weight, m.bias))
+        if self._fused is None or self._fused[0] != ver:
+            with torch.no_grad():
+                self._fused = (ver,
+                               torch.cat([m.weight for m in heads_i]).contiguous(), torch.cat([m.bias for m in heads_i]).contiguous(),
+                               torch.cat([m.weight for m in heads_g]).contiguous(), torch.cat([m.bias for m in heads_g]).contiguous())
+        return self._fused[1:]
 
     def forward(self, tensor, inference_pass=True, encoder_args=None, decoder_args=None):
         """resnet_vae.py:372-497."""
         inp = tensor
         tensor = F.elu(tensor)
         indices = None
+        s, d = self.stochastic_filters, self.deterministic_filters
+        w_i, b_i, w_g, b_g = self._fused_weights()
         if inference_pass:
-            self.infer_posterior_loc = self.infer_posterior_loc_head(tensor)
-            self.infer_posterior_log_scale = self.infer_posterior_log_scale_head(tensor)
+            y = F.conv2d(tensor, w_i, b_i, padding=self._pad)                     # [N, 2s (+ d), H, W]
+            self.infer_posterior_loc, self.infer_posterior_log_scale = y[:, :s], y[:, s:2 * s]
+            self._infer_heads = y[:, :2 * s]
             if not self.is_last:
-                tensor = self.infer_conv2(F.elu(self.infer_conv1(tensor)))
+                tensor = self.infer_conv2(F.elu(y[:, 2 * s:]))
         else:
-            prior_loc = self.prior_loc_head(tensor)
-            prior_scale = torch.exp(self.prior_log_scale_head(tensor))
-            self.prior = _Normal(_nhwc(prior_loc), _nhwc(prior_scale))            # coder sees NHWC, as in the reference
             if encoder_args is None and decoder_args is None:
                 raise ModelError("training / sampling passes are outside the compression shim")
+            y = F.conv2d(tensor, w_g, b_g, padding=self._pad)                     # [N, 4s + d, H, W]
+            n, _, h, w = y.shape
             if encoder_args is not None:                                          # :462-470
-                self.gen_posterior_loc = self.gen_posterior_loc_head(tensor)
-                self.gen_posterior_log_scale = self.gen_posterior_log_scale_head(tensor)
-                self.posterior = _Normal(_nhwc(self.posterior_loc), _nhwc(self.posterior_scale))
+                y[:, 2 * s:4 * s] += self._infer_heads                            # posterior loc / log-scale = inference + generative
+                st = y[:, :4 * s].view(n, 4, s, h, w).permute(1, 0, 3, 4, 2).contiguous()   # coder sees NHWC, as in the reference
+                st[1::2].exp_()                                                   # the two scales
+                self.prior, self.posterior = _Normal(st[0], st[1]), _Normal(st[2], st[3])
                 indices, latent_code = self.coder.encode(self.posterior, self.prior, **encoder_args)
             else:                                                                 # :475-476
+                st = y[:, :2 * s].view(n, 2, s, h, w).permute(1, 0, 3, 4, 2).contiguous()
+                st[1].exp_()
+                self.prior = _Normal(st[0], st[1])
                 latent_code = self.coder.decode(self.prior, **decoder_args)
-            latent_code = _nchw(latent_code)
-            tensor = self.gen_conv1(tensor)
-            tensor = torch.cat([tensor, latent_code], dim=1)
-            tensor = self.gen_conv2(F.elu(tensor))
-        tensor = inp + 0.1 * tensor
+            tensor = torch.cat([y[:, 4 * s:], latent_code.permute(0, 3, 1, 2)], dim=1)
+            tensor = self.gen_conv2(F.elu(tensor, inplace=True))
+        tensor = torch.add(inp, tensor, alpha=0.1)
         if encoder_args is not None:
             return indices, tensor
         return tensor
