@@ -54,10 +54,11 @@ typedef struct {
                           /* With it the encoder evaluates the shared-seed Philox draw once per call into a     */
                           /* proposal table (same seed for every block, coder.py:444-449) instead of once per   */
                           /* block; a block whose dim is not listed gets out_K = -1.  All zero = no hint.       */
-  int32_t table_steps;    /* partitions the proposal tables cover (0 = IREC_TABLE_STEPS_DEFAULT, clamped to     */
-                          /* [1, min(max_K, IREC_TABLE_STEPS_MAX)]).  Table scratch is O(table_steps * S * D):  */
-                          /* a block with more partitions is coded by the fused-Philox kernel in a second pass  */
-                          /* of the same call -- same outputs, bit for bit.                                     */
+  int32_t table_steps;    /* partitions the proposal tables cover (0 = IREC_TABLE_STEPS_DEFAULT), clamped to    */
+                          /* [1, min(max_K, IREC_TABLE_STEPS_MAX)] and to what IREC_TABLE_BYTES_MAX holds of the */
+                          /* call's tables (2 * S * sum of the table dims bytes per step).  Table scratch is     */
+                          /* O(table_steps * S * D): a block with more partitions is coded by the fused-Philox   */
+                          /* kernel in a second pass of the same call -- same outputs, bit for bit.              */
 } irec_params;
 
 #define IREC_FLAG_FORCE_GENERIC 1 /* use the generic (any D, any B) kernel even where the fast kernels apply   */
@@ -80,7 +81,8 @@ typedef struct {
 #define IREC_FLAG_SHAPE_2X2 (4 << IREC_FLAG_SHAPE_SHIFT) /* two 8-wave beam-striped teams (128 VGPRs)                 */
 
 #define IREC_TABLE_STEPS_DEFAULT 32
-#define IREC_TABLE_STEPS_MAX 64
+#define IREC_TABLE_STEPS_MAX 4096
+#define IREC_TABLE_BYTES_MAX (64u << 20)
 
 /* What irec_beam_encode does for a given call: filled by irec_encode_plan (same decision code as the launch). */
 typedef struct {

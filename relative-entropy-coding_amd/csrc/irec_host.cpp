@@ -517,6 +517,11 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
   // table window: the tables cover the first K_tab partitions; blocks with more go to the fused-Philox second pass
   const int want = p->table_steps > 0 ? p->table_steps : IREC_TABLE_STEPS_DEFAULT;
   pl.K_tab = std::max(1, std::min(std::min(want, IREC_TABLE_STEPS_MAX), max_K > 0 ? max_K : 1));
+  {
+    size_t per_step = 0;   // bytes of one partition step over all tables of the call
+    for (int q = 0; q < 4 && p->table_dims[q] > 0; ++q) per_step += (size_t)S * round_up(p->table_dims[q], 4) * 2;
+    if (per_step > 0) pl.K_tab = std::max(1, (int)std::min<size_t>((size_t)pl.K_tab, (size_t)IREC_TABLE_BYTES_MAX / per_step));
+  }
   if (pl.fast && !(p->flags & IREC_FLAG_FUSED_PHILOX) && p->table_dims[0] > 0) {
     pl.table = true;
     for (int q = 0; q < 4 && p->table_dims[q] > 0; ++q) {

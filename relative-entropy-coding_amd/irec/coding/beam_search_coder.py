@@ -38,8 +38,10 @@ class PendingCode:
             raise CodingError("a block exceeded the engine's dimension bound")
         need = int(K_host.max()) if K_host.size else 0
         self.coder._max_K_hint = max(self.coder._max_K_hint, need)
-        c = self.coder            # table window hint: the largest K of the first read, then a slowly decaying maximum
-        c._K_seen = need if c._K_reads == 0 else max(need, c._K_seen - 1 if c._K_reads % 16 == 0 else c._K_seen)
+        c = self.coder            # table window hint: what covers the bulk of the blocks read back (a few outliers take the
+        if K_host.size:           # second pass instead of stretching every later call's tables), decaying by an eighth per read
+            bulk = int(np.ceil(1.25 * float(np.quantile(K_host, 0.75))))
+            c._K_seen = bulk if c._K_reads == 0 else max(bulk, c._K_seen - max(1, c._K_seen // 8))
         c._K_reads += 1
         if need > _lib.MAX_PARTITIONS:
             raise CodingError(f"KL divergence needs {need} partitions; this build supports {_lib.MAX_PARTITIONS}")
@@ -107,7 +109,7 @@ class BeamSearchCoder(GaussianCoder):
         self.no_split = False        # debugging / testing knob: IREC_FLAG_NO_SPLIT (one workgroup per block also for small calls)
         self.team_shape = "default"  # diagnostics: IREC_FLAG_SHAPE_* workgroup shape of the team encoder
         self.table_steps = 0         # partitions the per-call proposal tables cover; 0 = sized from the partition counts
-                                     # this coder has seen so far (_K_seen + 4, between 8 and the library default of 32);
+                                     # this coder has seen so far (_K_seen + 4, at least 8; the library bounds the bytes);
                                      # blocks with more are coded by the fused-Philox kernel in a second pass of the same call
         self._max_K_hint = 32
         self._K_seen = 28            # largest K read back so far (starts at the default window; shrinks with evidence)
@@ -140,7 +142,7 @@ class BeamSearchCoder(GaussianCoder):
                 _lib.IREC_FLAG_SHAPE[self.team_shape]
         steps = self.table_steps
         if steps == 0:   # running hint: the tables cost set-up time and scratch per step they cover (typical K is ~8)
-            steps = min(_lib.IREC_TABLE_STEPS_DEFAULT, max(8, (self._K_seen + 4 + 3) // 4 * 4))
+            steps = min(_lib.IREC_TABLE_STEPS_MAX, max(8, (self._K_seen + 4 + 3) // 4 * 4))
         return get_engine().params(self.kl_per_partition, self.n_samples, self.n_beams, flags, table_steps=steps)
 
     @staticmethod

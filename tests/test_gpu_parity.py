@@ -442,8 +442,8 @@ def test_config5_stress_s403_full_tensors(engine, oracle):
 # ---- round 2: bounded proposal tables, plan export, per-stream scratch ------------------------------------------------
 def test_table_window_mixed_partition_counts_fit_256mb(engine, oracle):
     """Blocks with K = 7..8 and blocks with K ~ 3000 in ONE call at S = 403 (Omega = 5, eps = 0.2): the proposal tables
-    cover 32 steps whatever max_K is, the high-K blocks take the fused-Philox second pass, the scratch stays under
-    256 MB and every output is the oracle's, bit for bit."""
+    cover a window bounded in steps and bytes whatever max_K is, the high-K blocks take the fused-Philox second pass, the
+    scratch stays under 256 MB and every output is the oracle's, bit for bit."""
     n, bs, omega, eps1, B = 1064, 1000, 5.0, 1.2, 20
     S = oracle.n_samples(omega, eps1)
     assert S == 403
@@ -455,6 +455,9 @@ def test_table_window_mixed_partition_counts_fit_256mb(engine, oracle):
             l[0][tail] = (l[2][tail] + 21.7 * l[3][tail]).astype(np.float32)
     q = [np.stack([l[j] for l in lat]) for j in range(4)]
     c = _coder(omega, B, eps1, block_size=bs, variant="table")
+    lay = engine.layout(3, n, bs, 42)
+    plan0 = engine.plan(c._params(), lay, 4096)            # a fresh coder: the default window
+    assert plan0["table_steps"] == 32 and plan0["workspace_bytes"] < 256 * 2 ** 20, plan0
     idx, sample = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)
     Ks = [[len(b) for b in t] for t in idx]
     assert max(Ks[0]) > 2500 and max(Ks[1]) <= 32 and max(Ks[2]) > 2500, Ks
@@ -462,9 +465,13 @@ def test_table_window_mixed_partition_counts_fit_256mb(engine, oracle):
         ridx, rs = oracle.encode_tensor(q[0][i], q[1][i], q[2][i], q[3][i], 42, omega, S, B, block_size=bs)
         assert idx[i] == ridx, i
         assert np.array_equal(sample[i].cpu().numpy(), rs), i
-    lay = engine.layout(3, n, bs, 42)
+    # a third of this call's blocks have K ~ 3000: the coder's window hint follows them, the library bounds the tables' bytes
     plan = engine.plan(c._params(), lay, max(max(k) for k in Ks))
-    assert plan["table_steps"] == 32 and plan["workspace_bytes"] < 256 * 2 ** 20, plan
+    per_step = 2 * S * (1000 + 64)
+    assert c._params().table_steps > 2500 and plan["table_steps"] == (64 << 20) // per_step, plan
+    assert plan["workspace_bytes"] < 256 * 2 ** 20, plan
+    idx_b, sample_b = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)   # coded with that window
+    assert idx_b == idx and torch.equal(sample_b, sample)
     # round trip through the decoder
     rec = c.decode(_normal(q[2], q[3]), idx, seed=42, batched=True)
     assert torch.equal(rec, sample)
