@@ -730,6 +730,8 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
         fprintf(stderr, "[irec team stamps] share of wave time, wave 0 of a team | waves 1-3:\n");
         for (int k = 0; k < 11; ++k) fprintf(stderr, "  %-20s %5.1f%% | %5.1f%%\n", nm[k], 100 * w0[k] / t0, 100 * wo[k] / to);
         fprintf(stderr, "  cycles per wave: %.0f | %.0f\n", t0 / (tgrid * nwv / 4), to / (tgrid * nwv * 3 / 4));
+        if (h[13]) fprintf(stderr, "  shader clock of workgroup 0, wave 0: %.0f MHz over %.3f ms (s_memtime / s_memrealtime)\n",
+                           100.0 * (double)h[12] / (double)h[13], (double)h[13] / 1e5);
         return IREC_OK;
       }
     } else {

@@ -175,6 +175,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 #ifdef IREC_TEAM_STAMPS
   unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+  const unsigned long long st_t0 = st_prev, st_r0 = __builtin_amdgcn_s_memrealtime();   // shader clock = d(memtime) / d(memrealtime) x 100 MHz
 #endif
   // Block hand-out: the first block of team k of workgroup w is k * gridDim.x + w -- a call of fewer blocks than resident
   // teams (a mid-size batch: 38 images x 9 blocks) puts ONE block on every CU before any CU gets a second one, instead of
@@ -708,6 +709,10 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 #ifdef IREC_TEAM_STAMPS
   if (A.dbg && lane == 0)
     for (int k = 0; k < 12; ++k) A.dbg[((size_t)blockIdx.x * (TEAMS * 4) + wave_wg) * 16 + k] = st_acc[k];
+  if (A.dbg && lane == 0) {
+    A.dbg[((size_t)blockIdx.x * (TEAMS * 4) + wave_wg) * 16 + 12] = __builtin_amdgcn_s_memtime() - st_t0;
+    A.dbg[((size_t)blockIdx.x * (TEAMS * 4) + wave_wg) * 16 + 13] = __builtin_amdgcn_s_memrealtime() - st_r0;
+  }
 #endif
 }
 
