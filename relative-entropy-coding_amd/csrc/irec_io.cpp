@@ -39,6 +39,48 @@ struct BitSink {
   }
   void push(char b) { if (n < cap) out[n] = (uint8_t)b; else overflow = true; ++n; }
 };
+// the decoding loop of irec_ac_decode below; `emit(symbol)` receives every decoded symbol, the terminator 0 last
+template <class Emit>
+irec_status ac_decode_impl(const Cdf &cdf, const uint8_t *bits, int64_t n_bits, int32_t precision, Emit &&emit) {
+  const int32_t n_symbols = (int32_t)cdf.C.size();
+  const int64_t whole = (int64_t)1 << precision, half = whole >> 1, quarter = whole >> 2;
+  int64_t low = 0, high = whole, z = 0, i = 0, n = 0;
+  auto bit = [&](int64_t p) { return p < n_bits && bits[p] == '1'; };
+  while (i < precision && i < n_bits) { if (bit(i)) z += (int64_t)1 << (precision - i - 1); ++i; }
+  const int64_t max_out = n_bits * 64 + ((int64_t)1 << 22); // guards corrupt input only: a near-deterministic model (max_index 1)
+                                                            // legitimately packs thousands of symbols into a bit
+  for (;;) {
+    const int64_t width = high - low, target = z - low;
+    // largest j with (width*C[j])//R <= target (C[0] = 0 always qualifies).  floor(width*C/R) <= target  <=>
+    // width*C < (target+1)*R  <=>  C <= ((target+1)*R - 1)//width: ONE division, then a search over the integers C[j]
+    // ((target+1)*R <= width*R, the magnitude the reference's own width*D[j] reaches: no new overflow)
+    int32_t lo = 0, hi = n_symbols - 1, j = 0;
+    if (target < 0 || width <= 0) return io_fail("irec_ac_decode: corrupt stream");
+    const int64_t v = ((target + 1) * cdf.R - 1) / width;
+    while (lo <= hi) {
+      const int32_t mid = (lo + hi) / 2;
+      if (cdf.C[mid] <= v) { j = mid; lo = mid + 1; } else hi = mid - 1;
+    }
+    const int64_t low_ = low + (width * cdf.C[j]) / cdf.R, high_ = low + (width * cdf.D[j]) / cdf.R;
+    emit((int64_t)j);
+    ++n;
+    high = high_; low = low_;
+    if (j == 0) break;
+    if (n > max_out) return io_fail("irec_ac_decode: no terminator found");
+    while (high < half || low > half) {
+      if (high < half) { low *= 2; high *= 2; z *= 2; }
+      else { low = (low - half) * 2; high = (high - half) * 2; z = (z - half) * 2; }
+      if (bit(i)) z += 1;
+      ++i;
+    }
+    while (low > quarter && high < 3 * quarter) {
+      low = (low - quarter) * 2; high = (high - quarter) * 2; z = (z - quarter) * 2;
+      if (bit(i)) z += 1;
+      ++i;
+    }
+  }
+  return IREC_OK;
+}
 } // namespace
 
 extern "C" {
@@ -87,37 +129,8 @@ irec_status irec_ac_decode(const int64_t *counts, int32_t n_symbols, const uint8
   if (!cdf.build(counts, n_symbols)) return io_fail("irec_ac_decode: counts must be >= 1");
   if (precision < 8 || precision > 40 || !n_message || (n_bits > 0 && !bits) || (cap > 0 && !out_message))
     return io_fail("irec_ac_decode: bad arguments");
-  const int64_t whole = (int64_t)1 << precision, half = whole >> 1, quarter = whole >> 2;
-  int64_t low = 0, high = whole, z = 0, i = 0, n = 0;
-  auto bit = [&](int64_t p) { return p < n_bits && bits[p] == '1'; };
-  while (i < precision && i < n_bits) { if (bit(i)) z += (int64_t)1 << (precision - i - 1); ++i; }
-  const int64_t max_out = n_bits * 64 + 64; // a valid stream ends long before; guards corrupt input
-  for (;;) {
-    const int64_t width = high - low, target = z - low;
-    int32_t lo = 0, hi = n_symbols - 1, j = 0; // largest j with (width*C[j])//R <= target; C[0] = 0 always qualifies
-    if (target < 0) return io_fail("irec_ac_decode: corrupt stream");
-    while (lo <= hi) {
-      const int32_t mid = (lo + hi) / 2;
-      if ((width * cdf.C[mid]) / cdf.R <= target) { j = mid; lo = mid + 1; } else hi = mid - 1;
-    }
-    const int64_t low_ = low + (width * cdf.C[j]) / cdf.R, high_ = low + (width * cdf.D[j]) / cdf.R;
-    if (n < cap) out_message[n] = j;
-    ++n;
-    high = high_; low = low_;
-    if (j == 0) break;
-    if (n > max_out) return io_fail("irec_ac_decode: no terminator found");
-    while (high < half || low > half) {
-      if (high < half) { low *= 2; high *= 2; z *= 2; }
-      else { low = (low - half) * 2; high = (high - half) * 2; z = (z - half) * 2; }
-      if (bit(i)) z += 1;
-      ++i;
-    }
-    while (low > quarter && high < 3 * quarter) {
-      low = (low - quarter) * 2; high = (high - quarter) * 2; z = (z - quarter) * 2;
-      if (bit(i)) z += 1;
-      ++i;
-    }
-  }
+  int64_t n = 0;
+  if (irec_status st = ac_decode_impl(cdf, bits, n_bits, precision, [&](int64_t j) { if (n < cap) out_message[n] = j; ++n; })) return st;
   *n_message = n;
   if (n > cap) return io_fail("irec_ac_decode: output buffer too small");
   return IREC_OK;
@@ -183,17 +196,13 @@ bool decode_stream(const uint8_t *bytes, int64_t n_bytes, int32_t n_values, int6
   std::vector<uint8_t> bits((size_t)(n_bytes * 8 + 8));
   const int64_t nb = irec_rec_unpack_bits(bytes, n_bytes, bits.data(), (int64_t)bits.size());
   if (nb < 0) return false;
-  std::vector<int64_t> msg((size_t)(nb * 4 + 64));
-  int64_t nm = 0;
-  irec_status st = irec_ac_decode(model.data(), n_values + 1, bits.data(), nb, 32, msg.data(), (int64_t)msg.size(), &nm);
-  if (st != IREC_OK && nm > (int64_t)msg.size()) {
-    msg.resize((size_t)nm);
-    st = irec_ac_decode(model.data(), n_values + 1, bits.data(), nb, 32, msg.data(), (int64_t)msg.size(), &nm);
-  }
-  if (st != IREC_OK || nm < 1) return false;
-  values.resize((size_t)(nm - 1));
-  for (int64_t i = 0; i + 1 < nm; ++i) values[(size_t)i] = (int32_t)(msg[(size_t)i] - 1);
-  return true;
+  Cdf cdf;
+  if (!cdf.build(model.data(), n_values + 1)) return false;
+  values.clear();
+  values.reserve((size_t)(nb / 2 + 16));
+  bool ended = false;
+  const irec_status st = ac_decode_impl(cdf, bits.data(), nb, 32, [&](int64_t j) { if (j == 0) ended = true; else values.push_back((int32_t)(j - 1)); });
+  return st == IREC_OK && ended;
 }
 void put_u32(std::vector<uint8_t> &o, uint32_t v) { for (int k = 0; k < 4; ++k) o.push_back((uint8_t)(v >> (8 * k))); }
 void put_u16(std::vector<uint8_t> &o, uint16_t v) { o.push_back((uint8_t)v); o.push_back((uint8_t)(v >> 8)); }

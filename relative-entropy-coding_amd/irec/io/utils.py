@@ -13,6 +13,7 @@ A stream is an arithmetic-coded message (values + 1, terminated by symbol 0; mod
 is the C++ one of libirec_hip.so (irec.io.ArithmeticCoder).  Bytes are identical to the reference's writer
 (tests/test_rec_io.py).
 """
+import itertools
 import struct
 from dataclasses import dataclass
 from typing import List, Sequence, Tuple
@@ -95,7 +96,8 @@ def _native_encode(seed, image_shape, block_size, block_indices, max_index):
     lib = _lib.load()
     bpr = np.array([len(rb) for rb in block_indices], dtype=np.int32)
     K = np.array([len(ix) for rb in block_indices for ix in rb], dtype=np.int32)
-    flat = np.array([v for rb in block_indices for ix in rb for v in ix], dtype=np.int32)
+    flat = np.fromiter(itertools.chain.from_iterable(itertools.chain.from_iterable(block_indices)), dtype=np.int32,
+                       count=int(K.sum()))
     h, w, c = (int(v) for v in image_shape)
     cap = 64 + 16 * len(bpr) + 4 * (K.size + flat.size) + 64
     while True:
@@ -114,14 +116,19 @@ def _native_decode(data):
     buf = np.frombuffer(data, dtype=np.uint8)
     hdr = np.zeros(9, dtype=np.uint32)
     sizes = np.zeros(3, dtype=np.int64)
-    st = lib.irec_rec_decode_file(buf.ctypes.data, buf.size, hdr.ctypes.data, sizes.ctypes.data, None, 0, None, 0, None, 0)
-    if st != _lib.IREC_E_WORKSPACE:
-        raise ValueError(lib.irec_io_last_error().decode())
-    bpr = np.zeros(max(int(sizes[0]), 1), dtype=np.int32)
-    K = np.zeros(max(int(sizes[1]), 1), dtype=np.int32)
-    idx = np.zeros(max(int(sizes[2]), 1), dtype=np.int32)
-    st = lib.irec_rec_decode_file(buf.ctypes.data, buf.size, hdr.ctypes.data, sizes.ctypes.data, bpr.ctypes.data, bpr.size,
-                                  K.ctypes.data, K.size, idx.ctypes.data, idx.size)
+    # first try with buffers sized from the header (block counts) and the file size (an index costs >= 2 bits unless
+    # max_index is tiny); the library reports the exact sizes if they were short, and only then is the file decoded twice
+    n_res = int(np.frombuffer(data[26:28], dtype="<u2")[0]) if len(data) >= 28 else 0
+    n_blk = int(np.frombuffer(data[28:28 + 4 * n_res], dtype="<u4").sum()) if len(data) >= 28 + 4 * n_res else 0
+    sizes[:] = (n_res, n_blk, 4 * len(data) + 1024)
+    for _attempt in range(2):
+        bpr = np.empty(max(int(sizes[0]), 1), dtype=np.int32)
+        K = np.empty(max(int(sizes[1]), 1), dtype=np.int32)
+        idx = np.empty(max(int(sizes[2]), 1), dtype=np.int32)
+        st = lib.irec_rec_decode_file(buf.ctypes.data, buf.size, hdr.ctypes.data, sizes.ctypes.data, bpr.ctypes.data, bpr.size,
+                                      K.ctypes.data, K.size, idx.ctypes.data, idx.size)
+        if st != _lib.IREC_E_WORKSPACE:
+            break
     if st != 0:
         raise ValueError(lib.irec_io_last_error().decode())
     blocks, kb, ib = [], 0, 0

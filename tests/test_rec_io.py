@@ -106,6 +106,13 @@ def test_against_live_reference_when_available(tmp_path):
             mine = ArithmeticCoder(P, precision=32)
             assert "".join(mine.encode(msg)) == ref_code, trial
             assert mine.decode_fast(list(ref_code)) == msg.tolist()
+        for S1, n in ((1, 3000), (2, 800)):   # near-deterministic models: thousands of symbols per bit
+            P = np.array([1] + [1001] * S1, dtype=np.int32)
+            msg = np.concatenate([rng.integers(1, S1 + 1, size=n), [0]]).astype(np.int64)
+            ref_code = "".join(U.ArithmeticCoder(P, precision=32).encode(msg))
+            mine = ArithmeticCoder(P, precision=32)
+            assert "".join(mine.encode(msg)) == ref_code
+            assert mine.decode_fast(list(ref_code)) == msg.tolist()
         blocks = [[rng.integers(0, 36, size=int(k)).tolist() for k in rng.integers(1, 15, size=9)] for _ in range(24)]
         ref_path, my_path = tmp_path / "ref.rec", tmp_path / "mine.rec"
         U.write_compressed_code(str(ref_path), 42, (32, 32, 3), 1000, blocks, 40)
@@ -135,6 +142,16 @@ def test_native_container_equals_the_per_stream_writer(tmp_path):
         assert a.read_bytes() == b.read_bytes(), case
         assert U.read_compressed_code(str(a)) == (seed, shape, bs, blocks)               # native reader
         assert U._read_compressed_code_py(str(a)) == (seed, shape, bs, blocks)
+    # long chains (a lossy image at 0.7 bpp: 300 blocks of ~200 indices) and the near-deterministic model of max_index 1, which
+    # packs thousands of symbols into a few bits (the reader's first guess at the index count is then short: second call)
+    for blocks, S in (([[rng.integers(0, 20, int(k)).tolist() for k in rng.integers(180, 237, 302)]], 20),
+                      ([[[0] * 5000 for _ in range(3)]], 1)):
+        a, b = tmp_path / f"long{S}.rec", tmp_path / f"long{S}b.rec"
+        U.write_compressed_code(str(a), 7, (512, 768, 3), 1000, blocks, S)
+        U._write_compressed_code_py(str(b), 7, (512, 768, 3), 1000, blocks, S)
+        assert a.read_bytes() == b.read_bytes()
+        assert U.read_compressed_code(str(a)) == (7, (512, 768, 3), 1000, blocks)
+        assert U._read_compressed_code_py(str(a)) == (7, (512, 768, 3), 1000, blocks)
     with pytest.raises(ValueError):
         U.write_compressed_code(str(tmp_path / "bad.rec"), 1, (8, 8, 3), 1000, [[[0, 36]]], 36)   # index 36 needs max_index >= 37
     with pytest.raises(ValueError):
