@@ -111,11 +111,11 @@ class BidirectionalResidualBlock(nn.Module):
         launch-bound im2col + GEMM pair, and a single image spends more time in them than in the coder.  The compress and
         the decompress pass both run the SAME generative-side convolution (the decoder drops the posterior channels), so
         the prior the decoder rebuilds is bit-identical to the one the encoder coded against.  Rebuilt when a parameter
-        changes (tensor version counters)."""
+        changes in place, is replaced or moves (tensor version counters and storage addresses)."""
         heads_i = [self.infer_posterior_loc_head, self.infer_posterior_log_scale_head] + ([] if self.is_last else [self.infer_conv1])
         heads_g = [self.prior_loc_head, self.prior_log_scale_head, self.gen_posterior_loc_head,
                    self.gen_posterior_log_scale_head, self.gen_conv1]
-        ver = tuple((p._version, p.device, p.dtype) for m in heads_i + heads_g for p in (m.weight, m.bias))
+        ver = tuple((p._version, p.data_ptr(), p.dtype) for m in heads_i + heads_g for p in (m.weight, m.bias))
         if self._fused is None or self._fused[0] != ver:
             with torch.no_grad():
                 self._fused = (ver,
