@@ -79,6 +79,7 @@ typedef struct {
 #define IREC_FLAG_SHAPE_2 (2 << IREC_FLAG_SHAPE_SHIFT)   /* exactly two teams (also where three are the default)      */
 #define IREC_FLAG_SHAPE_3 (3 << IREC_FLAG_SHAPE_SHIFT)   /* three 4-wave teams (168 VGPRs)                            */
 #define IREC_FLAG_SHAPE_2X2 (4 << IREC_FLAG_SHAPE_SHIFT) /* two 8-wave beam-striped teams (128 VGPRs)                 */
+#define IREC_FLAG_SHAPE_1X2 (5 << IREC_FLAG_SHAPE_SHIFT) /* one 8-wave beam-striped team (the default of 64..n_CU blocks) */
 
 #define IREC_TABLE_STEPS_DEFAULT 32
 #define IREC_TABLE_STEPS_MAX 4096

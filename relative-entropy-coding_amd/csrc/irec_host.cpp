@@ -500,7 +500,7 @@ irec_status check_params(const irec_params *p) {
   if (p->n_samples < 1 || p->n_samples > (1 << 24)) return fail(IREC_E_INVALID, "n_samples %d out of range", p->n_samples);
   if (p->n_beams < 1 || p->n_beams > IREC_MAX_BEAMS) return fail(IREC_E_INVALID, "n_beams %d out of range [1,%d]", p->n_beams, IREC_MAX_BEAMS);
   if (p->table_steps < 0) return fail(IREC_E_INVALID, "table_steps %d < 0", p->table_steps);
-  if (((p->flags & IREC_FLAG_SHAPE_MASK) >> IREC_FLAG_SHAPE_SHIFT) > 4) return fail(IREC_E_INVALID, "unknown IREC_FLAG_SHAPE_* value");
+  if (((p->flags & IREC_FLAG_SHAPE_MASK) >> IREC_FLAG_SHAPE_SHIFT) > 5) return fail(IREC_E_INVALID, "unknown IREC_FLAG_SHAPE_* value");
   return IREC_OK;
 }
 
@@ -575,6 +575,19 @@ int split_width(const irec_context *ctx, const Plan &pl, const irec_params *p, i
 bool team_for_call(const Plan &pl, const irec_params *p, int64_t n_blocks) {
   return pl.team && ((p->flags & IREC_FLAG_TEAM) || n_blocks >= 64);
 }
+// Workgroup shape of the team encoder for THIS call.  With at most one block per CU a lone 4-wave team is latency-bound
+// (one wave per SIMD, ~43 us per step at B = 20, S = 36): the 8-wave beam-striped team (two stripes of 10 beams: half the
+// look-ups and half the update per wave) codes 252 blocks in 0.45 ms against 0.57 ms.  From ~1.3 blocks per CU on the
+// three-team shape wins again.  Same scratch (fewer slabs, same slab size), same outputs.
+int shape_for_call(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks) {
+  const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+  const int B = p->n_beams, S = p->n_samples;
+  if (pl.shape != 0 || !pl.team || n_blocks > n_cu || B <= 10 || B > 20) return pl.shape;
+  if (irec::team_count_for(B, S, 0) < 2) return pl.shape;                       // already one striped team
+  if (irec::team_lds_for(B, S, 5) == (size_t)-1 || irec::team_ws_extra_for(B, S, 5) > irec::team_ws_extra_for(B, S, 0))
+    return pl.shape;
+  return 5;
+}
 
 } // namespace
 
@@ -596,13 +609,15 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
   std::memset(out, 0, sizeof(*out));
   const int B = p->n_beams, S = p->n_samples;
   if (team) {
-    const int n_teams = irec::team_count_for(B, S, pl.shape);
-    std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::team_kernel_name(B, S, pl.shape));
+    const int shape = shape_for_call(ctx, pl, p, n_blocks);
+    const int n_teams = irec::team_count_for(B, S, shape);
+    const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+    std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::team_kernel_name(B, S, shape));
     std::snprintf(out->table_kernel, sizeof out->table_kernel, "alpha_choice_kernel");
-    out->grid = (int32_t)std::min<int64_t>(n_blocks, pl.grid_cap / n_teams);
-    out->waves_per_wg = irec::team_waves_for(B, S, pl.shape);
+    out->grid = (int32_t)std::min<int64_t>(n_blocks, std::min(pl.grid_cap / n_teams, n_cu));
+    out->waves_per_wg = irec::team_waves_for(B, S, shape);
     out->teams_per_wg = n_teams;
-    out->lds_bytes = (int32_t)irec::team_lds_for(B, S, pl.shape);
+    out->lds_bytes = (int32_t)irec::team_lds_for(B, S, shape);
   } else if (pl.fast) {
     std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::fast_kernel_name(B, S, pl.table));
     if (pl.table) std::snprintf(out->table_kernel, sizeof out->table_kernel, "alpha_table_kernel");
@@ -682,6 +697,7 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   // then the candidate exchange of the split encoder
   A.counter = (unsigned int *)workspace;
   A.defer_count = (unsigned int *)workspace + 1;
+  if (pl.team) pl.shape = shape_for_call(ctx, pl, p, n_blocks);
   A.K_tab = pl.K_tab; A.deferred_pass = 0; A.shape_override = pl.shape;
   A.coop_W = 1; A.coop_err = (unsigned int *)workspace + 3; A.coop_arrive = (unsigned int *)workspace + 64;
   A.coop_xch = (uint32_t *)((char *)workspace + irec::WS_COUNTER_BYTES);
@@ -714,7 +730,7 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
     if (pl.team) { // grid_cap counts teams (= scratch slabs): two per workgroup, one workgroup per CU
       const int n_teams = irec::team_count_for(p->n_beams, p->n_samples, pl.shape);
       // one workgroup per CU as soon as there is a block for it: team k of workgroup w starts on block k * grid + w
-      const int tgrid = (int)std::min<int64_t>(n_blocks, pl.grid_cap / n_teams);
+      const int tgrid = (int)std::min<int64_t>(n_blocks, std::min(pl.grid_cap / n_teams, ctx->n_cu > 0 ? ctx->n_cu : 256));
       HIP_TRY(irec::launch_encode_team(A, tgrid, st));
       if (!ctx->d_dbg) { if (irec_status s2 = deferred_pass()) return s2; }
       if (ctx->d_dbg) { // diagnostic build (-DIREC_TEAM_STAMPS) only: per-wave phase cycles, wave 0 of a team vs the others

@@ -818,6 +818,7 @@ static int team_cfg(int shape_override) {
     case 2: return 20;
     case 3: return 3;
     case 4: return 22;
+    case 5: return 12;
     default: return 2;
   }
 }
@@ -831,6 +832,7 @@ static TeamShape team_shape(int B, int S, int ovr) {
     if (cfg == 1) return TeamShape{20, 1, 1};
     if (cfg == 20) return TeamShape{20, 2, 1};
     if (cfg == 22) return TeamShape{20, 2, 2};
+    if (cfg == 12) return TeamShape{20, 1, 2};
     // three 4-wave teams (168 VGPRs: half-slot look-up pipeline, statistics / variance / scale parked in the slab, sort keys
     // over the partial scores) wherever their LDS fits next to the table copies -- S <= 38, the BASELINE workload: a third
     // team scores while another is in a serial phase (r02c: 13.2 ms against 13.7 ms of two teams)

@@ -535,7 +535,7 @@ def test_two_streams_encode_concurrently(engine, oracle):
             assert np.array_equal(pa.sample[i].cpu().numpy(), rsa) and np.array_equal(pb.sample[i].cpu().numpy(), rsb)
 
 
-@pytest.mark.parametrize("shape", ["1", "2", "3", "2x2"])
+@pytest.mark.parametrize("shape", ["1", "2", "3", "2x2", "1x2"])
 def test_diagnostic_team_shapes_are_bit_exact(engine, oracle, shape):
     q = [np.stack([oracle.synthetic_latent(20 + i, 8192)[j] for i in range(8)]) for j in range(4)]
     c = _coder(3.0, 20, 1.2, block_size=1000, variant="table")
@@ -543,6 +543,24 @@ def test_diagnostic_team_shapes_are_bit_exact(engine, oracle, shape):
     idx, sample = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)
     ridx, rs = oracle.encode_tensor(q[0][3], q[1][3], q[2][3], q[3][3], 42, 3.0, 36, 20, block_size=1000)
     assert idx[3] == ridx and np.array_equal(sample[3].cpu().numpy(), rs)
+
+
+@pytest.mark.parametrize("B,n_latents", [(20, 12), (11, 28), (16, 8)])
+def test_mid_size_calls_take_the_eight_wave_team(engine, oracle, B, n_latents):
+    """64 .. n_CU blocks with 10 < B <= 20: one block per CU at most, so the call runs ONE 8-wave beam-striped team per CU
+    (irec_encode_plan says so) -- and a larger call of the same coder the three-team shape; the oracle's outputs both ways."""
+    q = [np.stack([oracle.synthetic_latent(300 + i, 8192)[j] for i in range(n_latents)]) for j in range(4)]
+    c = _coder(3.0, B, 1.2, block_size=1000)
+    lay = engine.layout(n_latents, 8192, 1000, 42)
+    plan = engine.plan(c._params(), lay, 32)
+    assert 64 <= lay.n_blocks <= plan["n_cu"] and plan["kernel"] == "encode_team_kernel<20,1,2>" and plan["teams_per_wg"] == 1, plan
+    assert plan["grid"] == lay.n_blocks and plan["waves_per_wg"] == 8
+    big = engine.plan(c._params(), engine.layout(64, 8192, 1000, 42), 32)
+    assert big["kernel"] != plan["kernel"] and big["teams_per_wg"] >= 2, big
+    idx, sample = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)
+    for i in (0, n_latents // 2, n_latents - 1):
+        ridx, rs = oracle.encode_tensor(q[0][i], q[1][i], q[2][i], q[3][i], 42, 3.0, 36, B, block_size=1000)
+        assert idx[i] == ridx and np.array_equal(sample[i].cpu().numpy(), rs), i
 
 
 def test_library_errors_are_coding_errors(engine):
