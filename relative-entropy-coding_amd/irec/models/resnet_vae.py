@@ -84,6 +84,7 @@ class BidirectionalResidualBlock(nn.Module):
         self.posterior = self.prior = None
         self._pad = pad
         self._fused = None   # (parameter versions, inference-side weight / bias, generative-side weight / bias)
+        self._fuse_mods = None
         # ---- stuff for compression (resnet_vae.py:118-141) ----
         if sampler == "beam_search":
             self.coder = BeamSearchCoder(kl_per_partition=kl_per_partition, n_beams=sampler_args['n_beams'],
@@ -112,10 +113,15 @@ class BidirectionalResidualBlock(nn.Module):
         the decompress pass both run the SAME generative-side convolution (the decoder drops the posterior channels), so
         the prior the decoder rebuilds is bit-identical to the one the encoder coded against.  Rebuilt when a parameter
         changes in place, is replaced or moves (tensor version counters and storage addresses)."""
-        heads_i = [self.infer_posterior_loc_head, self.infer_posterior_log_scale_head] + ([] if self.is_last else [self.infer_conv1])
-        heads_g = [self.prior_loc_head, self.prior_log_scale_head, self.gen_posterior_loc_head,
-                   self.gen_posterior_log_scale_head, self.gen_conv1]
-        ver = tuple((p._version, p.data_ptr(), p.dtype) for m in heads_i + heads_g for p in (m.weight, m.bias))
+        mods = self._fuse_mods
+        if mods is None:   # (looked up once: nn.Module attribute access is a microsecond each, and this runs 48 times per image)
+            heads_i = [self.infer_posterior_loc_head, self.infer_posterior_log_scale_head] + ([] if self.is_last else [self.infer_conv1])
+            heads_g = [self.prior_loc_head, self.prior_log_scale_head, self.gen_posterior_loc_head,
+                       self.gen_posterior_log_scale_head, self.gen_conv1]
+            mods = self._fuse_mods = (heads_i, heads_g)
+        heads_i, heads_g = mods
+        ver = [x for m in heads_i + heads_g for p in (m._parameters["weight"], m._parameters["bias"])
+               for x in (id(p), p._version, p.data_ptr())]
         if self._fused is None or self._fused[0] != ver:
             with torch.no_grad():
                 self._fused = (ver,

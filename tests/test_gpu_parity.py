@@ -465,11 +465,13 @@ def test_table_window_mixed_partition_counts_fit_256mb(engine, oracle):
         ridx, rs = oracle.encode_tensor(q[0][i], q[1][i], q[2][i], q[3][i], 42, omega, S, B, block_size=bs)
         assert idx[i] == ridx, i
         assert np.array_equal(sample[i].cpu().numpy(), rs), i
-    # a third of this call's blocks have K ~ 3000: the coder's window hint follows them, the library bounds the tables' bytes
+    # the coder's window hint follows the bulk of the blocks (K = 8), not the two outliers; asked for more than fits, the
+    # library bounds the tables' bytes
+    assert 8 <= c._params().table_steps <= 16, c._params().table_steps
+    c.table_steps = 4000
     plan = engine.plan(c._params(), lay, max(max(k) for k in Ks))
     per_step = 2 * S * (1000 + 64)
-    assert c._params().table_steps > 2500 and plan["table_steps"] == (64 << 20) // per_step, plan
-    assert plan["workspace_bytes"] < 256 * 2 ** 20, plan
+    assert plan["table_steps"] == (64 << 20) // per_step and plan["workspace_bytes"] < 256 * 2 ** 20, plan
     idx_b, sample_b = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)   # coded with that window
     assert idx_b == idx and torch.equal(sample_b, sample)
     # round trip through the decoder
