@@ -314,6 +314,19 @@ def run_rank(args):
             traffic_note = (f"profiles/traffic.json is for sources {tr.get('source_sha16')} / {tr.get('kernel')}; "
                             f"this build is {src_hash} / {plan['kernel']}: not reported")
 
+    # decoder leg (outside the timed region): the batch just coded is decoded from its indices -- at the full size the
+    # round trip must be exact (decode == the encoder's sample, bit for bit), and the decoder's own rate is reported
+    samp_dec = eng.decode_blocks(params, lay, q[2], q[3], SEED, K, out[1])
+    torch.cuda.synchronize()
+    round_trip_exact = bool(torch.equal(samp_dec, out[2]))
+    d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    d0.record()
+    for _ in range(3):
+        eng.decode_blocks(params, lay, q[2], q[3], SEED, K, out[1])
+    d1.record(); torch.cuda.synchronize()
+    decode_ms = d0.elapsed_time(d1) / 3
+    assert round_trip_exact, "decode(encode) differs from the encoder's sample"
+
     result = {
         "metric": "encoded latents/sec", "value": world * L * args.steps / elapsed, "unit": "latents/s",
         "n_gpus": world, "world_size": dist.get_world_size() if dist is not None else 1,
@@ -339,7 +352,9 @@ def run_rank(args):
                       # assignment over three table copies, 8 waves per CU
                       "lds_gather_roofline": {"achieved": lookups, "peak": LDS_2CHOICE_LOOKUPS,
                                               "unit": "look-ups/clk/CU", "frac": lookups / LDS_2CHOICE_LOOKUPS},
-                      "mean_K": float(Kh.mean()), "code_nats_per_latent": float(gathered.mean().item())},
+                      "mean_K": float(Kh.mean()), "code_nats_per_latent": float(gathered.mean().item()),
+                      "decode_round_trip_exact": round_trip_exact, "decode_ms": decode_ms,
+                      "decoded_latents_per_s": L / (decode_ms * 1e-3)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O

@@ -824,26 +824,40 @@ __global__ __launch_bounds__(256) void decode_kernel(DecArgs A) {
     const int K = A.K[blk];
     const int32_t *idx = A.indices + blk * (int64_t)A.max_K;
     if (K > A.max_K || K < 0) continue;
-    for (int d = tid; d < D; d += 256) {
-      const int64_t ix = base + (A.perm ? (int64_t)A.perm[pos + d] : (int64_t)(pos + d));
-      const float sp = A.p_scale[ix];
-      const float var_p = sp * sp;
-      float c = 0.f, sample = 0.f;
+    // a thread decodes FOUR consecutive dims: one Philox block yields their four draws (two when the row start is not a
+    // multiple of 4), instead of one block per dim with three of its four words thrown away
+    for (int d0 = tid * 4; d0 < D; d0 += 256 * 4) {
+      int64_t ix[4];
+      float var_p[4], c[4], sample[4];
+      bool valid[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        valid[i] = d0 + i < D;
+        ix[i] = base + (A.perm ? (int64_t)A.perm[pos + (valid[i] ? d0 + i : d0)] : (int64_t)(pos + (valid[i] ? d0 + i : d0)));
+        const float sp = A.p_scale[ix[i]];
+        var_p[i] = sp * sp; c[i] = 0.f; sample[i] = 0.f;
+      }
       uint32_t hs = 0u;
       for (int t = 0; t < K; ++t) {
         const float rho = A.rho[K - 1 - t];
-        const float a = rho * (var_p - c);
-        const float sa = sqrtf(a);
         const StepSeed ss = make_step_seed(A.seed + t);
         const uint32_t it = (uint32_t)idx[t];
         const uint32_t h = hash_from_sum((int32_t)hs);
-        const uint32_t rm1 = draw_rm1(ss, (uint64_t)it * (uint64_t)D + (uint64_t)d);
-        const uint32_t k = ((rm1 + 1u) * h) % IREC_P;
-        sample = sample + sa * A.lut[k];
-        c = c + a;
+        uint32_t rm1[4];
+        draw_rm1_x4(ss, (uint64_t)it * (uint64_t)D + (uint64_t)d0, rm1);   // (it * D + d0) & 3 is uniform: d0 % 4 == 0
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float a = rho * (var_p[i] - c[i]);
+          const float sa = sqrtf(a);
+          const uint32_t k = ((rm1[i] + 1u) * h) % IREC_P;
+          sample[i] = sample[i] + sa * A.lut[k];
+          c[i] = c[i] + a;
+        }
         hs += it * (uint32_t)(69 + t);
       }
-      A.out_sample[ix] = sample + A.p_loc[ix];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (valid[i]) A.out_sample[ix[i]] = sample[i] + A.p_loc[ix[i]];
     }
   }
 }
