@@ -808,8 +808,7 @@ irec_status irec_beam_decode(irec_context *ctx, const irec_params *p, int64_t n_
   A.block_base = block_base; A.block_pos = block_pos; A.block_dim = block_dim; A.perm = perm;
   A.p_loc = p_loc; A.p_scale = p_scale; A.n_blocks = n_blocks; A.seed = seed; A.max_K = max_K; A.K = K;
   A.indices = indices; A.out_sample = out_sample; A.lut = ctx->d_lut; A.rho = ctx->d_rho;
-  const int grid = (int)std::min<int64_t>(n_blocks, 8LL * ctx->n_cu);
-  HIP_TRY(irec::launch_decode(A, grid, (hipStream_t)hip_stream));
+  HIP_TRY(irec::launch_decode(A, ctx->n_cu > 0 ? ctx->n_cu : 256, (hipStream_t)hip_stream));
   return IREC_OK;
 }
 

@@ -80,7 +80,7 @@ constexpr size_t WS_COUNTER_BYTES = 512;                  // [0,256): block / de
 constexpr int COOP_MAX_BLOCKS = 64, COOP_KEYS = 1024;      // split encoder: blocks per call, sort keys per step (S * NB, aliased-key builds)
 constexpr size_t WS_XCH_BYTES = (size_t)2 * COOP_MAX_BLOCKS * COOP_KEYS * 4;   // key exchange of the split encoder, double buffered
 constexpr size_t WS_HEAD_BYTES = WS_COUNTER_BYTES + WS_XCH_BYTES;
-hipError_t launch_decode(const DecArgs &A, int grid, hipStream_t st);
+hipError_t launch_decode(const DecArgs &A, int n_cu, hipStream_t st);
 hipError_t launch_uniform_int(int64_t seed, int64_t n, int32_t *out, hipStream_t st);
 hipError_t launch_select_test(const float *scores, int N, int Bnew, int Bcur, uint32_t *keys, int32_t *sel, hipStream_t st);
 hipError_t launch_reduce_scatter_test(const float *in, float *out, int width, hipStream_t st);

@@ -815,8 +815,18 @@ __global__ __launch_bounds__(256) void alpha_table_kernel(int64_t seed, int32_t 
 // ======================================================================================================
 //  decoder (beam_search_coder.py:124-148): only row indices[t] of each step's draw is needed
 // ======================================================================================================
+// LDS_LUT: the workgroup copies the 40 KB quantile table into LDS once and gathers from there (a random 64-lane gather
+// costs ~4 LDS cycles against ~64 cache-line requests through the vector L1); worth its set-up once a workgroup decodes
+// several blocks.  Small calls read the table through the L2 as before.
+template <bool LDS_LUT>
 __global__ __launch_bounds__(256) void decode_kernel(DecArgs A) {
   const int tid = threadIdx.x;
+  __shared__ float lut_s[LDS_LUT ? IREC_P : 1];
+  if constexpr (LDS_LUT) {
+    for (int k = tid; k < (int)IREC_P; k += 256) lut_s[k] = A.lut[k];
+    __syncthreads();
+  }
+  const float *lut = LDS_LUT ? lut_s : A.lut;
   for (int64_t blk = blockIdx.x; blk < A.n_blocks; blk += gridDim.x) {
     const int D = A.block_dim[blk];
     const int64_t base = A.block_base[blk];
@@ -850,7 +860,7 @@ __global__ __launch_bounds__(256) void decode_kernel(DecArgs A) {
           const float a = rho * (var_p[i] - c[i]);
           const float sa = sqrtf(a);
           const uint32_t k = ((rm1[i] + 1u) * h) % IREC_P;
-          sample[i] = sample[i] + sa * A.lut[k];
+          sample[i] = sample[i] + sa * lut[k];
           c[i] = c[i] + a;
         }
         hs += it * (uint32_t)(69 + t);
@@ -988,8 +998,11 @@ hipError_t launch_zero_counters(void *p, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_decode(const DecArgs &A, int grid, hipStream_t st) {
-  hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(256), 0, st, A);
+hipError_t launch_decode(const DecArgs &A, int n_cu, hipStream_t st) {
+  if (A.n_blocks >= 16LL * n_cu) // four resident workgroups per CU (40 KB of LDS each), four blocks or more per workgroup
+    hipLaunchKernelGGL(decode_kernel<true>, dim3(4 * n_cu), dim3(256), 0, st, A);
+  else
+    hipLaunchKernelGGL(decode_kernel<false>, dim3((unsigned)(A.n_blocks < 8LL * n_cu ? A.n_blocks : 8LL * n_cu)), dim3(256), 0, st, A);
   return hipGetLastError();
 }
 

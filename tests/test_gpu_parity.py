@@ -337,6 +337,36 @@ def test_high_kl_block_many_partitions(engine, oracle):
     assert len(ridx) > 64 and [int(i) for i in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
 
 
+def test_decoder_both_table_paths(engine, oracle):
+    """The decoder gathers the quantile table through the L2 for small calls and from an LDS copy from 16 blocks per CU on
+    (4608 blocks here): both must reproduce the encoder's sample, and the oracle's decode of the same indices."""
+    n_t, n, bs = 512, 8192, 1000
+    rng = np.random.default_rng(77)
+    mp = rng.normal(0, 1, (n_t, n)).astype(np.float32); lsp = rng.normal(0, 0.25, (n_t, n)).astype(np.float32)
+    sp = np.exp(lsp).astype(np.float32)
+    mq = (mp + sp * rng.normal(0, 0.2, (n_t, n))).astype(np.float32)
+    sq = np.exp(lsp - np.abs(rng.normal(0, 0.05, (n_t, n)))).astype(np.float32)
+    ql, qs, pl, ps = (torch.from_numpy(a).cuda().contiguous() for a in (mq, sq, mp, sp))
+    lay = engine.layout(n_t, n, bs, 42)
+    params = engine.params(3.0, 36, 20, 0)
+    K, idx, sample = engine.encode_blocks(params, lay, ql, qs, pl, ps, 42, 32)
+    assert lay.n_blocks >= 16 * engine.plan(params, lay, 32)["n_cu"]
+    rec = engine.decode_blocks(params, lay, pl, ps, 42, K, idx)                        # LDS-table decoder
+    assert torch.equal(rec, sample)
+    few = engine.layout(3, n, bs, 42)                                                   # 27 blocks: the L2 path
+    rows = torch.as_tensor(np.concatenate([lay.natural[i * 9:(i + 1) * 9] for i in (0, 255, 511)]))
+    sel = torch.as_tensor([0, 255, 511])
+    K3, idx3 = K.cpu()[rows], idx.cpu()[rows]
+    order = torch.as_tensor(np.argsort(few.natural))                                    # rows of `few` in its own layout order
+    rec3 = engine.decode_blocks(params, few, pl[sel.cuda()].contiguous(), ps[sel.cuda()].contiguous(), 42,
+                                K3[order].cuda().contiguous(), idx3[order].cuda().contiguous())
+    assert torch.equal(rec3, sample[sel.cuda()])
+    Kh, ih = K.cpu().numpy(), idx.cpu().numpy()
+    for i in (0, 511):
+        blocks = [ih[lay.natural[i * 9 + j], :Kh[lay.natural[i * 9 + j]]].tolist() for j in range(9)]
+        assert np.array_equal(oracle.decode_tensor(mp[i], sp[i], blocks, 42, 36, block_size=bs), sample[i].cpu().numpy())
+
+
 @pytest.mark.parametrize("flags", [8, 0, 4, 2], ids=["table", "auto", "one_table", "fused"])
 def test_full_size_properties(engine, oracle, flags):
     """BASELINE config 2 at bench size: properties that need no oracle run (round trip, ranges), plus a sampled
