@@ -582,7 +582,8 @@ bool team_for_call(const Plan &pl, const irec_params *p, int64_t n_blocks) {
 int shape_for_call(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks) {
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
   const int B = p->n_beams, S = p->n_samples;
-  if (pl.shape != 0 || !pl.team || n_blocks > n_cu || B <= 10 || B > 20) return pl.shape;
+  if (pl.shape != 0 || !pl.team || n_blocks < 64 || n_blocks > n_cu || B <= 10 || B > 20) return pl.shape;   // (< 64 blocks: only calls
+                                                                         // that pin IREC_FLAG_TEAM get here, tests of the default shape among them)
   if (irec::team_count_for(B, S, 0) < 2) return pl.shape;                       // already one striped team
   if (irec::team_lds_for(B, S, 5) == (size_t)-1 || irec::team_ws_extra_for(B, S, 5) > irec::team_ws_extra_for(B, S, 0))
     return pl.shape;
