@@ -70,6 +70,13 @@ typedef struct {
 #define IREC_FLAG_NO_SPLIT 16     /* never the split encoder (several workgroups per block for calls of few blocks)   */
 #define IREC_FLAG_TEST_SPLIT_ORPHAN 32 /* test hook: the partner workgroups of the split encoder leave at once, so workgroup 0  */
                                   /* of every block must take the 2-second give-up exit (out_K = -2) instead of hanging   */
+#define IREC_FLAG_REUSE_TABLES 64 /* the caller vouches for the workspace: its first 512 bytes were zero when it was allocated  */
+                                  /* and nothing but irec_beam_encode has written to it since.  Every call stamps the key of  */
+                                  /* each proposal table it builds (seed, S, D, table window, table kind, offset) into the    */
+                                  /* workspace head; with this flag a later call on the SAME workspace whose key matches the  */
+                                  /* stamp -- checked on the device, so also inside a replayed HIP graph -- keeps the table   */
+                                  /* instead of rebuilding it (the 24 residual blocks of an image share seed, S and dims:     */
+                                  /* beam_search_coder.py:38-43, resnet_vae.py:822-824).  Same outputs, bit for bit.          */
 #define IREC_FLAG_SPLIT_SHIFT 12  /* bits 12-15: workgroups per block of the split encoder, 0 = chosen by the library (diagnostics) */
 #define IREC_FLAG_SPLIT_MASK (0xF << IREC_FLAG_SPLIT_SHIFT)
 /* Diagnostic workgroup shapes of the team encoder for B <= 20 (bits 8-11 of flags; 0 = the default shape).  Same outputs. */

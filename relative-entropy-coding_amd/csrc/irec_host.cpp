@@ -705,7 +705,22 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   A.ws = (char *)workspace + irec::WS_HEAD_BYTES + pl.tab_bytes;
   A.ws_per_wg = pl.ws_per_wg;
   A.max_dim_pad = pl.dpad;
-  HIP_TRY(irec::launch_zero_counters(workspace, st));
+  // table bookkeeping (IREC_FLAG_REUSE_TABLES): the key of every proposal table this call needs -- what it is a function
+  // of (seed, S, D, window), which kernel writes it (the team encoder's rows carry copy bits) and where it lies -- is
+  // compared with the slot's stamp ON THE DEVICE by the head kernel; a slot the call does not use is stamped with zeros,
+  // so a call without tables (whose slabs may lie over the table area) invalidates what was there
+  irec::TableStamps stamps{};
+  if (pl.table)
+    for (int q = 0; q < pl.n_tab; ++q) {
+      uint32_t *w = stamps.w[q];
+      w[0] = 0x7ab1e000u | (pl.team ? 1u : 2u);
+      w[1] = (uint32_t)(uint64_t)seed; w[2] = (uint32_t)((uint64_t)seed >> 32);
+      w[3] = (uint32_t)p->n_samples; w[4] = (uint32_t)pl.tab_dim[q]; w[5] = (uint32_t)pl.K_tab;
+      w[6] = (uint32_t)pl.tab_off[q];
+      w[7] = ~(w[1] ^ w[2] ^ w[3] ^ w[4] ^ w[5] ^ w[6]);
+    }
+  stamps.reuse = (p->flags & IREC_FLAG_REUSE_TABLES) ? 1 : 0;
+  HIP_TRY(irec::launch_zero_counters(workspace, stamps, st));
   int grid = (int)std::min<int64_t>(n_blocks, pl.one_grid_cap);
   A.dbg = ctx->d_dbg;
   if (ctx->d_dbg) HIP_TRY(hipMemsetAsync(ctx->d_dbg, 0, 4096 * 16 * sizeof(unsigned long long), st));
@@ -713,8 +728,9 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
     for (int q = 0; q < 4; ++q) { A.tab[q] = nullptr; A.tab_dim[q] = -1; }
     for (int q = 0; q < pl.n_tab; ++q) {
       uint16_t *tab = (uint16_t *)((char *)workspace + irec::WS_HEAD_BYTES + pl.tab_off[q]);
-      if (pl.team) HIP_TRY(irec::launch_alpha_choice(seed, p->n_samples, pl.tab_dim[q], pl.K_tab, ctx->d_dlog4r, tab, st));
-      else HIP_TRY(irec::launch_alpha_table(seed, p->n_samples, pl.tab_dim[q], pl.K_tab, ctx->d_dlog4r, tab, st));
+      const uint32_t *keep = (const uint32_t *)workspace + irec::WS_KEEP_WORD + q;
+      if (pl.team) HIP_TRY(irec::launch_alpha_choice(seed, p->n_samples, pl.tab_dim[q], pl.K_tab, ctx->d_dlog4r, tab, keep, st));
+      else HIP_TRY(irec::launch_alpha_table(seed, p->n_samples, pl.tab_dim[q], pl.K_tab, ctx->d_dlog4r, tab, keep, st));
       A.tab[q] = tab; A.tab_dim[q] = pl.tab_dim[q];
     }
     // second pass (only when the window is shorter than max_K): the fused-Philox encoder codes the blocks whose K lies
@@ -843,7 +859,7 @@ irec_status irec_test_proposal_table(irec_context *ctx, int64_t seed, int32_t n_
   if (!ctx || !out_tab || n_samples < 1 || dim < 1 || dim > irec::FAST_MAX_DIM || n_steps < 1)
     return fail(IREC_E_INVALID, "irec_test_proposal_table: bad arguments");
   IREC_ON_DEVICE(ctx->device);
-  HIP_TRY(irec::launch_alpha_choice(seed, n_samples, dim, n_steps, ctx->d_dlog4r, out_tab, (hipStream_t)hip_stream));
+  HIP_TRY(irec::launch_alpha_choice(seed, n_samples, dim, n_steps, ctx->d_dlog4r, out_tab, nullptr, (hipStream_t)hip_stream));
   return IREC_OK;
 }
 

@@ -62,8 +62,10 @@ size_t fast_ws_for(int B, int max_K);
 size_t fast_ws_bytes_nb(int NB, int max_K);
 hipError_t launch_encode_fast(const EncArgs &A, bool table, int grid, hipStream_t st);
 int fast_waves_for(int B, int S, bool table);
+// (`keep`: device word the per-call head kernel has set to 1 when the table in place already is this one -- the kernel
+//  then returns at once; nullptr = always build)
 hipError_t launch_alpha_table(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *dlog4r, uint16_t *tab,
-                              hipStream_t st);
+                              const uint32_t *keep, hipStream_t st);
 // two-teams-per-CU encoder over three table copies (irec_team.hip)
 // (shape_override: 0 = default shape, 1..4 = the diagnostic shapes of IREC_FLAG_SHAPE_*, see team_cfg() in irec_team.hip)
 int team_count_for(int B, int S, int shape_override);   // teams per workgroup (= scratch slabs per workgroup) of the build that serves B beams
@@ -74,9 +76,16 @@ hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st);
 const char *team_kernel_name(int B, int S, int shape_override);   // e.g. "encode_team_kernel<20,2,1>"
 const char *fast_kernel_name(int B, int S, bool table);
 hipError_t launch_alpha_choice(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *dlog4r, uint16_t *tab,
-                               hipStream_t st);
-hipError_t launch_zero_counters(void *p, hipStream_t st);   // the 512-byte counter block
-constexpr size_t WS_COUNTER_BYTES = 512;                  // [0,256): block / deferred counters, [256,512): 64 arrival counters
+                               const uint32_t *keep, hipStream_t st);
+// Head of the workspace, 128 uint32: [0..3] block / deferred counters and the split encoder's error flag, [8..11] "keep"
+// words of the call's proposal tables, [16..47] the stamps of the four table slots (8 words each: what the table in place
+// was built for), [64..127] arrival counters of the split encoder.  The head kernel of every call zeroes the counters,
+// compares each slot's stamp with the call's key (IREC_FLAG_REUSE_TABLES; keep = 1 on a match, else 0) and stamps the key:
+// the table kernels that follow on the stream read `keep`, nobody writes it again before the next call's head kernel.
+constexpr int WS_KEEP_WORD = 8, WS_STAMP_WORD = 16, WS_STAMP_WORDS = 8;
+struct TableStamps { uint32_t w[4][WS_STAMP_WORDS]; int32_t reuse; };   // all-zero key = slot unused (never matches)
+hipError_t launch_zero_counters(void *p, const TableStamps &stamps, hipStream_t st);
+constexpr size_t WS_COUNTER_BYTES = 512;                  // [0,256): counters, keep words, table stamps; [256,512): 64 arrival counters
 constexpr int COOP_MAX_BLOCKS = 64, COOP_KEYS = 1024;      // split encoder: blocks per call, sort keys per step (S * NB, aliased-key builds)
 constexpr size_t WS_XCH_BYTES = (size_t)2 * COOP_MAX_BLOCKS * COOP_KEYS * 4;   // key exchange of the split encoder, double buffered
 constexpr size_t WS_HEAD_BYTES = WS_COUNTER_BYTES + WS_XCH_BYTES;

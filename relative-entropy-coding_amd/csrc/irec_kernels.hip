@@ -796,7 +796,9 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
 //  which the beam-striped encoder streams from L2 (8 bytes per lane per sample).
 // ======================================================================================================
 __global__ __launch_bounds__(256) void alpha_table_kernel(int64_t seed, int32_t S, int32_t D, int32_t K_tab,
-                                                          const uint16_t *__restrict__ dlog4r, uint16_t *__restrict__ tab) {
+                                                          const uint16_t *__restrict__ dlog4r, uint16_t *__restrict__ tab,
+                                                          const uint32_t *__restrict__ keep) {
+  if (keep && *keep) return;   // the table in place was built for exactly this key (head kernel of this call)
   const int Dp = (D + 3) & ~3;
   const int64_t per_step = (int64_t)S * Dp;
   const int64_t total = per_step * K_tab;
@@ -982,19 +984,34 @@ hipError_t launch_encode_fast(const EncArgs &A, bool table, int grid, hipStream_
 }
 
 hipError_t launch_alpha_table(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *dlog4r, uint16_t *tab,
-                              hipStream_t st) {
+                              const uint32_t *keep, hipStream_t st) {
   const int64_t quads = ((int64_t)S * ((D + 3) & ~3) * K_tab + 3) / 4;
   const int grid = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
-  hipLaunchKernelGGL(alpha_table_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, st, seed, S, D, K_tab, dlog4r, tab);
+  hipLaunchKernelGGL(alpha_table_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, st, seed, S, D, K_tab, dlog4r, tab, keep);
   return hipGetLastError();
 }
 
 // zeroes the 256-byte counter block at the head of the workspace.  A kernel, not hipMemsetAsync: the call sequence of
 // irec_beam_encode is then kernels only, which is also what a HIP-graph capture of it records (r02: replaying a capture
 // that held the memset node faulted on the second replay).
-__global__ void zero_counters_kernel(uint32_t *p) { p[threadIdx.x] = 0u; }
-hipError_t launch_zero_counters(void *p, hipStream_t st) {
-  hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(WS_COUNTER_BYTES / 4), 0, st, reinterpret_cast<uint32_t *>(p));
+// Since r02i it also keeps the books of the proposal tables (irec_kernels.h, "Head of the workspace"): thread q < 4 compares
+// the stamp of table slot q with this call's key, publishes keep[q] and stamps the key -- one thread owns a slot's words.
+__global__ void zero_counters_kernel(uint32_t *p, TableStamps ts) {
+  const int t = (int)threadIdx.x;
+  const bool book = (t >= WS_KEEP_WORD && t < WS_KEEP_WORD + 4) || (t >= WS_STAMP_WORD && t < WS_STAMP_WORD + 4 * WS_STAMP_WORDS);
+  if (!book) p[t] = 0u;
+  if (t < 4) {
+    uint32_t *stamp = p + WS_STAMP_WORD + t * WS_STAMP_WORDS;
+    bool same = ts.reuse != 0 && ts.w[t][0] != 0u;
+#pragma unroll
+    for (int k = 0; k < WS_STAMP_WORDS; ++k) same = same && stamp[k] == ts.w[t][k];
+    p[WS_KEEP_WORD + t] = same ? 1u : 0u;
+#pragma unroll
+    for (int k = 0; k < WS_STAMP_WORDS; ++k) stamp[k] = ts.w[t][k];
+  }
+}
+hipError_t launch_zero_counters(void *p, const TableStamps &stamps, hipStream_t st) {
+  hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(WS_COUNTER_BYTES / 4), 0, st, reinterpret_cast<uint32_t *>(p), stamps);
   return hipGetLastError();
 }
 

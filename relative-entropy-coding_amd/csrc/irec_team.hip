@@ -31,6 +31,9 @@
 #ifndef IREC_UB3
 #define IREC_UB3 5   // beams per load batch of the update in the register-short builds
 #endif
+#ifndef IREC_STEP0_WIDE
+#define IREC_STEP0_WIDE 1   // first step (one beam): RW samples per reduce-scatter instead of one (0: the beam-wise path, A/B builds)
+#endif
 namespace irec {
 
 constexpr int TEAM_NW = 4;                       // waves per team
@@ -437,6 +440,45 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 #undef IREC_ISSUE
 #undef IREC_CONSUME
 #undef IREC_AL
+      } else if (IREC_STEP0_WIDE && active && Bcur == 1 && bs == 0) {
+        // First step (beam_search_coder.py:97-106): ONE beam, so a sample is a single candidate.  Scored beam-wise it would
+        // pay a whole reduce-scatter (86 instructions) for 4 look-ups; here RW SAMPLES share one -- a sample sits where a
+        // beam sits in the steady state, every total still comes out of the same lane chain and lane tree.  36 samples: two
+        // rounds instead of 36 (r02i: step 0 cost half a full step's instructions for a twentieth of its look-ups).
+        const int n_mine = Sp > sw ? (Sp - sw + NSW - 1) / NSW : 0; // my samples of the pass: s_base + sw, + NSW, ...
+        const uint32_t bet0 = bet[0];
+        constexpr int HB = RW / 2;                                  // rows fetched together (20 registers, as the steady state's)
+        static_assert(RW % 2 == 0, "half batches");
+        for (int m0 = 0; m0 < n_mine; m0 += RW) {
+          float acc[ACC_ROOM];
+#pragma unroll
+          for (int p = 0; p < RW; ++p) acc[p] = 0.f;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            uint2 ap[HB];
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+              const int m = m0 + h * HB + k;                        // past my last sample: entry 0, the total is dropped
+              ap[k] = make_uint2(0u, 0u);
+              if (m < n_mine) ap[k] = *reinterpret_cast<const uint2 *>(tab_tu + ((uint32_t)(s_base + m * NSW + sw) * (uint32_t)Dp + tab_lo));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float z[HB];
+#pragma unroll
+              for (int k = 0; k < HB; ++k) {
+                const uint32_t w = (i & 2) ? ap[k].y : ap[k].x;
+                z[k] = lds_abs_f32((((i & 1) ? (w >> 16) : (w & 0xFFFFu)) << 2) + bet0);
+              }
+#pragma unroll
+              for (int k = 0; k < HB; ++k) acc[h * HB + k] = proposal_term(acc[h * HB + k], z[k], cH[i], G[0][i]);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+          const float tot = reduce_scatter_n<RW>(acc, lane);
+          const int m = m0 + rs_p;                                  // rs_p < 0: unused slot
+          if (rs_p >= 0 && (lane & 1) == 0 && m < n_mine) part_s[((size_t)g * SP + m * NSW + sw) * NB] = tot;
+        }
       } else if (active && nlive > 0) {
 #endif
         const int s_per_stripe = (Sp + NSW - 1) / NSW;
@@ -730,7 +772,9 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 //  One half-wave per (t, s, m); choice bits never change any emitted value (all three table copies are identical).
 // ======================================================================================================
 __global__ __launch_bounds__(256) void alpha_choice_kernel(int64_t seed, int32_t S, int32_t D, int32_t K_tab,
-                                                           const uint16_t *__restrict__ dlog4r, uint16_t *__restrict__ tab) {
+                                                           const uint16_t *__restrict__ dlog4r, uint16_t *__restrict__ tab,
+                                                           const uint32_t *__restrict__ keep) {
+  if (keep && *keep) return;   // the table in place was built for exactly this key (head kernel of this call): uniform exit
   __shared__ uint8_t n_s[8][4][32]; // [half-wave][slot][bank] look-ups whose c = 0 bank this is
   __shared__ uint8_t x_s[8][4][32]; // how many of them stay (c = 0)
   const int Dp = (D + 3) & ~3;
@@ -899,11 +943,11 @@ hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
 }
 
 hipError_t launch_alpha_choice(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *dlog4r, uint16_t *tab,
-                               hipStream_t st) {
+                               const uint32_t *keep, hipStream_t st) {
   const int64_t n_hw = (int64_t)K_tab * S * ((((D + 3) >> 2) + 31) >> 5);
   const int64_t want = (n_hw + 7) / 8;
   const int grid = (int)(want < 4096 ? want : 4096);
-  hipLaunchKernelGGL(alpha_choice_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, st, seed, S, D, K_tab, dlog4r, tab);
+  hipLaunchKernelGGL(alpha_choice_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, st, seed, S, D, K_tab, dlog4r, tab, keep);
   return hipGetLastError();
 }
 

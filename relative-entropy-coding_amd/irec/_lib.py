@@ -18,6 +18,7 @@ IREC_FLAG_FUSED_PHILOX = 2
 IREC_FLAG_ONE_TABLE = 4
 IREC_FLAG_TEAM = 8
 IREC_FLAG_NO_SPLIT = 16
+IREC_FLAG_REUSE_TABLES = 64        # keep a proposal table whose stamp in the workspace head matches the call's key
 IREC_FLAG_SHAPE_SHIFT = 8          # diagnostic workgroup shapes of the team encoder (include/irec.h)
 IREC_FLAG_SHAPE = {"default": 0, "1": 1 << 8, "2": 2 << 8, "3": 3 << 8, "2x2": 4 << 8, "1x2": 5 << 8}
 IREC_TABLE_STEPS_DEFAULT = 32

@@ -109,6 +109,8 @@ class BeamSearchCoder(GaussianCoder):
         self.team = False            # debugging / testing knob: IREC_FLAG_TEAM (the team encoder also for small calls)
         self.no_split = False        # debugging / testing knob: IREC_FLAG_NO_SPLIT (one workgroup per block also for small calls)
         self.team_shape = "default"  # diagnostics: IREC_FLAG_SHAPE_* workgroup shape of the team encoder
+        self.reuse_tables = True     # IREC_FLAG_REUSE_TABLES: a call whose proposal tables are already in the stream's scratch
+                                     # (same seed, S, dims and window: the 24 residual blocks of an image) does not rebuild them
         self.table_steps = 0         # partitions the per-call proposal tables cover; 0 = sized from the partition counts
                                      # this coder has seen so far (_K_seen + 4, at least 8; the library bounds the bytes);
                                      # blocks with more are coded by the fused-Philox kernel in a second pass of the same call
@@ -129,7 +131,14 @@ class BeamSearchCoder(GaussianCoder):
         return len(indicies) * np.log(self.n_samples)
 
     # ---- plumbing --------------------------------------------------------------------------------------------------
-    def _params(self):
+    def table_window(self):
+        """Partitions the per-call proposal tables cover: `table_steps`, or the running hint from the partition counts read
+        back so far (the tables cost set-up time and scratch per step they cover; typical K is ~8)."""
+        if self.table_steps:
+            return int(self.table_steps)
+        return min(_lib.IREC_TABLE_STEPS_MAX, max(8, (self._K_seen + 4 + 3) // 4 * 4))
+
+    def _params(self, table_steps=None):
         if not self.extrapolate_auxiliary_ratios:
             raise CodingError("only extrapolate_auxiliary_ratios=True is supported on the beam-search path")
         if not (1 <= self.n_beams <= _lib.MAX_BEAMS):
@@ -140,10 +149,8 @@ class BeamSearchCoder(GaussianCoder):
                 (_lib.IREC_FLAG_FUSED_PHILOX if self.fused_philox else 0) | \
                 (_lib.IREC_FLAG_ONE_TABLE if self.one_table else 0) | \
                 (_lib.IREC_FLAG_TEAM if self.team else 0) | (_lib.IREC_FLAG_NO_SPLIT if self.no_split else 0) | \
-                _lib.IREC_FLAG_SHAPE[self.team_shape]
-        steps = self.table_steps
-        if steps == 0:   # running hint: the tables cost set-up time and scratch per step they cover (typical K is ~8)
-            steps = min(_lib.IREC_TABLE_STEPS_MAX, max(8, (self._K_seen + 4 + 3) // 4 * 4))
+                (_lib.IREC_FLAG_REUSE_TABLES if self.reuse_tables else 0) | _lib.IREC_FLAG_SHAPE[self.team_shape]
+        steps = int(table_steps) if table_steps else self.table_window()
         return get_engine().params(self.kl_per_partition, self.n_samples, self.n_beams, flags, table_steps=steps)
 
     @staticmethod
@@ -155,13 +162,13 @@ class BeamSearchCoder(GaussianCoder):
         t = torch.as_tensor(tensor)
         return get_engine(t.device if t.device.type == "cuda" else None)
 
-    def encode_tensors_device(self, q_loc, q_scale, p_loc, p_scale, seed, block_size, max_K=None):
+    def encode_tensors_device(self, q_loc, q_scale, p_loc, p_scale, seed, block_size, max_K=None, table_steps=None):
         """Asynchronous core of encode: launches the encoder on the current stream and returns a `PendingCode` -- K,
         indices and sample still on the device, NO host synchronisation.  The caller reads the indices when it needs
         them (`PendingCode.to_lists`, one device-to-host copy; `PendingCode.gather` for many calls at once)."""
         src = torch.as_tensor(q_loc)
         eng = self._engine_for(src)
-        params = self._params()
+        params = self._params(table_steps)   # (a model passes ONE window to all its coders: equal keys, tables built once)
         n_tensors = src.shape[0]
         n = src[0].numel()
         shapes = {tuple(torch.as_tensor(t).shape) for t in (q_loc, q_scale, p_loc, p_scale)}
@@ -243,7 +250,8 @@ class BeamSearchCoder(GaussianCoder):
             raise CodingError("For encoding, batch size must be 1.")
         if defer:
             pending = self.encode_tensors_device(target_dist.loc, target_dist.scale, coding_dist.loc, coding_dist.scale,
-                                                 seed, self.block_size, kwargs.pop("max_K", None))
+                                                 seed, self.block_size, kwargs.pop("max_K", None),
+                                                 kwargs.pop("table_steps", None))
             return pending, pending.sample
         idx, sample = self.encode_tensors(target_dist.loc, target_dist.scale, coding_dist.loc, coding_dist.scale,
                                           seed, self.block_size)

@@ -74,6 +74,37 @@ class BlockLayout:
             self.perm = torch.from_numpy(self.perm_host.astype(np.int32)).to(device)
 
 
+    def subset(self, rows):
+        """The layout restricted to `rows` (indices into this layout's row order): what ONE rank codes when the blocks of a
+        call are spread over several GPUs (irec/sharding.py).  Same tensors, same permutation."""
+        rows = np.asarray(rows, dtype=np.int64)
+        sub = object.__new__(BlockLayout)
+        sub.n_tensors, sub.n, sub.block_size, sub.seed = self.n_tensors, self.n, self.block_size, self.seed
+        sub.blocks_per_tensor = self.blocks_per_tensor
+        sub.order = self.order[rows]
+        sub.natural = None                       # a subset has no (tensor, block) -> row map: the parent reassembles
+        sub.n_blocks = len(rows)
+        idx = torch.as_tensor(rows, device=self.block_base.device)
+        sub.block_base, sub.block_pos, sub.block_dim = self.block_base[idx], self.block_pos[idx], self.block_dim[idx]
+        sub.max_dim = self.max_dim               # (the scratch and the plan are sized for the parent's largest block)
+        sub.distinct_dims = self.distinct_dims
+        sub.perm_host, sub.perm = self.perm_host, self.perm
+        return sub
+
+    def element_index(self, rows, width):
+        """[len(rows), width] int64: flat position (over all tensors) of element i of block `rows[r]` in the shuffled order
+        (Coder.split, coder.py:62-83), -1 past the block's end."""
+        rows = np.asarray(rows, dtype=np.int64)
+        base = self.block_base.cpu().numpy()[rows]
+        pos = self.block_pos.cpu().numpy()[rows].astype(np.int64)
+        dim = self.block_dim.cpu().numpy()[rows].astype(np.int64)
+        i = np.arange(width, dtype=np.int64)[None, :]
+        inside = i < dim[:, None]
+        at = np.where(inside, pos[:, None] + i, 0)
+        src = self.perm_host[at] if self.perm_host is not None else at
+        return np.where(inside, base[:, None] + src, -1)
+
+
 class Engine:
     def __init__(self, device):
         if not torch.cuda.is_available():
@@ -121,7 +152,10 @@ class Engine:
         if ws is None or ws.numel() < need:
             if ws is None and len(self._ws) >= 16:
                 self._ws.clear()       # streams come and go: drop the lot rather than grow without bound
+            # head zeroed once: IREC_FLAG_REUSE_TABLES trusts the table stamps there, and only this engine's
+            # irec_beam_encode calls ever write to the buffer
             ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            ws[:512].zero_()
             self._ws[key] = ws
         return ws, need
 

@@ -229,10 +229,16 @@ class BidirectionalResNetVAE(nn.Module):
                 tensor = resnet_block(tensor, inference_pass=True)
             tensor = self.generative_base(batch_size=batch_size, width=width, height=height)
             pendings = []
+            # every residual block codes with the same seed, S and block dims (:822-824): with ONE table window for all of them
+            # the proposal tables of the first block serve the other 23 (IREC_FLAG_REUSE_TABLES)
+            # (one max_K too: it bounds the window, and a window that covers max_K leaves no second pass to launch -- built
+            #  once per image, a long window costs next to nothing)
+            max_K = max(blk.coder._max_K_hint for blk in self.residual_blocks)
+            window = max(max(blk.coder.table_window() for blk in self.residual_blocks), min(max_K, 64))
             for resnet_block in self.residual_blocks:                     # strictly sequential (:821-826)
                 pending, tensor = resnet_block(tensor, inference_pass=False,
-                                               encoder_args={"seed": seed, "update_sampler": update_sampler,
-                                                             "batched": True, "defer": True})
+                                               encoder_args={"seed": seed, "update_sampler": update_sampler, "batched": True,
+                                                             "defer": True, "table_steps": window, "max_K": max_K})
                 pendings.append(pending)
             return pendings, self._finish(tensor)
 

@@ -678,3 +678,92 @@ def test_table_window_follows_the_partition_counts(engine, oracle):
     fresh = irec.BeamSearchCoder(kl_per_partition=3., n_beams=20, extra_samples=1.2, block_size=1000)
     idx4, sample4 = fresh.encode(_normal(q2[0], q2[1]), _normal(q2[2], q2[3]), seed=42, batched=True)
     assert idx3 == idx4 and torch.equal(sample3, sample4) and max(len(b) for t in idx3 for b in t) > 20
+
+
+def _keep_words(engine):
+    """keep[0..3] of the current stream's scratch after the last call (irec_kernels.h, head of the workspace)."""
+    ws = engine._ws[int(torch.cuda.current_stream(engine.device).cuda_stream)]
+    return ws[:512].view(torch.int32)[8:12].cpu().tolist()
+
+
+def test_proposal_tables_are_reused_only_when_the_stamp_matches(engine, oracle):
+    """IREC_FLAG_REUSE_TABLES: a call whose tables are already in the scratch keeps them (the device compares the stamps);
+    another seed, another window, another table kernel or a call without tables in between all force a rebuild -- and every
+    result equals the oracle's whichever way the tables came about."""
+    q = [np.stack([oracle.synthetic_latent(300 + i, 8192)[j] for i in range(8)]) for j in range(4)]
+    t = [torch.as_tensor(a, device="cuda") for a in q]
+    ref = {}
+
+    def check(coder, seed, n_t=8):
+        idx, sample = coder.encode(_normal(t[0][:n_t], t[1][:n_t]), _normal(t[2][:n_t], t[3][:n_t]), seed=seed, batched=True)
+        for i in (0, n_t - 1):
+            if (seed, i) not in ref:
+                ref[(seed, i)] = oracle.encode_tensor(q[0][i], q[1][i], q[2][i], q[3][i], seed, 3.0, 36, 20, block_size=1000)
+            assert idx[i] == ref[(seed, i)][0] and np.array_equal(sample[i].cpu().numpy(), ref[(seed, i)][1]), (seed, i)
+        return _keep_words(engine)
+
+    team = _coder(3.0, 20, 1.2, block_size=1000, variant="table")
+    team.table_steps = 12
+    engine._ws.pop(int(torch.cuda.current_stream(engine.device).cuda_stream), None)   # a fresh (zero-filled) scratch
+    assert check(team, 42)[:2] == [0, 0]            # first call: built
+    assert check(team, 42)[:2] == [1, 1]            # same key: kept
+    assert check(team, 43)[:2] == [0, 0]            # another seed: rebuilt ...
+    assert check(team, 42)[:2] == [0, 0]            # ... and the old seed's tables are gone
+    assert check(team, 42)[:2] == [1, 1]
+    team.table_steps = 16
+    assert check(team, 42)[:2] == [0, 0]            # another window (the second table also moves)
+    assert check(team, 42)[:2] == [1, 1]
+    one = _coder(3.0, 20, 1.2, block_size=1000, variant="one_table")
+    one.table_steps = 16
+    assert check(one, 42)[:2] == [0, 0]             # same key but the other table kernel (rows without copy bits)
+    assert check(one, 42)[:2] == [1, 1]
+    assert check(team, 42)[:2] == [0, 0]
+    fused = _coder(3.0, 20, 1.2, block_size=1000, variant="fused")
+    check(fused, 42)                                 # no tables: its slabs lie over the table area, the stamps are cleared
+    assert check(team, 42)[:2] == [0, 0]
+    assert check(team, 42)[:2] == [1, 1]
+    off = _coder(3.0, 20, 1.2, block_size=1000, variant="table")
+    off.table_steps, off.reuse_tables = 16, False
+    assert check(off, 42)[:2] == [0, 0]             # without the flag: always rebuilt (and stamped: the next call may keep)
+    assert check(team, 42)[:2] == [1, 1]
+    assert check(team, 42, n_t=1)[:2] == [1, 1]     # the tables do not depend on the blocks of the call
+    auto = _coder(3.0, 20, 1.2, block_size=1000, variant="auto")
+    auto.table_steps = 16
+    assert check(auto, 42, n_t=1)[:2] == [0, 0]     # 9 blocks without the team flag: the one-table encoder, other rows
+    assert check(auto, 42, n_t=1)[:2] == [1, 1]
+    assert check(auto, 42)[:2] == [0, 0]            # 72 blocks: the team encoder again
+
+
+def test_table_reuse_inside_a_replayed_graph(engine, oracle):
+    """The stamp comparison runs on the device, so a captured sequence of calls stays correct on every replay -- also after
+    other calls have used the same scratch in between."""
+    q = [np.stack([oracle.synthetic_latent(330 + i, 8192)[j] for i in range(2)]) for j in range(4)]
+    t = [torch.as_tensor(a, device="cuda") for a in q]
+    c = _coder(3.0, 20, 1.2, block_size=1000, variant="auto")
+    c.table_steps = 12
+    refs = [oracle.encode_tensor(q[0][i], q[1][i], q[2][i], q[3][i], 42, 3.0, 36, 20, block_size=1000) for i in range(2)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        c.encode_tensors_device(*t, 42, 1000)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        cap_stream = int(torch.cuda.current_stream().cuda_stream)
+        p1 = c.encode_tensors_device(*t, 42, 1000)
+        p2 = c.encode_tensors_device(*t, 42, 1000)      # second call of the capture: keeps the first one's tables
+    for rep in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        keep = engine._ws[cap_stream][:512].view(torch.int32)[8:12].cpu().tolist()
+        assert keep[:2] == [1, 1]
+        for p in (p1, p2):
+            lists = p.to_lists()
+            for i in range(2):
+                assert lists[i] == refs[i][0] and np.array_equal(p.sample[i].cpu().numpy(), refs[i][1])
+        # somebody else codes with another seed on the capture stream's scratch between the replays
+        ext = torch.cuda.ExternalStream(cap_stream)
+        with torch.cuda.stream(ext):
+            c.encode_tensors_device(*t, 7 + rep, 1000)
+        torch.cuda.synchronize()
