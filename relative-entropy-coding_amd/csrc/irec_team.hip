@@ -31,6 +31,10 @@
 #ifndef IREC_UB3
 #define IREC_UB3 5   // beams per load batch of the update in the register-short builds
 #endif
+#ifndef IREC_LAST_ONE
+#define IREC_LAST_ONE 1     // last step: only beam 0 is gathered and formed (0: all B, A/B builds; 2: also leaves the batch
+                            // loop early -- r02i: that form makes the allocator spill G inside the scoring loop, 48 -> 76 ms)
+#endif
 #ifndef IREC_STEP0_WIDE
 #define IREC_STEP0_WIDE 1   // first step (one beam): RW samples per reduce-scatter instead of one (0: the beam-wise path, A/B builds)
 #endif
@@ -627,11 +631,15 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 #pragma unroll
         for (int j = 0; j < rsn_room(NBW); ++j) cacc[j] = 0.f;
         constexpr int UB = (TEAMS >= 3 || BS >= 2) ? IREC_UB3 : NBW;              // beams per load batch: all at once (G's registers are free) unless registers are short
+        // the last step keeps ONE beam: beams[0] is all that leaves the block (beam_search_coder.py:118-122), so the parents,
+        // rows and look-ups of the other new beams are not fetched at all
+        const int Bupd = (IREC_LAST_ONE && last) ? 1 : Bnew;
         // lane j fetches the selection of new beam j and the offset of its parent: two LDS round trips for all beams
         const int32_t v_sp = sel_s[lane < Bnew ? lane : 0], v_bp = sel_b[lane < Bnew ? lane : 0];
         const uint32_t v_bo = sm->sel_bo[lane < Bnew ? lane : 0];
 #pragma unroll
         for (int j0 = 0; j0 < NBW; j0 += UB) {
+          if (IREC_LAST_ONE >= 2 && last && j0 > 0) break;   // (wave-uniform) only beam 0 is formed in the last step
           // ---- issue the batch's global reads (proposal rows, old beams) back to back ----
           uint2 apv[UB];
           float4 obv4[UB];
@@ -642,7 +650,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
             apv[u] = make_uint2(0u, 0u);
             obv4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             bet_old[u] = 0u;
-            if (jj < NBW && j < Bnew) { // wave-uniform
+            if (jj < NBW && j < Bupd) { // wave-uniform
               const int32_t sp_ = __builtin_amdgcn_readlane(v_sp, j);
               const int32_t bp_ = __builtin_amdgcn_readlane(v_bp, j);
               bet_old[u] = (uint32_t)__builtin_amdgcn_readlane((int)v_bo, j);
@@ -670,7 +678,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
               }
             }
             const int jj = j0 + u, j = b_lo + jj;
-            if (jj < NBW && j < Bnew) { // wave-uniform
+            if (jj < NBW && j < Bupd) { // wave-uniform
               const float obv[4] = {obv4[u].x, obv4[u].y, obv4[u].z, obv4[u].w};
               float nb[4];
 #pragma unroll

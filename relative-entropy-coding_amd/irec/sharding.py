@@ -90,8 +90,16 @@ def _encode_block_sharded_once(coder, q_loc, q_scale, p_loc, p_scale, seed, rank
     # ---- the exchange: per block row [K | idx[max_K] | the block's sample elements in shuffled order (as int32 bits)] ----
     per_rank = (lay.n_blocks + world - 1) // world
     width = 1 + max(max_K, 1) + bs
-    take = torch.as_tensor(lay.element_index(mine, bs), device=sample.device)          # [rows, bs], -1 = padding
-    vals = sample.reshape(-1)[take.clamp(min=0)].contiguous().view(torch.int32)
+    cache = lay.__dict__.setdefault("_shard_maps", {})         # index maps of this (layout, rank, world): built once
+    key = (rank, world, str(sample.device))
+    if key not in cache:
+        r = np.arange(lay.n_blocks)
+        put = torch.as_tensor(lay.element_index(r, bs), device=sample.device)
+        cache[key] = (torch.as_tensor(lay.element_index(mine, bs), device=sample.device).clamp(min=0),
+                      torch.as_tensor((r % world) * ((lay.n_blocks + world - 1) // world) + r // world, device=sample.device),
+                      put[put >= 0], put >= 0)
+    take, slot, put_at, ok = cache[key]                        # take: [rows, bs] (padding reads element 0, never used)
+    vals = sample.reshape(-1)[take].contiguous().view(torch.int32)
     packed = torch.zeros((per_rank, width), dtype=torch.int32, device=sample.device)
     packed[:len(mine), 0] = K
     packed[:len(mine), 1:1 + idx.shape[1]] = idx
@@ -104,14 +112,10 @@ def _encode_block_sharded_once(coder, q_loc, q_scale, p_loc, p_scale, seed, rank
     else:
         everyone = packed
     # ---- reassembly: rank rr's j-th row is layout row rr + j * world ----
-    r = np.arange(lay.n_blocks)
-    slot = torch.as_tensor((r % world) * per_rank + r // world, device=sample.device)
     rows_all = everyone[slot]                                                            # layout row order
     K_all = rows_all[:, 0].contiguous()
     idx_all = rows_all[:, 1:1 + max(max_K, 1)].contiguous()
-    put = torch.as_tensor(lay.element_index(np.arange(lay.n_blocks), bs), device=sample.device)
-    ok = put >= 0
     full = torch.empty(n_tensors * n, dtype=torch.float32, device=sample.device)
-    full[put[ok]] = rows_all[:, 1 + max(max_K, 1):].contiguous().view(torch.float32)[ok]
+    full[put_at] = rows_all[:, 1 + max(max_K, 1):].contiguous().view(torch.float32)[ok]
     pending = PendingCode(coder, lay, K_all, idx_all, full.reshape(src.shape), max_K)
     return pending.to_lists(), pending.sample

@@ -16,6 +16,31 @@ if os.environ.get("NO_SPLIT"): flags |= 16
 params = eng.params(omega, S, B, flags)
 q = bench.synthetic_batch(L, eng.device, 0)
 lay = eng.layout(L, bench.N_DIMS, bench.BLOCK_SIZE, bench.SEED)
+order = os.environ.get("ORDER", "")   # diagnostic: the order in which the persistent kernel meets the blocks
+if order:
+    dim = lay.block_dim.cpu().numpy()
+    nat = np.argsort(lay.order, kind="stable")                    # rows in natural (tensor, block) order
+    if order == "natural":
+        rows = nat
+    elif order == "natural_tail":                                 # natural, but the last small blocks close the launch
+        small = nat[dim[nat] < dim.max()]
+        keep_tail = set(small[-int(os.environ.get("TAIL", "1536")):].tolist())
+        rows = np.array([r for r in nat if r not in keep_tail] + [r for r in nat if r in keep_tail])
+    elif order == "spread":                                       # big blocks first-come, one small block after every 8 big
+        big, small = np.nonzero(dim == dim.max())[0], np.nonzero(dim < dim.max())[0]
+        tail = int(os.environ.get("TAIL", "1536"))
+        body_small = small[:-tail] if tail < len(small) else small[:0]
+        per = max(1, len(big) // max(1, len(body_small)))
+        rows = []
+        js = 0
+        for i, r in enumerate(big):
+            rows.append(r)
+            if (i + 1) % per == 0 and js < len(body_small):
+                rows.append(body_small[js]); js += 1
+        rows += body_small[js:].tolist() + small[len(body_small):].tolist()
+        rows = np.array(rows)
+    assert sorted(rows.tolist()) == list(range(lay.n_blocks))
+    lay = lay.subset(rows)
 out = None
 print("plan:", eng.plan(params, lay, 32)["kernel"], flush=True)
 for i in range(int(os.environ.get("REPS", "3"))):
