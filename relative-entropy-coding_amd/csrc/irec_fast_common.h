@@ -367,6 +367,107 @@ __device__ __forceinline__ int rsn_owner(int lane) {
   return cnt >= 1 ? idx : -1;
 }
 
+// ---- the scoring loop's reduce-scatter: 20 values held as 10 register pairs (r02i) ---------------------------------
+// Same lane tree as reduce_scatter_n<20> (pairs at lane distance 32, 16, 8, 4, 2, 1: every total has the bits the
+// specification gives it); what differs is the cost and, at distance 16, which value goes with which lane:
+//  * distance 32 / 16: the halves arrive by v_permlane{32,16}_swap as before, but the additions run on the register PAIRS
+//    the accumulators already live in (v_pk_add_f32: 5 + 2 + 1 instructions instead of 10 + 5).  At distance 16 pair k
+//    goes with pair k + 2 (k = 0, 1) and the two halves of pair 4 with each other, so a lane whose bit 4 is clear keeps
+//    the values 0, 1, 2, 3, 8 of its ten and its partner 4, 5, 6, 7, 9 (rs20_owner);
+//  * distance 8 / 4: ONE v_add_f32 with a DPP operand and a bank mask per kept value and lane half (the lanes whose bit is
+//    clear add their partner's copy of the value they keep, the others theirs) instead of two v_cndmask, a DPP move and
+//    an add -- 8 instructions instead of ~22.  Inline assembly: the compiler's DPP combiner only folds full-mask moves.
+//    The s_nop in front of each group covers the "VALU write -> DPP read: 2 wait states" hazard, which the hazard
+//    recogniser cannot see inside an asm statement; no instruction of a group reads a register another one of it wrote.
+#ifndef IREC_RS20
+#define IREC_RS20 7   // bit 0: pair arithmetic at distance 32 / 16; bit 1: bank-masked DPP adds at distance 8 / 4; bit 2: DPP adds
+                      // at distance 2 / 1; 0: reduce_scatter_n<20>
+#endif
+typedef float rs_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float reduce_scatter_20(rs_f2 (&a)[10], int lane) {
+  float w[6];
+  if constexpr ((IREC_RS20 & 1) != 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      float px = a[k].x, py = a[k].y, qx = a[k + 5].x, qy = a[k + 5].y;
+      swap32(px, qx); swap32(py, qy);
+      a[k] = (rs_f2){px, py} + (rs_f2){qx, qy};
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      float px = a[k].x, py = a[k].y, qx = a[k + 2].x, qy = a[k + 2].y;
+      swap16(px, qx); swap16(py, qy);
+      a[k] = (rs_f2){px, py} + (rs_f2){qx, qy};
+    }
+    float tx = a[4].x, ty = a[4].y;
+    swap16(tx, ty);
+    w[0] = a[0].x; w[1] = a[0].y; w[2] = a[1].x; w[3] = a[1].y; w[4] = tx + ty;
+  } else {
+    float v[20];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { v[2 * k] = a[k].x; v[2 * k + 1] = a[k].y; }
+    rsn_stage<32, 20>(v, lane);
+    rsn_stage<16, 10>(v, lane);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) w[k] = v[k];
+  }
+  if constexpr ((IREC_RS20 & 2) != 0) {
+    float r0, r1, r2, q0, q1;
+    // distance 8: 5 -> 3 values; pairs (w0, w3), (w1, w4), (w2, -)
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2) : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]));
+    // distance 4: 3 -> 2 values; pairs (r0, r2), (r1, -)
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %1, %3, %3 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa"
+        : "=&v"(q0), "=&v"(q1) : "v"(r0), "v"(r1), "v"(r2));
+    w[0] = q0; w[1] = q1;
+  } else {
+    rsn_stage<8, 5>(w, lane);
+    rsn_stage<4, 3>(w, lane);
+  }
+  if constexpr ((IREC_RS20 & 4) != 0) {
+    // distance 2: both candidates add their partner's copy (a quad permutation has no per-lane mask), one select picks the
+    // value the lane keeps; distance 1: the closing all-reduce
+    float s0, s1, tot;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+        : "=&v"(s0), "=&v"(s1) : "v"(w[0]), "v"(w[1]));
+    const float kept = (lane & 2) ? s1 : s0;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+        : "=&v"(tot) : "v"(kept));
+    return tot;
+  }
+  rsn_stage<2, 2>(w, lane);
+  rsn_stage<1, 1>(w, lane);
+  return w[0];
+}
+// index (0..19) of the value whose total reduce_scatter_20 leaves in this lane, or -1 (unused slot)
+__device__ __forceinline__ int rs20_owner(int lane) {
+  if constexpr ((IREC_RS20 & 1) == 0) return rsn_owner<20>(lane);
+  int o5 = 0, cnt = 5, n = 5;                      // distances 8, 4, 2, 1 over the five values a lane quarter keeps
+#pragma unroll
+  for (int dist = 8; dist >= 1; dist >>= 1) {
+    if (n >= 2) {
+      const int H = (n + 1) / 2;
+      if (lane & dist) { o5 += H; cnt -= H; } else cnt = cnt < H ? cnt : H;
+      n = H;
+    }
+  }
+  if (cnt < 1) return -1;
+  const int hi16 = (lane >> 4) & 1;
+  const int v10 = o5 < 4 ? o5 + 4 * hi16 : 8 + hi16;
+  return v10 + ((lane & 32) ? 10 : 0);
+}
+
 // The fast kernel addresses its LUT by ABSOLUTE LDS byte address (the table is the first thing in the dynamic LDS
 // region, which starts at 0 because the kernel has no static __shared__): saves one VALU add per proposal.
 typedef __attribute__((address_space(3))) const float lds_cfloat;

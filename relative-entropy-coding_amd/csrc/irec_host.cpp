@@ -838,7 +838,7 @@ irec_status irec_device_uniform_int(irec_context *ctx, int64_t seed, int64_t n, 
 }
 
 irec_status irec_test_reduce_scatter(irec_context *ctx, const float *in, float *out, int32_t width, void *hip_stream) {
-  if (!ctx || !in || !out || (width != 64 && width != 32 && width != 20 && width != 10)) return fail(IREC_E_INVALID, "irec_test_reduce_scatter: bad arguments");
+  if (!ctx || !in || !out || (width != 64 && width != 32 && width != 20 && width != 21 && width != 10)) return fail(IREC_E_INVALID, "irec_test_reduce_scatter: bad arguments");
   IREC_ON_DEVICE(ctx->device);
   HIP_TRY(irec::launch_reduce_scatter_test(in, out, width, (hipStream_t)hip_stream));
   return IREC_OK;

@@ -911,6 +911,12 @@ __global__ void reduce_scatter_test_kernel(const float *in, float *out, int widt
     for (int j = 0; j < 20; ++j) v[j] = in[lane * 20 + j];
     out[lane] = reduce_scatter_n<20>(v, lane);
     out[64 + lane] = (float)rsn_owner<20>(lane);
+  } else if (width == 21) { // the scoring loop's form of the 20-value reduce-scatter (register pairs, bank-masked DPP adds)
+    rs_f2 a[10];
+#pragma unroll
+    for (int j = 0; j < 10; ++j) a[j] = (rs_f2){in[lane * 20 + 2 * j], in[lane * 20 + 2 * j + 1]};
+    out[lane] = reduce_scatter_20(a, lane);
+    out[64 + lane] = (float)rs20_owner(lane);
   } else {
     float v[rsn_room(10)];
 #pragma unroll

@@ -31,6 +31,9 @@
 #ifndef IREC_UB3
 #define IREC_UB3 5   // beams per load batch of the update in the register-short builds
 #endif
+#ifndef IREC_ROW_EARLY
+#define IREC_ROW_EARLY 1    // 1: the scoring loop fetches the rows of the chunk after next at the chunk's start instead of its end
+#endif
 #ifndef IREC_LAST_ONE
 #define IREC_LAST_ONE 1     // last step: only beam 0 is gathered and formed (0: all B, A/B builds; 2: also leaves the batch
                             // loop early -- r02i: that form makes the allocator spill G inside the scoring loop, 48 -> 76 ms)
@@ -150,6 +153,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   float *cpart_s = &sm->cpart[0][0];
   const uint16_t *dlog_s = A.dlog4r;                                            // [10006] 4*dlog(j+1), global (L2)
   const int rs_p = rsn_owner<RW>(lane);                                         // accumulator whose total reduce_scatter_n<20> leaves here
+  const int rs_p20 = RW == 20 ? rs20_owner(lane) : -1;                          // same for the scoring loop's reduce_scatter_20
   const int rs_c = rsn_owner<NBW>(lane);                                        // same for the NBW C_b partials of the update
 
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap(); // see lds_abs_f32
@@ -414,6 +418,11 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           for (int cc = 0; cc < SPC; ++cc)
 #pragma unroll
             for (int k = 0; k < NP; ++k) acc2[cc][k] = (f2){0.f, 0.f};
+#if IREC_ROW_EARLY
+          uint2 ap_new[SPC];                                        // rows of the chunk after next: a whole chunk of lead
+#pragma unroll
+          for (int cc = 0; cc < SPC; ++cc) ap_new[cc] = row((ch + 2) * SPC + cc);
+#endif
 #pragma unroll
           for (int qh = 0; qh < NQH; ++qh) {
             constexpr int dummy_ = 0; (void)dummy_;
@@ -424,20 +433,37 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
             } else {
               // next chunk's rows
 #pragma unroll
+#if IREC_ROW_EARLY
+              for (int cc = 0; cc < SPC; ++cc) { ap_cur[cc] = ap_nxt[cc]; ap_nxt[cc] = ap_new[cc]; }
+#else
               for (int cc = 0; cc < SPC; ++cc) { ap_cur[cc] = ap_nxt[cc]; ap_nxt[cc] = row((ch + 2) * SPC + cc); }
+#endif
               IREC_ISSUE(zz[0], IREC_AL(0, 0), 0);
             }
             IREC_CONSUME(zz[qh & 1], q & 3, acc2[q >> 2], h * HP);
           }
-          float acc[ACC_ROOM];
+          float tot;
+          int own;                                                  // value of the chunk whose total this lane ends up with
+          if constexpr (RW == 20 && IREC_RS20 != 0) {               // the accumulator pairs go in as they are
+            rs_f2 a20[10];
 #pragma unroll
-          for (int cc = 0; cc < SPC; ++cc)
+            for (int cc = 0; cc < SPC; ++cc)
 #pragma unroll
-            for (int k = 0; k < NP; ++k) { acc[cc * NBW + 2 * k] = acc2[cc][k].x; acc[cc * NBW + 2 * k + 1] = acc2[cc][k].y; }
-          const float tot = reduce_scatter_n<RW>(acc, lane);
-          const int cc = rs_p / NBW, b = rs_p - cc * NBW;          // rs_p < 0: unused slot
+              for (int k = 0; k < NP; ++k) a20[cc * NP + k] = acc2[cc][k];
+            tot = reduce_scatter_20(a20, lane);
+            own = rs_p20;
+          } else {
+            float acc[ACC_ROOM];
+#pragma unroll
+            for (int cc = 0; cc < SPC; ++cc)
+#pragma unroll
+              for (int k = 0; k < NP; ++k) { acc[cc * NBW + 2 * k] = acc2[cc][k].x; acc[cc * NBW + 2 * k + 1] = acc2[cc][k].y; }
+            tot = reduce_scatter_n<RW>(acc, lane);
+            own = rs_p;
+          }
+          const int cc = own / NBW, b = own - cc * NBW;            // own < 0: unused slot
           const int m = ch * SPC + cc;                              // my m-th sample
-          if (rs_p >= 0 && (lane & 1) == 0 && m < n_mine) part_s[((size_t)g * SP + m * NSW + sw) * NB + b_lo + b] = tot;
+          if (own >= 0 && (lane & 1) == 0 && m < n_mine) part_s[((size_t)g * SP + m * NSW + sw) * NB + b_lo + b] = tot;
         }
 #pragma unroll
         for (int k = 0; k < HP; ++k) asm volatile("" : "+v"(zz[0][k])); // drain the look-ups issued past the last sample

@@ -247,8 +247,8 @@ class Engine:
                                              _ptr(sel), self._stream()), "irec_test_select")
         return sel
 
-    def test_reduce_scatter(self, x):
-        width = x.shape[1]
+    def test_reduce_scatter(self, x, scoring_form=False):
+        width = x.shape[1] + (1 if scoring_form else 0)    # 21 = the scoring loop's form of the 20-value reduce-scatter
         out = torch.zeros(128, dtype=torch.float32, device=self.device)
         _lib.check(self.lib.irec_test_reduce_scatter(self.ctx, _ptr(x), _ptr(out), int(width), self._stream()),
                    "irec_test_reduce_scatter")

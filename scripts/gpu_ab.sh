@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of the product library against one diagnostic build on the same box in one session (alternating runs).
-# usage: VARIANT=step0narrow [LATENTS=8192] scripts/gpu_ab.sh
+# usage: VARIANT="name [name ...]" [LATENTS=8192] scripts/gpu_ab.sh
 set -u
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -9,6 +9,6 @@ V=${VARIANT:?name of csrc/variants/<name>.so}
 {
 for rep in 1 2; do
   echo "== product"; LATENTS=${LATENTS:-8192} REPS=4 timeout 300 python scripts/run_variant.py 2>&1 | tail -2
-  echo "== $V"; IREC_LIB_PATH=$C/variants/$V.so LATENTS=${LATENTS:-8192} REPS=4 timeout 300 python scripts/run_variant.py 2>&1 | tail -2
+  for v in $V; do echo "== $v"; IREC_LIB_PATH=$C/variants/$v.so LATENTS=${LATENTS:-8192} REPS=4 timeout 300 python scripts/run_variant.py 2>&1 | tail -2; done
 done
-} | tee gpurun_out/ab_$V.log
+} | tee gpurun_out/ab_$(echo $V | tr ' ' '_').log

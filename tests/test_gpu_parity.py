@@ -55,13 +55,15 @@ def test_reduce_scatter_is_the_canonical_tree(engine, width):
         assert got[lane] == part[0], (lane, got[lane], part[0])
 
 
-@pytest.mark.parametrize("width", [20, 10])
+@pytest.mark.parametrize("width", [20, 10, 21])
 def test_arbitrary_width_reduce_scatter_is_the_canonical_tree(engine, width):
     """The team encoder's 20-/10-value reduce-scatter: every column's total comes out of the same tree (lanes paired at
     distance 32, 16, 8, 4, 2, 1); the trailing all-reduce stages leave each column's total in 2 (4) neighbouring lanes."""
+    scoring_form = width == 21      # reduce_scatter_20: register pairs + bank-masked DPP adds, other value-to-lane map
+    width = 20 if scoring_form else width
     rng = np.random.default_rng(100 + width)
     x = (rng.standard_normal((64, width)) * np.exp(rng.uniform(-3, 3, (64, width)))).astype(np.float32)
-    out = engine.test_reduce_scatter(torch.from_numpy(x).cuda()).cpu().numpy()
+    out = engine.test_reduce_scatter(torch.from_numpy(x).cuda(), scoring_form=scoring_form).cpu().numpy()
     tot, owner = out[:64], out[64:].astype(np.int64)
     for col in range(width):
         part = x[:, col].copy()
