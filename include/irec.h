@@ -70,6 +70,8 @@ typedef struct {
 #define IREC_FLAG_NO_SPLIT 16     /* never the split encoder (several workgroups per block for calls of few blocks)   */
 #define IREC_FLAG_TEST_SPLIT_ORPHAN 32 /* test hook: the partner workgroups of the split encoder leave at once, so workgroup 0  */
                                   /* of every block must take the 2-second give-up exit (out_K = -2) instead of hanging   */
+#define IREC_FLAG_SPLIT_SAMPLES 128 /* split encoder: share a block's samples among its workgroups (the r02b form: every workgroup */
+                                  /* repeats the whole beam update) instead of its beams (default where <= 2 beams per workgroup)  */
 #define IREC_FLAG_REUSE_TABLES 64 /* the caller vouches for the workspace: its first 512 bytes were zero when it was allocated  */
                                   /* and nothing but irec_beam_encode has written to it since.  Every call stamps the key of  */
                                   /* each proposal table it builds (seed, S, D, table window, table kind, offset) into the    */
@@ -105,6 +107,8 @@ typedef struct {
   int32_t split;           /* workgroups that share one block (split encoder of small calls), 0 = one block per workgroup */
   int32_t n_cu;            /* compute units of the context's device                                             */
   int32_t clock_mhz;       /* its maximum engine clock                                                          */
+  int32_t split_beams;     /* split encoder: 1 = the workgroups of a block share its beams (each owns <= 2 beam slots,  */
+                           /* scores every sample for them, forms only its own new beams), 0 = they share its samples  */
   int64_t table_bytes;     /* proposal tables inside the workspace                                              */
   int64_t workspace_bytes; /* = irec_encode_workspace_bytes()                                                   */
 } irec_plan_info;

@@ -568,6 +568,19 @@ int split_width(const irec_context *ctx, const Plan &pl, const irec_params *p, i
   W = std::min<int64_t>(W, want >= 2 ? want : 12);                         // exchange + merge grow with W; scoring is ~S/W
   return W >= 2 ? (int)W : 0;
 }
+// Beam mode of the split encoder (irec_kernels.hip): the W workgroups of a block own its beam slots w, w + W instead of
+// sample stripes -- possible when two slots per workgroup cover the B beams.  Returns the width to launch with (the
+// fewest workgroups that still own at most as many slots each: 10, not 12, for B = 20), 0 = stay with sample stripes.
+int split_beam_width(const irec_params *p, int W) {
+  if (W < 2 || (p->flags & IREC_FLAG_SPLIT_SAMPLES)) return 0;
+  const int B = p->n_beams;
+  if (W > B) W = B;
+  if (W < 2) return 0;
+  const int per = (B + W - 1) / W;                                         // slots per workgroup
+  if (per > 2) return 0;
+  while (W > 2 && (B + (W - 1) - 1) / (W - 1) == per) --W;
+  return W;
+}
 
 // small calls (a single image's res-block: 9 blocks) are latency-bound: the one-table encoder's set-up (a 6 us proposal
 // table, 40 KB of LDS to fill) beats the team encoder's (38 us per table for the bank assignment, 120 KB); the scratch
@@ -624,6 +637,7 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
     if (pl.table) std::snprintf(out->table_kernel, sizeof out->table_kernel, "alpha_table_kernel");
     out->grid = (int32_t)std::min<int64_t>(n_blocks, pl.one_grid_cap);
     out->split = split_width(ctx, pl, p, n_blocks);
+    if (const int wb = split_beam_width(p, out->split)) { out->split = wb; out->split_beams = 1; }
     if (out->split >= 2) out->grid = (int32_t)(n_blocks * out->split);
     out->waves_per_wg = irec::fast_waves_for(B, S, pl.table);
     out->teams_per_wg = 1;
@@ -768,7 +782,8 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
         return IREC_OK;
       }
     } else {
-      const int W = split_width(ctx, pl, p, n_blocks);
+      int W = split_width(ctx, pl, p, n_blocks);
+      if (const int wb = split_beam_width(p, W)) { W = wb; A.coop_beams = 1; }
       if (W >= 2) {
         A.coop_W = W;
         A.coop_test_orphan = (p->flags & IREC_FLAG_TEST_SPLIT_ORPHAN) ? 1 : 0;

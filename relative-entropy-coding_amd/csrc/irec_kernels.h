@@ -40,6 +40,7 @@ struct EncArgs {
   // the step's keys back and run the same selection.  *coop_err != 0: a workgroup gave up waiting (partners not resident):
   // block not coded.
   int32_t coop_W; unsigned int *coop_arrive; uint32_t *coop_xch; unsigned int *coop_err;
+  int32_t coop_beams;         // 1: the workgroups of a block share its beams (slots w, w + coop_W) instead of its samples
   int32_t coop_test_orphan;   // IREC_FLAG_TEST_SPLIT_ORPHAN: partners leave at once (exercises the give-up exit)
   // diagnostics (IREC_STAMPS=1): per-workgroup cycle sums [grid][8]; nullptr in normal runs
   unsigned long long *dbg;

@@ -350,6 +350,18 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
   const int coop_W = TABLE && NW == 4 ? A.coop_W : 1;
   const int coop_w = coop_W > 1 ? (int)(blockIdx.x % (unsigned)coop_W) : 0;
   bool coop_done = false;
+  // Beam mode of the split encoder (r02i): the workgroups of a block share its BEAMS instead of its samples -- workgroup w
+  // owns the beam slots w, w + W (at most NOWN = 2), scores every sample for the beams it owns, and after the common
+  // selection gathers / forms only the NEW beams that land in its slots.  The update -- the longest piece of a split
+  // step, and until now repeated in full by every workgroup -- shrinks to two beams; the beams themselves live in ONE
+  // slab per block (that of the block's workgroup 0), stored and loaded `sc1` like the exchanged keys and ordered by the
+  // same per-step arrival counter (a workgroup reads step t - 1's beams behind step t's counter wait, and nobody can be
+  // more than one step ahead, so the double buffer suffices).
+  constexpr int NOWN = 2;
+  const bool beam_mode = coop_W > 1 && A.coop_beams != 0;
+  // the block's beams: the slab of its first workgroup (beam mode), or my own
+  float *beams_blk = reinterpret_cast<float *>(A.ws + (size_t)(blockIdx.x - (unsigned)(beam_mode ? coop_w : 0)) * A.ws_per_wg +
+                                               A.ws_per_wg - (size_t)2 * NB * FAST_MAX_DIM * 4);
   if (coop_W > 1 && A.coop_test_orphan && coop_w != 0) return;   // test hook: workgroup 0 of each block is left waiting
   for (;;) {
     __syncthreads();
@@ -502,6 +514,78 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
       const int s_lo = coop_W > 1 ? (coop_w * S_w < S ? coop_w * S_w : S) : 0;
       const int s_hi = coop_W > 1 ? (s_lo + S_w < S ? s_lo + S_w : S) : S;
       const int N = (s_hi - s_lo) * Bcur;                       // candidates scored HERE (all of the step's unless split)
+      // beam mode: the slots I own and which of them hold a beam in this step
+      int own_b[NOWN];
+      uint32_t own_bet[NOWN];
+#pragma unroll
+      for (int o = 0; o < NOWN; ++o) {
+        own_b[o] = coop_w + o * coop_W;
+        own_bet[o] = __builtin_amdgcn_readfirstlane(beta4[cur * 64 + (own_b[o] < Bcur ? own_b[o] : 0)]);
+      }
+      if (beam_mode) {
+        // ---------------- scoring: every sample x the beams I own (beam_search_coder.py:80-84) ----------------
+        constexpr int SPB = RW / NOWN;                            // samples per reduce-scatter: accumulator sl * NOWN + o
+        constexpr int HB = SPB < 8 ? SPB : 8;                     // rows fetched together
+        if (active && own_b[0] < Bcur) {
+          const int n_mine = S > sw ? (S - sw + NSW - 1) / NSW : 0;   // my samples: sw, sw + NSW, ...
+          for (int m0 = 0; m0 < n_mine; m0 += SPB) {
+            float acc[RW];
+#pragma unroll
+            for (int p = 0; p < RW; ++p) acc[p] = 0.f;
+#pragma unroll
+            for (int h = 0; h < SPB; h += HB) {
+              uint2 ap[HB];
+#pragma unroll
+              for (int k = 0; k < HB; ++k) {
+                const int m = m0 + h + k;                          // past my last sample: entry 0, the total is dropped
+                ap[k] = make_uint2(0u, 0u);
+                if (m < n_mine) ap[k] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)(m * NSW + sw) * Dp);
+              }
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                float z[HB][NOWN];
+#pragma unroll
+                for (int k = 0; k < HB; ++k) {
+                  const uint32_t w = (i & 2) ? ap[k].y : ap[k].x;
+                  const uint32_t al = (i & 1) ? (w >> 16) : (w & 0xFFFFu);
+#pragma unroll
+                  for (int o = 0; o < NOWN; ++o) {
+                    uint32_t ad = al + own_bet[o];
+                    const uint32_t ad2 = ad - IREC_LUT2_BYTES;
+                    ad = ad2 < ad ? ad2 : ad;
+                    z[k][o] = lds_abs_f32(ad);
+                  }
+                }
+#pragma unroll
+                for (int k = 0; k < HB; ++k)
+#pragma unroll
+                  for (int o = 0; o < NOWN; ++o)
+                    acc[(h + k) * NOWN + o] = proposal_term(acc[(h + k) * NOWN + o], z[k][o], cH[i], G[o][i]);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+            const float tot = reduce_scatter<RW>(acc, lane);
+            const int p = RW == 64 ? lane : (lane >> 1);
+            const int sl = p / NOWN, o = p - sl * NOWN;
+            const int m = m0 + sl, b = coop_w + o * coop_W;
+            if (m < n_mine && b < Bcur && (RW == 64 || (lane & 1) == 0)) part_s[((size_t)g * SP + (m * NSW + sw)) * NB + b] = tot;
+          }
+        }
+        __syncthreads();
+        IREC_STAMP(1);
+        // ---------------- my candidates' keys go straight into the exchange (flat f = s * Bcur + b) ----------------
+        {
+          uint32_t *xk = A.coop_xch + ((size_t)(t & 1) * COOP_MAX_BLOCKS + (size_t)blk) * COOP_KEYS;
+          for (int idx = tid; idx < S * NOWN; idx += NT) {
+            const int s_ = idx / NOWN, o = idx - s_ * NOWN, b = coop_w + o * coop_W;
+            if (b < Bcur) {
+              float sc = part_s[((size_t)0 * SP + s_) * NB + b];
+              for (int gg = 1; gg < NG; ++gg) sc = sc + part_s[((size_t)gg * SP + s_) * NB + b];
+              __hip_atomic_store(&xk[s_ * Bcur + b], score_key(sc + Cb_s[b]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        }
+      } else
       for (int s_base = s_lo; s_base < s_hi || s_base == s_lo; s_base += SP) {
       const int s_end = s_base + SP < s_hi ? s_base + SP : s_hi;
       // ---------------- scoring: samples [s_base, s_end) x Bcur candidates (beam_search_coder.py:80-84) ----------------
@@ -637,8 +721,9 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
         auto sub_stamp = [&](int slot) {
           if (A.dbg && tid == 0) { const unsigned long long now_ = stamp_now(); A.dbg[(size_t)blockIdx.x * 16 + slot] += now_ - sub_prev; sub_prev = now_; }
         };
-        __syncthreads();   // (aliased keys: all of them written)
-        for (int f = tid; f < N; f += NT) __hip_atomic_store(&xk[s_lo * Bcur + f], key_s[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();   // (aliased keys: all of them written; beam mode: every partial read before key_s is refilled)
+        if (!beam_mode)
+          for (int f = tid; f < N; f += NT) __hip_atomic_store(&xk[s_lo * Bcur + f], key_s[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
@@ -647,13 +732,15 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
           const uint32_t want = (uint32_t)coop_W * (uint32_t)(t + 1);
           const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
           int32_t bad = 0;
-          while (__hip_atomic_load(&A.coop_arrive[blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+          // (the counter load's own round trip paces the loop; the error flag -- a second far load -- and the clock are
+          //  looked at every 32nd turn only: r02i, the wait is the longest piece of a split step)
+          for (uint32_t turn = 1; __hip_atomic_load(&A.coop_arrive[blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want; ++turn) {
+            if ((turn & 31u) != 0u) continue;
             if (__hip_atomic_load(A.coop_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bad = 1; break; }
             if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { // 2 s: the partners are not resident -- give up, loudly
               __hip_atomic_store(A.coop_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               bad = 1; break;
             }
-            __builtin_amdgcn_s_sleep(2);
           }
           misc[6] = bad;
           sub_stamp(13);
@@ -663,7 +750,20 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
           if (tid == 0 && coop_w == 0) A.out_K[blk] = -2;
           break;
         }
-        for (int f = tid; f < Ng; f += NT) key_s[f] = __hip_atomic_load(&xk[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        {   // all of a thread's loads in flight before the first is stored (Ng <= 1024 in split mode)
+          constexpr int MKX = (1024 + NT - 1) / NT;
+          uint32_t kk[MKX];
+#pragma unroll
+          for (int q = 0; q < MKX; ++q) {
+            const int f = q * NT + tid;
+            kk[q] = f < Ng ? __hip_atomic_load(&xk[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+          }
+#pragma unroll
+          for (int q = 0; q < MKX; ++q) {
+            const int f = q * NT + tid;
+            if (f < Ng) key_s[f] = kk[q];
+          }
+        }
         sub_stamp(14);
       }
       select_topB<NT>(key_s, Ng, Bnew, Bcur, sm, A.dbg ? A.dbg + (size_t)blockIdx.x * 16 : nullptr); // first barrier inside orders key_s writes
@@ -679,7 +779,76 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
       // ---------------- gather the surviving beams (beam_search_coder.py:92-93), prepare the next step ----------------
       const bool last = (t == K - 1);
       __builtin_amdgcn_s_setprio(2); // serial phase: ahead of the co-resident workgroup's scoring waves
-      if (active) {
+      if (active && beam_mode) {
+        // beam mode: only the new beams that land in my slots; parents come from (and new beams go to) the block's shared slab
+        const float sa_t[4] = {sa[0], sa[1], sa[2], sa[3]};
+        const float *bold = beams_blk + ((size_t)cur * NB) * FAST_MAX_DIM + d0;
+        float *bnew = beams_blk + ((size_t)(cur ^ 1) * NB) * FAST_MAX_DIM + d0;
+        uint2 apv[NOWN];
+        float obv[NOWN][4];
+        uint32_t bet_old[NOWN];
+#pragma unroll
+        for (int o = 0; o < NOWN; ++o) {
+          const int j = coop_w + o * coop_W;
+          apv[o] = make_uint2(0u, 0u); bet_old[o] = 0u;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) obv[o][i] = 0.f;
+          if (j < Bnew) { // wave-uniform
+            const int32_t sp_ = __builtin_amdgcn_readfirstlane(sel_s[j]);
+            const int32_t bp_ = __builtin_amdgcn_readfirstlane(sel_b[j]);
+            bet_old[o] = __builtin_amdgcn_readfirstlane(beta4[cur * 64 + bp_]);
+            apv[o] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sp_ * Dp);
+            if (t) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                obv[o][i] = __hip_atomic_load(bold + (size_t)bp_ * FAST_MAX_DIM + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        }
+        float m[4] = {0.f, 0.f, 0.f, 0.f}, cA[4] = {0.f, 0.f, 0.f, 0.f}, cBv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!last) step_consts(t + 1, m, cA, cBv); // next step's constants, under the loads' latency
+#pragma unroll
+        for (int o = 0; o < NOWN; ++o) {
+          const int j = coop_w + o * coop_W;
+          float cacc = 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) G[o][i] = 0.f;
+          if (j < Bnew) { // wave-uniform
+            const uint32_t al[4] = {apv[o].x & 0xFFFFu, apv[o].x >> 16, apv[o].y & 0xFFFFu, apv[o].y >> 16};
+            float nb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              uint32_t ad = al[i] + bet_old[o];
+              const uint32_t ad2 = ad - IREC_LUT2_BYTES;
+              ad = ad2 < ad ? ad2 : ad;
+              const float y = sa_t[i] * lds_abs_f32(ad); // dist.quantile(.), :48-49
+              nb[i] = obv[o][i] + y;                       // combined_samples[best_ind_aux, best_ind_beam], :81,92-93
+            }
+            if (last) {
+              if (j == 0 && sw == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                  if (valid[i]) A.out_sample[ix[i]] = nb[i] + A.p_loc[ix[i]]; // beams[0] + coding_dist.loc, :122
+              }
+            } else {
+              if (sw == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                  __hip_atomic_store(bnew + (size_t)j * FAST_MAX_DIM + i, nb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                G[o][i] = beam_G(nb[i], m[i], cA[i], cBv[i], sa[i]);
+                cacc = beam_C_term(cacc, nb[i], m[i], cA[i], cBv[i]);
+              }
+            }
+          }
+          if (!last) {   // (every wave of the group computes the same bits; one writes)
+            const float ctot = wave_tree_sum(cacc);
+            if (sw == 0 && lane == 0 && j < Bnew) cpart_s[g * 32 + j] = ctot;
+          }
+        }
+      } else if (active) {
         const float sa_t[4] = {sa[0], sa[1], sa[2], sa[3]};   // this step's sample scale
         const float *bold = beams_g + ((size_t)cur * NB) * FAST_MAX_DIM + d0;
         float *bnew = beams_g + ((size_t)(cur ^ 1) * NB) * FAST_MAX_DIM + d0;

@@ -18,6 +18,7 @@ IREC_FLAG_FUSED_PHILOX = 2
 IREC_FLAG_ONE_TABLE = 4
 IREC_FLAG_TEAM = 8
 IREC_FLAG_NO_SPLIT = 16
+IREC_FLAG_SPLIT_SAMPLES = 128      # split encoder: share samples (r02b form) instead of beams
 IREC_FLAG_REUSE_TABLES = 64        # keep a proposal table whose stamp in the workspace head matches the call's key
 IREC_FLAG_SHAPE_SHIFT = 8          # diagnostic workgroup shapes of the team encoder (include/irec.h)
 IREC_FLAG_SHAPE = {"default": 0, "1": 1 << 8, "2": 2 << 8, "3": 3 << 8, "2x2": 4 << 8, "1x2": 5 << 8}
@@ -38,7 +39,7 @@ class IrecPlanInfo(ctypes.Structure):
     _fields_ = [("kernel", ctypes.c_char * 64), ("table_kernel", ctypes.c_char * 32), ("grid", ctypes.c_int32),
                 ("waves_per_wg", ctypes.c_int32), ("teams_per_wg", ctypes.c_int32), ("lds_bytes", ctypes.c_int32),
                 ("table_steps", ctypes.c_int32), ("n_tables", ctypes.c_int32), ("split", ctypes.c_int32), ("n_cu", ctypes.c_int32),
-                ("clock_mhz", ctypes.c_int32), ("table_bytes", ctypes.c_int64), ("workspace_bytes", ctypes.c_int64)]
+                ("clock_mhz", ctypes.c_int32), ("split_beams", ctypes.c_int32), ("table_bytes", ctypes.c_int64), ("workspace_bytes", ctypes.c_int64)]
 
     def as_dict(self):
         return {name: (getattr(self, name).decode() if isinstance(getattr(self, name), bytes) else int(getattr(self, name)))

@@ -108,6 +108,7 @@ class BeamSearchCoder(GaussianCoder):
         self.one_table = False       # debugging / testing knob: IREC_FLAG_ONE_TABLE
         self.team = False            # debugging / testing knob: IREC_FLAG_TEAM (the team encoder also for small calls)
         self.no_split = False        # debugging / testing knob: IREC_FLAG_NO_SPLIT (one workgroup per block also for small calls)
+        self.split_samples = False   # IREC_FLAG_SPLIT_SAMPLES: the split encoder shares a block's samples (r02b form), not its beams
         self.team_shape = "default"  # diagnostics: IREC_FLAG_SHAPE_* workgroup shape of the team encoder
         self.reuse_tables = True     # IREC_FLAG_REUSE_TABLES: a call whose proposal tables are already in the stream's scratch
                                      # (same seed, S, dims and window: the 24 residual blocks of an image) does not rebuild them
@@ -149,7 +150,8 @@ class BeamSearchCoder(GaussianCoder):
                 (_lib.IREC_FLAG_FUSED_PHILOX if self.fused_philox else 0) | \
                 (_lib.IREC_FLAG_ONE_TABLE if self.one_table else 0) | \
                 (_lib.IREC_FLAG_TEAM if self.team else 0) | (_lib.IREC_FLAG_NO_SPLIT if self.no_split else 0) | \
-                (_lib.IREC_FLAG_REUSE_TABLES if self.reuse_tables else 0) | _lib.IREC_FLAG_SHAPE[self.team_shape]
+                (_lib.IREC_FLAG_REUSE_TABLES if self.reuse_tables else 0) | \
+                (_lib.IREC_FLAG_SPLIT_SAMPLES if self.split_samples else 0) | _lib.IREC_FLAG_SHAPE[self.team_shape]
         steps = int(table_steps) if table_steps else self.table_window()
         return get_engine().params(self.kl_per_partition, self.n_samples, self.n_beams, flags, table_steps=steps)
 

@@ -613,18 +613,23 @@ def test_library_errors_are_coding_errors(engine):
 @pytest.mark.parametrize("n_tensors,n,bs,omega,eps1,B", [(1, 8192, 1000, 3.0, 1.2, 20), (1, 1000, None, 3.0, 1.2, 20),
                                                          (3, 2048, 1000, 3.0, 1.0, 10), (1, 777, None, 2.0, 1.0, 7),
                                                          (2, 4096, 1000, 3.0, 1.2, 11), (1, 64, None, 1.5, 1.0, 20)])
-def test_split_encoder_small_calls(engine, oracle, n_tensors, n, bs, omega, eps1, B):
-    """Calls of few blocks run W workgroups per block (plan['split']), each scoring a stripe of the samples and exchanging
-    its local top-B every step: the merged selection, and therefore every output, is the one-workgroup encoder's and the
-    oracle's, bit for bit -- also with K of several hundred steps' worth of cross-workgroup hand-offs."""
+@pytest.mark.parametrize("mode", ["beams", "samples"])
+def test_split_encoder_small_calls(engine, oracle, n_tensors, n, bs, omega, eps1, B, mode):
+    """Calls of few blocks run W workgroups per block (plan['split']) that share the block's beams (each owns at most two
+    beam slots: scores every sample for them, forms only its own new beams; plan['split_beams']) or, in the r02b form, its
+    samples, and exchange their sort keys every step: the common selection, and therefore every output, is the
+    one-workgroup encoder's and the oracle's, bit for bit -- also with K of several hundred steps' worth of cross-workgroup
+    hand-offs (in beam mode: of beams read from another workgroup's stores)."""
     S = oracle.n_samples(omega, eps1)
     q = [np.stack([oracle.synthetic_latent(300 + i, n)[j] for i in range(n_tensors)]) for j in range(4)]
     if n == 777:
         q[1] = (q[1] * 0.3).astype(np.float32)            # sharper posterior: K in the hundreds
     c = _coder(omega, B, eps1, block_size=bs, variant="one_table")
+    c.split_samples = mode == "samples"
     lay = engine.layout(n_tensors, n, bs, 42)
     plan = engine.plan(c._params(), lay, 32)
     assert plan["split"] >= 2 and plan["grid"] == lay.n_blocks * plan["split"], plan
+    assert plan["split_beams"] == (1 if mode == "beams" and -(-B // plan["split"]) <= 2 else 0), plan
     idx, sample = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)
     c2 = _coder(omega, B, eps1, block_size=bs, variant="one_table_nosplit")
     assert engine.plan(c2._params(), lay, 32)["split"] == 0
