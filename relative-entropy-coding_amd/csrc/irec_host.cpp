@@ -743,6 +743,8 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
     for (int q = 0; q < pl.n_tab; ++q) {
       uint16_t *tab = (uint16_t *)((char *)workspace + irec::WS_HEAD_BYTES + pl.tab_off[q]);
       const uint32_t *keep = (const uint32_t *)workspace + irec::WS_KEEP_WORD + q;
+      A.tab[q] = tab; A.tab_dim[q] = pl.tab_dim[q];
+      if (p->flags & IREC_FLAG_TABLES_PRESENT) continue;   // the caller's previous call on this workspace built exactly these
       if (pl.team) HIP_TRY(irec::launch_alpha_choice(seed, p->n_samples, pl.tab_dim[q], pl.K_tab, ctx->d_dlog4r, tab, keep, st));
       else HIP_TRY(irec::launch_alpha_table(seed, p->n_samples, pl.tab_dim[q], pl.K_tab, ctx->d_dlog4r, tab, keep, st));
       A.tab[q] = tab; A.tab_dim[q] = pl.tab_dim[q];

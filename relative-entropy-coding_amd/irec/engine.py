@@ -120,6 +120,7 @@ class Engine:
         self.ctx = ctx
         self._layouts = {}
         self._ws = {}      # one scratch buffer per HIP stream: calls on different streams never share counters / slabs
+        self._session = None   # table_session(): key of the previous call of a back-to-back run of twin calls
 
     def __del__(self):
         try:
@@ -158,6 +159,23 @@ class Engine:
             ws[:512].zero_()
             self._ws[key] = ws
         return ws, need
+
+    def table_session(self):
+        """Context manager around a run of encode calls issued back to back on ONE stream by ONE thread (the residual blocks
+        of a model pass): a call whose parameters, seed, layout sizes and max_K equal the previous call's finds that call's
+        proposal tables still in place, so the table kernels are not even launched (IREC_FLAG_TABLES_PRESENT).  Safe
+        inside a HIP-graph capture as well: the first call of the captured run keeps its (device-checked) table kernels."""
+        eng = self
+
+        class _Session:
+            def __enter__(self_):
+                eng._session = {"key": None}
+                return self_
+
+            def __exit__(self_, *exc):
+                eng._session = None
+                return False
+        return _Session()
 
     def plan(self, params, lay, max_K):
         """What irec_beam_encode launches for this call (kernel names, grid, LDS, table window): irec_encode_plan."""
@@ -207,6 +225,13 @@ class Engine:
         else:
             out_K, out_idx, sample = out
         ws, need = self.workspace(params, lay.max_dim, max_K)
+        if self._session is not None and (params.flags & _lib.IREC_FLAG_REUSE_TABLES):
+            key = (ws.data_ptr(), int(torch.cuda.current_stream(self.device).cuda_stream), int(seed), int(max_K), lay.n_blocks,
+                   lay.max_dim, bytes(params))
+            if self._session["key"] == key:
+                params = self.params(params.kl_per_partition, params.n_samples, params.n_beams,
+                                     params.flags | _lib.IREC_FLAG_TABLES_PRESENT, list(params.table_dims), params.table_steps)
+            self._session["key"] = key
         _lib.check(self.lib.irec_beam_encode(self.ctx, ctypes.byref(params), lay.n_blocks, _ptr(lay.block_base),
                                              _ptr(lay.block_pos), _ptr(lay.block_dim), lay.max_dim, _ptr(lay.perm),
                                              _ptr(q_loc), _ptr(q_scale), _ptr(p_loc), _ptr(p_scale), int(seed),

@@ -235,11 +235,13 @@ class BidirectionalResNetVAE(nn.Module):
             #  once per image, a long window costs next to nothing)
             max_K = max(blk.coder._max_K_hint for blk in self.residual_blocks)
             window = max(max(blk.coder.table_window() for blk in self.residual_blocks), min(max_K, 64))
-            for resnet_block in self.residual_blocks:                     # strictly sequential (:821-826)
-                pending, tensor = resnet_block(tensor, inference_pass=False,
-                                               encoder_args={"seed": seed, "update_sampler": update_sampler, "batched": True,
-                                                             "defer": True, "table_steps": window, "max_K": max_K})
-                pendings.append(pending)
+            from ..engine import get_engine
+            with get_engine(tensor.device).table_session():              # twin calls back to back: no table launches after the first
+                for resnet_block in self.residual_blocks:                 # strictly sequential (:821-826)
+                    pending, tensor = resnet_block(tensor, inference_pass=False,
+                                                   encoder_args={"seed": seed, "update_sampler": update_sampler, "batched": True,
+                                                                 "defer": True, "table_steps": window, "max_K": max_K})
+                    pendings.append(pending)
             return pendings, self._finish(tensor)
 
     def _indices_structure(self, per_block, batch_size):

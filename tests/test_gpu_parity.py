@@ -774,3 +774,21 @@ def test_table_reuse_inside_a_replayed_graph(engine, oracle):
         with torch.cuda.stream(ext):
             c.encode_tensors_device(*t, 7 + rep, 1000)
         torch.cuda.synchronize()
+
+
+def test_table_session_skips_only_twin_calls(engine, oracle):
+    """Engine.table_session(): inside a run of back-to-back calls a twin of the previous call launches no table kernels
+    (IREC_FLAG_TABLES_PRESENT); any difference -- seed, window, number of tensors -- makes the call build or check its tables
+    as usual.  Every result is the oracle's."""
+    q = [np.stack([oracle.synthetic_latent(350 + i, 8192)[j] for i in range(2)]) for j in range(4)]
+    t = [torch.as_tensor(a, device="cuda") for a in q]
+    refs = {seed: [oracle.encode_tensor(q[0][i], q[1][i], q[2][i], q[3][i], seed, 3.0, 36, 20, block_size=1000) for i in range(2)]
+            for seed in (42, 43)}
+    c = _coder(3.0, 20, 1.2, block_size=1000, variant="auto")
+    c.table_steps = 12
+    with engine.table_session():
+        for seed, n_t in ((42, 2), (42, 2), (42, 2), (43, 2), (42, 2), (42, 1), (42, 1), (42, 2)):
+            idx, sample = c.encode(_normal(t[0][:n_t], t[1][:n_t]), _normal(t[2][:n_t], t[3][:n_t]), seed=seed, batched=True)
+            for i in range(n_t):
+                assert idx[i] == refs[seed][i][0] and np.array_equal(sample[i].cpu().numpy(), refs[seed][i][1]), (seed, n_t, i)
+    assert engine._session is None
