@@ -149,3 +149,21 @@ def test_block_layout_descriptors(oracle):
     assert np.array_equal(lay.perm_host, oracle.tf_shuffle_perm(42, 8192))
     lay1 = BlockLayout(torch.device("cpu"), 2, 50, None, 42)
     assert lay1.perm is None and lay1.n_blocks == 2 and lay1.block_dim.tolist() == [50, 50]
+
+
+def test_flag_bits_do_not_collide():
+    """irec_params.flags packs single-bit switches next to two 4-bit fields (bits 8-11: team shape, 12-15: split width).
+    r02i had IREC_FLAG_TABLES_PRESENT on bit 8 = IREC_FLAG_SHAPE_1 for half an hour: shape "1" silently skipped its tables."""
+    import re
+    text = open(os.path.join(ROOT, "include", "irec.h")).read()
+    vals = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define (IREC_FLAG_[A-Z_0-9]+) (\d+)\b", text)}
+    fields = 0xF << vals.pop("IREC_FLAG_SHAPE_SHIFT") | 0xF << vals.pop("IREC_FLAG_SPLIT_SHIFT")
+    seen = 0
+    for name, v in vals.items():
+        assert v and v & (v - 1) == 0, (name, v)              # a single bit
+        assert not v & fields and not v & seen, (name, v)     # outside the fields, not taken
+        seen |= v
+    import irec
+    for name, v in vals.items():                              # the Python mirror agrees where it mirrors
+        if hasattr(irec._lib, name):
+            assert getattr(irec._lib, name) == v, name
