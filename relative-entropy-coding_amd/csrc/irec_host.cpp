@@ -595,14 +595,16 @@ bool team_for_call(const Plan &pl, const irec_params *p, int64_t n_blocks) {
 int shape_for_call(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks) {
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
   const int B = p->n_beams, S = p->n_samples;
-  if (pl.shape != 0 || !pl.team || n_blocks < 64 || n_blocks > 2 * (int64_t)n_cu || B <= 10 || B > 20) return pl.shape;   // (< 64 blocks: only calls
+  if (pl.shape != 0 || !pl.team || n_blocks < 64 || n_blocks > 2 * (int64_t)n_cu || B > 20) return pl.shape;   // (< 64 blocks: only calls
                                                                          // that pin IREC_FLAG_TEAM get here, tests of the default shape among them)
   if (irec::team_count_for(B, S, 0) < 2) return pl.shape;                       // already one striped team
+  if (n_blocks <= n_cu && B <= 10) return pl.shape;                             // (no 8-wave build for 10 beams)
   if (n_blocks > n_cu) {
     // One to two blocks per CU (config 3's per-GPU share: 38 images = 342 blocks per call): every block finds a team at
     // once either way, and the two-team build's teams are the faster ones (256 VGPRs: full look-up pipeline, nothing
     // parked or spilled) -- r02i: 342 blocks 0.63 -> 0.595 ms, 513 blocks 0.675 -> 0.64 ms; from 2.7 blocks per CU on the
-    // third team wins again (684 blocks: 0.83 against 0.87 ms).
+    // third team wins again (684 blocks: 0.83 against 0.87 ms).  The 10-beam build likewise (the 302 blocks of a Kodak
+    // image's first level: B = 10, 306 blocks 0.28 -> 0.26 ms, 513 blocks 0.31 -> 0.29 ms; 630 blocks 0.355 against 0.385 ms).
     if (irec::team_count_for(B, S, 0) < 3 || irec::team_lds_for(B, S, 2) == (size_t)-1 ||
         irec::team_ws_extra_for(B, S, 2) > irec::team_ws_extra_for(B, S, 0))
       return pl.shape;

@@ -597,19 +597,22 @@ def test_mid_size_calls_take_the_eight_wave_team(engine, oracle, B, n_latents):
         assert idx[i] == ridx and np.array_equal(sample[i].cpu().numpy(), rs), i
 
 
-def test_one_to_two_blocks_per_cu_take_the_two_team_shape(engine, oracle):
-    """n_CU < blocks <= 2 n_CU with 10 < B <= 20 (config 3's per-GPU share: 38 images = 342 blocks per call): two 4-wave teams
-    per CU at the full register budget instead of three at 168 VGPRs; same outputs."""
+@pytest.mark.parametrize("B,eps1", [(20, 1.2), (10, 1.0)])
+def test_one_to_two_blocks_per_cu_take_the_two_team_shape(engine, oracle, B, eps1):
+    """n_CU < blocks <= 2 n_CU with B <= 20 (config 3's per-GPU share: 38 images = 342 blocks per call; the 302 blocks of a
+    Kodak image's first level at B = 10): two 4-wave teams per CU at the full register budget instead of three at 168 VGPRs;
+    same outputs."""
     n_latents = 38
+    S = oracle.n_samples(3.0, eps1)
     q = [np.stack([oracle.synthetic_latent(700 + i, 8192)[j] for i in range(n_latents)]) for j in range(4)]
-    c = _coder(3.0, 20, 1.2, block_size=1000)
+    c = _coder(3.0, B, eps1, block_size=1000)
     lay = engine.layout(n_latents, 8192, 1000, 42)
     plan = engine.plan(c._params(), lay, 32)
-    assert plan["n_cu"] < lay.n_blocks <= 2 * plan["n_cu"] and plan["kernel"] == "encode_team_kernel<20,2,1>", plan
+    assert plan["n_cu"] < lay.n_blocks <= 2 * plan["n_cu"] and plan["kernel"] == f"encode_team_kernel<{B},2,1>", plan
     assert plan["teams_per_wg"] == 2 and plan["grid"] == plan["n_cu"]
     idx, sample = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)
     for i in (0, 17, 37):
-        ridx, rs = oracle.encode_tensor(q[0][i], q[1][i], q[2][i], q[3][i], 42, 3.0, 36, 20, block_size=1000)
+        ridx, rs = oracle.encode_tensor(q[0][i], q[1][i], q[2][i], q[3][i], 42, 3.0, S, B, block_size=1000)
         assert idx[i] == ridx and np.array_equal(sample[i].cpu().numpy(), rs), i
 
 
