@@ -13,6 +13,7 @@ flags = {"table": 8, "auto": 0, "one_table": 4, "fused": 2, "generic": 1}[varian
 flags |= irec._lib.IREC_FLAG_SHAPE[os.environ.get("SHAPE", "default")]   # team-encoder workgroup shape (diagnostics)
 flags |= int(os.environ.get("SPLIT_W", "0")) << 12                         # split-encoder width (diagnostics)
 if os.environ.get("NO_SPLIT"): flags |= 16
+if os.environ.get("SPLIT_SAMPLES"): flags |= 128                                      # split encoder: samples, not beams
 params = eng.params(omega, S, B, flags)
 q = bench.synthetic_batch(L, eng.device, 0)
 lay = eng.layout(L, bench.N_DIMS, bench.BLOCK_SIZE, bench.SEED)
