@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of the product library against one diagnostic build on the same box in one session (alternating runs).
 # usage: VARIANT="name [name ...]" [LATENTS=8192] scripts/gpu_ab.sh
+# (build the diagnostic libraries first: make -C relative-entropy-coding_amd/csrc variant NAME=<name> DEFS=-DIREC_...=0)
 set -u
 export TMPDIR=/tmp
 mkdir -p gpurun_out
