@@ -278,8 +278,8 @@ def run_rank(args):
         a.record()
         eng.encode_blocks(params, lay, *q, SEED, max_K, out=out)   # same stream as the events (torch current stream)
         b.record()
+        gathered = exchange(out[0])                                # every step ends with the path's exchange (no host sync over RCCL)
     K = out[0]
-    gathered = exchange(K)
     barrier()
     my_elapsed = time.perf_counter() - t0
     elapsed = my_elapsed
