@@ -168,3 +168,26 @@ def test_block_sharded_call_on_the_device_two_ranks(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert res["sharded_equals_whole"] and res["n_indices"] > 0 and res["backend"] == "gloo"
+
+
+def test_layout_subset_and_element_index():
+    """BlockLayout.subset keeps the parent's tensors / permutation and lists only the chosen rows; element_index walks a block
+    in the shuffled order of Coder.split (coder.py:62-83): together every element of every tensor is named exactly once."""
+    from irec.engine import BlockLayout
+    lay = BlockLayout(torch.device("cpu"), 2, 2500, 700, 42)
+    assert lay.n_blocks == 8 and sorted(lay.block_dim.tolist(), reverse=True) == lay.block_dim.tolist()   # largest first
+    rows = np.array([1, 4, 6])
+    sub = lay.subset(rows)
+    assert sub.n_blocks == 3 and sub.max_dim == lay.max_dim and sub.perm is lay.perm
+    assert sub.block_dim.tolist() == lay.block_dim[rows].tolist() and sub.block_base.tolist() == lay.block_base[rows].tolist()
+    at = lay.element_index(np.arange(lay.n_blocks), 700)
+    named = at[at >= 0]
+    assert named.size == 2 * 2500 and np.array_equal(np.sort(named), np.arange(2 * 2500))
+    assert ((at >= 0).sum(axis=1) == lay.block_dim.numpy()).all()
+    # a block's elements are perm[pos : pos + dim] of its tensor
+    r = 5
+    base, pos, dim = int(lay.block_base[r]), int(lay.block_pos[r]), int(lay.block_dim[r])
+    assert np.array_equal(at[r][:dim], base + lay.perm_host[pos:pos + dim])
+    # without block_size: one block per tensor, natural order
+    flat = BlockLayout(torch.device("cpu"), 3, 100, None, 7)
+    assert np.array_equal(flat.element_index(np.arange(3), 100), np.arange(300).reshape(3, 100))
