@@ -15,6 +15,10 @@
 //                              (lane owns 4 dims), ONE copy of the quantile table in LDS; proposals from the per-call
 //                              table (TABLE) or from the Philox stream fused into the kernel.  Serves B > 20, large S*B,
 //                              calls without dim hints, and IREC_FLAG_ONE_TABLE / IREC_FLAG_FUSED_PHILOX.
+//                              In SPLIT mode (calls of few blocks: A.coop_W workgroups per block, exchanging their sort keys
+//                              through L2 every step) the workgroups share the block's beams (A.coop_beams: each owns at most
+//                              two beam slots, scores every sample for them and forms only its own new beams in the block's
+//                              shared slab) or, in the older form, its samples.
 //   encode_generic_kernel      any D, B <= 64: beams in a global scratch slab; correctness fallback.
 //
 // Compiled with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (no implicit fma: see irec_device.h).

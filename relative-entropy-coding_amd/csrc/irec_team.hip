@@ -17,9 +17,13 @@
 //   * one workgroup owns the CU; its teams code blocks independently (own block counter pulls, own LDS scratch, own
 //     scratch slab) and synchronise with team barriers (an LDS counter), never with s_barrier, so one team's serial
 //     phases (top-B, beam update) overlap the other teams' scoring.
-// Shapes (team_shape() at the end of the file): B <= 10: three 4-wave teams (two if the LDS is short); B <= 20: two 4-wave
-// teams -- the BASELINE workload; 20 < B <= 32, or B <= 20 with more samples than one scoring pass holds: ONE team whose
-// waves split the beams into stripes (12 waves x 10 beams, 8 x 16, 8 x 10) and that scores the samples in passes.
+// Around the steady-state scoring loop (r02i, DESIGN.md §4 "Outside the steady state"): the first step (one beam) reduces RW
+// SAMPLES per reduce-scatter instead of one; the last step forms beam 0 only; the loop's 20-value reduce-scatter runs on the
+// accumulator pairs with bank-masked DPP adds (reduce_scatter_20, irec_fast_common.h); rows are fetched a chunk ahead.
+// Shapes (team_shape() at the end of the file): B <= 10: three 4-wave teams (two if the LDS is short); B <= 20: three 4-wave
+// teams at 168 VGPRs -- the BASELINE workload (two at 256 VGPRs for calls of one to two blocks per CU); 20 < B <= 32, or
+// B <= 20 with more samples than one scoring pass holds: ONE team whose waves split the beams into stripes (12 waves x 10
+// beams, 8 x 16, 8 x 10) and that scores the samples in passes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
