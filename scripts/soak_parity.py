@@ -70,6 +70,8 @@ for case in range(n_cases):
     for Kn in Ks:
         stats["evals"] += S * D * (1 + max(Kn - 1, 0) * B)
     done += len(tens); stats["K"].append(K)
+    if case % 250 == 249:   # a long run must keep writing: the GPU box takes minutes of silence for a hang
+        print(f"[soak] case {case + 1}/{n_cases}: {done} blocks, {len(bad)} mismatches, {time.time() - t0:.0f} s", flush=True)
 print(f"soak: {done} random blocks x 4 variants in {time.time() - t0:.0f} s; K range {min(stats['K'])}..{max(stats['K'])}; "
       f"{stats['evals'] / 1e9:.2f} G proposal evals checked; mismatches: {len(bad)}")
 for b in bad[:20]:
