@@ -117,5 +117,5 @@ def _encode_block_sharded_once(coder, q_loc, q_scale, p_loc, p_scale, seed, rank
     idx_all = rows_all[:, 1:1 + max(max_K, 1)].contiguous()
     full = torch.empty(n_tensors * n, dtype=torch.float32, device=sample.device)
     full[put_at] = rows_all[:, 1 + max(max_K, 1):].contiguous().view(torch.float32)[ok]
-    pending = PendingCode(coder, lay, K_all, idx_all, full.reshape(src.shape), max_K)
+    pending = PendingCode(coder, lay, K_all, idx_all, full.reshape(src.shape).to(src.device), max_K)   # (sample on the inputs' device)
     return pending.to_lists(), pending.sample
