@@ -76,22 +76,31 @@ static void tf_seed_pair(int64_t global_seed, int64_t op_seed, uint64_t *seed1, 
 
 /* One uint32 of the stream PhiloxRandom(seed1, seed2) at flat element index e:
  * key = (lo32(seed1), hi32(seed1)); counter = (0,0,lo32(seed2),hi32(seed2)) + (e>>2); lane e&3. */
-static uint32_t philox_stream_u32(uint64_t seed1, uint64_t seed2, uint64_t e) {
+static uint32_t philox_stream_u32_at(uint64_t seed1, uint64_t seed2, uint64_t skip128, uint64_t e) {
   uint32_t key[2] = {(uint32_t)seed1, (uint32_t)(seed1 >> 32)};
-  uint64_t blk = e >> 2;
-  uint32_t ctr[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)seed2, (uint32_t)(seed2 >> 32)};
+  uint64_t blk = (e >> 2) + skip128;            /* PhiloxRandom::Skip adds to the 128-bit counter; the low 64 bits never */
+  uint64_t hi = seed2 + (blk < skip128 ? 1 : 0); /* wrap in any use here, the carry is kept for completeness               */
+  uint32_t ctr[4] = {(uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
   uint32_t out[4];
   irec_oracle_philox4x32(key, ctr, out);
   return out[e & 3];
 }
+static uint32_t philox_stream_u32(uint64_t seed1, uint64_t seed2, uint64_t e) {
+  return philox_stream_u32_at(seed1, seed2, 0, e);
+}
 
 /* beam_search_coder.py:38-43 -- tf.random.set_seed(seed); tf.random.uniform(shape, 1, 10007, seed=seed, int32)
  * flat row-major element e -> 1 + u32 % 10006. */
+void irec_oracle_tf_uniform_int_pair(uint64_t s1, uint64_t s2, uint64_t skip128, int32_t lo, int32_t hi, int64_t n,
+                                     int32_t *out) { /* random_op.cc RandomUniformIntOp + UniformDistribution<.., int32>: lo + u32 % (hi - lo) */
+  const uint32_t range = (uint32_t)hi - (uint32_t)lo;
+  for (int64_t e = 0; e < n; ++e)
+    out[e] = (int32_t)((uint32_t)lo + philox_stream_u32_at(s1, s2, skip128, (uint64_t)e) % range);
+}
 void irec_oracle_uniform_int(int64_t seed, int64_t n, int32_t *out) {
   uint64_t s1, s2;
   tf_seed_pair(seed, seed, &s1, &s2);
-  for (int64_t e = 0; e < n; ++e)
-    out[e] = 1 + (int32_t)(philox_stream_u32(s1, s2, (uint64_t)e) % (uint32_t)(IREC_P - 1));
+  irec_oracle_tf_uniform_int_pair(s1, s2, 0, 1, IREC_P, n, out);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -239,15 +248,29 @@ static uint32_t mt_genrand(mt_state *st) {
 
 /* random.Random(seed).randint(0, 2**31 - 1): seed(int) -> init_by_array(32-bit words of |seed|);
  * randint -> _randbelow(2**31) -> k = (2**31).bit_length() = 32; r = getrandbits(32) until r < 2**31. */
-int64_t irec_oracle_py_first_randint31(int64_t seed) {
+int64_t irec_oracle_py_randint31_nth(int64_t seed, int64_t nth) { /* nth = 0: the first draw after seeding */
   uint64_t a = seed < 0 ? (uint64_t)(-(seed + 1)) + 1u : (uint64_t)seed;
   uint32_t key[2] = {(uint32_t)a, (uint32_t)(a >> 32)};
   int klen = key[1] ? 2 : 1;
   mt_state st;
   mt_init_by_array(&st, key, klen);
-  uint32_t r;
-  do { r = mt_genrand(&st); } while (r >= 0x80000000u);
+  uint32_t r = 0;
+  for (int64_t k = 0; k <= nth; ++k)
+    do { r = mt_genrand(&st); } while (r >= 0x80000000u);
   return (int64_t)r;
+}
+int64_t irec_oracle_py_first_randint31(int64_t seed) { return irec_oracle_py_randint31_nth(seed, 0); }
+
+/* python/framework/random_seed.py get_seed() in eager mode, all four cases.  has_* = 0 stands for None.
+ * nth_auto: how many seedless random ops ran since tf.random.set_seed (each takes one randint from the context's
+ * random.Random(global seed)).  Returns 0, or -1 for (None, None) = non-deterministic. */
+int irec_oracle_tf_get_seed(int has_global, int64_t global_seed, int has_op, int64_t op_seed, int64_t nth_auto,
+                            uint64_t *seed1, uint64_t *seed2) {
+  if (!has_global && !has_op) return -1;
+  if (!has_global) global_seed = 87654321;                          /* DEFAULT_GRAPH_SEED */
+  else if (!has_op) op_seed = irec_oracle_py_randint31_nth(global_seed, nth_auto); /* context.internal_operation_seed() */
+  tf_seed_pair(global_seed, op_seed, seed1, seed2);
+  return 0;
 }
 
 /* perm[i] = position-i value of tf.random.shuffle(range(n)) after tf.random.set_seed(seed).
@@ -634,12 +657,24 @@ static float oracle_uint32_to_float(uint32_t x) {
   return r - 1.0f;
 }
 
+/* tf.random.uniform(shape, dtype=float32): random_op.cc PhiloxRandomOp<UniformDistribution<PhiloxRandom, float>>,
+ * element e <- Uint32ToFloat(lane e & 3 of block e >> 2).  skip128: the 128-bit blocks earlier calls on the SAME cached eager
+ * kernel reserved (GuardedPhiloxRandom::ReserveRandomOutputs(n, 256) skips n * 256 per call; tf.random.set_seed clears the
+ * kernel cache, so every draw on the coder's path starts at 0). */
+void irec_oracle_tf_uniform_float_pair(uint64_t s1, uint64_t s2, uint64_t skip128, int64_t n, float *out) {
+  for (int64_t e = 0; e < n; ++e) out[e] = oracle_uint32_to_float(philox_stream_u32_at(s1, s2, skip128, (uint64_t)e));
+}
+
+void irec_oracle_tf_normal_pair(uint64_t s1, uint64_t s2, uint64_t skip128, int64_t count, float *out);
 void irec_oracle_tf_random_normal(int64_t seed, int64_t count, float *out) {
   uint64_t s1, s2;
   tf_seed_pair(seed, irec_oracle_py_first_randint31(seed), &s1, &s2);
+  irec_oracle_tf_normal_pair(s1, s2, 0, count, out);
+}
+void irec_oracle_tf_normal_pair(uint64_t s1, uint64_t s2, uint64_t skip128, int64_t count, float *out) {
   for (int64_t g = 0; 4 * g < count; ++g) {
     uint32_t x[4];
-    for (int k = 0; k < 4; ++k) x[k] = philox_stream_u32(s1, s2, (uint64_t)(4 * g + k));
+    for (int k = 0; k < 4; ++k) x[k] = philox_stream_u32_at(s1, s2, skip128, (uint64_t)(4 * g + k));
     float f[4];
     for (int h = 0; h < 2; ++h) { /* BoxMullerFloat(x[2h], x[2h+1], &f[2h], &f[2h+1]) */
       const float epsilon = 1.0e-7f;

@@ -53,6 +53,16 @@ def lib():
         L.irec_oracle_build_lut.argtypes = [f32p]
         L.irec_oracle_py_first_randint31.argtypes = [ctypes.c_int64]
         L.irec_oracle_py_first_randint31.restype = ctypes.c_int64
+        L.irec_oracle_py_randint31_nth.argtypes = [ctypes.c_int64, ctypes.c_int64]
+        L.irec_oracle_py_randint31_nth.restype = ctypes.c_int64
+        u64p = ctypes.POINTER(ctypes.c_uint64)
+        L.irec_oracle_tf_get_seed.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                              u64p, u64p]
+        L.irec_oracle_tf_get_seed.restype = ctypes.c_int
+        L.irec_oracle_tf_uniform_float_pair.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, f32p]
+        L.irec_oracle_tf_uniform_int_pair.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int32,
+                                                      ctypes.c_int32, ctypes.c_int64, i32p]
+        L.irec_oracle_tf_normal_pair.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int64, f32p]
         L.irec_oracle_tf_shuffle_perm.argtypes = [ctypes.c_int64, ctypes.c_int64, i64p]
         L.irec_oracle_simple_hash.argtypes = [i32p, ctypes.c_int]
         L.irec_oracle_simple_hash.restype = ctypes.c_int32
@@ -123,6 +133,61 @@ def build_lut():
 
 def py_first_randint31(seed):
     return lib().irec_oracle_py_first_randint31(int(seed))
+
+
+class TfEagerRandom:
+    """The seed plumbing of TF 2.x eager stateful random ops as the oracle restates it, written as
+    the little state machine it is so that the eager outputs printed in TensorFlow's public API docs can be replayed:
+    tf.random.set_seed(g) re-creates random.Random(g) and clears the kernel cache; an op WITHOUT an op seed takes the next
+    randint of that generator (a fresh kernel every time); an op WITH one re-uses the cached kernel of its (seed, seed2,
+    shape, dtype) attributes, whose Philox counter each call advances by 256 blocks per output element."""
+
+    def __init__(self, global_seed=None):
+        self.set_seed(global_seed)
+
+    def set_seed(self, global_seed):
+        self.g = global_seed
+        self.n_auto = 0
+        self.skips = {}
+
+    def _stream(self, kind, n, op_seed):
+        s1, s2 = ctypes.c_uint64(), ctypes.c_uint64()
+        rc = lib().irec_oracle_tf_get_seed(self.g is not None, int(self.g or 0), op_seed is not None, int(op_seed or 0),
+                                           self.n_auto, ctypes.byref(s1), ctypes.byref(s2))
+        if rc != 0:
+            raise ValueError("(None, None): TensorFlow seeds this op non-deterministically")
+        if op_seed is None and self.g is not None:
+            self.n_auto += 1
+        key = (kind, s1.value, s2.value, n)
+        skip = self.skips.get(key, 0)
+        self.skips[key] = skip + 256 * n
+        return s1.value, s2.value, skip
+
+    def uniform(self, n, seed=None):
+        """tf.random.uniform([n], seed=seed) (float32, [0, 1))"""
+        s1, s2, skip = self._stream("uf", n, seed)
+        o = np.zeros(n, dtype=np.float32)
+        lib().irec_oracle_tf_uniform_float_pair(s1, s2, skip, n, _p(o, ctypes.c_float))
+        return o
+
+    def uniform_int(self, n, minval, maxval, seed=None):
+        """tf.random.uniform([n], minval, maxval, dtype=tf.int32, seed=seed)"""
+        s1, s2, skip = self._stream(("ui", minval, maxval), n, seed)
+        o = np.zeros(n, dtype=np.int32)
+        lib().irec_oracle_tf_uniform_int_pair(s1, s2, skip, int(minval), int(maxval), n, _p(o, ctypes.c_int32))
+        return o
+
+    def normal(self, n, seed=None):
+        """tf.random.normal([n], seed=seed)"""
+        s1, s2, skip = self._stream("n", n, seed)
+        o = np.zeros(n, dtype=np.float32)
+        lib().irec_oracle_tf_normal_pair(s1, s2, skip, n, _p(o, ctypes.c_float))
+        return o
+
+
+def tf_uniform_float(global_seed, op_seed, n):
+    """tf.random.set_seed(global_seed); tf.random.uniform([n], seed=op_seed) -- either seed may be None."""
+    return TfEagerRandom(global_seed).uniform(n, seed=op_seed)
 
 
 def tf_shuffle_perm(seed, n):
