@@ -212,6 +212,34 @@ irec_status irec_beam_decode(irec_context *ctx, const irec_params *p, int64_t n_
                              const float *p_loc, const float *p_scale, int64_t seed, int32_t max_K, const int32_t *K,
                              const int32_t *indices, float *out_sample, void *hip_stream);
 
+/* The same decode with caller-provided scratch (irec_decode_workspace_bytes(), 256-byte aligned; may be NULL / 0): with
+ * p->table_dims set the shared-seed draw of the call is evaluated once into per-call proposal tables (every block of one dim
+ * count reads its rows from the same S rows per step, beam_search_coder.py:38-43,141-146) instead of once per block -- same
+ * outputs, bit for bit.  max_block_dim: upper bound of block_dim[] (>= every listed table dim).  A block whose dim exceeds it
+ * is not decoded.  With table_dims set, irec_beam_decode above takes the same kernel without the tables. */
+size_t irec_decode_workspace_bytes(const irec_context *ctx, const irec_params *p, int32_t max_K);
+irec_status irec_beam_decode_ws(irec_context *ctx, const irec_params *p, int64_t n_blocks, const int64_t *block_base,
+                                const int32_t *block_pos, const int32_t *block_dim, int32_t max_block_dim,
+                                const int32_t *perm, const float *p_loc, const float *p_scale, int64_t seed, int32_t max_K,
+                                const int32_t *K, const int32_t *indices, float *out_sample, void *workspace,
+                                size_t workspace_bytes, void *hip_stream);
+
+/* GaussianCoder.decode (coder.py:459-491) on n_tensors whole tensors of tensor_dims dims lying back to back in p_loc /
+ * p_scale / out_sample, cut the way Coder.split cuts them (coder.py:69-83): block j of a tensor = shuffled positions
+ * [j * block_size, min((j + 1) * block_size, tensor_dims)) through perm [tensor_dims] (NULL: no shuffle).  One workgroup
+ * decodes all blocks of a tensor with sigma_p / mu_p / the samples staged in LDS, so split and merge touch global memory
+ * in natural order only (the element-wise gathers of irec_beam_decode cost three times the arithmetic).
+ *   K [n_tensors * bpt], indices [n_tensors * bpt, max_K], bpt = ceil(tensor_dims / block_size): row of block j of tensor i
+ *   is block_row[i * bpt + j] (device int32; NULL: i * bpt + j).  p->table_dims is ignored (derived from the sizes).
+ * Same outputs as irec_beam_decode, bit for bit.  Applies when irec_decode_tensors_supported() (tensors that fit the LDS);
+ * workspace as for irec_beam_decode_ws (irec_decode_workspace_bytes with table_dims = {block_size, last block's dim}). */
+int32_t irec_decode_tensors_supported(const irec_params *p, int32_t tensor_dims, int32_t block_size);
+irec_status irec_beam_decode_tensors(irec_context *ctx, const irec_params *p, int64_t n_tensors, int32_t tensor_dims,
+                                     int32_t block_size, const int32_t *block_row, const int32_t *perm, const float *p_loc,
+                                     const float *p_scale, int64_t seed, int32_t max_K, const int32_t *K,
+                                     const int32_t *indices, float *out_sample, void *workspace, size_t workspace_bytes,
+                                     void *hip_stream);
+
 /* ---- .rec wire format: entropy coder of the index streams (host memory; the reference's is CPU Cython too) ------------ */
 const char *irec_io_last_error(void);
 /* ArithmeticCoder(counts, precision).encode(message) -- rec/io/entropy_coding.pyx:51-121.  out_bits: one ASCII '0'/'1'
@@ -245,6 +273,10 @@ irec_status irec_rec_decode_file(const uint8_t *bytes, int64_t n_bytes, uint32_t
 /* ---- test hooks (device pointers) ---------------------------------------------------------------------------- */
 /* r[s*D + d] of get_pseudo_random_sample's int32 draw, generated by the in-kernel Philox stream.  out: int32 [n]. */
 irec_status irec_device_uniform_int(irec_context *ctx, int64_t seed, int64_t n, int32_t *out, void *hip_stream);
+/* The decoder's short correctly-rounded square root against sqrtf on every float32 bit pattern it is allowed to see (all
+ * but the non-zero values below 2^-96, which take sqrtf itself): out2[0] = mismatches, out2[1] = patterns compared.
+ * out2: device uint64 [2]. */
+irec_status irec_test_decoder_sqrt(irec_context *ctx, uint64_t *out2, void *hip_stream);
 /* in: float [64 lanes][width]; out: float [128].  width in {64, 32}: out[lane] = sum over lanes of
  * in[.][lane*width/64] in the canonical 64-lane reduction tree of the score kernels.  width in {20, 10}
  * (the arbitrary-width reduce-scatter of the team encoder): out[lane] = such a total of column out[64 + lane] (a column

@@ -838,24 +838,121 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   return IREC_OK;
 }
 
-irec_status irec_beam_decode(irec_context *ctx, const irec_params *p, int64_t n_blocks, const int64_t *block_base,
-                             const int32_t *block_pos, const int32_t *block_dim, const int32_t *perm,
-                             const float *p_loc, const float *p_scale, int64_t seed, int32_t max_K, const int32_t *K,
-                             const int32_t *indices, float *out_sample, void *hip_stream) {
+// Table window of a decode call: the proposal tables pay when the call's blocks share rows (S * K_tab rows per dim count
+// against n_blocks * K row reads) and fit the scratch.
+struct DecPlan { int upb; int K_tab; int n_tab; int tab_dim[4]; size_t tab_off[4]; size_t bytes; };
+static DecPlan make_dec_plan(const irec_params *p, int64_t n_blocks, int32_t max_block_dim, int32_t max_K, bool have_ws) {
+  DecPlan d{};
+  int maxd = max_block_dim;
+  for (int q = 0; q < 4 && p->table_dims[q] > 0; ++q) maxd = std::max(maxd, p->table_dims[q]);
+  d.upb = maxd > 0 ? (maxd + 255) / 256 : 0;
+  if (!have_ws || p->table_dims[0] <= 0 || max_K < 1 || (p->flags & IREC_FLAG_FUSED_PHILOX)) return d;
+  if (n_blocks >= 0 && (int64_t)p->n_samples > 2 * n_blocks) return d;   // fewer row reads than rows: draw in the kernel
+  size_t per_step = 0;
+  for (int q = 0; q < 4 && p->table_dims[q] > 0; ++q) per_step += (size_t)p->n_samples * round_up(p->table_dims[q], 4) * 2;
+  const int want = p->table_steps > 0 ? p->table_steps : IREC_TABLE_STEPS_DEFAULT;
+  int kt = std::min(std::min(want, IREC_TABLE_STEPS_MAX), (int)max_K);
+  kt = (int)std::min<size_t>((size_t)kt, (size_t)IREC_TABLE_BYTES_MAX / per_step);
+  if (kt < 1) return d;
+  d.K_tab = kt;
+  for (int q = 0; q < 4 && p->table_dims[q] > 0; ++q) {
+    d.tab_dim[d.n_tab] = p->table_dims[q];
+    d.tab_off[d.n_tab] = d.bytes;
+    d.bytes += round_up_sz((size_t)kt * p->n_samples * round_up(p->table_dims[q], 4) * 2, 256);
+    ++d.n_tab;
+  }
+  return d;
+}
+
+size_t irec_decode_workspace_bytes(const irec_context *ctx, const irec_params *p, int32_t max_K) {
+  if (!ctx || check_params(p) != IREC_OK || max_K < 0) return 0;
+  return make_dec_plan(p, -1, 0, max_K, true).bytes;
+}
+
+struct DecTensors { int64_t n_tensors; int32_t n, bs; const int32_t *block_row; };
+static irec_status beam_decode_impl(irec_context *ctx, const irec_params *p, int64_t n_blocks, const int64_t *block_base,
+                                    const int32_t *block_pos, const int32_t *block_dim, int32_t max_block_dim,
+                                    const int32_t *perm, const float *p_loc, const float *p_scale, int64_t seed,
+                                    int32_t max_K, const int32_t *K, const int32_t *indices, float *out_sample,
+                                    void *workspace, size_t workspace_bytes, void *hip_stream, const DecTensors *tens = nullptr) {
   if (!ctx) return fail(IREC_E_INVALID, "irec_beam_decode: null context");
   if (irec_status s = check_params(p)) return s;
   if (n_blocks < 0) return fail(IREC_E_INVALID, "irec_beam_decode: n_blocks < 0");
   if (n_blocks == 0) return IREC_OK;
-  if (!block_base || !block_pos || !block_dim || !p_loc || !p_scale || !K || !out_sample || (max_K > 0 && !indices))
+  if ((!tens && (!block_base || !block_pos || !block_dim)) || !p_loc || !p_scale || !K || !out_sample || (max_K > 0 && !indices))
     return fail(IREC_E_INVALID, "irec_beam_decode: null pointer argument");
   if (max_K < 0 || max_K > IREC_MAX_PARTITIONS) return fail(IREC_E_INVALID, "irec_beam_decode: max_K %d out of range", max_K);
+  if (max_block_dim < 0 || max_block_dim > (1 << 22)) return fail(IREC_E_INVALID, "irec_beam_decode: max_block_dim %d out of range", max_block_dim);
+  const DecPlan dp = make_dec_plan(p, n_blocks, max_block_dim, max_K, workspace != nullptr);
+  if (dp.K_tab > 0) {
+    if (workspace_bytes < dp.bytes) return fail(IREC_E_WORKSPACE, "irec_beam_decode_ws: workspace %zu bytes < required %zu", workspace_bytes, dp.bytes);
+    if (((uintptr_t)workspace & 255) != 0) return fail(IREC_E_WORKSPACE, "irec_beam_decode_ws: workspace must be 256-byte aligned");
+  }
   IREC_ON_DEVICE(ctx->device);
+  hipStream_t st = (hipStream_t)hip_stream;
   irec::DecArgs A{};
   A.block_base = block_base; A.block_pos = block_pos; A.block_dim = block_dim; A.perm = perm;
   A.p_loc = p_loc; A.p_scale = p_scale; A.n_blocks = n_blocks; A.seed = seed; A.max_K = max_K; A.K = K;
   A.indices = indices; A.out_sample = out_sample; A.lut = ctx->d_lut; A.rho = ctx->d_rho;
-  HIP_TRY(irec::launch_decode(A, ctx->n_cu > 0 ? ctx->n_cu : 256, (hipStream_t)hip_stream));
+  A.upb = dp.upb; A.S = p->n_samples; A.K_tab = dp.K_tab; A.lut2 = ctx->d_lut2; A.dlog4r = ctx->d_dlog4r;
+  for (int q = 0; q < 4; ++q) { A.tab[q] = nullptr; A.tab_dim[q] = -1; }
+  for (int q = 0; q < dp.n_tab && dp.K_tab > 0; ++q) {
+    uint16_t *tab = (uint16_t *)((char *)workspace + dp.tab_off[q]);
+    HIP_TRY(irec::launch_alpha_table(seed, p->n_samples, dp.tab_dim[q], dp.K_tab, ctx->d_dlog4r, tab, nullptr, st));
+    A.tab[q] = tab; A.tab_dim[q] = dp.tab_dim[q];
+  }
+  if (tens) {
+    A.n_tensors = tens->n_tensors; A.tn = tens->n; A.tbs = tens->bs; A.tbpt = (tens->n + tens->bs - 1) / tens->bs;
+    A.block_row = tens->block_row;
+  }
+  HIP_TRY(irec::launch_decode(A, ctx->n_cu > 0 ? ctx->n_cu : 256, st));
   return IREC_OK;
+}
+
+irec_status irec_beam_decode(irec_context *ctx, const irec_params *p, int64_t n_blocks, const int64_t *block_base,
+                             const int32_t *block_pos, const int32_t *block_dim, const int32_t *perm,
+                             const float *p_loc, const float *p_scale, int64_t seed, int32_t max_K, const int32_t *K,
+                             const int32_t *indices, float *out_sample, void *hip_stream) {
+  return beam_decode_impl(ctx, p, n_blocks, block_base, block_pos, block_dim, 0, perm, p_loc, p_scale, seed, max_K, K, indices,
+                          out_sample, nullptr, 0, hip_stream);
+}
+
+irec_status irec_beam_decode_ws(irec_context *ctx, const irec_params *p, int64_t n_blocks, const int64_t *block_base,
+                                const int32_t *block_pos, const int32_t *block_dim, int32_t max_block_dim,
+                                const int32_t *perm, const float *p_loc, const float *p_scale, int64_t seed, int32_t max_K,
+                                const int32_t *K, const int32_t *indices, float *out_sample, void *workspace,
+                                size_t workspace_bytes, void *hip_stream) {
+  if (max_block_dim < 1) return fail(IREC_E_INVALID, "irec_beam_decode_ws: max_block_dim %d < 1", max_block_dim);
+  return beam_decode_impl(ctx, p, n_blocks, block_base, block_pos, block_dim, max_block_dim, perm, p_loc, p_scale, seed, max_K, K,
+                          indices, out_sample, workspace, workspace_bytes, hip_stream);
+}
+
+int32_t irec_decode_tensors_supported(const irec_params *p, int32_t tensor_dims, int32_t block_size) {
+  if (check_params(p) != IREC_OK || tensor_dims < 1 || block_size < 1) return 0;
+  block_size = std::min(block_size, tensor_dims);
+  return irec::decode_tensor_waves(tensor_dims, block_size, true, nullptr) > 0 && irec::decode_tensor_waves(tensor_dims, block_size, false, nullptr) > 0;
+}
+
+irec_status irec_beam_decode_tensors(irec_context *ctx, const irec_params *p, int64_t n_tensors, int32_t tensor_dims,
+                                     int32_t block_size, const int32_t *block_row, const int32_t *perm, const float *p_loc,
+                                     const float *p_scale, int64_t seed, int32_t max_K, const int32_t *K,
+                                     const int32_t *indices, float *out_sample, void *workspace, size_t workspace_bytes,
+                                     void *hip_stream) {
+  if (n_tensors < 0 || tensor_dims < 1 || block_size < 1) return fail(IREC_E_INVALID, "irec_beam_decode_tensors: bad sizes");
+  if (!irec_decode_tensors_supported(p, tensor_dims, block_size))
+    return fail(IREC_E_INVALID, "irec_beam_decode_tensors: tensors of %d dims in blocks of %d do not fit the staged decoder "
+                                "(irec_decode_tensors_supported); use irec_beam_decode_ws", tensor_dims, block_size);
+  block_size = std::min(block_size, tensor_dims);
+  const int bpt = (tensor_dims + block_size - 1) / block_size;
+  // the proposal tables cover the distinct block dims of Coder.split: block_size and the short last block
+  irec_params q = *p;
+  const int last = tensor_dims - (bpt - 1) * block_size;
+  q.table_dims[0] = block_size;
+  q.table_dims[1] = last != block_size ? last : 0;
+  q.table_dims[2] = q.table_dims[3] = 0;
+  const DecTensors tens{n_tensors, tensor_dims, block_size, block_row};
+  return beam_decode_impl(ctx, &q, n_tensors * bpt, nullptr, nullptr, nullptr, block_size, perm, p_loc, p_scale, seed,
+                          max_K, K, indices, out_sample, workspace, workspace_bytes, hip_stream, &tens);
 }
 
 irec_status irec_device_uniform_int(irec_context *ctx, int64_t seed, int64_t n, int32_t *out, void *hip_stream) {
@@ -863,6 +960,13 @@ irec_status irec_device_uniform_int(irec_context *ctx, int64_t seed, int64_t n, 
   if (n == 0) return IREC_OK;
   IREC_ON_DEVICE(ctx->device);
   HIP_TRY(irec::launch_uniform_int(seed, n, out, (hipStream_t)hip_stream));
+  return IREC_OK;
+}
+
+irec_status irec_test_decoder_sqrt(irec_context *ctx, uint64_t *out2, void *hip_stream) {
+  if (!ctx || !out2) return fail(IREC_E_INVALID, "irec_test_decoder_sqrt: bad arguments");
+  IREC_ON_DEVICE(ctx->device);
+  HIP_TRY(irec::launch_dec_sqrt_test(reinterpret_cast<unsigned long long *>(out2), (hipStream_t)hip_stream));
   return IREC_OK;
 }
 

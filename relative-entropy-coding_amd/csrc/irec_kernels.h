@@ -52,6 +52,15 @@ struct DecArgs {
   int64_t n_blocks; int64_t seed;
   int32_t max_K; const int32_t *K; const int32_t *indices; float *out_sample;
   const float *lut; const float *rho;
+  // wave-granular decoder (irec_decode.hip): upb = 256-dim units per block (0: the call gave no dim hints -> round-2 kernel),
+  // quantile table in discrete-log order, and the per-call proposal tables tab[q][t][s][d] = 4 * dlog_g(r) of the first
+  // K_tab steps for blocks of tab_dim[q] dims (K_tab = 0: no tables, the draw is fused into the kernel)
+  int32_t upb; int32_t S; int32_t K_tab;
+  const float *lut2; const uint16_t *dlog4r;
+  const uint16_t *tab[4]; int32_t tab_dim[4];
+  // tensor-staged decoder (tn > 0): n_tensors tensors of tn dims back to back, cut into blocks of tbs shuffled positions
+  // (tbpt per tensor); K / index row of block j of tensor i: block_row[i * tbpt + j], or i * tbpt + j without a map
+  int64_t n_tensors; int32_t tn, tbs, tbpt; const int32_t *block_row;
 };
 
 hipError_t launch_block_kl(const EncArgs &A, float *out_kl, int grid, hipStream_t st);
@@ -90,7 +99,9 @@ constexpr size_t WS_COUNTER_BYTES = 512;                  // [0,256): counters, 
 constexpr int COOP_MAX_BLOCKS = 64, COOP_KEYS = 1024;      // split encoder: blocks per call, sort keys per step (S * NB, aliased-key builds)
 constexpr size_t WS_XCH_BYTES = (size_t)2 * COOP_MAX_BLOCKS * COOP_KEYS * 4;   // key exchange of the split encoder, double buffered
 constexpr size_t WS_HEAD_BYTES = WS_COUNTER_BYTES + WS_XCH_BYTES;
-hipError_t launch_decode(const DecArgs &A, int n_cu, hipStream_t st);
+hipError_t launch_decode(const DecArgs &A, int n_cu, hipStream_t st);   // irec_decode.hip
+int decode_tensor_waves(int n, int bs, bool table, size_t *lds_out);     // waves per workgroup of the tensor-staged decoder, 0 = does not apply
+hipError_t launch_dec_sqrt_test(unsigned long long *out, hipStream_t st);
 hipError_t launch_uniform_int(int64_t seed, int64_t n, int32_t *out, hipStream_t st);
 hipError_t launch_select_test(const float *scores, int N, int Bnew, int Bcur, uint32_t *keys, int32_t *sel, hipStream_t st);
 hipError_t launch_reduce_scatter_test(const float *in, float *out, int width, hipStream_t st);

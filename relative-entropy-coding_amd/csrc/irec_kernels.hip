@@ -6,7 +6,7 @@
 //     simple_hash                           rec/coding/beam_search_coder.py:33-35
 //     get_auxiliary_coder / _target         rec/coding/coder.py:141-154
 //     get_auxiliary_ratio                   rec/coding/coder.py:16,218-220
-//   BeamSearchCoder.decode_block            rec/coding/beam_search_coder.py:124-148
+//   (BeamSearchCoder.decode_block, rec/coding/beam_search_coder.py:124-148: irec_decode.hip)
 //   Coder.split / merge (as gather/scatter) rec/coding/coder.py:38-122
 //
 // All encoders share one arithmetic specification; the default one is encode_team_kernel (irec_team.hip).
@@ -988,66 +988,6 @@ __global__ __launch_bounds__(256) void alpha_table_kernel(int64_t seed, int32_t 
 }
 
 // ======================================================================================================
-//  decoder (beam_search_coder.py:124-148): only row indices[t] of each step's draw is needed
-// ======================================================================================================
-// LDS_LUT: the workgroup copies the 40 KB quantile table into LDS once and gathers from there (a random 64-lane gather
-// costs ~4 LDS cycles against ~64 cache-line requests through the vector L1); worth its set-up once a workgroup decodes
-// several blocks.  Small calls read the table through the L2 as before.
-template <bool LDS_LUT>
-__global__ __launch_bounds__(256) void decode_kernel(DecArgs A) {
-  const int tid = threadIdx.x;
-  __shared__ float lut_s[LDS_LUT ? IREC_P : 1];
-  if constexpr (LDS_LUT) {
-    for (int k = tid; k < (int)IREC_P; k += 256) lut_s[k] = A.lut[k];
-    __syncthreads();
-  }
-  const float *lut = LDS_LUT ? lut_s : A.lut;
-  for (int64_t blk = blockIdx.x; blk < A.n_blocks; blk += gridDim.x) {
-    const int D = A.block_dim[blk];
-    const int64_t base = A.block_base[blk];
-    const int32_t pos = A.block_pos[blk];
-    const int K = A.K[blk];
-    const int32_t *idx = A.indices + blk * (int64_t)A.max_K;
-    if (K > A.max_K || K < 0) continue;
-    // a thread decodes FOUR consecutive dims: one Philox block yields their four draws (two when the row start is not a
-    // multiple of 4), instead of one block per dim with three of its four words thrown away
-    for (int d0 = tid * 4; d0 < D; d0 += 256 * 4) {
-      int64_t ix[4];
-      float var_p[4], c[4], sample[4];
-      bool valid[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        valid[i] = d0 + i < D;
-        ix[i] = base + (A.perm ? (int64_t)A.perm[pos + (valid[i] ? d0 + i : d0)] : (int64_t)(pos + (valid[i] ? d0 + i : d0)));
-        const float sp = A.p_scale[ix[i]];
-        var_p[i] = sp * sp; c[i] = 0.f; sample[i] = 0.f;
-      }
-      uint32_t hs = 0u;
-      for (int t = 0; t < K; ++t) {
-        const float rho = A.rho[K - 1 - t];
-        const StepSeed ss = make_step_seed(A.seed + t);
-        const uint32_t it = (uint32_t)idx[t];
-        const uint32_t h = hash_from_sum((int32_t)hs);
-        uint32_t rm1[4];
-        draw_rm1_x4(ss, (uint64_t)it * (uint64_t)D + (uint64_t)d0, rm1);   // (it * D + d0) & 3 is uniform: d0 % 4 == 0
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float a = rho * (var_p[i] - c[i]);
-          const float sa = sqrtf(a);
-          const uint32_t k = ((rm1[i] + 1u) * h) % IREC_P;
-          sample[i] = sample[i] + sa * lut[k];
-          c[i] = c[i] + a;
-        }
-        hs += it * (uint32_t)(69 + t);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (valid[i]) A.out_sample[ix[i]] = sample[i] + A.p_loc[ix[i]];
-    }
-  }
-}
-
-// ======================================================================================================
 //  test hooks
 // ======================================================================================================
 __global__ void uniform_int_kernel(int64_t seed, int64_t n, int32_t *out) {
@@ -1191,14 +1131,6 @@ __global__ void zero_counters_kernel(uint32_t *p, TableStamps ts) {
 }
 hipError_t launch_zero_counters(void *p, const TableStamps &stamps, hipStream_t st) {
   hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(WS_COUNTER_BYTES / 4), 0, st, reinterpret_cast<uint32_t *>(p), stamps);
-  return hipGetLastError();
-}
-
-hipError_t launch_decode(const DecArgs &A, int n_cu, hipStream_t st) {
-  if (A.n_blocks >= 16LL * n_cu) // four resident workgroups per CU (40 KB of LDS each), four blocks or more per workgroup
-    hipLaunchKernelGGL(decode_kernel<true>, dim3(4 * n_cu), dim3(256), 0, st, A);
-  else
-    hipLaunchKernelGGL(decode_kernel<false>, dim3((unsigned)(A.n_blocks < 8LL * n_cu ? A.n_blocks : 8LL * n_cu)), dim3(256), 0, st, A);
   return hipGetLastError();
 }
 

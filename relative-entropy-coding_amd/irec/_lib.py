@@ -75,6 +75,12 @@ SIGNATURES = {
     "irec_beam_encode": (ctypes.c_int, [_vp, _PP, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32,
                                         _vp, _vp, _vp, _vp, ctypes.c_size_t, _vp]),
     "irec_beam_decode": (ctypes.c_int, [_vp, _PP, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "irec_decode_workspace_bytes": (ctypes.c_size_t, [_vp, _PP, _i32]),
+    "irec_beam_decode_ws": (ctypes.c_int, [_vp, _PP, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp,
+                                           ctypes.c_size_t, _vp]),
+    "irec_decode_tensors_supported": (_i32, [_PP, _i32, _i32]),
+    "irec_beam_decode_tensors": (ctypes.c_int, [_vp, _PP, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp,
+                                                ctypes.c_size_t, _vp]),
     "irec_io_last_error": (ctypes.c_char_p, []),
     "irec_ac_encode": (ctypes.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _i64, ctypes.POINTER(_i64)]),
     "irec_ac_decode": (ctypes.c_int, [_vp, _i32, _vp, _i64, _i32, _vp, _i64, ctypes.POINTER(_i64)]),
@@ -83,6 +89,7 @@ SIGNATURES = {
     "irec_rec_encode_file": (_i64, [ctypes.c_uint32] * 6 + [_i32, _vp, _vp, _vp, _vp, _i64]),
     "irec_rec_decode_file": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64]),
     "irec_device_uniform_int": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
+    "irec_test_decoder_sqrt": (ctypes.c_int, [_vp, _vp, _vp]),
     "irec_test_reduce_scatter": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "irec_test_select": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "irec_test_proposal_table": (ctypes.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),

@@ -74,6 +74,12 @@ class BlockLayout:
             self.perm = torch.from_numpy(self.perm_host.astype(np.int32)).to(device)
 
 
+    def natural_dev(self):
+        """int32 device copy of `natural` (row of block j of tensor i at [i * blocks_per_tensor + j])."""
+        if getattr(self, "_natural_dev", None) is None:
+            self._natural_dev = torch.from_numpy(self.natural.astype(np.int32)).to(self.block_base.device)
+        return self._natural_dev
+
     def subset(self, rows):
         """The layout restricted to `rows` (indices into this layout's row order): what ONE rank codes when the blocks of a
         call are spread over several GPUs (irec/sharding.py).  Same tensors, same permutation."""
@@ -83,6 +89,7 @@ class BlockLayout:
         sub.blocks_per_tensor = self.blocks_per_tensor
         sub.order = self.order[rows]
         sub.natural = None                       # a subset has no (tensor, block) -> row map: the parent reassembles
+        sub._natural_dev = None
         sub.n_blocks = len(rows)
         idx = torch.as_tensor(rows, device=self.block_base.device)
         sub.block_base, sub.block_pos, sub.block_dim = self.block_base[idx], self.block_pos[idx], self.block_dim[idx]
@@ -121,6 +128,7 @@ class Engine:
         self._layouts = {}
         self._ws = {}      # one scratch buffer per HIP stream: calls on different streams never share counters / slabs
         self._session = None   # table_session(): key of the previous call of a back-to-back run of twin calls
+        self._dec_ws = {}  # decode scratch (proposal tables of a call) per HIP stream
 
     def __del__(self):
         try:
@@ -239,15 +247,69 @@ class Engine:
                                              ws.numel(), self._stream()), "irec_beam_encode")
         return out_K, out_idx, sample
 
-    def decode_blocks(self, params, lay, p_loc, p_scale, seed, K, indices):
+    def _decode_ws(self, params, max_K):
+        """Decode scratch of the current stream (the proposal tables of one call), or None when the call needs none."""
+        need = self.lib.irec_decode_workspace_bytes(self.ctx, ctypes.byref(params), int(max_K))
+        if not need:
+            return None
+        key = int(torch.cuda.current_stream(self.device).cuda_stream)
+        ws = self._dec_ws.get(key)
+        if ws is None or ws.numel() < need:
+            if ws is None and len(self._dec_ws) >= 16:
+                self._dec_ws.clear()
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._dec_ws[key] = ws
+        return ws
+
+    def decode_blocks(self, params, lay, p_loc, p_scale, seed, K, indices, mode="auto"):
+        """Asynchronous.  K / indices rows in `lay` order.  mode:
+          "auto"    whole tensors staged in LDS (irec_beam_decode_tensors) when `lay` is a complete layout whose tensors fit,
+                    else "tables";
+          "tensors" / "tensors_fused"   that entry point, with / without the per-call proposal tables;
+          "tables"  block-wise, the call's draw evaluated once into proposal tables where that pays (irec_beam_decode_ws);
+          "fused"   block-wise, Philox in the kernel (irec_beam_decode with dim hints);
+          "legacy"  irec_beam_decode without hints: the round-2 kernel.
+        Same outputs, bit for bit."""
         for t in (p_loc, p_scale):
             assert t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device
         assert K.dtype == torch.int32 and indices.dtype == torch.int32 and indices.is_contiguous()
         sample = torch.empty_like(p_loc)
-        _lib.check(self.lib.irec_beam_decode(self.ctx, ctypes.byref(params), lay.n_blocks, _ptr(lay.block_base),
-                                             _ptr(lay.block_pos), _ptr(lay.block_dim), _ptr(lay.perm), _ptr(p_loc),
-                                             _ptr(p_scale), int(seed), int(indices.shape[1]), _ptr(K), _ptr(indices),
-                                             _ptr(sample), self._stream()), "irec_beam_decode")
+        max_K = int(indices.shape[1])
+        bs_eff = lay.n if lay.block_size is None else int(lay.block_size)
+        fits = lay.natural is not None and bool(self.lib.irec_decode_tensors_supported(ctypes.byref(params), lay.n, bs_eff))
+        if mode == "auto":
+            mode = "tensors" if fits else "tables"
+        if mode in ("tensors", "tensors_fused"):
+            if not fits:
+                raise ValueError("decode mode 'tensors' needs a complete layout whose tensors fit the LDS")
+            if mode == "tensors_fused":
+                params = self.params(params.kl_per_partition, params.n_samples, params.n_beams,
+                                     params.flags | _lib.IREC_FLAG_FUSED_PHILOX, list(params.table_dims), params.table_steps)
+            tparams = self.with_table_dims(params, lay)
+            ws = self._decode_ws(tparams, max_K)
+            _lib.check(self.lib.irec_beam_decode_tensors(self.ctx, ctypes.byref(tparams), lay.n_tensors, lay.n, bs_eff,
+                                                         _ptr(lay.natural_dev()), _ptr(lay.perm), _ptr(p_loc), _ptr(p_scale),
+                                                         int(seed), max_K, _ptr(K), _ptr(indices), _ptr(sample), _ptr(ws),
+                                                         ws.numel() if ws is not None else 0, self._stream()),
+                       "irec_beam_decode_tensors")
+            return sample
+        if mode != "tables":
+            if mode == "fused":
+                params = self.with_table_dims(params, lay)
+            elif mode != "legacy":
+                raise ValueError(f"unknown decode mode {mode!r}")
+            _lib.check(self.lib.irec_beam_decode(self.ctx, ctypes.byref(params), lay.n_blocks, _ptr(lay.block_base),
+                                                 _ptr(lay.block_pos), _ptr(lay.block_dim), _ptr(lay.perm), _ptr(p_loc),
+                                                 _ptr(p_scale), int(seed), max_K, _ptr(K), _ptr(indices),
+                                                 _ptr(sample), self._stream()), "irec_beam_decode")
+            return sample
+        params = self.with_table_dims(params, lay)
+        ws = self._decode_ws(params, max_K)
+        _lib.check(self.lib.irec_beam_decode_ws(self.ctx, ctypes.byref(params), lay.n_blocks, _ptr(lay.block_base),
+                                                _ptr(lay.block_pos), _ptr(lay.block_dim), lay.max_dim, _ptr(lay.perm),
+                                                _ptr(p_loc), _ptr(p_scale), int(seed), max_K, _ptr(K), _ptr(indices),
+                                                _ptr(sample), _ptr(ws), ws.numel() if ws is not None else 0,
+                                                self._stream()), "irec_beam_decode_ws")
         return sample
 
     # ---- test hooks ------------------------------------------------------------------------------------------------

@@ -3,6 +3,8 @@ golden fixtures.  Bar: bit-exact indices, K and codelength; bit-exact samples (t
 north_star is 1e-5 on reconstructions -- we require equality and also assert the 1e-5 bound explicitly)."""
 import os
 
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -367,6 +369,81 @@ def test_decoder_both_table_paths(engine, oracle):
     for i in (0, 511):
         blocks = [ih[lay.natural[i * 9 + j], :Kh[lay.natural[i * 9 + j]]].tolist() for j in range(9)]
         assert np.array_equal(oracle.decode_tensor(mp[i], sp[i], blocks, 42, 36, block_size=bs), sample[i].cpu().numpy())
+
+
+def test_decoder_fast_sqrt_exhaustive(engine):
+    """The decoder's 9-instruction square root (irec_decode.hip: dec_sqrt_core) returns sqrtf's bits -- the correctly rounded
+    value the oracle's libm gives -- for EVERY float32 bit pattern it is allowed to see: all 2^32 patterns are run on the
+    device (the excluded ones, non-zero values below 2^-96, take sqrtf itself)."""
+    out = torch.zeros(2, dtype=torch.int64, device=engine.device)
+    from irec import _lib
+    _lib.check(engine.lib.irec_test_decoder_sqrt(engine.ctx, ctypes.c_void_p(out.data_ptr()), engine._stream()), "irec_test_decoder_sqrt")
+    bad, seen = (int(v) for v in out.cpu())
+    assert seen > 1_800_000_000 and bad == 0, (bad, seen)   # 224 binades x 2^23 + the zeros, +inf and the NaN patterns
+
+
+def test_decoder_tiny_variances_take_the_slow_sqrt(engine, oracle):
+    """Scales so small that a step's auxiliary variance drops below 2^-96: the wave leaves the short square root for sqrtf
+    (scaled inputs); still the encoder's sample and the oracle's, bit for bit."""
+    n = 600
+    mq, sq, mp, sp = oracle.synthetic_latent(31, n)
+    tiny = np.float32(1e-16)
+    mq, sq, mp, sp = (mq * tiny).astype(np.float32), (sq * tiny).astype(np.float32), (mp * tiny).astype(np.float32), (sp * tiny).astype(np.float32)
+    ql, qs, pl, ps = (torch.from_numpy(a[None]).cuda().contiguous() for a in (mq, sq, mp, sp))
+    lay = engine.layout(1, n, 300, 42)
+    params = engine.params(3.0, 20, 10)
+    K, idx, sample = engine.encode_blocks(params, lay, ql, qs, pl, ps, 42, 64)
+    Kh, ih = K.cpu().numpy(), idx.cpu().numpy()
+    assert Kh.min() >= 1
+    for mode in ("auto", "tables", "fused", "legacy", "tensors"):
+        assert torch.equal(engine.decode_blocks(params, lay, pl, ps, 42, K, idx, mode=mode), sample), mode
+    blocks = [ih[lay.natural[j], :Kh[lay.natural[j]]].tolist() for j in range(2)]
+    assert np.array_equal(oracle.decode_tensor(mp, sp, blocks, 42, 20, block_size=300), sample[0].cpu().numpy())
+
+
+@pytest.mark.parametrize("n_t,n,bs,omega,eps1,B", [(64, 8192, 1000, 3.0, 1.2, 20), (3, 8192, 1000, 3.0, 1.2, 20),
+                                                   (2, 301056, 1000, 3.0, 1.0, 10), (5, 1234, 300, 2.0, 1.0, 1),
+                                                   (4, 4099, 4099, 3.0, 1.5, 5), (3, 700, 7, 3.0, 1.0, 10),
+                                                   (1, 5000, 1000, 5.0, 1.2, 3), (2, 12000, 1000, 3.0, 1.0, 10)])
+def test_decoder_variants_agree_with_the_oracle(engine, oracle, n_t, n, bs, omega, eps1, B):
+    """Round 3 decoder (irec_decode.hip): one wave per 256 dims of a block, index path held in a lane vector, rows from the
+    per-call proposal tables ("tables") or from the fused Philox draw ("fused"); the round-2 kernel ("legacy") serves calls
+    without dim hints.  All three must reproduce the encoder's sample bit for bit, and the oracle's decode_tensor of the same
+    indices (beam_search_coder.py:124-148, coder.py:459-491): ragged tails, blocks of more than 1024 dims, 7-dim blocks whose
+    rows do not start on a Philox-block boundary, tensors larger than the LDS, S larger than the block count."""
+    S = oracle.n_samples(omega, eps1)
+    stats = [oracle.synthetic_latent(7000 + i, n) for i in range(n_t)]
+    ql, qs, pl, ps = (torch.from_numpy(np.stack([s[k] for s in stats])).cuda().contiguous() for k in range(4))
+    lay = engine.layout(n_t, n, bs, 42)
+    params = engine.params(omega, S, B)
+    max_K = 96
+    K, idx, sample = engine.encode_blocks(params, lay, ql, qs, pl, ps, 42, max_K)
+    assert int(K.max()) <= max_K and int(K.min()) >= 0
+    modes = ["auto", "tables", "fused", "legacy"]
+    if engine.lib.irec_decode_tensors_supported(ctypes.byref(params), n, min(bs, n)):
+        modes += ["tensors", "tensors_fused"]
+    else:
+        assert n > 10000 or lay.n_blocks // n_t > 10      # (tensors beyond the LDS, or of more units than a workgroup takes)
+    for mode in modes:
+        rec = engine.decode_blocks(params, lay, pl, ps, 42, K, idx, mode=mode)
+        assert torch.equal(rec, sample), mode
+    # a table window shorter than the longest index path: those blocks draw in the kernel
+    short = engine.params(omega, S, B, table_steps=max(1, int(K.max()) // 2))
+    assert torch.equal(engine.decode_blocks(short, lay, pl, ps, 42, K, idx), sample)
+    Kh, ih = K.cpu().numpy(), idx.cpu().numpy()
+    bpt = lay.blocks_per_tensor
+    for i in sorted({0, n_t - 1}):
+        blocks = [ih[lay.natural[i * bpt + j], :Kh[lay.natural[i * bpt + j]]].tolist() for j in range(bpt)]
+        if bpt > 40:                                     # (the oracle decodes a sample of the blocks of a big tensor)
+            perm = oracle.tf_shuffle_perm(42, n)
+            for j in (0, bpt // 2, bpt - 1):
+                lo, hi = oracle.split_blocks(n, bs)[j]
+                g = perm[lo:hi]
+                want = oracle.decode_block(stats[i][2][g], stats[i][3][g], blocks[j], 42, S)
+                assert np.array_equal(sample[i].cpu().numpy()[g], want)
+        else:
+            want = oracle.decode_tensor(stats[i][2], stats[i][3], blocks, 42, S, block_size=bs)
+            assert np.array_equal(sample[i].cpu().numpy(), want)
 
 
 @pytest.mark.parametrize("flags", [8, 0, 4, 2], ids=["table", "auto", "one_table", "fused"])
