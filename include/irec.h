@@ -56,7 +56,8 @@ typedef struct {
                           /* block; a block whose dim is not listed gets out_K = -1.  All zero = no hint.       */
   int32_t table_steps;    /* partitions the proposal tables cover (0 = IREC_TABLE_STEPS_DEFAULT), clamped to    */
                           /* [1, min(max_K, IREC_TABLE_STEPS_MAX)] and to what IREC_TABLE_BYTES_MAX holds of the */
-                          /* call's tables (2 * S * sum of the table dims bytes per step).  Table scratch is     */
+                          /* call's tables (2 * S * sum of the table dims bytes per step; at least               */
+                          /* IREC_TABLE_STEPS_FLOOR steps within IREC_TABLE_BYTES_HARD).  Table scratch is       */
                           /* O(table_steps * S * D): a block with more partitions is coded by the fused-Philox   */
                           /* kernel in a second pass of the same call -- same outputs, bit for bit.              */
 } irec_params;
@@ -97,6 +98,8 @@ typedef struct {
 #define IREC_TABLE_STEPS_DEFAULT 32
 #define IREC_TABLE_STEPS_MAX 4096
 #define IREC_TABLE_BYTES_MAX (64u << 20)
+#define IREC_TABLE_STEPS_FLOOR 8            /* ... but the byte bound never cuts the window below 8 steps (one step of S = 8103, */
+#define IREC_TABLE_BYTES_HARD (1u << 30)    /* the reference's largest, is 19 MB for 1000 + 192 dims) unless those exceed 1 GB   */
 
 /* What irec_beam_encode does for a given call: filled by irec_encode_plan (same decision code as the launch). */
 typedef struct {

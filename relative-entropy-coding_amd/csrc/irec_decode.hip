@@ -256,15 +256,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(IREC_DEC_W
   const int n = A.tn, bs = A.tbs, bpt = A.tbpt;
   const int upb = (bs + 255) >> 8;                          // units of a full block
   const int upt = bpt * upb;                                // unit slots per tensor (the short last block leaves some empty)
-  // A thread's share of a tensor for the staging passes: 16 floats (four 16-byte pieces when the tensor allows), enough for
-  // every tensor the host sends here (n <= 1024 * NW <= 16 * NT).
+  // A thread's share of a tensor for the staging passes: PF = 4 * RMAX floats (RMAX 16-byte pieces when the tensor allows).
+  // Enough for every tensor the host sends here: its unit slots cover it (upt * 256 >= n) and NW * RMAX >= upt, so
+  // NT * 4 * RMAX >= n.
+  constexpr int PF = 4 * DEC_RMAX;
   const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(A.p_scale) | reinterpret_cast<uintptr_t>(A.p_loc) |
                                       reinterpret_cast<uintptr_t>(A.out_sample)) & 15) == 0;
-  auto fetch16 = [&](const float *src, float (&v)[16]) {
+  auto fetch16 = [&](const float *src, float (&v)[PF]) {
     if (vec) {
       const float4 *s4 = reinterpret_cast<const float4 *>(src);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < DEC_RMAX; ++k) {
         const int i = k * NT + tid;
         float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
         if (4 * i < n) q = s4[i];
@@ -272,10 +274,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(IREC_DEC_W
       }
     } else {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) { const int i = k * NT + tid; v[k] = i < n ? src[i] : 0.f; }
+      for (int k = 0; k < PF; ++k) { const int i = k * NT + tid; v[k] = i < n ? src[i] : 0.f; }
     }
   };
-  float psn[16];                                            // sigma_p of the NEXT tensor, fetched a tensor ahead
+  float psn[PF];                                            // sigma_p of the NEXT tensor, fetched a tensor ahead
   if ((int64_t)blockIdx.x < A.n_tensors && !(IREC_DEC_ABLATE & 1)) fetch16(A.p_scale + (int64_t)blockIdx.x * n, psn);
   for (int64_t tensor = blockIdx.x; tensor < A.n_tensors; tensor += gridDim.x) {
     const int64_t base = tensor * (int64_t)n;
@@ -283,13 +285,13 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(IREC_DEC_W
     if (!(IREC_DEC_ABLATE & 1)) {
       if (vec) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < DEC_RMAX; ++k) {
           const int i = k * NT + tid;
           if (4 * i < n) reinterpret_cast<float4 *>(region)[i] = make_float4(psn[4 * k], psn[4 * k + 1], psn[4 * k + 2], psn[4 * k + 3]);
         }
       } else {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { const int i = k * NT + tid; if (i < n) region[i] = psn[k]; }
+        for (int k = 0; k < PF; ++k) { const int i = k * NT + tid; if (i < n) region[i] = psn[k]; }
       }
     }
     __syncthreads();
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(IREC_DEC_W
     // global reads of the passes to come, issued now that the unit loop has released its registers: mu_p of this tensor (added
     // in natural order when the region leaves) and sigma_p of the next one.  Their latency hides behind the barriers and the
     // merge below -- and behind the other workgroup of the CU.
-    float pln[16];
+    float pln[PF];
     if (!(IREC_DEC_ABLATE & 1)) {
       fetch16(A.p_loc + base, pln);
       // (unconditional, so that psn is dead across the unit loop: the last round fetches its own tensor again)
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(IREC_DEC_W
     if (!(IREC_DEC_ABLATE & 1)) {                           // sample + coding_dist.loc (:148), leaving in natural order
       if (vec) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < DEC_RMAX; ++k) {
           const int i = k * NT + tid;
           if (4 * i < n) {
             const float4 sv = reinterpret_cast<const float4 *>(region)[i];
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(IREC_DEC_W
         }
       } else {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { const int i = k * NT + tid; if (i < n) A.out_sample[base + i] = region[i] + pln[k]; }
+        for (int k = 0; k < PF; ++k) { const int i = k * NT + tid; if (i < n) A.out_sample[base + i] = region[i] + pln[k]; }
       }
     }
   }

@@ -19,12 +19,16 @@ __device__ __forceinline__ int64_t src_index(const EncArgs &A, int64_t base, int
 // Diagnostic phase stamps (only when EncArgs.dbg != nullptr; the values never reach an output of the coder).
 __device__ __forceinline__ unsigned long long stamp_now() { return __builtin_amdgcn_s_memtime(); }
 
-// Small per-workgroup (or per-team) LDS state shared by the encoders; MB = most beams the kernel serves.
-template <int MB>
+// Small per-workgroup (or per-team) LDS state shared by the encoders; MB = most beams the kernel serves, CPW = beams the
+// C_b partial rows hold, NC = survivors of the threshold selection that can be refined (64: ranked directly; more beams than
+// ~32 leave more than 64 candidates above the B-th largest lane maximum, see select_topB_sync).
+template <int MB, int CPW = 32, int NC = 64>
 struct SmallLdsT {
+  static constexpr int CANDS = NC;
+  static constexpr int CP = CPW;
   union {                           // the two selection paths never run at the same time
     unsigned long long wb[32];      // per-wave maxima of the scan-based selection, double buffered (<= 16 waves)
-    unsigned long long cand[64];    // compacted (key, flat) survivors of the threshold selection
+    unsigned long long cand[NC];    // compacted (key, flat) survivors of the threshold selection
   };
   int32_t sel_s[MB], sel_b[MB];     // selected (sample, beam) per new beam
   uint32_t sel_bo[MB];              // 4 * dlog(hash) of the selected parent beam (team encoder)
@@ -33,9 +37,9 @@ struct SmallLdsT {
   int32_t misc[8];                  // [0] block id, [1] K, [7] selection path flag
   union {                           // KL partials are consumed before the first C_b partial is written
     double gpart[4];                // per dim-group KL partial sums
-    float cpart[4][32];             // per dim-group partial C_b
+    float cpart[4][CPW];            // per dim-group partial C_b
   };
-  float Cb[32];                     // C_b of the live beams
+  float Cb[CPW];                    // C_b of the live beams
 };
 using SmallLds = SmallLdsT<64>;
 constexpr size_t SMALL_LDS_BYTES = (sizeof(SmallLds) + 15) & ~(size_t)15;
@@ -57,6 +61,67 @@ constexpr size_t SMALL_LDS_BYTES = (sizeof(SmallLds) + 15) & ~(size_t)15;
 // `post(j, s, b, key)` is called by the thread that has just recorded new beam j = candidate (sample s, parent beam b)
 // with sort key `key`, before the barrier that publishes the selection.
 struct NoPost { __device__ __forceinline__ void operator()(int, int32_t, int32_t, uint32_t) const {} };
+// Stage 3 of the threshold selection, run by ONE wave (lane = tid < 64): cand[0, C) holds the (key, flat) pairs of every
+// candidate >= T, at least Bnew of them.  Ranks them by (key descending, flat ascending) and records rank r < Bnew as new beam
+// r (sel_s / sel_b, post()).  More than 64 survivors (many beams: the B-th largest of 64 lane maxima leaves ~2 B candidates
+// above it) are first cut down: the exact Bnew-th largest key T' is found bit by bit -- 32 rounds of "how many survivors
+// are >= T' | bit" over the <= NC / 64 survivors a lane holds in registers -- and the survivors >= T' are compacted again.
+// Returns false when more than 64 candidates remain at the threshold (ties) or C exceeded the buffer: caller falls back.
+template <class SM, class Post>
+__device__ __forceinline__ bool rank_survivors(SM *sm, uint32_t C, int Bnew, int Bcur, int tid, Post &&post) {
+  constexpr int NQ = SM::CANDS / 64;
+  if (C > (uint32_t)SM::CANDS) return false;
+  if (C > 64u) {
+    if constexpr (NQ > 1) {
+      uint32_t mk[NQ], mf[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const uint32_t at = (uint32_t)(q * 64 + tid);
+        const unsigned long long v = at < C ? sm->cand[at] : 0ull;
+        mk[q] = (uint32_t)(v >> 32); mf[q] = (uint32_t)v;
+      }
+      uint32_t T2 = 0u;
+      for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t tryT = T2 | (1u << bit);
+        uint32_t cnt = 0u;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) cnt += (uint32_t)__popcll(__ballot(mk[q] >= tryT));
+        if (cnt >= (uint32_t)Bnew) T2 = tryT;                // wave-uniform
+      }
+      uint32_t base = 0u;                                    // compact the survivors >= T2 (all reads above are complete)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const bool in = mk[q] >= T2 && mk[q] != 0u;
+        const unsigned long long mask = __ballot(in);
+        const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (in && pos < 64u) sm->cand[pos] = ((unsigned long long)mk[q] << 32) | mf[q];
+        base += (uint32_t)__popcll(mask);
+      }
+      C = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      if (C > 64u) return false;
+    } else {
+      return false;
+    }
+  }
+  // rank the C <= 64 survivors; lanes >= C hold a null candidate
+  const unsigned long long mine = tid < (int)C ? sm->cand[tid] : 0ull;
+  const uint32_t mk1 = (uint32_t)(mine >> 32), mf1 = (uint32_t)mine;
+  uint32_t rank = 0u;
+  for (uint32_t l = 0; l < C; ++l) {
+    const uint32_t ok_ = (uint32_t)__builtin_amdgcn_readlane((int)mk1, (int)l);
+    const uint32_t of_ = (uint32_t)__builtin_amdgcn_readlane((int)mf1, (int)l);
+    rank += (ok_ > mk1 || (ok_ == mk1 && of_ < mf1)) ? 1u : 0u;
+  }
+  if (tid < (int)C && rank < (uint32_t)Bnew) {
+    const int32_t s_ = (int32_t)(mf1 / (uint32_t)Bcur); // best_ind_aux  (beam_search_coder.py:89)
+    const int32_t b_ = (int32_t)(mf1 % (uint32_t)Bcur); // best_ind_beam (beam_search_coder.py:88)
+    sm->sel_s[rank] = s_;
+    sm->sel_b[rank] = b_;
+    post((int)rank, s_, b_, mk1);
+  }
+  return true;
+}
+
 template <int NT, class SM, class Sync, class Post = NoPost>
 __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew, int Bcur, SM *sm, const int tid, Sync &&sync,
                                                  unsigned long long *dbg = nullptr, Post &&post = Post()) {
@@ -92,32 +157,12 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
           const bool in = k[q] >= T;
           const unsigned long long mask = __ballot(in);
           const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-          if (in && pos < 64u) sm->cand[pos] = ((unsigned long long)k[q] << 32) | (uint32_t)(q * 64 + tid);
+          if (in && pos < (uint32_t)SM::CANDS) sm->cand[pos] = ((unsigned long long)k[q] << 32) | (uint32_t)(q * 64 + tid);
           base += (uint32_t)__popcll(mask);
         }
       }
       const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      if (C <= 64u) {
-        // 3. rank the C survivors; lanes >= C hold a null candidate
-        const unsigned long long mine = tid < (int)C ? sm->cand[tid] : 0ull;
-        const uint32_t mk = (uint32_t)(mine >> 32), mf = (uint32_t)mine;
-        uint32_t rank = 0u;
-        for (uint32_t l = 0; l < C; ++l) {
-          const uint32_t ok_ = (uint32_t)__builtin_amdgcn_readlane((int)mk, (int)l);
-          const uint32_t of_ = (uint32_t)__builtin_amdgcn_readlane((int)mf, (int)l);
-          rank += (ok_ > mk || (ok_ == mk && of_ < mf)) ? 1u : 0u;
-        }
-        if (tid < (int)C && rank < (uint32_t)Bnew) {
-          const int32_t s_ = (int32_t)(mf / (uint32_t)Bcur); // best_ind_aux  (beam_search_coder.py:89)
-          const int32_t b_ = (int32_t)(mf % (uint32_t)Bcur); // best_ind_beam (beam_search_coder.py:88)
-          sel_s[rank] = s_;
-          sel_b[rank] = b_;
-          post((int)rank, s_, b_, mk);
-        }
-        sm->misc[7] = 1;
-      } else {
-        sm->misc[7] = 0; // pathological tie storm: fall back to the scan below
-      }
+      sm->misc[7] = rank_survivors(sm, C, Bnew, Bcur, tid, post) ? 1 : 0;   // 0: pathological tie storm -> the scan below
       __builtin_amdgcn_s_setprio(0);
       if (dbg && tid == 0) { const unsigned long long t1 = stamp_now(); dbg[9] += t1 - t0; t0 = t1; } // wave-0 selection
     }
@@ -150,7 +195,7 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
         const unsigned long long mask = __ballot(in);
         if (mask) {                                          // wave-uniform
           const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-          if (in && pos < 64u) sm->cand[pos] = ((unsigned long long)k << 32) | flat;
+          if (in && pos < (uint32_t)SM::CANDS) sm->cand[pos] = ((unsigned long long)k << 32) | flat;
           base += (uint32_t)__popcll(mask);
         }
       };
@@ -171,25 +216,7 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
         put(k >= T, k, (uint32_t)f);
       }
       const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      if (C <= 64u) {
-        const unsigned long long mine = tid < (int)C ? sm->cand[tid] : 0ull;
-        const uint32_t mk = (uint32_t)(mine >> 32), mf = (uint32_t)mine;
-        uint32_t rank = 0u;
-        for (uint32_t l = 0; l < C; ++l) {
-          const uint32_t ok_ = (uint32_t)__builtin_amdgcn_readlane((int)mk, (int)l);
-          const uint32_t of_ = (uint32_t)__builtin_amdgcn_readlane((int)mf, (int)l);
-          rank += (ok_ > mk || (ok_ == mk && of_ < mf)) ? 1u : 0u;
-        }
-        if (tid < (int)C && rank < (uint32_t)Bnew) {
-          const int32_t s_ = (int32_t)(mf / (uint32_t)Bcur), b_ = (int32_t)(mf % (uint32_t)Bcur);
-          sel_s[rank] = s_;
-          sel_b[rank] = b_;
-          post((int)rank, s_, b_, mk);
-        }
-        sm->misc[7] = 1;
-      } else {
-        sm->misc[7] = 0;
-      }
+      sm->misc[7] = rank_survivors(sm, C, Bnew, Bcur, tid, post) ? 1 : 0;
       __builtin_amdgcn_s_setprio(0);
     }
     sync();

@@ -481,6 +481,7 @@ struct Plan {
   bool fast;         // register-resident fast encoder with the Philox draw fused in
   bool table;        // fast encoder fed by per-call proposal tables (Philox hoisted out of the block kernel)
   bool team;         // table && two-teams-per-CU encoder over three table copies (the default where it applies)
+  bool team_only;    // B > 32: no one-table / fused fast encoder exists; the team encoder takes every call, the generic kernel its deferred pass
   int shape;         // team-encoder workgroup shape override (IREC_FLAG_SHAPE_*; 0 = default)
   int grid_cap;      // scratch slabs = resident workgroups / teams (persistent kernels pull blocks from an atomic counter)
   int one_grid_cap;  // resident workgroups of the one-workgroup-per-block encoder of this plan (small calls of a team plan too)
@@ -493,6 +494,13 @@ struct Plan {
   size_t tab_off[4]; // byte offsets of the proposal tables inside the workspace (after the 256-byte counter block)
   size_t tab_bytes;  // total
 };
+
+// steps of proposal tables the byte bounds allow at `per_step` bytes per step: what IREC_TABLE_BYTES_MAX holds, but not fewer
+// than IREC_TABLE_STEPS_FLOOR while those stay within IREC_TABLE_BYTES_HARD
+size_t table_steps_that_fit(size_t per_step) {
+  const size_t soft = (size_t)IREC_TABLE_BYTES_MAX / per_step, hard = (size_t)IREC_TABLE_BYTES_HARD / per_step;
+  return std::max(soft, std::min<size_t>((size_t)IREC_TABLE_STEPS_FLOOR, hard));
+}
 
 irec_status check_params(const irec_params *p) {
   if (!p) return fail(IREC_E_INVALID, "null irec_params");
@@ -520,9 +528,13 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
   {
     size_t per_step = 0;   // bytes of one partition step over all tables of the call
     for (int q = 0; q < 4 && p->table_dims[q] > 0; ++q) per_step += (size_t)S * round_up(p->table_dims[q], 4) * 2;
-    if (per_step > 0) pl.K_tab = std::max(1, (int)std::min<size_t>((size_t)pl.K_tab, (size_t)IREC_TABLE_BYTES_MAX / per_step));
+    if (per_step > 0) pl.K_tab = std::max(1, (int)std::min<size_t>((size_t)pl.K_tab, table_steps_that_fit(per_step)));
   }
-  if (pl.fast && !(p->flags & IREC_FLAG_FUSED_PHILOX) && p->table_dims[0] > 0) {
+  // B > 32 has no one-workgroup-per-block encoder; where the team encoder serves it (32 < B <= 60) it is the only table
+  // consumer and its deferred pass is the generic kernel
+  pl.team_only = !pl.fast && !(p->flags & IREC_FLAG_FORCE_GENERIC) && max_dim <= irec::FAST_MAX_DIM && (int64_t)S * B < (1 << 24) &&
+                 !(p->flags & (IREC_FLAG_FUSED_PHILOX | IREC_FLAG_ONE_TABLE)) && irec::team_lds_for(B, S, pl.shape) != (size_t)-1;
+  if ((pl.fast || pl.team_only) && !(p->flags & IREC_FLAG_FUSED_PHILOX) && p->table_dims[0] > 0) {
     pl.table = true;
     for (int q = 0; q < 4 && p->table_dims[q] > 0; ++q) {
       if (p->table_dims[q] > irec::FAST_MAX_DIM) { pl.table = false; break; }
@@ -533,8 +545,10 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
     }
     if (!pl.table) { pl.n_tab = 0; pl.tab_bytes = 0; }
     pl.team = pl.table && !(p->flags & IREC_FLAG_ONE_TABLE) && irec::team_lds_for(B, S, pl.shape) != (size_t)-1;
+    if (pl.team_only && !pl.team) { pl.table = false; pl.n_tab = 0; pl.tab_bytes = 0; }
     if (pl.team) pl.grid_cap = irec::team_count_for(B, S, pl.shape) * n_cu; // one scratch slab per team
   }
+  if (!pl.table) pl.team_only = false;
   // resident workgroups of the one-workgroup-per-block encoders: two per CU, one for the big-LDS 8-wave configurations
   auto one_cap = [&](bool table) { return (irec::fast_waves_for(B, S, table) == 8 ? 1 : 2) * n_cu; };
   if (pl.fast) {
@@ -543,10 +557,19 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
     if (!pl.team) pl.grid_cap = pl.one_grid_cap;
     pl.grid_cap = std::max(pl.grid_cap, pl.fast_grid_cap);          // both passes index the same slabs
     pl.ws_per_wg = round_up_sz(irec::fast_ws_for(B, max_K) + (pl.team ? irec::team_ws_extra_for(B, S, pl.shape) : 0), 256);
+    if (pl.team) pl.ws_per_wg = std::max(pl.ws_per_wg, round_up_sz(irec::team_ws_bytes_for(B, S, pl.shape, max_K), 256));
   } else {
-    pl.one_grid_cap = pl.grid_cap; pl.fast_grid_cap = 0;
-    pl.ws_per_wg = round_up_sz((size_t)10 * pl.dpad * 4 + (size_t)2 * B * pl.dpad * 4 +
-                                   (size_t)(max_K > 0 ? max_K : 1) * B * 4 + (size_t)S * B * 4, 256);
+    const size_t generic_ws = round_up_sz((size_t)10 * pl.dpad * 4 + (size_t)2 * B * pl.dpad * 4 +
+                                          (size_t)(max_K > 0 ? max_K : 1) * B * 4 + (size_t)S * B * 4, 256);
+    if (pl.team_only) {   // slabs serve the team encoder and, for blocks beyond the table window, the generic kernel
+      pl.one_grid_cap = 0;
+      pl.fast_grid_cap = 2 * n_cu;
+      pl.grid_cap = std::max(pl.grid_cap, pl.fast_grid_cap);
+      pl.ws_per_wg = std::max(generic_ws, round_up_sz(irec::team_ws_bytes_for(B, S, pl.shape, max_K), 256));
+    } else {
+      pl.one_grid_cap = pl.grid_cap; pl.fast_grid_cap = 0;
+      pl.ws_per_wg = generic_ws;
+    }
   }
   if (!pl.table) pl.K_tab = 0;
   return pl;
@@ -586,7 +609,7 @@ int split_beam_width(const irec_params *p, int W) {
 // table, 40 KB of LDS to fill) beats the team encoder's (38 us per table for the bank assignment, 120 KB); the scratch
 // sized for the team plan covers both
 bool team_for_call(const Plan &pl, const irec_params *p, int64_t n_blocks) {
-  return pl.team && ((p->flags & IREC_FLAG_TEAM) || n_blocks >= 64);
+  return pl.team && (pl.team_only || (p->flags & IREC_FLAG_TEAM) || n_blocks >= 64);
 }
 // Workgroup shape of the team encoder for THIS call.  With at most one block per CU a lone 4-wave team is latency-bound
 // (one wave per SIMD, ~43 us per step at B = 20, S = 36): the 8-wave beam-striped team (two stripes of 10 beams: half the
@@ -769,7 +792,8 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
       A2.deferred_pass = 1; A2.coop_W = 1;
       A2.counter = (unsigned int *)workspace + 2;
       for (int q = 0; q < 4; ++q) { A2.tab[q] = nullptr; A2.tab_dim[q] = -1; }
-      HIP_TRY(irec::launch_encode_fast(A2, false, (int)std::min<int64_t>(n_blocks, pl.fast_grid_cap), st));
+      if (pl.team_only) HIP_TRY(irec::launch_encode_generic(A2, (int)std::min<int64_t>(n_blocks, pl.fast_grid_cap), st));
+      else HIP_TRY(irec::launch_encode_fast(A2, false, (int)std::min<int64_t>(n_blocks, pl.fast_grid_cap), st));
       return IREC_OK;
     };
     if (pl.team) { // grid_cap counts teams (= scratch slabs): two per workgroup, one workgroup per CU
@@ -852,7 +876,7 @@ static DecPlan make_dec_plan(const irec_params *p, int64_t n_blocks, int32_t max
   for (int q = 0; q < 4 && p->table_dims[q] > 0; ++q) per_step += (size_t)p->n_samples * round_up(p->table_dims[q], 4) * 2;
   const int want = p->table_steps > 0 ? p->table_steps : IREC_TABLE_STEPS_DEFAULT;
   int kt = std::min(std::min(want, IREC_TABLE_STEPS_MAX), (int)max_K);
-  kt = (int)std::min<size_t>((size_t)kt, (size_t)IREC_TABLE_BYTES_MAX / per_step);
+  kt = (int)std::min<size_t>((size_t)kt, table_steps_that_fit(per_step));
   if (kt < 1) return d;
   d.K_tab = kt;
   for (int q = 0; q < 4 && p->table_dims[q] > 0; ++q) {

@@ -81,6 +81,7 @@ hipError_t launch_alpha_table(int64_t seed, int32_t S, int32_t D, int32_t K_tab,
 int team_count_for(int B, int S, int shape_override);   // teams per workgroup (= scratch slabs per workgroup) of the build that serves B beams
 int team_waves_for(int B, int S, int shape_override);   // waves per workgroup of that build
 size_t team_ws_extra_for(int B, int S, int shape_override); // extra scratch-slab bytes of that build
+size_t team_ws_bytes_for(int B, int S, int shape_override, int max_K);   // whole scratch slab of one team of that build
 size_t team_lds_for(int B, int S, int shape_override);  // LDS bytes of one workgroup, or (size_t)-1 when the configuration is not served
 hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st);
 const char *team_kernel_name(int B, int S, int shape_override);   // e.g. "encode_team_kernel<20,2,1>"

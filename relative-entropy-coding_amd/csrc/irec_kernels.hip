@@ -127,6 +127,11 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
     __syncthreads();
     const int64_t blk = misc[0];
     if (blk >= A.n_blocks) break; // every wave of every workgroup reaches this
+    if (A.deferred_pass) { // second pass of a windowed-table call of the team encoder (B > 32): only the blocks it left
+      if (*A.defer_count == 0u) break;   // (uniform over the grid: nothing was deferred)
+      const int32_t k1 = A.out_K[blk];
+      if (k1 <= A.K_tab || k1 > A.max_K) continue;
+    }
     const int D = A.block_dim[blk];
     const int64_t base = A.block_base[blk];
     const int32_t pos = A.block_pos[blk];
@@ -999,9 +1004,9 @@ __global__ void uniform_int_kernel(int64_t seed, int64_t n, int32_t *out) {
 // scores[N] float -> sel[2 * Bnew] = (sample, beam) of the Bnew best candidates in order (tie -> lower flat index)
 __global__ __launch_bounds__(256) void select_test_kernel(const float *scores, int N, int Bnew, int Bcur, uint32_t *keys,
                                                           int32_t *sel) {
-  __shared__ SmallLds sm;
+  __shared__ SmallLdsT<64, 64, 512> sm;   // (the 60-beam team build's: room to refine up to 512 survivors)
   for (int f = threadIdx.x; f < N; f += 256) keys[f] = score_key(scores[f]);
-  select_topB<256>(keys, N, Bnew, Bcur, &sm);
+  select_topB_sync<256>(keys, N, Bnew, Bcur, &sm, (int)threadIdx.x, WorkgroupSync());
   if (threadIdx.x < Bnew) { sel[2 * threadIdx.x] = sm.sel_s[threadIdx.x]; sel[2 * threadIdx.x + 1] = sm.sel_b[threadIdx.x]; }
 }
 

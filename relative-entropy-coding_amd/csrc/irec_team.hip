@@ -49,44 +49,58 @@ namespace irec {
 
 constexpr int TEAM_NW = 4;                       // waves per team
 constexpr int TEAM_NT = TEAM_NW * 64;            // threads per team
-constexpr int TEAM_MB = 32;                      // beams a team serves at most (sizes its small LDS arrays)
-using TeamLds = SmallLdsT<TEAM_MB>;
-constexpr size_t TEAM_SMALL_BYTES = (sizeof(TeamLds) + 15) & ~(size_t)15;
+// beams a team serves at most (sizes its small LDS arrays): 32 for the builds of up to 32 beams -- the three-team 20-beam
+// build has no LDS to spare -- and 64 (with room for 512 selection survivors) for the 60-beam build
+__host__ __device__ constexpr int team_mb(int NB) { return NB <= 32 ? 32 : 64; }
+template <int NB> using TeamLdsT = SmallLdsT<(NB <= 32 ? 32 : 64), (NB <= 32 ? 32 : 64), (NB <= 32 ? 64 : 512)>;
+__host__ __device__ inline size_t team_small_bytes(int NB) {
+  return NB <= 32 ? ((sizeof(TeamLdsT<32>) + 15) & ~(size_t)15) : ((sizeof(TeamLdsT<64>) + 15) & ~(size_t)15);
+}
 constexpr uint32_t T3_FLOATS = 3u * IREC_PM1;    // three copies of lut2
 constexpr size_t T3_BYTES = ((size_t)T3_FLOATS * 4 + 15) & ~(size_t)15;
 
 // Sample passes.  The per-group partial scores of SP samples sit in LDS at a time ([4][SP][NB] f32); a step scores S in
 // ceil(S / SP) passes, each followed by the group combine into the sort keys ([S*NB] u32, all of them resident).  Every
 // BASELINE configuration with B <= 20 takes one pass; the 30-beam stress configuration (S = 148) takes four of 37.
-__host__ __device__ inline size_t team_key_bytes(int NB, int S) { return (((size_t)S * NB * 4) + 15) & ~(size_t)15; }
+// (`ps` below: beam slots per sample in the partial-score rows and the key array -- NB, or 1 when the call has ONE beam
+//  (B = 1 of the reference's sweep: a 10-beam layout would spend ten times the LDS per sample and ten times the passes))
+__host__ __device__ inline int team_row(int NB, int B) { return (NB == 10 && B == 1) ? 1 : NB; }
+__host__ __device__ inline size_t team_key_bytes(int ps, int S) { return (((size_t)S * ps * 4) + 15) & ~(size_t)15; }
 // Keys in LDS unless they alone would leave room for fewer than 16 samples of partials (single-team builds only: 12 090
 // candidates of B = 30, S = 403 are 48 KB); then they live in the team's scratch slab (L2) and the selection scans them there.
-__host__ __device__ inline bool team_keys_in_lds(int NB, int S, int teams) {
-  const long long avail = (long long)((FAST_LDS_LIMIT - T3_BYTES) / (size_t)teams) - (long long)team_key_bytes(NB, S) -
-                          (long long)TEAM_SMALL_BYTES - 32;
-  return teams > 1 || avail / (4LL * NB * 4) >= (S < 16 ? S : 16);
+// (`passes`: a multi-team build that scores S in passes -- round 3, B <= 10 with more samples than one pass holds; the
+//  other multi-team builds take S in one pass and keep their keys in LDS by construction)
+__host__ __device__ inline bool team_keys_in_lds(int NB, int S, int teams, bool passes, int ps = 0) {
+  if (ps <= 0) ps = NB;
+  const long long avail = (long long)((FAST_LDS_LIMIT - T3_BYTES) / (size_t)teams) - (long long)team_key_bytes(ps, S) -
+                          (long long)team_small_bytes(NB) - 32;
+  return (teams > 1 && !passes) || avail / (4LL * ps * 4) >= (S < 16 ? S : 16);
 }
 // Three 20-beam teams only fit the 160 KB next to the table copies if the sort keys are written over group 0 of the partial
 // scores (key f = s * Bcur + b lands on partial s * NB + b: the same word when Bcur == NB, which every step but the first
 // has; otherwise a barrier separates the partial reads from the key writes).
 __host__ __device__ inline bool team_keys_alias(int NB, int teams) { return teams >= 3 && NB == 20; }
-__host__ __device__ inline int team_s_pass(int NB, int S, int teams, int cmax) {
+__host__ __device__ inline int team_s_pass(int NB, int S, int teams, int cmax, bool passes = false, int ps = 0) {
+  if (ps <= 0) ps = NB;
   const long long avail = (long long)((FAST_LDS_LIMIT - T3_BYTES) / (size_t)teams) -
-                          ((team_keys_in_lds(NB, S, teams) && !team_keys_alias(NB, teams)) ? (long long)team_key_bytes(NB, S) : 0) -
-                          (long long)TEAM_SMALL_BYTES - 32;
-  long long fit = avail / (4LL * NB * 4);           // samples whose partials fit
-  if (fit > cmax / NB) fit = cmax / NB;             // and whose candidates one combine round covers
+                          ((team_keys_in_lds(NB, S, teams, passes, ps) && !(team_keys_alias(NB, teams) && !passes)) ? (long long)team_key_bytes(ps, S) : 0) -
+                          (long long)team_small_bytes(NB) - 32;
+  long long fit = avail / (4LL * ps * 4);           // samples whose partials fit
+  if (fit > cmax / ps) fit = cmax / ps;             // and whose candidates one combine round covers
   if (fit < 1) return 0;
   if (fit >= S) return S;
   const int n_pass = (int)((S + fit - 1) / fit);
   return (S + n_pass - 1) / n_pass;                 // balanced passes
 }
-__host__ __device__ inline size_t team_part_bytes(int NB, int SP) { return (((size_t)4 * SP * NB * 4) + 15) & ~(size_t)15; }
-__host__ __device__ inline size_t team_lds_one(int NB, int S, int SP, int teams) {
-  return team_part_bytes(NB, SP) + ((team_keys_in_lds(NB, S, teams) && !team_keys_alias(NB, teams)) ? team_key_bytes(NB, S) : 0) +
-         TEAM_SMALL_BYTES + 16;
+__host__ __device__ inline size_t team_part_bytes(int ps, int SP) { return (((size_t)4 * SP * ps * 4) + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t team_lds_one(int NB, int S, int SP, int teams, bool passes = false, int ps = 0) {
+  if (ps <= 0) ps = NB;
+  return team_part_bytes(ps, SP) + ((team_keys_in_lds(NB, S, teams, passes, ps) && !(team_keys_alias(NB, teams) && !passes)) ? team_key_bytes(ps, S) : 0) +
+         team_small_bytes(NB) + 16;
 }
-__host__ __device__ inline size_t team_lds_total(int NB, int S, int SP, int teams) { return T3_BYTES + (size_t)teams * team_lds_one(NB, S, SP, teams); }
+__host__ __device__ inline size_t team_lds_total(int NB, int S, int SP, int teams, bool passes = false, int ps = 0) {
+  return T3_BYTES + (size_t)teams * team_lds_one(NB, S, SP, teams, passes, ps);
+}
 
 // Barrier of the 4 waves of one team: a monotonic LDS counter.  LDS operations of one wave execute in program order and
 // the LDS serves one instruction at a time, so a wave's earlier writes are in place before its add lands; the fences
@@ -118,8 +132,16 @@ struct TeamBarrier {
 // LDS carve (bytes): lut2 x 3 [120080] | team 0: part [4][S][NB] f32 | sort keys [S*NB] | TeamLds | barrier | team 1: same
 // BS = beam stripes: with BS == 2 a team has 8 waves, wave w serves dim group / sample stripe (w & 3) and the beams
 // [NBW * (w >> 2), + NBW), NBW = NB / BS: half the G registers per lane (128-VGPR budget, 16 waves per CU).
-template <int NB, int TEAMS, int BS>
+// PASSES: a multi-team build that scores the S samples of a step in several passes and may keep its sort keys in the slab
+// (the single-team builds always can): S beyond what a team's share of the LDS holds -- the reference's sweep reaches
+// S = int(e^9) = 8103 (examples/lossless/data_aggregation.py:5-7).
+template <int NB, int TEAMS, int BS, bool PASSES = false>
 __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(EncArgs A) {
+  using TeamLds = TeamLdsT<NB>;
+  constexpr int TEAM_MB = team_mb(NB);
+  constexpr size_t TEAM_SMALL_BYTES = (sizeof(TeamLds) + 15) & ~(size_t)15;
+  constexpr bool MULTI_PASS = TEAMS == 1 || PASSES;
+  constexpr bool SHORT = TEAMS * BS >= 3 && NB / BS == 20;   // 12 waves per CU x 20 beams per wave: the 168-VGPR builds
   constexpr int NW = TEAM_NW;                    // waves per beam stripe (dim groups x sample stripes)
   constexpr int NWT = TEAM_NW * BS, NT = 64 * NWT; // waves / threads per team
   constexpr int NBW = NB / BS;                   // beams per wave
@@ -127,6 +149,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   // 20 accumulators are reduced together (one sample x 20 beams, or two samples x 10 beams) by the 20-value
   // reduce-scatter: 22 exchange+add pairs instead of the 31 of a zero-padded 32-wide one, and 12 registers fewer
   static_assert(NBW == 10 || NBW == 16 || NBW == 20, "the team encoder is built for 10, 16 or 20 beams per wave");
+  static_assert(NB <= TEAM_MB && NB <= 64, "beam indices are lane indices and 6-bit back-pointers");
   constexpr int CMAX = TEAMS == 1 ? 2048 : 1024;    // candidates one combine round covers (host: SP * NB <= CMAX)
   constexpr int SPC = BS >= 2 ? 1 : 20 / NBW;   // samples per chunk (beam-striped builds: one, to fit 128 VGPRs)
   constexpr int RW = NBW * SPC;                  // accumulators reduced together
@@ -141,14 +164,15 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   const int tid = (int)threadIdx.x - team * NT;                                 // index inside the team
   // samples scored per pass: only the single-team builds take more than one pass (the host checked that the others fit
   // S in one -- then the pass loop below folds away)
-  const int SP = TEAMS == 1 ? team_s_pass(NB, S, TEAMS, CMAX) : S;
-  const bool keys_lds = TEAMS > 1 || team_keys_in_lds(NB, S, TEAMS);            // (compile-time true for the multi-team builds)
-  constexpr bool KEYS_ALIAS = TEAMS >= 3 && NB == 20;                          // team_keys_alias()
-  const size_t key_lds_bytes = (keys_lds && !KEYS_ALIAS) ? team_key_bytes(NB, S) : 0;
-  char *tbase = smem + T3_BYTES + (size_t)team * team_lds_one(NB, S, SP, TEAMS);
-  float *part_s = reinterpret_cast<float *>(tbase);                             // [4][SP][NB] per-group partial scores
-  TeamLds *sm = reinterpret_cast<TeamLds *>(tbase + team_part_bytes(NB, SP) + key_lds_bytes);
-  uint32_t *bar_word = reinterpret_cast<uint32_t *>(tbase + team_part_bytes(NB, SP) + key_lds_bytes + TEAM_SMALL_BYTES);
+  const int PS = NB == 10 ? team_row(NB, B) : NB;                              // beam slots per sample row (1 for a one-beam call)
+  const int SP = MULTI_PASS ? team_s_pass(NB, S, TEAMS, CMAX, PASSES, PS) : S;
+  const bool keys_lds = !MULTI_PASS || team_keys_in_lds(NB, S, TEAMS, PASSES, PS); // (compile-time true for the one-pass multi-team builds)
+  constexpr bool KEYS_ALIAS = TEAMS >= 3 && NB == 20 && !PASSES;               // team_keys_alias()
+  const size_t key_lds_bytes = (keys_lds && !KEYS_ALIAS) ? team_key_bytes(PS, S) : 0;
+  char *tbase = smem + T3_BYTES + (size_t)team * team_lds_one(NB, S, SP, TEAMS, PASSES, PS);
+  float *part_s = reinterpret_cast<float *>(tbase);                             // [4][SP][PS] per-group partial scores
+  TeamLds *sm = reinterpret_cast<TeamLds *>(tbase + team_part_bytes(PS, SP) + key_lds_bytes);
+  uint32_t *bar_word = reinterpret_cast<uint32_t *>(tbase + team_part_bytes(PS, SP) + key_lds_bytes + TEAM_SMALL_BYTES);
   double *gpart = sm->gpart;
   int32_t *sel_s = sm->sel_s, *sel_b = sm->sel_b;
   int32_t *hsum = &sm->hsum[0][0];
@@ -173,9 +197,9 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   TeamBarrier tsync{bar_word, 0u, (uint32_t)NWT};
 
   char *slab = A.ws + ((size_t)blockIdx.x * TEAMS + team) * A.ws_per_wg;
-  const size_t key_glb_bytes = keys_lds ? 0 : ((team_key_bytes(NB, S) + 255) & ~(size_t)255);   // sort keys at the slab's end
+  const size_t key_glb_bytes = keys_lds ? 0 : ((team_key_bytes(PS, S) + 255) & ~(size_t)255);   // sort keys at the slab's end
   uint32_t *key_s = KEYS_ALIAS ? reinterpret_cast<uint32_t *>(tbase)                            // over partial group 0
-                    : keys_lds ? reinterpret_cast<uint32_t *>(tbase + team_part_bytes(NB, SP))     // [S*NB] sort keys
+                    : keys_lds ? reinterpret_cast<uint32_t *>(tbase + team_part_bytes(PS, SP))     // [S*PS] sort keys
                                : reinterpret_cast<uint32_t *>(slab + A.ws_per_wg - key_glb_bytes);
   int32_t *bp = reinterpret_cast<int32_t *>(slab);                                            // [max_K][NB]
   float *beams_g = reinterpret_cast<float *>(slab + A.ws_per_wg - key_glb_bytes - (size_t)2 * NB * FAST_MAX_DIM * 4); // [2][NB][1024]
@@ -183,7 +207,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   float *park_g = stats_g - 2 * FAST_MAX_DIM;   // [2][1024]: c (cumulative variance) and sa of the PARK builds
   // Three-team builds have 168 VGPRs: the cumulative variance and the sample scale (needed only by the update) are parked
   // in the slab across the scoring loop instead of being spilled inside it
-  constexpr bool PARK = TEAMS >= 3 && NBW == 20;
+  constexpr bool PARK = SHORT;
   constexpr bool LATE_G = false;   // (tried: new beams wait in G's registers and G is formed after the batches -- the
                                    //  register allocator then shuffles eight registers through scratch per beam: 844 B)
 
@@ -229,7 +253,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
     // the wave that reads a dim group's statistics keeps them in registers; only the other waves of the group (sample /
     // beam stripes of short blocks and of the striped builds) re-read them from the slab every step
     float own_dmu[4], own_vq[4], own_vp[4];
-    const bool own_stats = active && sw == 0 && bs == 0 && TEAMS < 3;   // (three-team builds: 168 VGPRs, the slab keeps them)
+    const bool own_stats = active && sw == 0 && bs == 0 && TEAMS < 3 && !SHORT;   // (168-VGPR builds: the slab keeps them)
     double klacc = 0.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -336,7 +360,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         cacc = beam_C_term(cacc, 0.f, m[i], cA[i], cBv[i]);
       }
       const float cg = wave_tree_sum(cacc);
-      if (active && sw == 0 && bs == 0 && lane == 0) cpart_s[g * 32 + 0] = cg;
+      if (active && sw == 0 && bs == 0 && lane == 0) cpart_s[g * TEAM_MB + 0] = cg;
       // (visibility of the C_b partials: the barrier after scoring)
     }
 
@@ -365,7 +389,10 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 #ifdef IREC_ABLATE_SCORING
       if (false) {
 #else
-      if (active && nlive == NBW) {
+      // Steady state: every beam of my stripe alive -- or at least half of them (B = 50 on the 60-beam build: the third stripe
+      // holds beams 40..49): the dead ones are scored as PHANTOM beams (G = 0, the address of beam 0: finite values that no
+      // candidate ever reads) rather than sending the whole stripe down the beam-by-beam path below.
+      if (active && Bcur > 1 && (nlive == NBW || 2 * nlive >= NBW)) {
         // Steady state, software pipelined by dim slot: the NBW gathers of the NEXT slot (of this sample, of the chunk's
         // next sample, or of the next chunk's first sample) are issued before the current slot's values are consumed, so
         // the wave always has look-ups in flight -- also under the fma chain and the reduce-scatter.  A wave can have at
@@ -393,7 +420,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         // Pipeline granule: a whole dim slot (NP beam pairs per look-up buffer), or HALF a slot for the three-team
         // 20-beam build (5 pairs per buffer: 20 instead of 40 look-up registers -- three waves per SIMD hide what the
         // shallower pipeline exposes).
-        constexpr int NH = (TEAMS >= 3 && NBW == 20) ? 2 : 1;       // granules per dim slot
+        constexpr int NH = SHORT ? 2 : 1;                           // granules per dim slot
         constexpr int HP = NP / NH;                                 // beam pairs per granule
         constexpr int NQH = NQ * NH;                                // granules per chunk
         static_assert(NP % NH == 0 && NQH % 2 == 0, "granules must tile the slots and alternate buffers cleanly");
@@ -467,7 +494,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           }
           const int cc = own / NBW, b = own - cc * NBW;            // own < 0: unused slot
           const int m = ch * SPC + cc;                              // my m-th sample
-          if (own >= 0 && (lane & 1) == 0 && m < n_mine) part_s[((size_t)g * SP + m * NSW + sw) * NB + b_lo + b] = tot;
+          if (own >= 0 && (lane & 1) == 0 && m < n_mine && b < nlive) part_s[((size_t)g * SP + m * NSW + sw) * PS + b_lo + b] = tot;
         }
 #pragma unroll
         for (int k = 0; k < HP; ++k) asm volatile("" : "+v"(zz[0][k])); // drain the look-ups issued past the last sample
@@ -481,37 +508,72 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         // rounds instead of 36 (r02i: step 0 cost half a full step's instructions for a twentieth of its look-ups).
         const int n_mine = Sp > sw ? (Sp - sw + NSW - 1) / NSW : 0; // my samples of the pass: s_base + sw, + NSW, ...
         const uint32_t bet0 = bet[0];
-        constexpr int HB = RW / 2;                                  // rows fetched together (20 registers, as the steady state's)
-        static_assert(RW % 2 == 0, "half batches");
-        for (int m0 = 0; m0 < n_mine; m0 += RW) {
-          float acc[ACC_ROOM];
+        // two half batches of rows (even sizes: samples go through the fma in pairs), 20 registers as the steady state's
+        constexpr int HA = ((RW / 2) + 1) & ~1, HBb = RW - HA;
+        static_assert(RW % 2 == 0 && HBb >= 2 && HBb % 2 == 0, "half batches of sample pairs");
+        // round 3 (one-beam calls live here for EVERY step): the rows of the next half batch are in flight under the current
+        // one's look-ups (they used to be fetched and waited for batch by batch), and two samples share each v_pk_fma_f32
+        typedef float f2w __attribute__((ext_vector_type(2)));
+        // Row of my m-th sample: a wave-uniform base (scalar arithmetic) plus my quad's byte offset -- no vector address
+        // arithmetic per row; past my last sample the LAST row is read again (its totals are dropped at the store).
+        const uint32_t lane_off = tab_lo * 2u;
+        auto rows = [&](int m_first, auto &ap) {
+          constexpr int H = (int)(sizeof(ap) / sizeof(ap[0]));
 #pragma unroll
-          for (int p = 0; p < RW; ++p) acc[p] = 0.f;
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            uint2 ap[HB];
-#pragma unroll
-            for (int k = 0; k < HB; ++k) {
-              const int m = m0 + h * HB + k;                        // past my last sample: entry 0, the total is dropped
-              ap[k] = make_uint2(0u, 0u);
-              if (m < n_mine) ap[k] = *reinterpret_cast<const uint2 *>(tab_tu + ((uint32_t)(s_base + m * NSW + sw) * (uint32_t)Dp + tab_lo));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              float z[HB];
-#pragma unroll
-              for (int k = 0; k < HB; ++k) {
-                const uint32_t w = (i & 2) ? ap[k].y : ap[k].x;
-                z[k] = lds_abs_f32((((i & 1) ? (w >> 16) : (w & 0xFFFFu)) << 2) + bet0);
-              }
-#pragma unroll
-              for (int k = 0; k < HB; ++k) acc[h * HB + k] = proposal_term(acc[h * HB + k], z[k], cH[i], G[0][i]);
-              __builtin_amdgcn_sched_barrier(0);
-            }
+          for (int k = 0; k < H; ++k) {
+            int m = m_first + k;
+            m = m < n_mine ? m : n_mine - 1;
+            const char *rowp = reinterpret_cast<const char *>(tab_tu) + (size_t)((uint32_t)(s_base + m * NSW + sw) * (uint32_t)Dp) * 2u;
+            ap[k] = *reinterpret_cast<const uint2 *>(rowp + lane_off);
           }
-          const float tot = reduce_scatter_n<RW>(acc, lane);
-          const int m = m0 + rs_p;                                  // rs_p < 0: unused slot
-          if (rs_p >= 0 && (lane & 1) == 0 && m < n_mine) part_s[((size_t)g * SP + m * NSW + sw) * NB] = tot;
+        };
+        auto half = [&](const auto &ap, f2w *acc2) {
+          constexpr int H = (int)(sizeof(ap) / sizeof(ap[0]));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float z[H];
+#pragma unroll
+            for (int k = 0; k < H; ++k) {
+              const uint32_t w = (i & 2) ? ap[k].y : ap[k].x;
+              const uint32_t e = __builtin_amdgcn_ubfe(w, (i & 1) ? 16u : 0u, 16u);   // v_bfe_u32, then one v_lshl_add_u32 (an
+              z[k] = lds_abs_f32((e << 2) + bet0);                  // `& 0xFFFF` is folded into shift + mask + add: three)
+            }
+            const f2w h2 = {cH[i], cH[i]}, g2 = {G[0][i], G[0][i]};
+#pragma unroll
+            for (int k = 0; k < H / 2; ++k) {
+              const f2w z2 = {z[2 * k], z[2 * k + 1]};
+              acc2[k] = __builtin_elementwise_fma(__builtin_elementwise_fma(h2, z2, g2), z2, acc2[k]);   // proposal_term, two samples
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        };
+        uint2 apA[HA], apB[HBb];
+        rows(0, apA);
+        for (int m0 = 0; m0 < n_mine; m0 += RW) {
+          f2w acc2[RW / 2];
+#pragma unroll
+          for (int p = 0; p < RW / 2; ++p) acc2[p] = (f2w){0.f, 0.f};
+          rows(m0 + HA, apB);
+          half(apA, &acc2[0]);
+          rows(m0 + RW, apA);                                       // first half of the next round
+          half(apB, &acc2[HA / 2]);
+          float tot;
+          int own;
+          if constexpr (RW == 20 && IREC_RS20 != 0) {
+            rs_f2 a20[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) a20[k] = acc2[k];
+            tot = reduce_scatter_20(a20, lane);
+            own = rs_p20;
+          } else {
+            float acc[ACC_ROOM];
+#pragma unroll
+            for (int k = 0; k < RW / 2; ++k) { acc[2 * k] = acc2[k].x; acc[2 * k + 1] = acc2[k].y; }
+            tot = reduce_scatter_n<RW>(acc, lane);
+            own = rs_p;
+          }
+          const int m = m0 + own;                                   // own < 0: unused slot
+          if (own >= 0 && (lane & 1) == 0 && m < n_mine) part_s[((size_t)g * SP + m * NSW + sw) * PS] = tot;
         }
       } else if (active && nlive > 0) {
 #endif
@@ -571,7 +633,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           const float tot = reduce_scatter_n<RW>(acc, lane);
           const int cc = rs_p / NBW, b = rs_p - cc * NBW;   // rs_p < 0: unused slot
           const int s = (ch * SPC + cc) * NSW + sw;
-          if (rs_p >= 0 && (lane & 1) == 0 && s < Sp && b < nlive) part_s[((size_t)g * SP + s) * NB + b_lo + b] = tot;
+          if (rs_p >= 0 && (lane & 1) == 0 && s < Sp && b < nlive) part_s[((size_t)g * SP + s) * PS + b_lo + b] = tot;
         }
       }
       TSTAMP(2);
@@ -585,15 +647,15 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           // every partial of my candidates (and of their beams' C_b) is fetched before the first is used: one LDS
           // latency instead of 4 per key
           float pr[MK][4], cbv[MK][4];
-          const int gstride = SP * NB;
+          const int gstride = SP * PS;
 #pragma unroll
           for (int q = 0; q < MK; ++q) {
             const int f = q * NT + tid, fs = f < Np ? f : 0;
             const int s = Bcur == NB ? fs / NB : fs / Bcur, b = fs - s * Bcur;   // s: sample index inside the pass
 #pragma unroll
-            for (int gg = 0; gg < 4; ++gg) pr[q][gg] = part_s[(gg < NG ? gg : 0) * gstride + s * NB + b];
+            for (int gg = 0; gg < 4; ++gg) pr[q][gg] = part_s[(gg < NG ? gg : 0) * gstride + s * PS + b];
 #pragma unroll
-            for (int gg = 0; gg < 4; ++gg) cbv[q][gg] = cpart_s[(gg < NG ? gg : 0) * 32 + b];
+            for (int gg = 0; gg < 4; ++gg) cbv[q][gg] = cpart_s[(gg < NG ? gg : 0) * TEAM_MB + b];
           }
           if (KEYS_ALIAS && Bcur != NB) { // key f and partial f belong to different candidates: all reads before any write
 #pragma unroll
@@ -765,7 +827,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         TSTAMP(10);                 // (diagnostic build: the load batches -- new beams, G, C)
         if (!last) {
           const float ctot = reduce_scatter_n<NBW>(cacc, lane);
-          if (sw == 0 && (lane & 1) == 0 && rs_c >= 0 && b_lo + rs_c < Bnew) cpart_s[g * 32 + b_lo + rs_c] = ctot;
+          if (sw == 0 && (lane & 1) == 0 && rs_c >= 0 && b_lo + rs_c < Bnew) cpart_s[g * TEAM_MB + b_lo + rs_c] = ctot;
         }
       }
       TSTAMP(6);
@@ -905,39 +967,53 @@ static int team_cfg(int shape_override) {
   }
 }
 // shape of the workgroup that serves B beams: beams per build, teams per workgroup, beam stripes per team
-struct TeamShape { int nb, teams, bs; };
+struct TeamShape { int nb, teams, bs; bool passes; };
 static TeamShape team_shape(int B, int S, int ovr) {
   const int cfg = team_cfg(ovr);
   // 10 beams: G is 40 registers per lane, three teams fit the register file (168 VGPRs) and, for small S, the LDS: +9 %
-  if (B <= 10) return TeamShape{10, (cfg == 3 || (cfg == 2 && team_s_pass(10, S, 3, 1024) == S)) ? 3 : 2, 1};
+  if (B <= 10) {
+    const int ps = team_row(10, B);
+    if (cfg == 3 || (cfg == 2 && team_s_pass(10, S, 3, 1024, false, ps) == S)) return TeamShape{10, 3, 1, false};
+    if (cfg != 2 || team_s_pass(10, S, 2, 1024, false, ps) == S) return TeamShape{10, 2, 1, false};
+    return TeamShape{10, 3, 1, true};   // more samples than one pass of two teams holds (S > 102): three teams, sample passes
+  }
   if (B <= 20) {
-    if (cfg == 1) return TeamShape{20, 1, 1};
-    if (cfg == 20) return TeamShape{20, 2, 1};
-    if (cfg == 22) return TeamShape{20, 2, 2};
-    if (cfg == 12) return TeamShape{20, 1, 2};
+    if (cfg == 1) return TeamShape{20, 1, 1, false};
+    if (cfg == 20) return TeamShape{20, 2, 1, false};
+    if (cfg == 22) return TeamShape{20, 2, 2, false};
+    if (cfg == 12) return TeamShape{20, 1, 2, false};
     // three 4-wave teams (168 VGPRs: half-slot look-up pipeline, statistics / variance / scale parked in the slab, sort keys
     // over the partial scores) wherever their LDS fits next to the table copies -- S <= 38, the BASELINE workload: a third
     // team scores while another is in a serial phase (r02c: 13.2 ms against 13.7 ms of two teams)
-    if (team_s_pass(20, S, 3, 1024) == S) return TeamShape{20, 3, 1};
+    if (team_s_pass(20, S, 3, 1024) == S) return TeamShape{20, 3, 1, false};
     // more samples than two teams can hold in one pass (e.g. Omega = 5: S = 148): one 8-wave team with two beam stripes
     // and sample passes
-    if (team_s_pass(20, S, 2, 1024) != S) return TeamShape{20, 1, 2};
-    return TeamShape{20, 2, 1};
+    if (team_s_pass(20, S, 2, 1024) != S) return TeamShape{20, 1, 2, false};
+    return TeamShape{20, 2, 1, false};
   }
-  if (B <= 30) return TeamShape{30, 1, 3};   // one 12-wave team: three stripes of 10 beams (the B = 30 stress configuration)
-  if (B <= 32) return TeamShape{32, 1, 2};   // one 8-wave team: two stripes of 16 beams
-  return TeamShape{0, 0, 0};
+  if (B <= 30) return TeamShape{30, 1, 3, false};   // one 12-wave team: three stripes of 10 beams (the B = 30 stress configuration)
+  if (B <= 32) return TeamShape{32, 1, 2, false};   // one 8-wave team: two stripes of 16 beams
+  // round 3: B = 50 of the reference's sweep (examples/lossless/data_aggregation.py:7).  One 12-wave team, three stripes of
+  // 20 beams at 168 VGPRs (the three-team build's register diet: half-slot pipeline, parked state); a stripe that is at least
+  // half alive scores its missing beams as phantoms
+  if (B <= 60) return TeamShape{60, 1, 3, false};
+  return TeamShape{0, 0, 0, false};
 }
 int team_count_for(int B, int S, int ovr) { return team_shape(B, S, ovr).teams; }
 int team_waves_for(int B, int S, int ovr) { const TeamShape sh = team_shape(B, S, ovr); return sh.teams * sh.bs * TEAM_NW; }
 size_t team_ws_extra_for(int B, int S, int ovr) { // scratch-slab bytes on top of fast_ws_for(): the sort keys when they do not fit the LDS
   const TeamShape sh = team_shape(B, S, ovr);
-  return (sh.nb && !team_keys_in_lds(sh.nb, S, sh.teams)) ? ((team_key_bytes(sh.nb, S) + 255) & ~(size_t)255) : 0;
+  const int ps = sh.nb ? team_row(sh.nb, B) : 0;
+  return (sh.nb && !team_keys_in_lds(sh.nb, S, sh.teams, sh.passes, ps)) ? ((team_key_bytes(ps, S) + 255) & ~(size_t)255) : 0;
+}
+size_t team_ws_bytes_for(int B, int S, int ovr, int max_K) {
+  const TeamShape sh = team_shape(B, S, ovr);
+  return sh.nb ? fast_ws_bytes(sh.nb, max_K) + team_ws_extra_for(B, S, ovr) : 0;
 }
 const char *team_kernel_name(int B, int S, int ovr) {
   static thread_local char buf[64];
   const TeamShape sh = team_shape(B, S, ovr);
-  snprintf(buf, sizeof buf, "encode_team_kernel<%d,%d,%d>", sh.nb, sh.teams, sh.bs);
+  snprintf(buf, sizeof buf, sh.passes ? "encode_team_kernel<%d,%d,%d,passes>" : "encode_team_kernel<%d,%d,%d>", sh.nb, sh.teams, sh.bs);
   return buf;
 }
 
@@ -945,28 +1021,32 @@ size_t team_lds_for(int B, int S, int ovr) {
   const TeamShape sh = team_shape(B, S, ovr);
   if (!sh.nb) return (size_t)-1;
   if ((int64_t)S * sh.nb >= (1 << 24)) return (size_t)-1;
-  const int sp = team_s_pass(sh.nb, S, sh.teams, sh.teams == 1 ? 2048 : 1024);
-  if (sp < 1 || (sp < S && (sp < 16 || sh.teams > 1))) return (size_t)-1;   // does not fit (multi-team builds: in one pass),
-                                                                             // or only in slivers: the one-table encoder takes it
-  const size_t b = team_lds_total(sh.nb, S, sp, sh.teams);
+  const int ps = team_row(sh.nb, B);
+  const int sp = team_s_pass(sh.nb, S, sh.teams, sh.teams == 1 ? 2048 : 1024, sh.passes, ps);
+  if (sp < 1 || (sp < S && (sp < 16 || (sh.teams > 1 && !sh.passes)))) return (size_t)-1;   // does not fit (one-pass builds: in one
+                                                                             // pass), or only in slivers: the one-table encoder takes it
+  const size_t b = team_lds_total(sh.nb, S, sp, sh.teams, sh.passes, ps);
   return b <= FAST_LDS_LIMIT ? b : (size_t)-1;
 }
 
-template <int NB, int TEAMS, int BS>
+template <int NB, int TEAMS, int BS, bool PASSES = false>
 static hipError_t launch_team_t(const EncArgs &A, int grid, hipStream_t st) {
-  const int sp = TEAMS == 1 ? team_s_pass(NB, A.S, TEAMS, 2048) : A.S;
-  const size_t lds = team_lds_total(NB, A.S, sp, TEAMS);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_team_kernel<NB, TEAMS, BS>),
+  const int ps = team_row(NB, A.B);
+  const int sp = (TEAMS == 1 || PASSES) ? team_s_pass(NB, A.S, TEAMS, TEAMS == 1 ? 2048 : 1024, PASSES, ps) : A.S;
+  const size_t lds = team_lds_total(NB, A.S, sp, TEAMS, PASSES, ps);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_team_kernel<NB, TEAMS, BS, PASSES>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((encode_team_kernel<NB, TEAMS, BS>), dim3(grid), dim3(TEAMS * BS * TEAM_NT), lds, st, A);
+  hipLaunchKernelGGL((encode_team_kernel<NB, TEAMS, BS, PASSES>), dim3(grid), dim3(TEAMS * BS * TEAM_NT), lds, st, A);
   return hipGetLastError();
 }
 
 hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
   const TeamShape sh = team_shape(A.B, A.S, A.shape_override);
-  const int key = sh.nb * 100 + sh.teams * 10 + sh.bs;
+  const int key = sh.nb * 100 + sh.teams * 10 + sh.bs + (sh.passes ? 10000 : 0);
   switch (key) {
+    case 11031: return launch_team_t<10, 3, 1, true>(A, grid, st);
+    case 6013: return launch_team_t<60, 1, 3>(A, grid, st);
     case 1021: return launch_team_t<10, 2, 1>(A, grid, st);
     case 1031: return launch_team_t<10, 3, 1>(A, grid, st);
     case 2011: return launch_team_t<20, 1, 1>(A, grid, st);

@@ -37,15 +37,16 @@ class PendingCode:
         if (K_host < 0).any():
             raise CodingError("a block exceeded the engine's dimension bound")
         need = int(K_host.max()) if K_host.size else 0
-        self.coder._max_K_hint = max(self.coder._max_K_hint, need)
+        if need > _lib.MAX_PARTITIONS:   # (before any hint is touched: one degenerate block -- an infinite KL reads back as
+            # 10^9 partitions -- must not leave the coder, or the model that shares its hints, asking for more than the library takes)
+            raise CodingError(f"KL divergence needs {need} partitions; this build supports {_lib.MAX_PARTITIONS}")
+        self.coder._max_K_hint = min(max(self.coder._max_K_hint, need), _lib.MAX_PARTITIONS)
         c = self.coder            # table window hint: what covers the bulk of the blocks read back (a few outliers take the
         if K_host.size:           # second pass instead of stretching every later call's tables), decaying by an eighth per read
             upper_quartile = int(np.partition(K_host, (3 * (K_host.size - 1)) // 4)[(3 * (K_host.size - 1)) // 4])   # (np.quantile
             bulk = (5 * upper_quartile + 3) // 4                       #  costs 40 us a call: 1 ms per 24-block image)
             c._K_seen = bulk if c._K_reads == 0 else max(bulk, c._K_seen - max(1, c._K_seen // 8))
         c._K_reads += 1
-        if need > _lib.MAX_PARTITIONS:
-            raise CodingError(f"KL divergence needs {need} partitions; this build supports {_lib.MAX_PARTITIONS}")
         if need > self.max_K:
             raise MorePartitionsNeeded(need)
         lay = self.lay

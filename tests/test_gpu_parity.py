@@ -279,10 +279,33 @@ def test_large_block_uses_generic_path(engine, oracle):
 
 def test_wide_beam_uses_generic_path(engine, oracle):
     mq, sq, mp, sp = oracle.synthetic_latent(78, 300)
-    c = _coder(2.0, 50, 1.0)  # B = 50 > 32, S = 7 < B
-    idx, sample = c.encode(_normal(mq[None], sq[None]), _normal(mp[None], sp[None]), seed=9)
     ridx, rs = oracle.encode_block(mq, sq, mp, sp, 9, 2.0, 7, 50)
+    for generic in (False, True):    # B = 50 > 32, S = 7 < B: the 60-beam team build (round 3), and the generic kernel pinned
+        c = _coder(2.0, 50, 1.0)
+        c.force_generic = generic
+        idx, sample = c.encode(_normal(mq[None], sq[None]), _normal(mp[None], sp[None]), seed=9)
+        assert [int(i) for i in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs), generic
+    ridx, rs = oracle.encode_block(mq, sq, mp, sp, 9, 2.0, 7, 64)
+    c = _coder(2.0, 64, 1.0)         # 60 < B <= 64: generic kernel
+    idx, sample = c.encode(_normal(mq[None], sq[None]), _normal(mp[None], sp[None]), seed=9)
     assert [int(i) for i in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
+
+
+def test_wide_beam_blocks_beyond_the_table_window_take_the_generic_kernel(engine, oracle):
+    """B = 50 has no fused-Philox fast encoder: blocks with more partitions than the proposal tables cover are coded by the
+    generic kernel in the call's second pass (irec_host.cpp: team_only plans) -- same outputs as the oracle's."""
+    n, bs = 2192, 1000
+    stats = oracle.synthetic_latent(515, n)
+    ql, qs, pl, ps = (torch.from_numpy(a[None]).cuda().contiguous() for a in stats)
+    lay = engine.layout(1, n, bs, 42)
+    ridx, rs = oracle.encode_tensor(*stats, 42, 3.0, 20, 50, block_size=bs)
+    assert max(len(i) for i in ridx) >= 6 and min(len(i) for i in ridx) <= 3       # two long blocks, one short
+    params = engine.params(3.0, 20, 50, table_steps=3)
+    K, idx, sample = engine.encode_blocks(params, lay, ql, qs, pl, ps, 42, 32)
+    Kh, ih = K.cpu().numpy(), idx.cpu().numpy()
+    got = [ih[lay.natural[j], :Kh[lay.natural[j]]].tolist() for j in range(3)]
+    assert engine.plan(params, lay, 32)["table_steps"] == 3 and got == ridx
+    assert np.array_equal(sample.cpu().numpy()[0], rs)
 
 
 @pytest.mark.parametrize("variant", ["table", "fused"])
@@ -371,6 +394,58 @@ def test_decoder_both_table_paths(engine, oracle):
         assert np.array_equal(oracle.decode_tensor(mp[i], sp[i], blocks, 42, 36, block_size=bs), sample[i].cpu().numpy())
 
 
+# ---- the reference's own hyper-parameter sweep (examples/lossless/data_aggregation.py:5-7) -------------------------------
+SWEEP_OMEGA = (2, 3, 4, 5, 6)
+SWEEP_EPS1 = (1.0, 1.1, 1.2, 1.5)
+SWEEP_BEAMS = (1, 10, 50)
+
+
+@pytest.mark.parametrize("B", SWEEP_BEAMS)
+@pytest.mark.parametrize("omega", SWEEP_OMEGA)
+def test_reference_sweep_grid(engine, oracle, omega, B):
+    """All 60 cells of the grid the reference sweeps -- kl_per_partition in 2..6 x extra_samples in {1, 1.1, 1.2, 1.5} x
+    n_beams in {1, 10, 50}, S = int(exp(Omega * (1 + eps))) from 7 to 8103 (beam_search_coder.py:28-29) -- on one 1000-dim and
+    one 192-dim block each: emitted indices and sample bit-exact against the oracle, once the way the library picks its
+    kernels for a call this small and once with the team encoder pinned (what a batch of such blocks runs on:
+    encode_team_kernel<10,3,1[,passes]> for B <= 10, <60,1,3> for B = 50; S * B reaches 405 150 candidates per step)."""
+    from irec import _lib
+    n, bs = 1192, 1000
+    stats = oracle.synthetic_latent(4242, n)
+    ql, qs, pl, ps = (torch.from_numpy(a[None]).cuda().contiguous() for a in stats)
+    lay = engine.layout(1, n, bs, 42)
+    for eps1 in SWEEP_EPS1:
+        S = oracle.n_samples(float(omega), eps1)
+        ridx, rs = oracle.encode_tensor(*stats, 42, float(omega), S, B, block_size=bs)
+        assert max(len(i) for i in ridx) <= 32
+        for flags in (0, _lib.IREC_FLAG_TEAM):
+            params = engine.params(float(omega), S, B, flags)
+            K, idx, sample = engine.encode_blocks(params, lay, ql, qs, pl, ps, 42, 32)
+            Kh, ih = K.cpu().numpy(), idx.cpu().numpy()
+            got = [ih[lay.natural[j], :Kh[lay.natural[j]]].tolist() for j in range(2)]
+            plan = engine.plan(params, lay, 32)
+            assert got == ridx, (omega, eps1, S, B, flags, plan["kernel"])
+            assert np.array_equal(sample.cpu().numpy()[0], rs), (omega, eps1, S, B, flags, plan["kernel"])
+            if flags and B <= 60:
+                assert plan["kernel"].startswith("encode_team_kernel"), plan
+            assert torch.equal(engine.decode_blocks(params, lay, pl, ps, 42, K, idx), sample)
+
+
+def test_many_beams_selection_refinement(engine):
+    """top-B with B up to 64 (irec_fast_common.h: rank_survivors): the B-th largest of the 64 lane maxima leaves more than 64
+    candidates above it, which are cut down to the exact B best by a bitwise search for the B-th largest key; against
+    torch.sort (value descending, ties to the lower flat index), including heavy ties."""
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    for n, nsel, bcur, ties in [(3000, 50, 50, False), (1000, 64, 20, False), (777, 60, 7, False), (405150, 50, 50, False),
+                                (3000, 50, 50, True), (12000, 33, 30, True), (60, 50, 10, False)]:
+        sc = torch.randn(n, generator=g, device="cuda")
+        if ties:
+            sc = torch.round(sc * 8) / 8
+        sel = engine.test_select(sc, nsel, bcur).cpu().numpy()
+        order = torch.sort(sc.cpu().double() * 1.0, descending=True, stable=True).indices[:nsel].numpy()
+        want = np.stack([order // bcur, order % bcur], axis=1)
+        assert np.array_equal(sel, want), (n, nsel, bcur, ties)
+
+
 def test_decoder_fast_sqrt_exhaustive(engine):
     """The decoder's 9-instruction square root (irec_decode.hip: dec_sqrt_core) returns sqrtf's bits -- the correctly rounded
     value the oracle's libm gives -- for EVERY float32 bit pattern it is allowed to see: all 2^32 patterns are run on the
@@ -404,7 +479,7 @@ def test_decoder_tiny_variances_take_the_slow_sqrt(engine, oracle):
 @pytest.mark.parametrize("n_t,n,bs,omega,eps1,B", [(64, 8192, 1000, 3.0, 1.2, 20), (3, 8192, 1000, 3.0, 1.2, 20),
                                                    (2, 301056, 1000, 3.0, 1.0, 10), (5, 1234, 300, 2.0, 1.0, 1),
                                                    (4, 4099, 4099, 3.0, 1.5, 5), (3, 700, 7, 3.0, 1.0, 10),
-                                                   (1, 5000, 1000, 5.0, 1.2, 3), (2, 12000, 1000, 3.0, 1.0, 10)])
+                                                   (1, 5000, 1000, 5.0, 1.2, 3), (2, 12288, 1000, 3.0, 1.0, 10)])
 def test_decoder_variants_agree_with_the_oracle(engine, oracle, n_t, n, bs, omega, eps1, B):
     """Round 3 decoder (irec_decode.hip): one wave per 256 dims of a block, index path held in a lane vector, rows from the
     per-call proposal tables ("tables") or from the fused Philox draw ("fused"); the round-2 kernel ("legacy") serves calls
@@ -613,7 +688,12 @@ def test_plan_names_the_kernels_that_run(engine, oracle):
     assert engine.plan(engine.params(3.0, S, 20, irec._lib.IREC_FLAG_FUSED_PHILOX), big, 32)["table_kernel"] == ""
     assert engine.plan(engine.params(3.0, 20, 10), big, 32)["kernel"] == "encode_team_kernel<10,3,1>"
     assert engine.plan(engine.params(5.0, 148, 30), big, 32)["kernel"] == "encode_team_kernel<30,1,3>"
-    assert engine.plan(engine.params(3.0, S, 40), big, 32)["kernel"] == "encode_generic_kernel"
+    assert engine.plan(engine.params(3.0, S, 40), big, 32)["kernel"] == "encode_team_kernel<60,1,3>"     # round 3: 32 < B <= 60
+    assert engine.plan(engine.params(3.0, S, 40), small, 32)["kernel"] == "encode_team_kernel<60,1,3>"   # (no one-table encoder there)
+    assert engine.plan(engine.params(3.0, S, 64), big, 32)["kernel"] == "encode_generic_kernel"          # 60 < B <= 64
+    assert engine.plan(engine.params(6.0, 8103, 10), big, 32)["kernel"] == "encode_team_kernel<10,3,1,passes>"
+    assert engine.plan(engine.params(6.0, 8103, 1), big, 32)["kernel"] == "encode_team_kernel<10,3,1,passes>"
+    assert engine.plan(engine.params(5.0, 403, 1), big, 32)["kernel"] == "encode_team_kernel<10,3,1>"    # one beam: 403 samples in one pass
     info = engine.plan(p, big, 32)
     assert info["n_cu"] == 256 and info["clock_mhz"] > 1000 and info["lds_bytes"] <= 160 * 1024
 
