@@ -2,7 +2,7 @@
 """bench.py -- encoded latents/s of the iREC beam-search encoder on MI355X (BASELINE.json metric).
 
 One "step" = one pass of the hot path (irec_beam_encode: one persistent kernel launch) over one batch of
---latents (default 8192) synthetic RVAE latent tensors [16,16,32] (8192 dims -> 8 blocks of 1000 + 1 of 192 dims each) that are
+--latents (default 32768) synthetic RVAE latent tensors [16,16,32] (8192 dims -> 8 blocks of 1000 + 1 of 192 dims each) that are
 already resident in HBM, with B=20, Omega=3, 1+eps=1.2 (S=36): BASELINE.json configs[1].  Multi-GPU: one process per
 GPU, every rank codes its own batch (weak scaling, no data-path collective); the only collective is the final RCCL
 all_gather of the per-latent code lengths.
@@ -35,7 +35,8 @@ for p in (ROOT, PKG):
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 LDS_HW_LOOKUPS = 32.0     # ds_read_b32: 128 B/clk/CU = 32 four-byte look-ups per clock per CU (MI355X_MICROARCH.md §LDS)
-LDS_2CHOICE_LOOKUPS = 13.4  # measured ceiling of random look-ups with the 2-choice bank assignment (profiles/r01j)
+LDS_2CHOICE_LOOKUPS = 13.70  # measured ceiling of random look-ups with the 2-choice bank assignment at the 12 waves per CU
+                             # the default kernel runs (profiles/r01j/gather_rates.log; 13.4 at 8 waves, 14.0 at 16)
 TENSOR_SHAPE = (16, 16, 32)
 N_DIMS = 8192
 BLOCK_SIZE = 1000
@@ -100,13 +101,13 @@ def launch_ranks(args, argv):
 # ---------------------------------------------------------------------------------------------------------------------
 #  one rank
 # ---------------------------------------------------------------------------------------------------------------------
-def synthetic_batch(n_latents, device, rank):
+def synthetic_batch(n_latents, device, rank, n_dims=N_DIMS):
     """SURVEY.md §8d statistics, drawn on the device (torch generator seeded per rank); values differ from the numpy
     fixtures, the distribution does not."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(1234 + rank)
-    shape = (n_latents, N_DIMS)
+    shape = (n_latents, n_dims)
     mp = torch.randn(shape, generator=g, device=device)
     lsp = 0.25 * torch.randn(shape, generator=g, device=device)
     sp = torch.exp(lsp)
@@ -166,9 +167,9 @@ def cpu_baselines(q, n_ref, n_opt_budget_s):
     log(f"cpu-ref repeats (latents/s): {[round(r, 2) for r in reps]}")
 
     # CPU-opt: batches of 2 latents per core until the budget is spent; the first batch is also the parity sample
-    batch = max(16, 2 * cores)
-    done, t_opt, first = 0, 0.0, None
-    while t_opt < n_opt_budget_s and done + batch <= q[0].shape[0]:
+    batch = min(max(16, 2 * cores), int(q[0].shape[0]))     # (at least one batch also when --latents is small)
+    done, t_opt, first, used = 0, 0.0, None, cores
+    while (t_opt < n_opt_budget_s or done == 0) and done + batch <= q[0].shape[0]:
         hb = [t[done:done + batch].cpu().numpy() for t in q]
         t0 = time.perf_counter()
         idx, samp, used = O.encode_tensors_omp(*hb, SEED, OMEGA, S, BEAMS, BLOCK_SIZE, n_threads=cores)
@@ -177,7 +178,59 @@ def cpu_baselines(q, n_ref, n_opt_budget_s):
             first = (idx, samp)
         done += batch
     return {"ref_lps": ref_lps, "ref_threads": threads, "ref_probe": probe, "ref_reps": reps, "n_ref": n_ref,
-            "opt_lps": done / t_opt, "opt_threads": used, "opt_latents": done, "opt_first": first}
+            "opt_lps": done / max(t_opt, 1e-9), "opt_threads": used, "opt_latents": done, "opt_first": first}
+
+
+def secondary_config(eng, device, name, omega, eps1, beams, n_tensors, n_dims, reps, check, ref_line):
+    """One further BASELINE configuration, outside the timed headline: `reps` calls of irec_beam_encode on `n_tensors`
+    synthetic tensors of `n_dims` dims (blocks of 1000) by HIP events; kernel from irec_encode_plan; look-ups per clock per
+    CU; the first `check` tensors compared with the oracle (indices and sample, bit for bit)."""
+    import torch
+    from oracle import oracle as O
+    S = int(np.exp(omega * eps1))
+    params = eng.params(omega, S, beams)
+    q = synthetic_batch(n_tensors, device, 77, n_dims)
+    lay = eng.layout(n_tensors, n_dims, BLOCK_SIZE, SEED)
+    max_K = 48
+    out = (torch.empty(lay.n_blocks, dtype=torch.int32, device=device),
+           torch.empty((lay.n_blocks, max_K), dtype=torch.int32, device=device), torch.empty_like(q[0]))
+    plan = eng.plan(params, lay, max_K)
+    for _ in range(2):
+        eng.encode_blocks(params, lay, *q, SEED, max_K, out=out)
+    torch.cuda.synchronize(device)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for r in range(reps):
+        eng.encode_blocks(params, lay, *q, SEED, max_K, out=out)
+        ev[r + 1].record()
+    torch.cuda.synchronize(device)
+    ms = float(np.median([ev[r].elapsed_time(ev[r + 1]) for r in range(reps)]))
+    Kh = out[0].cpu().numpy().astype(np.int64)
+    assert Kh.min() >= 0 and Kh.max() <= max_K, (name, int(Kh.min()), int(Kh.max()))
+    dims = lay.block_dim.cpu().numpy().astype(np.int64)
+    evals = float((S * dims * (1 + np.maximum(Kh - 1, 0) * beams) * (Kh > 0)).sum())
+    lookups = evals / (ms * 1e-3) / (plan["n_cu"] * plan["clock_mhz"] * 1e6)
+    checked = 0
+    if check:
+        c = min(check, n_tensors)
+        hb = [t[:c].cpu().numpy() for t in q]
+        ridx, rsamp, _ = O.encode_tensors_omp(*hb, SEED, omega, S, beams, BLOCK_SIZE, max_K=max_K, n_threads=host_cores())
+        ih, sh = out[1].cpu().numpy(), out[2][:c].cpu().numpy()
+        bpt = lay.blocks_per_tensor
+        for i in range(c):
+            for j in range(bpt):
+                row = lay.natural[i * bpt + j]
+                assert ih[row, :Kh[row]].tolist() == ridx[i][j], f"{name}: parity, tensor {i} block {j}"
+            assert np.array_equal(sh[i], rsamp[i]), f"{name}: parity, tensor {i} sample"
+        checked = c
+    res = {"name": name, "reference": ref_line, "omega": omega, "extra_samples": eps1, "n_beams": beams, "n_samples": S,
+           "tensors_per_call": n_tensors, "dims_per_tensor": n_dims, "blocks_per_call": int(lay.n_blocks), "kernel": plan["kernel"],
+           "grid": plan["grid"], "ms_per_call": ms, "tensors_per_s": n_tensors / (ms * 1e-3),
+           "lookups_per_clk_per_cu": lookups, "mean_K": float(Kh.mean()), "oracle_checked_tensors": checked}
+    log(f"secondary {name}: {plan['kernel']} {ms:.3f} ms/call, {res['tensors_per_s']:.0f} tensors/s, {lookups:.2f} look-ups/clk/CU, "
+        f"oracle-checked {checked}")
+    del q, out
+    return res
 
 
 def run_rank_launch_only(args):
@@ -356,6 +409,27 @@ def run_rank(args):
                       "decode_round_trip_exact": round_trip_exact, "decode_ms": decode_ms,
                       "decoded_latents_per_s": L / (decode_ms * 1e-3)},
     }
+    # decoder: its own roofline entry (12 D + 4 K algorithmic bytes per block)
+    dec_bytes = int((12 * dims + 4 * Kh).sum())
+    result["secondary"]["decode_roofline"] = {"bound": "hbm", "achieved": dec_bytes / (decode_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                              "unit": "GB/s", "frac": dec_bytes / (decode_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                              "algorithmic_bytes": dec_bytes, "kernel_ms": decode_ms,
+                                              "kernel": "decode_tensor_kernel<true,3> (whole tensors staged in LDS) + 2 x alpha_table_kernel",
+                                              "note": "VALU-bound on the IEEE chain a = rho (var_p - c), sqrt, c += a of "
+                                                      "beam_search_coder.py:131-147 (DESIGN.md §4)"}
+    if rank == 0 and world == 1 and not args.no_secondary:
+        # BASELINE configs[3] and configs[4] (and the lossy settings on a latent batch), outside the timed region
+        del samp_dec
+        torch.cuda.empty_cache()
+        lossy = "examples/lossy/compress_with_lossy_model.py:120-124,222-227 (B = 10, Omega = 3, S = 20)"
+        stress = "BASELINE.json configs[4] (ImageNet32 RVAE stress: B = 30, Omega = 5)"
+        sec = []
+        sec.append(secondary_config(eng, device, "configs[3] Kodak level 2 (one image: 12 288 dims = 13 blocks)", 3.0, 1.0, 10, 1, 12288, 20, 1, lossy))
+        sec.append(secondary_config(eng, device, "configs[3] Kodak level 1 (one image: 301 056 dims = 302 blocks)", 3.0, 1.0, 10, 1, 301056, 20, 1, lossy))
+        sec.append(secondary_config(eng, device, "configs[3] settings, 1024 latents of 8192 dims", 3.0, 1.0, 10, 1024, N_DIMS, 10, 16, lossy))
+        sec.append(secondary_config(eng, device, "configs[4] S = 148, 1024 latents of 8192 dims", 5.0, 1.0, 30, 1024, N_DIMS, 5, 16, stress))
+        sec.append(secondary_config(eng, device, "configs[4] S = 403 (eps = 0.2), 1024 latents of 8192 dims", 5.0, 1.2, 30, 1024, N_DIMS, 3, 16, stress))
+        result["secondary"]["configs"] = sec
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
         cb = cpu_baselines(q, args.cpu_ref_latents, args.cpu_opt_seconds)
@@ -389,12 +463,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--latents", type=int, default=8192, help="latent tensors per step per GPU (8192: 73 728 blocks, 53 ms "
-                    "per step -- a timed region of about a second at the driver's 20 steps; 2048 gives 2.5 %% less: set-up "
-                    "and tail of the persistent kernel weigh more)")
+    ap.add_argument("--latents", type=int, default=32768, help="latent tensors per step per GPU (32 768: 294 912 blocks, "
+                    "~190 ms per step -- a timed region of almost four seconds at the driver's 20 steps, long enough for its "
+                    "5-second device samples to see the GPU busy; 8192 latents were 47 ms per step, under a second in all)")
     ap.add_argument("--cpu-ref-latents", type=int, default=20, help="latents per CPU-ref repeat (5 repeats, median)")
     ap.add_argument("--cpu-opt-seconds", type=float, default=8.0, help="time budget of the CPU-opt (OpenMP oracle) leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[3] / configs[4] runs after the timed region")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

@@ -42,6 +42,12 @@
 #define IREC_LAST_ONE 1     // last step: only beam 0 is gathered and formed (0: all B, A/B builds; 2: also leaves the batch
                             // loop early -- r02i: that form makes the allocator spill G inside the scoring loop, 48 -> 76 ms)
 #endif
+#ifndef IREC_WIDE_V2
+#define IREC_WIDE_V2 1      // one-beam steps: rows prefetched a half batch ahead, two samples per v_pk_fma_f32 (0: round-2 form; 2: also the 168-VGPR builds)
+#endif
+#ifndef IREC_PHANTOM
+#define IREC_PHANTOM 1      // stripes at least half alive score their dead beams as phantoms in the pipelined loop (0: beam-by-beam path)
+#endif
 #ifndef IREC_STEP0_WIDE
 #define IREC_STEP0_WIDE 1   // first step (one beam): RW samples per reduce-scatter instead of one (0: the beam-wise path, A/B builds)
 #endif
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
       // Steady state: every beam of my stripe alive -- or at least half of them (B = 50 on the 60-beam build: the third stripe
       // holds beams 40..49): the dead ones are scored as PHANTOM beams (G = 0, the address of beam 0: finite values that no
       // candidate ever reads) rather than sending the whole stripe down the beam-by-beam path below.
-      if (active && Bcur > 1 && (nlive == NBW || 2 * nlive >= NBW)) {
+      if (active && Bcur > 1 && (nlive == NBW || (IREC_PHANTOM != 0 && 2 * nlive >= NBW))) {
         // Steady state, software pipelined by dim slot: the NBW gathers of the NEXT slot (of this sample, of the chunk's
         // next sample, or of the next chunk's first sample) are issued before the current slot's values are consumed, so
         // the wave always has look-ups in flight -- also under the fma chain and the reduce-scatter.  A wave can have at
@@ -508,6 +514,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         // rounds instead of 36 (r02i: step 0 cost half a full step's instructions for a twentieth of its look-ups).
         const int n_mine = Sp > sw ? (Sp - sw + NSW - 1) / NSW : 0; // my samples of the pass: s_base + sw, + NSW, ...
         const uint32_t bet0 = bet[0];
+        if constexpr (IREC_WIDE_V2 != 0 && (!SHORT || IREC_WIDE_V2 >= 2)) {
         // two half batches of rows (even sizes: samples go through the fma in pairs), 20 registers as the steady state's
         constexpr int HA = ((RW / 2) + 1) & ~1, HBb = RW - HA;
         static_assert(RW % 2 == 0 && HBb >= 2 && HBb % 2 == 0, "half batches of sample pairs");
@@ -574,6 +581,40 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           }
           const int m = m0 + own;                                   // own < 0: unused slot
           if (own >= 0 && (lane & 1) == 0 && m < n_mine) part_s[((size_t)g * SP + m * NSW + sw) * PS] = tot;
+        }
+        } else {   // the round-2 form (the 168-VGPR builds keep it: only their first step comes here, and the wider one costs them registers)
+          constexpr int HB = RW / 2;                                  // rows fetched together (20 registers, as the steady state's)
+          static_assert(RW % 2 == 0, "half batches");
+          for (int m0 = 0; m0 < n_mine; m0 += RW) {
+            float acc[ACC_ROOM];
+#pragma unroll
+            for (int p = 0; p < RW; ++p) acc[p] = 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              uint2 ap[HB];
+#pragma unroll
+              for (int k = 0; k < HB; ++k) {
+                const int m = m0 + h * HB + k;                        // past my last sample: entry 0, the total is dropped
+                ap[k] = make_uint2(0u, 0u);
+                if (m < n_mine) ap[k] = *reinterpret_cast<const uint2 *>(tab_tu + ((uint32_t)(s_base + m * NSW + sw) * (uint32_t)Dp + tab_lo));
+              }
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                float z[HB];
+#pragma unroll
+                for (int k = 0; k < HB; ++k) {
+                  const uint32_t w = (i & 2) ? ap[k].y : ap[k].x;
+                  z[k] = lds_abs_f32((((i & 1) ? (w >> 16) : (w & 0xFFFFu)) << 2) + bet0);
+                }
+#pragma unroll
+                for (int k = 0; k < HB; ++k) acc[h * HB + k] = proposal_term(acc[h * HB + k], z[k], cH[i], G[0][i]);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+            const float tot = reduce_scatter_n<RW>(acc, lane);
+            const int m = m0 + rs_p;                                  // rs_p < 0: unused slot
+            if (rs_p >= 0 && (lane & 1) == 0 && m < n_mine) part_s[((size_t)g * SP + m * NSW + sw) * PS] = tot;
+          }
         }
       } else if (active && nlive > 0) {
 #endif

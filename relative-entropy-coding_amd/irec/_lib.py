@@ -110,6 +110,8 @@ def load():
                 "(or `python -c 'import __graft_entry__ as g; g.build()'`).  irec has no CPU fallback.")
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if os.environ.get("IREC_LIB_PATH") and not hasattr(lib, name):
+                continue             # a diagnostic build of older sources (same-box A/B against an earlier round) may lack newer entries
             fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
