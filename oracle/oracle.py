@@ -16,7 +16,9 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libirec_oracle.so")
+# IREC_ORACLE_LIB_PATH: load another build of the same source by path (scripts/sanitize_oracle.sh: the ASan + UBSan build) --
+# the library in this directory is never overwritten
+_SO = os.environ.get("IREC_ORACLE_LIB_PATH") or os.path.join(_HERE, "libirec_oracle.so")
 
 CANONICAL = 0
 LITERAL = 1
@@ -25,6 +27,8 @@ P = 10007
 
 def build(force=False):
     src = os.path.join(_HERE, "irec_oracle.c")
+    if os.environ.get("IREC_ORACLE_LIB_PATH"):
+        return _SO
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libirec_oracle.so"], stdout=subprocess.DEVNULL)
     return _SO

@@ -454,9 +454,11 @@ irec_status irec_create(int device, irec_context **out) {
     HIP_TRY(hipMemcpy(ctx->d_lut2, lut2.data(), (P - 1) * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_dlog4r, dlog4r.data(), (P - 1) * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_rho, rho.data(), rho.size() * sizeof(float), hipMemcpyHostToDevice));
-    if (const char *e = std::getenv("IREC_STAMPS"); e && e[0] == '1') { // diagnostic builds only (scripts/gpu_stamps.sh)
+#ifdef IREC_HOST_STAMPS   // the stamps build only (make variants: variants/stamps.so, scripts/gpu_stamps.sh); the product reads no environment
+    if (const char *e = std::getenv("IREC_STAMPS"); e && e[0] == '1') {
       HIP_TRY(hipMalloc(&ctx->d_dbg, 4096 * 16 * sizeof(unsigned long long)));
     }
+#endif
     return IREC_OK;
   }();
   if (st != IREC_OK) { irec_destroy(ctx); return st; }
@@ -771,8 +773,11 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   stamps.reuse = (p->flags & IREC_FLAG_REUSE_TABLES) ? 1 : 0;
   HIP_TRY(irec::launch_zero_counters(workspace, stamps, st));
   int grid = (int)std::min<int64_t>(n_blocks, pl.one_grid_cap);
+  A.dbg = nullptr;
+#ifdef IREC_HOST_STAMPS
   A.dbg = ctx->d_dbg;
   if (ctx->d_dbg) HIP_TRY(hipMemsetAsync(ctx->d_dbg, 0, 4096 * 16 * sizeof(unsigned long long), st));
+#endif
   if (pl.table) {
     for (int q = 0; q < 4; ++q) { A.tab[q] = nullptr; A.tab_dim[q] = -1; }
     for (int q = 0; q < pl.n_tab; ++q) {
@@ -801,6 +806,9 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
       // one workgroup per CU as soon as there is a block for it: team k of workgroup w starts on block k * grid + w
       const int tgrid = (int)std::min<int64_t>(n_blocks, std::min(pl.grid_cap / n_teams, ctx->n_cu > 0 ? ctx->n_cu : 256));
       HIP_TRY(irec::launch_encode_team(A, tgrid, st));
+#ifndef IREC_HOST_STAMPS
+      if (irec_status s2 = deferred_pass()) return s2;
+#else
       if (!ctx->d_dbg) { if (irec_status s2 = deferred_pass()) return s2; }
       if (ctx->d_dbg) { // diagnostic build (-DIREC_TEAM_STAMPS) only: per-wave phase cycles, wave 0 of a team vs the others
         const int nwv = irec::team_waves_for(p->n_beams, p->n_samples, pl.shape);
@@ -819,6 +827,7 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
                            100.0 * (double)h[12] / (double)h[13], (double)h[13] / 1e5);
         return IREC_OK;
       }
+#endif
     } else {
       int W = split_width(ctx, pl, p, n_blocks);
       if (const int wb = split_beam_width(p, W)) { W = wb; A.coop_beams = 1; }
@@ -826,7 +835,9 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
         A.coop_W = W;
         A.coop_test_orphan = (p->flags & IREC_FLAG_TEST_SPLIT_ORPHAN) ? 1 : 0;
         HIP_TRY(irec::launch_encode_fast(A, true, (int)(n_blocks * W), st));
+#ifdef IREC_HOST_STAMPS
         if (ctx->d_dbg) grid = (int)(n_blocks * W);   // (diagnostics below: the stamps of every workgroup)
+#endif
       } else HIP_TRY(irec::launch_encode_fast(A, true, grid, st));
       if (irec_status s2 = deferred_pass()) return s2;
     }
@@ -835,6 +846,7 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   } else {
     HIP_TRY(irec::launch_encode_generic(A, grid, st));
   }
+#ifdef IREC_HOST_STAMPS
   if (ctx->d_dbg) { // diagnostic build only: synchronous read-back of the phase stamps
     std::vector<unsigned long long> h((size_t)grid * 16);
     HIP_TRY(hipStreamSynchronize(st));
@@ -859,6 +871,7 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
             pl.table ? "table" : pl.fast ? "fused" : "generic", grid, sum[0] / grid, 100 * sum[0] / tot, sum[1] / grid,
             100 * sum[1] / tot, sum[2] / grid, 100 * sum[2] / tot, sum[3] / grid, 100 * sum[3] / tot);
   }
+#endif
   return IREC_OK;
 }
 

@@ -23,6 +23,11 @@ class MorePartitionsNeeded(CodingError):
         self.need = need
 
 
+class SplitNotResident(CodingError):
+    """The split encoder (several workgroups per block, calls of few blocks) gave up waiting for partner workgroups that were
+    not resident -- other work held the CUs.  The blocks were NOT coded; code again with coder.no_split = True."""
+
+
 class PendingCode:
     """Result of one asynchronous encode call: everything stays on the device until the host asks.
     K [n_blocks] int32, idx [n_blocks, max_K] int32 (rows in layout order), sample (input shape)."""
@@ -32,8 +37,8 @@ class PendingCode:
 
     def _lists(self, K_host, idx_host):
         if (K_host == -2).any():
-            raise CodingError("the split encoder's cooperating workgroups were not all resident (too many small calls in "
-                              "flight on this device): encode again, or set coder.no_split = True")
+            raise SplitNotResident("the split encoder's cooperating workgroups were not all resident (too many small calls in "
+                                   "flight on this device): encode again with coder.no_split = True")
         if (K_host < 0).any():
             raise CodingError("a block exceeded the engine's dimension bound")
         need = int(K_host.max()) if K_host.size else 0
@@ -82,14 +87,21 @@ class PendingCode:
                 r = torch.nn.functional.pad(r, (0, width + 1 - r.shape[1]))
             rows.append(r)
         both = torch.cat(rows, dim=0).cpu().numpy()
-        out, at, retry = [], 0, None
+        out, at, retry, split_failed = [], 0, None, False
         for p in pendings:
             n = p.K.shape[0]
             try:
                 out.append(p._lists(both[at:at + n, 0], both[at:at + n, 1:1 + p.idx.shape[1]]))
             except MorePartitionsNeeded as e:     # keep going: every coder's hint is raised before the caller codes again
                 retry = e if retry is None or e.need > retry.need else retry
+            except SplitNotResident as e:         # likewise: every coder of the pass leaves the split encoder before it is coded again
+                p.coder.no_split = True
+                retry = retry if isinstance(retry, MorePartitionsNeeded) else e
+                split_failed = True
             at += n
+        if split_failed:
+            for p in pendings:
+                p.coder.no_split = True
         if retry is not None:
             raise retry
         return out
@@ -110,6 +122,7 @@ class BeamSearchCoder(GaussianCoder):
         self.team = False            # debugging / testing knob: IREC_FLAG_TEAM (the team encoder also for small calls)
         self.no_split = False        # debugging / testing knob: IREC_FLAG_NO_SPLIT (one workgroup per block also for small calls)
         self.split_samples = False   # IREC_FLAG_SPLIT_SAMPLES: the split encoder shares a block's samples (r02b form), not its beams
+        self._test_split_orphan = False  # test hook (IREC_FLAG_TEST_SPLIT_ORPHAN): the split encoder's partners leave at once
         self.team_shape = "default"  # diagnostics: IREC_FLAG_SHAPE_* workgroup shape of the team encoder
         self.reuse_tables = True     # IREC_FLAG_REUSE_TABLES: a call whose proposal tables are already in the stream's scratch
                                      # (same seed, S, dims and window: the 24 residual blocks of an image) does not rebuild them
@@ -152,7 +165,8 @@ class BeamSearchCoder(GaussianCoder):
                 (_lib.IREC_FLAG_ONE_TABLE if self.one_table else 0) | \
                 (_lib.IREC_FLAG_TEAM if self.team else 0) | (_lib.IREC_FLAG_NO_SPLIT if self.no_split else 0) | \
                 (_lib.IREC_FLAG_REUSE_TABLES if self.reuse_tables else 0) | \
-                (_lib.IREC_FLAG_SPLIT_SAMPLES if self.split_samples else 0) | _lib.IREC_FLAG_SHAPE[self.team_shape]
+                (_lib.IREC_FLAG_SPLIT_SAMPLES if self.split_samples else 0) | _lib.IREC_FLAG_SHAPE[self.team_shape] | \
+                (32 if self._test_split_orphan and not self.no_split else 0)
         steps = int(table_steps) if table_steps else self.table_window()
         return get_engine().params(self.kl_per_partition, self.n_samples, self.n_beams, flags, table_steps=steps)
 
@@ -193,6 +207,10 @@ class BeamSearchCoder(GaussianCoder):
                 return pending.to_lists(), pending.sample
             except MorePartitionsNeeded as e:     # a block's KL asks for more partitions than the index buffer holds
                 max_K = e.need
+            except SplitNotResident:              # partner workgroups not resident (the device is shared): one workgroup per
+                if self.no_split:                 # block from now on -- slower for calls this small, but it cannot wait in vain
+                    raise
+                self.no_split = True
     def decode_tensors(self, p_loc, p_scale, indices, seed, block_size):
         src = torch.as_tensor(p_loc)
         eng = self._engine_for(src)

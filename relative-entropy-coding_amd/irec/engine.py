@@ -6,6 +6,7 @@ Host-side counterpart of the loops in the reference's
     Coder.split / merge             rec/coding/coder.py:38-122   (here: gather/scatter through `perm` inside the kernels)
 """
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -127,7 +128,7 @@ class Engine:
         self.ctx = ctx
         self._layouts = {}
         self._ws = {}      # one scratch buffer per HIP stream: calls on different streams never share counters / slabs
-        self._session = None   # table_session(): key of the previous call of a back-to-back run of twin calls
+        self._tls = threading.local()   # table_session(): key of the calling THREAD's previous call of a back-to-back run of twins
         self._dec_ws = {}  # decode scratch (proposal tables of a call) per HIP stream
 
     def __del__(self):
@@ -177,11 +178,12 @@ class Engine:
 
         class _Session:
             def __enter__(self_):
-                eng._session = {"key": None}
+                self_.outer = getattr(eng._tls, "session", None)
+                eng._tls.session = {"key": None}
                 return self_
 
             def __exit__(self_, *exc):
-                eng._session = None
+                eng._tls.session = self_.outer
                 return False
         return _Session()
 
@@ -233,18 +235,26 @@ class Engine:
         else:
             out_K, out_idx, sample = out
         ws, need = self.workspace(params, lay.max_dim, max_K)
-        if self._session is not None and (params.flags & _lib.IREC_FLAG_REUSE_TABLES):
-            key = (ws.data_ptr(), int(torch.cuda.current_stream(self.device).cuda_stream), int(seed), int(max_K), lay.n_blocks,
-                   lay.max_dim, bytes(params))
-            if self._session["key"] == key:
-                params = self.params(params.kl_per_partition, params.n_samples, params.n_beams,
-                                     params.flags | _lib.IREC_FLAG_TABLES_PRESENT, list(params.table_dims), params.table_steps)
-            self._session["key"] = key
+        session = getattr(self._tls, "session", None)
+        if session is not None:
+            # EVERY call inside a session moves the key on: one that does not carry REUSE_TABLES (another coder's settings, a
+            # direct call) may lay its slabs over the tables and stamps the slots zero, so the next call must not be told the
+            # tables are present because an EARLIER twin left them.  The session belongs to the calling thread.
+            key = None
+            if params.flags & _lib.IREC_FLAG_REUSE_TABLES:
+                key = (ws.data_ptr(), int(torch.cuda.current_stream(self.device).cuda_stream), int(seed), int(max_K), lay.n_blocks,
+                       lay.max_dim, bytes(params))
+                if session["key"] == key:
+                    params = self.params(params.kl_per_partition, params.n_samples, params.n_beams,
+                                         params.flags | _lib.IREC_FLAG_TABLES_PRESENT, list(params.table_dims), params.table_steps)
+            session["key"] = None      # (until the call below has been issued: an error leaves nothing to trust)
         _lib.check(self.lib.irec_beam_encode(self.ctx, ctypes.byref(params), lay.n_blocks, _ptr(lay.block_base),
                                              _ptr(lay.block_pos), _ptr(lay.block_dim), lay.max_dim, _ptr(lay.perm),
                                              _ptr(q_loc), _ptr(q_scale), _ptr(p_loc), _ptr(p_scale), int(seed),
                                              int(max_K), _ptr(out_K), _ptr(out_idx), _ptr(sample), _ptr(ws),
                                              ws.numel(), self._stream()), "irec_beam_encode")
+        if session is not None:
+            session["key"] = key
         return out_K, out_idx, sample
 
     def _decode_ws(self, params, max_K):

@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..coding import BeamSearchCoder
-from ..coding.beam_search_coder import MorePartitionsNeeded, PendingCode
+from ..coding.beam_search_coder import MorePartitionsNeeded, PendingCode, SplitNotResident
 
 
 class ModelError(Exception):
@@ -213,8 +213,9 @@ class BidirectionalResNetVAE(nn.Module):
             try:
                 per_block = PendingCode.gather(pendings)     # [res_block][image][coder_block]; the only host sync
                 break
-            except MorePartitionsNeeded:
-                continue   # some block's KL needs more index slots than the coders' hint: the hints are raised, code again
+            except (MorePartitionsNeeded, SplitNotResident):
+                continue   # some block's KL needs more index slots than the coders' hint (the hints are raised), or the split
+                           # encoder's partner workgroups were not resident (every coder now has no_split set): code again
         else:
             raise MorePartitionsNeeded(max(b.coder._max_K_hint for b in self.residual_blocks) + 1)
         return self._indices_structure(per_block, image.shape[0]), reconstruction
@@ -304,7 +305,7 @@ class GraphedCompress:
         self.graph.replay()
         try:
             per_block = PendingCode.gather(self.pendings)
-        except MorePartitionsNeeded:
-            self.graph = None                                          # hints were raised: eager now, re-capture next time
+        except (MorePartitionsNeeded, SplitNotResident):
+            self.graph = None                                          # hints were raised / the split left: eager now, re-capture next time
             return self.model.compress(image, seed=self.seed, update_sampler=self.update_sampler)
         return self.model._indices_structure(per_block, image.shape[0]), self.reconstruction.clone()

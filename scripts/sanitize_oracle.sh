@@ -7,9 +7,8 @@ OUT=profiles/sanitizer_oracle.log
 TMP=$(mktemp -d)
 gcc -O1 -g -mfma -ffp-contract=off -fno-fast-math -fPIC -Wall -Wextra -std=gnu11 -fopenmp -fsanitize=address,undefined \
     -fno-omit-frame-pointer -shared -o $TMP/libirec_oracle.so oracle/irec_oracle.c -lm || exit 1
-cp oracle/libirec_oracle.so $TMP/libirec_oracle.prod.so
-cp $TMP/libirec_oracle.so oracle/libirec_oracle.so
-trap 'cp $TMP/libirec_oracle.prod.so oracle/libirec_oracle.so; touch oracle/libirec_oracle.so' EXIT INT TERM
+export IREC_ORACLE_LIB_PATH=$TMP/libirec_oracle.so    # loaded by path: the library in oracle/ is never touched
+trap 'rm -rf $TMP' EXIT
 {
 echo "# $(date -u +%FT%TZ)  gcc $(gcc -dumpversion)  -fsanitize=address,undefined  (oracle/irec_oracle.c)"
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 \

@@ -841,6 +841,56 @@ def test_split_encoder_gives_up_instead_of_hanging(engine, oracle):
     assert [int(v) for v in i2] == ridx and np.array_equal(s2.cpu().numpy()[0], rs)
 
 
+def test_split_encoder_give_up_is_coded_again_without_the_split(engine, oracle):
+    """a split-encoder call whose partner workgroups are not resident reads back K = -2; the coder codes the
+    blocks again with one workgroup per block instead of handing the caller a failed image."""
+    mq, sq, mp, sp = (torch.as_tensor(a[None], device="cuda") for a in oracle.synthetic_latent(77, 1000))
+    c = _coder(3.0, 20, 1.2, variant="one_table")
+    c._test_split_orphan = True                              # every split call gives up after its 2-second wait
+    idx, sample = c.encode(_normal(mq, sq), _normal(mp, sp), seed=42)
+    assert c.no_split                                        # the coder left the split encoder
+    ridx, rs = oracle.encode_block(mq.cpu().numpy()[0], sq.cpu().numpy()[0], mp.cpu().numpy()[0], sp.cpu().numpy()[0], 42, 3.0, 36, 20)
+    assert [int(v) for v in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
+
+
+def test_infinite_kl_block_does_not_poison_the_partition_hint(engine, oracle):
+    """a degenerate block (zero prior scale: infinite KL, 10^9 partitions) is a CodingError for ITS tensor and must
+    leave the coder's max_K hint usable: the next, ordinary tensor codes as if nothing had happened."""
+    import irec
+    good = oracle.synthetic_latent(611, 2192)
+    bad = [a.copy() for a in good]
+    bad[3][:5] = 0.0                                         # p_scale = 0 on a few dims
+    c = irec.BeamSearchCoder(kl_per_partition=3., n_beams=20, extra_samples=1.2, block_size=1000)
+    with pytest.raises(irec.CodingError):
+        c.encode(_normal(*(a[None] for a in bad[:2])), _normal(*(a[None] for a in bad[2:])), seed=42)
+    assert c._max_K_hint <= irec._lib.MAX_PARTITIONS
+    idx, sample = c.encode(_normal(*(a[None] for a in good[:2])), _normal(*(a[None] for a in good[2:])), seed=42)
+    ridx, rs = oracle.encode_tensor(*good, 42, 3.0, 36, 20, block_size=1000)
+    assert idx == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
+
+
+def test_table_session_key_moves_with_every_call(engine, oracle):
+    """inside Engine.table_session a call WITHOUT the reuse flag (another coder's settings) lays its slabs over the
+    proposal tables; the twin call that follows must rebuild them instead of being told they are present."""
+    import irec
+    stats = [oracle.synthetic_latent(620 + i, 8192) for i in range(2)]
+    q = [torch.from_numpy(np.stack([s[j] for s in stats])).cuda().contiguous() for j in range(4)]
+    lay = engine.layout(2, 8192, 1000, 42)
+    reuse = engine.params(3.0, 36, 20, irec._lib.IREC_FLAG_REUSE_TABLES)
+    other = engine.params(3.0, 36, 20, irec._lib.IREC_FLAG_FUSED_PHILOX)          # no tables: slabs at the head of the scratch
+    K0, i0, s0 = engine.encode_blocks(reuse, lay, *q, 42, 32)
+    K0, i0, s0 = K0.clone(), i0.clone(), s0.clone()
+    with engine.table_session():
+        engine.encode_blocks(reuse, lay, *q, 42, 32)
+        engine.encode_blocks(reuse, lay, *q, 42, 32)                              # twin: tables present
+        engine.encode_blocks(other, lay, *q, 42, 32)                              # writes over the table area
+        K1, i1, s1 = engine.encode_blocks(reuse, lay, *q, 42, 32)                 # must NOT skip its table kernels
+    assert torch.equal(K1, K0) and torch.equal(s1, s0)
+    Kh = K0.cpu().numpy()
+    for r in range(lay.n_blocks):
+        assert torch.equal(i1[r, :Kh[r]], i0[r, :Kh[r]])
+
+
 def test_table_window_follows_the_partition_counts(engine, oracle):
     """The Python coder sizes the proposal tables from the K it has read back (32 steps of table for K ~ 8)."""
     import irec
