@@ -273,6 +273,20 @@ irec_status irec_rec_decode_file(const uint8_t *bytes, int64_t n_bytes, uint32_t
                                  int32_t *blocks_per_res, int64_t cap_res, int32_t *K, int64_t cap_blocks, int32_t *indices,
                                  int64_t cap_indices);
 
+/* Many containers at once (host threads; n_threads = 0: one per core, at most 32).  A batched model pass hands over ONE packed
+ * read-back for all its images -- K [n_images][R][bpt], idx [n_images][R][bpt][max_K] (first K entries of a row count), R
+ * residual blocks of bpt coded blocks each -- instead of nested per-image lists (the per-image loop of
+ * compression_performance.py:350-375: write_compressed_code, then read_compressed_code and compare).
+ * irec_rec_encode_files: the n_images files back to back in out, offsets [n_images + 1]; every file byte for byte what
+ * irec_rec_encode_file gives for that image.  Returns the total byte count (also when > cap: call again), -1 on error.
+ * irec_rec_decode_files: the inverse, rows zero-filled past K; headers [n_images][9] as irec_rec_decode_file's header_out. */
+int64_t irec_rec_encode_files(uint32_t seed, uint32_t block_size, uint32_t max_index, uint32_t height, uint32_t width,
+                              uint32_t channels, int32_t n_images, int32_t n_res_blocks, int32_t blocks_per_res, int32_t max_K,
+                              const int32_t *K, const int32_t *idx, uint8_t *out, int64_t cap, int64_t *offsets, int32_t n_threads);
+irec_status irec_rec_decode_files(const uint8_t *bytes, const int64_t *offsets, int32_t n_images, int32_t n_res_blocks,
+                                  int32_t blocks_per_res, int32_t max_K, uint32_t *headers, int32_t *K, int32_t *idx,
+                                  int32_t n_threads);
+
 /* ---- test hooks (device pointers) ---------------------------------------------------------------------------- */
 /* r[s*D + d] of get_pseudo_random_sample's int32 draw, generated by the in-kernel Philox stream.  out: int32 [n]. */
 irec_status irec_device_uniform_int(irec_context *ctx, int64_t seed, int64_t n, int32_t *out, void *hip_stream);

@@ -3,9 +3,11 @@
 // C ABI of include/irec.h.  Host code: the reference's coder is CPU code too (its only native component), and the
 // streams are a few hundred bits per image.  Bit-for-bit the reference's output (tests/test_rec_io.py pins it against
 // the real reference coder, built by the test infrastructure, and against committed golden .rec files).
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "irec.h"
@@ -289,6 +291,122 @@ irec_status irec_rec_decode_file(const uint8_t *bytes, int64_t n_bytes, uint32_t
     for (int32_t c : counts[(size_t)r]) K[kb++] = c;
     for (int32_t v : vals[(size_t)r]) indices[ib++] = v;
   }
+  return IREC_OK;
+}
+
+// ---- many containers at once (round 3) --------------------------------------------------------------------------------------
+// The per-image loop of the reference's evaluation script writes one .rec per image (compression_performance.py:350-365) and
+// reads it back (:369-375).  A batched model pass hands over ONE packed read-back for all images:
+//     K   [n_images][R][bpt]            partitions of block j of residual block r of image i
+//     idx [n_images][R][bpt][max_K]     its index row (the first K entries count)
+// irec_rec_encode_files builds the n_images containers from it on `n_threads` host threads (0 = one per core, at most 32):
+// out = the files back to back, offsets[n_images + 1].  Each file is byte for byte what irec_rec_encode_file / the
+// reference's write_compressed_code produce for that image.  Returns the total byte count (also when it exceeds cap: call
+// again with room), -1 on invalid input.
+} // extern "C"
+namespace {
+template <class F>
+void for_each_image(int32_t n_images, int32_t n_threads, F &&body) {
+  int T = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+  T = T < 1 ? 1 : (T > 32 ? 32 : T);
+  if (T > n_images) T = n_images;
+  if (T <= 1) { for (int32_t i = 0; i < n_images; ++i) body(i); return; }
+  std::vector<std::thread> pool;
+  for (int t = 0; t < T; ++t)
+    pool.emplace_back([&, t]() { for (int32_t i = t; i < n_images; i += T) body(i); });
+  for (auto &th : pool) th.join();
+}
+} // namespace
+extern "C" {
+
+int64_t irec_rec_encode_files(uint32_t seed, uint32_t block_size, uint32_t max_index, uint32_t height, uint32_t width,
+                              uint32_t channels, int32_t n_images, int32_t n_res_blocks, int32_t blocks_per_res, int32_t max_K,
+                              const int32_t *K, const int32_t *idx, uint8_t *out, int64_t cap, int64_t *offsets, int32_t n_threads) {
+  if (n_images < 0 || n_res_blocks < 1 || blocks_per_res < 1 || max_K < 0 || !K || (max_K > 0 && !idx) || !offsets) {
+    io_fail("irec_rec_encode_files: bad arguments"); return -1; }
+  std::vector<std::vector<uint8_t>> files((size_t)n_images);
+  std::vector<std::string> errs((size_t)n_images);
+  const int64_t per_img = (int64_t)n_res_blocks * blocks_per_res;
+  const std::vector<int32_t> bpr((size_t)n_res_blocks, blocks_per_res);
+  for_each_image(n_images, n_threads, [&](int32_t i) {
+    const int32_t *Ki = K + (int64_t)i * per_img;
+    std::vector<int32_t> flat;
+    flat.reserve((size_t)per_img * 8);
+    for (int64_t b = 0; b < per_img; ++b) {
+      const int32_t k = Ki[b];
+      if (k < 0 || k > max_K) { errs[(size_t)i] = "irec_rec_encode_files: K out of range"; return; }
+      const int32_t *row = idx + ((int64_t)i * per_img + b) * max_K;
+      flat.insert(flat.end(), row, row + k);
+    }
+    std::vector<uint8_t> &f = files[(size_t)i];
+    f.resize((size_t)(64 + 16 * n_res_blocks + 4 * (per_img + (int64_t)flat.size()) + 64));
+    int64_t n = irec_rec_encode_file(seed, block_size, max_index, height, width, channels, n_res_blocks, bpr.data(), Ki,
+                                     flat.empty() ? nullptr : flat.data(), f.data(), (int64_t)f.size());
+    if (n > (int64_t)f.size()) {
+      f.resize((size_t)n);
+      n = irec_rec_encode_file(seed, block_size, max_index, height, width, channels, n_res_blocks, bpr.data(), Ki,
+                               flat.empty() ? nullptr : flat.data(), f.data(), (int64_t)f.size());
+    }
+    if (n < 0) { errs[(size_t)i] = g_io_error; return; }
+    f.resize((size_t)n);
+  });
+  int64_t total = 0;
+  for (int32_t i = 0; i < n_images; ++i) {
+    if (!errs[(size_t)i].empty()) { g_io_error = errs[(size_t)i] + " (image " + std::to_string(i) + ")"; return -1; }
+    offsets[i] = total; total += (int64_t)files[(size_t)i].size();
+  }
+  offsets[n_images] = total;
+  if (out && cap >= total)
+    for (int32_t i = 0; i < n_images; ++i) std::memcpy(out + offsets[i], files[(size_t)i].data(), files[(size_t)i].size());
+  return total;
+}
+
+// The inverse: n_images containers (bytes at offsets[i] .. offsets[i + 1]) decoded on host threads into the packed layout
+// above (rows zero-filled past K).  headers [n_images][9] as irec_rec_decode_file's; every file must hold n_res_blocks
+// residual blocks of blocks_per_res coded blocks with at most max_K partitions, else the call fails naming the image.
+irec_status irec_rec_decode_files(const uint8_t *bytes, const int64_t *offsets, int32_t n_images, int32_t n_res_blocks,
+                                  int32_t blocks_per_res, int32_t max_K, uint32_t *headers, int32_t *K, int32_t *idx,
+                                  int32_t n_threads) {
+  if (!bytes || !offsets || n_images < 0 || n_res_blocks < 1 || blocks_per_res < 1 || max_K < 0 || !headers || !K || (max_K > 0 && !idx))
+    return io_fail("irec_rec_decode_files: bad arguments");
+  std::vector<std::string> errs((size_t)n_images);
+  const int64_t per_img = (int64_t)n_res_blocks * blocks_per_res;
+  for_each_image(n_images, n_threads, [&](int32_t i) {
+    std::vector<int32_t> bpr((size_t)n_res_blocks), flat;
+    int64_t sizes[3] = {0, 0, 0};
+    int32_t *Ki = K + (int64_t)i * per_img;
+    const uint8_t *p = bytes + offsets[i];
+    const int64_t nb = offsets[i + 1] - offsets[i];
+    // an index costs at least ~1.4 bits under the default model unless max_index is tiny: size the buffer from the file, retry once
+    flat.resize((size_t)(8 * nb + 1024));
+    irec_status st = IREC_E_WORKSPACE;
+    for (int attempt = 0; attempt < 2 && st == IREC_E_WORKSPACE; ++attempt) {
+      std::vector<int32_t> Ktmp((size_t)std::max<int64_t>(per_img, sizes[1]));
+      st = irec_rec_decode_file(p, nb, headers + 9 * (int64_t)i, sizes, bpr.data(), n_res_blocks, Ktmp.data(), (int64_t)Ktmp.size(),
+                                flat.data(), (int64_t)flat.size());
+      if (st == IREC_E_WORKSPACE) {
+        if (sizes[0] != n_res_blocks || sizes[1] != per_img) { st = IREC_E_INVALID; g_io_error = "irec_rec_decode_files: block structure differs"; break; }
+        flat.resize((size_t)sizes[2] + 1);
+      } else if (st == IREC_OK) {
+        if (sizes[0] != n_res_blocks || sizes[1] != per_img) { st = IREC_E_INVALID; g_io_error = "irec_rec_decode_files: block structure differs"; break; }
+        for (int32_t r = 0; r < n_res_blocks; ++r)
+          if (bpr[(size_t)r] != blocks_per_res) { st = IREC_E_INVALID; g_io_error = "irec_rec_decode_files: block structure differs"; }
+        if (st != IREC_OK) break;
+        int64_t at = 0;
+        for (int64_t b = 0; b < per_img; ++b) {
+          const int32_t k = Ktmp[(size_t)b];
+          if (k > max_K) { st = IREC_E_INVALID; g_io_error = "irec_rec_decode_files: more partitions than max_K"; break; }
+          Ki[b] = k;
+          int32_t *row = idx + ((int64_t)i * per_img + b) * max_K;
+          for (int32_t t = 0; t < max_K; ++t) row[t] = t < k ? flat[(size_t)(at + t)] : 0;
+          at += k;
+        }
+      }
+    }
+    if (st != IREC_OK) errs[(size_t)i] = g_io_error.empty() ? std::string("irec_rec_decode_files: failed") : g_io_error;
+  });
+  for (int32_t i = 0; i < n_images; ++i)
+    if (!errs[(size_t)i].empty()) { g_io_error = errs[(size_t)i] + " (image " + std::to_string(i) + ")"; return IREC_E_INVALID; }
   return IREC_OK;
 }
 

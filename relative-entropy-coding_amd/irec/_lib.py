@@ -88,6 +88,8 @@ SIGNATURES = {
     "irec_rec_unpack_bits": (_i64, [_vp, _i64, _vp, _i64]),
     "irec_rec_encode_file": (_i64, [ctypes.c_uint32] * 6 + [_i32, _vp, _vp, _vp, _vp, _i64]),
     "irec_rec_decode_file": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64]),
+    "irec_rec_encode_files": (_i64, [ctypes.c_uint32] * 6 + [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i32]),
+    "irec_rec_decode_files": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32]),
     "irec_device_uniform_int": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "irec_test_decoder_sqrt": (ctypes.c_int, [_vp, _vp, _vp]),
     "irec_test_reduce_scatter": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp]),

@@ -35,7 +35,8 @@ class PendingCode:
     def __init__(self, coder, lay, K, idx, sample, max_K):
         self.coder, self.lay, self.K, self.idx, self.sample, self.max_K = coder, lay, K, idx, sample, max_K
 
-    def _lists(self, K_host, idx_host):
+    def _check(self, K_host):
+        """Errors and hints from the partition counts read back (shared by the list and the packed read-backs)."""
         if (K_host == -2).any():
             raise SplitNotResident("the split encoder's cooperating workgroups were not all resident (too many small calls in "
                                    "flight on this device): encode again with coder.no_split = True")
@@ -48,12 +49,16 @@ class PendingCode:
         self.coder._max_K_hint = min(max(self.coder._max_K_hint, need), _lib.MAX_PARTITIONS)
         c = self.coder            # table window hint: what covers the bulk of the blocks read back (a few outliers take the
         if K_host.size:           # second pass instead of stretching every later call's tables), decaying by an eighth per read
-            upper_quartile = int(np.partition(K_host, (3 * (K_host.size - 1)) // 4)[(3 * (K_host.size - 1)) // 4])   # (np.quantile
+            flat = K_host.reshape(-1)
+            upper_quartile = int(np.partition(flat, (3 * (flat.size - 1)) // 4)[(3 * (flat.size - 1)) // 4])   # (np.quantile
             bulk = (5 * upper_quartile + 3) // 4                       #  costs 40 us a call: 1 ms per 24-block image)
             c._K_seen = bulk if c._K_reads == 0 else max(bulk, c._K_seen - max(1, c._K_seen // 8))
         c._K_reads += 1
         if need > self.max_K:
             raise MorePartitionsNeeded(need)
+
+    def _lists(self, K_host, idx_host):
+        self._check(K_host)
         lay = self.lay
         bpt = lay.blocks_per_tensor
         # One C-speed conversion, the per-block lists are slices of it; the cyclic collector is paused meanwhile (a batched
@@ -73,6 +78,40 @@ class PendingCode:
         """Indices per tensor per block (host lists): ONE device-to-host copy (K and the index rows together)."""
         both = torch.cat([self.K[:, None], self.idx], dim=1).cpu().numpy()
         return self._lists(both[:, 0], both[:, 1:])
+
+    @staticmethod
+    def gather_packed(pendings):
+        """Indices of R calls on the SAME layout (the residual blocks of a batched model pass) as packed arrays, image-major:
+        K [N, R, bpt] int32, idx [N, R, bpt, max_K] int32 (numpy; rows are valid up to K) -- ONE gather on the device and ONE
+        device-to-host copy, no per-index Python object.  irec.io.encode_files takes them as they are."""
+        lay = pendings[0].lay
+        assert all(p.lay is lay for p in pendings) and lay.natural is not None
+        width = max(p.idx.shape[1] for p in pendings)
+        rows = []
+        for p in pendings:
+            r = torch.cat([p.K[:, None], p.idx], dim=1)
+            if r.shape[1] < width + 1:
+                r = torch.nn.functional.pad(r, (0, width + 1 - r.shape[1]))
+            rows.append(r)
+        n, bpt, R = lay.n_tensors, lay.blocks_per_tensor, len(pendings)
+        sel = lay.packed_index(R)                                             # row of (image i, residual block r, block j)
+        both = torch.cat(rows, dim=0).index_select(0, sel).cpu().numpy().reshape(n, R, bpt, width + 1)
+        K, idx = both[..., 0], both[..., 1:]
+        retry, split_failed = None, False
+        for r, p in enumerate(pendings):
+            try:
+                p._check(K[:, r, :])
+            except MorePartitionsNeeded as e:
+                retry = e if retry is None or not isinstance(retry, MorePartitionsNeeded) or e.need > retry.need else retry
+            except SplitNotResident as e:
+                split_failed = True
+                retry = retry if isinstance(retry, MorePartitionsNeeded) else e
+        if split_failed:
+            for p in pendings:
+                p.coder.no_split = True
+        if retry is not None:
+            raise retry
+        return np.ascontiguousarray(K), np.ascontiguousarray(idx)
 
     @staticmethod
     def gather(pendings):

@@ -81,6 +81,16 @@ class BlockLayout:
             self._natural_dev = torch.from_numpy(self.natural.astype(np.int32)).to(self.block_base.device)
         return self._natural_dev
 
+    def packed_index(self, n_calls):
+        """int64 device index into the rows of `n_calls` read-backs of this layout stacked call after call: position
+        (image i, call r, block j) -> r * n_blocks + natural[i * blocks_per_tensor + j] (PendingCode.gather_packed)."""
+        cache = self.__dict__.setdefault("_packed_index", {})
+        if n_calls not in cache:
+            nat = self.natural.reshape(self.n_tensors, 1, self.blocks_per_tensor).astype(np.int64)
+            g = nat + (np.arange(n_calls, dtype=np.int64) * self.n_blocks).reshape(1, n_calls, 1)
+            cache[n_calls] = torch.from_numpy(np.ascontiguousarray(g.reshape(-1))).to(self.block_base.device)
+        return cache[n_calls]
+
     def subset(self, rows):
         """The layout restricted to `rows` (indices into this layout's row order): what ONE rank codes when the blocks of a
         call are spread over several GPUs (irec/sharding.py).  Same tensors, same permutation."""

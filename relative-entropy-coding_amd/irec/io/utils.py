@@ -141,6 +141,48 @@ def _native_decode(data):
     return int(hdr[0]), (int(hdr[3]), int(hdr[4]), int(hdr[5])), int(hdr[1]), blocks
 
 
+def encode_files(seed, image_shape, block_size, K, idx, max_index, n_threads=0):
+    """N containers at once from a packed read-back (irec_rec_encode_files): K [N, R, bpt] int32, idx [N, R, bpt, max_K] int32.
+    Returns (blob uint8, offsets int64 [N + 1]): file i = blob[offsets[i]:offsets[i + 1]], byte for byte what
+    write_compressed_code writes for image i (rec/io/utils.py:7-106, default symbol models)."""
+    lib = _lib.load()
+    K = np.ascontiguousarray(K, dtype=np.int32)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    n, r, bpt = K.shape
+    max_K = idx.shape[3] if idx.ndim == 4 else 0
+    assert idx.shape[:3] == K.shape
+    h, w, c = (int(v) for v in image_shape)
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    cap = n * (64 + 16 * r) + 2 * int(K.sum()) + 16 * K.size + 1024
+    while True:
+        out = np.empty(cap, dtype=np.uint8)
+        total = lib.irec_rec_encode_files(int(seed), int(block_size), int(max_index), h, w, c, n, r, bpt, max_K, K.ctypes.data,
+                                          idx.ctypes.data if idx.size else None, out.ctypes.data, cap, offsets.ctypes.data,
+                                          int(n_threads))
+        if total < 0:
+            raise ValueError(lib.irec_io_last_error().decode())
+        if total <= cap:
+            return out[:total], offsets
+        cap = int(total)
+
+
+def decode_files(blob, offsets, n_res_blocks, blocks_per_res, max_K, n_threads=0):
+    """The inverse of encode_files (irec_rec_decode_files): (headers [N, 9] uint32 -- seed, block_size, max_index, height,
+    width, channels, two flags, R --, K [N, R, bpt], idx [N, R, bpt, max_K] with rows zero-filled past K)."""
+    lib = _lib.load()
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = offsets.size - 1
+    hdr = np.zeros((n, 9), dtype=np.uint32)
+    K = np.zeros((n, n_res_blocks, blocks_per_res), dtype=np.int32)
+    idx = np.zeros((n, n_res_blocks, blocks_per_res, max(max_K, 1)), dtype=np.int32)
+    st = lib.irec_rec_decode_files(blob.ctypes.data, offsets.ctypes.data, n, int(n_res_blocks), int(blocks_per_res), int(max_K),
+                                   hdr.ctypes.data, K.ctypes.data, idx.ctypes.data, int(n_threads))
+    if st != 0:
+        raise ValueError(lib.irec_io_last_error().decode())
+    return hdr, K, idx[..., :max_K]
+
+
 def write_compressed_code(file_path, seed, image_shape, block_size, block_indices, max_index,
                           num_aux_var_counts_file=None, index_counts_file=None):
     """Same signature as rec/io/utils.py:7.  block_indices[r][k] = sample indices of coded block k of residual block r.

@@ -220,6 +220,20 @@ class BidirectionalResNetVAE(nn.Module):
             raise MorePartitionsNeeded(max(b.coder._max_K_hint for b in self.residual_blocks) + 1)
         return self._indices_structure(per_block, image.shape[0]), reconstruction
 
+    @torch.no_grad()
+    def compress_packed(self, image, seed, update_sampler=False):
+        """`compress` for a batch, with the indices left packed: (K [N, R, bpt], idx [N, R, bpt, max_K] int32 numpy arrays,
+        reconstruction) -- what irec.io.encode_files turns into N .rec files without one Python object per index.  Needs every
+        residual block to share one block layout (they do: same latent shape and block_size)."""
+        for _attempt in range(6):
+            pendings, reconstruction = self._compress_device(image, seed, update_sampler)
+            try:
+                K, idx = PendingCode.gather_packed(pendings)
+                return K, idx, reconstruction
+            except (MorePartitionsNeeded, SplitNotResident):
+                continue
+        raise MorePartitionsNeeded(max(b.coder._max_K_hint for b in self.residual_blocks) + 1)
+
     def _compress_device(self, image, seed, update_sampler=False):
         """Everything of `compress` that runs on the device, with no host synchronisation: (PendingCode per residual
         block, reconstruction).  Capturable in a HIP graph (GraphedCompress)."""
@@ -275,37 +289,72 @@ class GraphedCompress:
     and later calls replay it (one graph launch instead of several hundred kernel launches; the coder's entry points are
     asynchronous and allocation-free, so they capture like any other kernel).  Inputs are copied into the graph's static
     image buffer; indices are read back with the usual single device-to-host copy.  Same outputs as `model.compress`.
-    A block that needs more partitions than the captured index buffers hold falls back to the eager path and re-captures."""
+    A block that needs more partitions than the captured index buffers hold falls back to the eager path and re-captures.
 
-    def __init__(self, model, image_shape, seed, update_sampler=False):
+    lanes > 1 (round 3; off by default, see below): the batch is cut into `lanes` independent sub-batches, each captured
+    as its own graph on its own stream and replayed side by side.  Images are independent (compression_performance.py:305 is
+    a plain loop), only the 24 residual blocks of ONE image are sequential (resnet_vae.py:821-826): while one lane waits for
+    the single-wave tail of its coder call -- a mid-size call is one or two blocks per CU and lasts as long as its slowest
+    block's K sequential steps -- the other lane's convolutions and coder fill the device.  Each lane has its own scratch
+    (the engine keys it by stream), its own static buffers and index rows; the indices are the same, image for image."""
+
+    def __init__(self, model, image_shape, seed, update_sampler=False, lanes=None):
         self.model, self.seed, self.update_sampler = model, seed, update_sampler
         self.device = next(model.parameters()).device
-        self.static_image = torch.zeros(image_shape, device=self.device)
-        self.graph = None
+        n = int(image_shape[0])
+        if lanes is None:
+            lanes = 1   # (measured r03d: two lanes do not overlap -- the convolutions' 64 KB and the coder's 160 KB of LDS per workgroup cannot share a CU)
+        self.lanes = max(1, min(int(lanes), n))
+        cuts = [n * k // self.lanes for k in range(self.lanes + 1)]
+        self.slices = [slice(cuts[k], cuts[k + 1]) for k in range(self.lanes)]
+        self.static_images = [torch.zeros((sl.stop - sl.start,) + tuple(image_shape[1:]), device=self.device) for sl in self.slices]
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.lanes)]
+        self.graphs = None
+
+    @property
+    def graph(self):                        # (kept for callers that test "has it been captured")
+        return self.graphs
+
+    @graph.setter
+    def graph(self, value):
+        self.graphs = value
 
     @torch.no_grad()
     def _capture(self):
-        side = torch.cuda.Stream(device=self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side):                                  # warm-up on the capture side: caches, scratch, MIOpen
-            for _ in range(2):
-                self.model._compress_device(self.static_image, self.seed, self.update_sampler)
-        torch.cuda.current_stream(self.device).wait_stream(side)
+        cur = torch.cuda.current_stream(self.device)
+        self.graphs, self.pendings, self.reconstructions = [], [], []
+        for lane, st in enumerate(self.streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):                                # warm-up on the lane's stream: caches, ITS scratch, MIOpen
+                for _ in range(2):
+                    self.model._compress_device(self.static_images[lane], self.seed, self.update_sampler)
+            cur.wait_stream(st)
         torch.cuda.synchronize(self.device)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.pendings, self.reconstruction = self.model._compress_device(self.static_image, self.seed,
-                                                                             self.update_sampler)
+        for lane, st in enumerate(self.streams):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                pend, rec = self.model._compress_device(self.static_images[lane], self.seed, self.update_sampler)
+            self.graphs.append(g); self.pendings.append(pend); self.reconstructions.append(rec)
 
     @torch.no_grad()
     def __call__(self, image):
-        self.static_image.copy_(image)
-        if self.graph is None:
+        for lane, sl in enumerate(self.slices):
+            self.static_images[lane].copy_(image[sl])
+        if self.graphs is None:
             self._capture()
-        self.graph.replay()
+        cur = torch.cuda.current_stream(self.device)
+        for lane, st in enumerate(self.streams):                       # the lanes' graphs side by side, each on its own stream
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                self.graphs[lane].replay()
+        for st in self.streams:
+            cur.wait_stream(st)
         try:
-            per_block = PendingCode.gather(self.pendings)
+            flat = PendingCode.gather([p for lane in self.pendings for p in lane])   # ONE device-to-host copy for all lanes
         except (MorePartitionsNeeded, SplitNotResident):
-            self.graph = None                                          # hints were raised / the split left: eager now, re-capture next time
+            self.graphs = None                                         # hints were raised / the split left: eager now, re-capture next time
             return self.model.compress(image, seed=self.seed, update_sampler=self.update_sampler)
-        return self.model._indices_structure(per_block, image.shape[0]), self.reconstruction.clone()
+        n_res = len(self.pendings[0])
+        per_block = [[img for lane in range(self.lanes) for img in flat[lane * n_res + r]] for r in range(n_res)]
+        rec = self.reconstructions[0].clone() if self.lanes == 1 else torch.cat(self.reconstructions, dim=0)
+        return self.model._indices_structure(per_block, image.shape[0]), rec

@@ -1017,4 +1017,4 @@ def test_table_session_skips_only_twin_calls(engine, oracle):
             idx, sample = c.encode(_normal(t[0][:n_t], t[1][:n_t]), _normal(t[2][:n_t], t[3][:n_t]), seed=seed, batched=True)
             for i in range(n_t):
                 assert idx[i] == refs[seed][i][0] and np.array_equal(sample[i].cpu().numpy(), refs[seed][i][1]), (seed, n_t, i)
-    assert engine._session is None
+    assert getattr(engine._tls, "session", None) is None

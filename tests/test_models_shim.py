@@ -162,6 +162,16 @@ def test_batched_compress_equals_one_by_one_and_writes_rec(engine, oracle, tmp_p
     s, shape, bs, bi_file = irec.io.read_compressed_code(str(tmp_path / "img_00003.rec"))
     assert (s, shape, bs) == (42, (32, 32, 3), 1000) and bi_file == bi_batch[3]
     assert rows[3]["n_indices"] == sum(len(ix) for b in bi_batch[3] for ix in b)
+    # the per-image form of the driver (reference's write_compressed_code / read_compressed_code on nested lists): same rows
+    rows_py = harness.compress_images(m, images, [f"py_{i}" for i in range(5)], 42, 1000, str(tmp_path), batch=3, packed=False)
+    for a, b in zip(rows, rows_py):
+        assert (a["comp_codelength"], a["n_indices"], a["indices_recovered"]) == (b["comp_codelength"], b["n_indices"], b["indices_recovered"])
+    assert (tmp_path / "py_3.rec").read_bytes() == (tmp_path / "img_00003.rec").read_bytes()
+    # the packed read-back itself
+    K, idx, recon_p = m.compress_packed(images, seed=42)
+    assert K.shape == (5, 4, 3) and torch.equal(recon_p, recon_batch)
+    for i in range(5):
+        assert [[idx[i, r, j, :K[i, r, j]].tolist() for j in range(3)] for r in range(4)] == bi_batch[i]
 
 
 @pytest.mark.gpu
@@ -179,6 +189,24 @@ def test_graphed_compress_replays_the_whole_pass(engine):
         assert idx_g == idx_e and torch.equal(rec_g, rec_e), k
     assert graphed.graph is not None
     assert torch.equal(m.decompress(idx_g, seed=42, image_shape=images[2].shape), rec_g)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [2, 3])
+def test_graphed_compress_lanes_code_a_batch_side_by_side(engine, lanes):
+    """A batch cut into independent sub-batches, each its own captured graph on its own stream with its own scratch (round
+    3: a mid-size coder call is latency-bound, a second lane fills the device meanwhile): same indices and reconstruction,
+    image for image, as the eager batched pass -- also for a second batch replayed through the same graphs."""
+    from irec.models import GraphedCompress
+    m = _model("cuda", blocks=4)
+    torch.manual_seed(19)
+    batches = torch.rand(2, 7, 3, 32, 32, device="cuda") - 0.5
+    graphed = GraphedCompress(m, (7, 3, 32, 32), seed=42, lanes=lanes)
+    assert graphed.lanes == lanes
+    for k in range(2):
+        idx_e, rec_e = m.compress(batches[k], seed=42)
+        idx_g, rec_g = graphed(batches[k])
+        assert idx_g == idx_e and torch.equal(rec_g, rec_e), k
 
 
 @pytest.mark.gpu

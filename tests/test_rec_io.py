@@ -156,3 +156,48 @@ def test_native_container_equals_the_per_stream_writer(tmp_path):
         U.write_compressed_code(str(tmp_path / "bad.rec"), 1, (8, 8, 3), 1000, [[[0, 36]]], 36)   # index 36 needs max_index >= 37
     with pytest.raises(ValueError):
         U._native_decode(b"\x00" * 26 + b"\x05\x00" + b"\x00" * 12)            # R = 5 but the dynamic header is truncated
+
+
+def test_batched_container_calls_equal_the_per_image_writer(tmp_path):
+    """irec_rec_encode_files / irec_rec_decode_files (round 3: the files of a whole batch from ONE packed read-back, on host
+    threads) against the per-image writer that the golden tests above pin to the real reference: byte-identical files, for the
+    golden structures re-packed and for random ones (rows of K = 0, ragged K, a single residual block), and the inverse."""
+    from irec.io import utils as U
+    rng = np.random.default_rng(17)
+    cases = []
+    for name, seed, shape, bs, max_index, blocks, golden in _rec_sets():
+        if len({len(rb) for rb in blocks}) == 1:                           # (packed form: the same block count per residual block)
+            R, bpt = len(blocks), len(blocks[0])
+            mk = max(len(ix) for rb in blocks for ix in rb)
+            K = np.array([[len(ix) for ix in rb] for rb in blocks], dtype=np.int32)[None]
+            idx = np.zeros((1, R, bpt, mk), dtype=np.int32)
+            for r, rb in enumerate(blocks):
+                for j, ix in enumerate(rb):
+                    idx[0, r, j, :len(ix)] = ix
+            cases.append((seed, shape, bs, max_index, K, idx, [golden]))
+    for n, R, bpt, mk, S in ((9, 5, 9, 12, 36), (3, 1, 1, 4, 20), (40, 24, 9, 16, 36)):
+        K = rng.integers(0, mk + 1, (n, R, bpt)).astype(np.int32)
+        idx = rng.integers(0, S, (n, R, bpt, mk)).astype(np.int32)
+        cases.append((42, (32, 32, 3), 1000, S, K, idx, None))
+    for seed, shape, bs, max_index, K, idx, goldens in cases:
+        blob, off = U.encode_files(seed, shape, bs, K, idx, max_index)
+        n, R, bpt = K.shape
+        for i in range(n):
+            bi = [[idx[i, r, j, :K[i, r, j]].tolist() for j in range(bpt)] for r in range(R)]
+            want = goldens[i] if goldens else U._native_encode(seed, shape, bs, bi, max_index)
+            assert blob[off[i]:off[i + 1]].tobytes() == want, i
+        hdr, K2, idx2 = U.decode_files(blob, off, R, bpt, idx.shape[3])
+        live = np.arange(idx.shape[3])[None, None, None, :] < K[..., None]
+        assert (K2 == K).all() and ((idx2 == idx) | ~live).all() and (idx2[~live] == 0).all()
+        assert (hdr[:, 0] == seed).all() and (hdr[:, 2] == max_index).all() and (hdr[:, 8] == R).all()
+    # errors name the image: an index beyond max_index, a partition count beyond the rows, a file of another structure
+    K = np.ones((3, 2, 2), dtype=np.int32); idx = np.zeros((3, 2, 2, 2), dtype=np.int32)
+    bad = idx.copy(); bad[1, 0, 0, 0] = 99
+    with pytest.raises(ValueError, match="image 1"):
+        U.encode_files(1, (8, 8, 3), 10, K, bad, 36)
+    Kbad = K.copy(); Kbad[2, 1, 1] = 3
+    with pytest.raises(ValueError, match="image 2"):
+        U.encode_files(1, (8, 8, 3), 10, Kbad, idx, 36)
+    blob, off = U.encode_files(1, (8, 8, 3), 10, K, idx, 36)
+    with pytest.raises(ValueError, match="structure"):
+        U.decode_files(blob, off, 2, 3, 2)
