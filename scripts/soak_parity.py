@@ -14,11 +14,11 @@ bad, done, t0 = [], 0, time.time()
 stats = {"K": [], "evals": 0}
 for case in range(n_cases):
     D = int(rng.choice([1, 2, 3, 5, 63, 64, 65, 192, 255, 256, 257, 511, 777, 1000, 1023, 1024, int(rng.integers(1, 1025))]))
-    B = int(rng.choice([1, 2, 7, 10, 11, 20, 21, 30, 32, int(rng.integers(1, 33))]))
+    B = int(rng.choice([1, 2, 7, 10, 11, 20, 21, 30, 32, 33, 50, 60, 61, 64, int(rng.integers(1, 65))]))   # (round 3: up to IREC_MAX_BEAMS)
     omega = float(rng.choice([1.0, 2.0, 3.0, 4.0, float(rng.uniform(0.7, 5.0))]))
     eps1 = float(rng.choice([1.0, 1.2, 1.5]))
     if os.environ.get("SOAK_BIG"):   # bias towards more than 1024 candidates per step (streamed top-B, sample passes, keys in the slab)
-        B = int(rng.choice([11, 16, 20, 21, 30, 31, 32])); omega = float(rng.choice([4.0, 5.0, 5.5, 6.0])); eps1 = float(rng.choice([1.0, 1.1, 1.2]))
+        B = int(rng.choice([1, 10, 11, 16, 20, 21, 30, 31, 32, 40, 50, 60])); omega = float(rng.choice([4.0, 5.0, 5.5, 6.0])); eps1 = float(rng.choice([1.0, 1.1, 1.2]))
         D = int(rng.choice([192, 777, 1000, 1024]))
     S = int(np.exp(omega * eps1))
     if S * B * D > (1.3e7 if os.environ.get("SOAK_BIG") else 6e6):          # keep the oracle fast
@@ -70,7 +70,7 @@ for case in range(n_cases):
     for Kn in Ks:
         stats["evals"] += S * D * (1 + max(Kn - 1, 0) * B)
     done += len(tens); stats["K"].append(K)
-    if case % 250 == 249:   # a long run must keep writing: the GPU box takes minutes of silence for a hang
+    if case % 100 == 99:   # a long run must keep writing: the GPU box takes minutes of silence for a hang
         print(f"[soak] case {case + 1}/{n_cases}: {done} blocks, {len(bad)} mismatches, {time.time() - t0:.0f} s", flush=True)
 print(f"soak: {done} random blocks x 4 variants in {time.time() - t0:.0f} s; K range {min(stats['K'])}..{max(stats['K'])}; "
       f"{stats['evals'] / 1e9:.2f} G proposal evals checked; mismatches: {len(bad)}")

@@ -394,6 +394,20 @@ def test_decoder_both_table_paths(engine, oracle):
         assert np.array_equal(oracle.decode_tensor(mp[i], sp[i], blocks, 42, 36, block_size=bs), sample[i].cpu().numpy())
 
 
+def test_randomised_soak_every_variant_against_the_oracle():
+    """scripts/soak_parity.py in the driver's run (the soaks were builder-run only): random block shapes (1 to 1024
+    dims), beams 1 to 64, S from 2 to several hundred, five statistics regimes incl. K up to 300, 1 to 8 blocks per call --
+    the team, one-table, fused-Philox and generic encoders and the decoder against the CPU oracle, bit for bit; then the same
+    biased to more than 1024 candidates per step (sample passes, keys in the slab, streamed top-B)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ({"SOAK_CASES": "150", "SOAK_SEED": "31"}, {"SOAK_CASES": "40", "SOAK_SEED": "32", "SOAK_BIG": "1"}):
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "soak_parity.py")], env=dict(os.environ, **extra),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "mismatches: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 # ---- the reference's own hyper-parameter sweep (examples/lossless/data_aggregation.py:5-7) -------------------------------
 SWEEP_OMEGA = (2, 3, 4, 5, 6)
 SWEEP_EPS1 = (1.0, 1.1, 1.2, 1.5)
