@@ -287,6 +287,27 @@ irec_status irec_rec_decode_files(const uint8_t *bytes, const int64_t *offsets, 
                                   int32_t blocks_per_res, int32_t max_K, uint32_t *headers, int32_t *K, int32_t *idx,
                                   int32_t n_threads);
 
+/* ---- hand-offs of the RVAE model shim (device pointers, asynchronous; rec/models/resnet_vae.py:372-497) -------------------------
+ * What lies between the convolutions of BidirectionalResidualBlock.call on the compression path, one launch each instead of
+ * ~10 elementwise PyTorch launches per residual block and pass.  Activations NCHW float32 contiguous; statistics / latent NHWC.
+ * irec_shim_stats: out [n_stats][n][hw][stochastic] = prior loc, exp(prior log-scale) (:409-413) and, for n_stats = 4, posterior
+ *   loc = generative + inference side, exp(posterior log-scale) (:148-154, :464-469) from y [n][channels_y][hw] (channels
+ *   0 .. n_stats * stochastic) and the inference pass's heads infer_heads [n][channels_infer][hw] (channels 0 .. 2 * stochastic).
+ * irec_shim_cat_elu: out [n][deterministic + stochastic][hw] = elu(concat(y[:, channel_offset : + deterministic], latent NHWC))
+ *   (:479-488); stochastic = 0: the ELU of a channel slice (:398-400).
+ * irec_shim_residual_elu: out = input + alpha * tensor (:492-496), out_elu = elu(out) (the next block's first op, :385);
+ *   tensors [n][channels][hw].
+ * bias_* (device, per channel; may be NULL): the bias of the convolution that produced the operand, added first -- the
+ *   convolution is then called without one, which saves its separate bias-add launch. */
+irec_status irec_shim_stats(irec_context *ctx, const float *y, const float *infer_heads, float *out, int32_t n_stats, int32_t n,
+                            int32_t channels_y, int32_t channels_infer, int32_t stochastic, int32_t hw, const float *bias_y,
+                            const float *bias_infer, void *hip_stream);
+irec_status irec_shim_cat_elu(irec_context *ctx, const float *y, const float *latent, float *out, int32_t n, int32_t channels_y,
+                              int32_t channel_offset, int32_t deterministic, int32_t stochastic, int32_t hw, const float *bias_y,
+                              void *hip_stream);
+irec_status irec_shim_residual_elu(irec_context *ctx, const float *input, const float *tensor, float alpha, float *out, float *out_elu,
+                                   int32_t n, int32_t channels, int32_t hw, const float *bias_tensor, void *hip_stream);
+
 /* ---- test hooks (device pointers) ---------------------------------------------------------------------------- */
 /* r[s*D + d] of get_pseudo_random_sample's int32 draw, generated by the in-kernel Philox stream.  out: int32 [n]. */
 irec_status irec_device_uniform_int(irec_context *ctx, int64_t seed, int64_t n, int32_t *out, void *hip_stream);

@@ -1000,6 +1000,37 @@ irec_status irec_device_uniform_int(irec_context *ctx, int64_t seed, int64_t n, 
   return IREC_OK;
 }
 
+// ---- hand-offs of the RVAE host shim (irec_shim.hip): device pointers, asynchronous on the stream ----
+irec_status irec_shim_stats(irec_context *ctx, const float *y, const float *infer_heads, float *out, int32_t n_stats, int32_t n,
+                            int32_t channels_y, int32_t channels_infer, int32_t stochastic, int32_t hw, const float *bias_y,
+                            const float *bias_infer, void *hip_stream) {
+  if (!ctx || !y || !out || (n_stats != 2 && n_stats != 4) || (n_stats == 4 && !infer_heads) || n < 1 || stochastic < 1 || hw < 1 ||
+      channels_y < n_stats * stochastic || (n_stats == 4 && channels_infer < 2 * stochastic))
+    return fail(IREC_E_INVALID, "irec_shim_stats: bad arguments");
+  IREC_ON_DEVICE(ctx->device);
+  HIP_TRY(irec::launch_shim_stats(y, infer_heads, out, n_stats, n, channels_y, channels_infer, stochastic, hw, bias_y, bias_infer,
+                                  (hipStream_t)hip_stream));
+  return IREC_OK;
+}
+irec_status irec_shim_cat_elu(irec_context *ctx, const float *y, const float *latent, float *out, int32_t n, int32_t channels_y,
+                              int32_t channel_offset, int32_t deterministic, int32_t stochastic, int32_t hw, const float *bias_y,
+                              void *hip_stream) {
+  if (!ctx || !y || !out || n < 1 || deterministic < 0 || stochastic < 0 || deterministic + stochastic < 1 || hw < 1 || channel_offset < 0 ||
+      channel_offset + deterministic > channels_y || (stochastic > 0 && !latent))
+    return fail(IREC_E_INVALID, "irec_shim_cat_elu: bad arguments");
+  IREC_ON_DEVICE(ctx->device);
+  HIP_TRY(irec::launch_shim_cat_elu(y, latent, out, n, channels_y, channel_offset, deterministic, stochastic, hw, bias_y, (hipStream_t)hip_stream));
+  return IREC_OK;
+}
+irec_status irec_shim_residual_elu(irec_context *ctx, const float *input, const float *tensor, float alpha, float *out, float *out_elu,
+                                   int32_t n, int32_t channels, int32_t hw, const float *bias_tensor, void *hip_stream) {
+  if (!ctx || !input || !tensor || !out || !out_elu || n < 1 || channels < 1 || hw < 1) return fail(IREC_E_INVALID, "irec_shim_residual_elu: bad arguments");
+  IREC_ON_DEVICE(ctx->device);
+  HIP_TRY(irec::launch_shim_residual_elu(input, tensor, alpha, out, out_elu, (int64_t)n * channels * hw, bias_tensor, channels, hw,
+                                         (hipStream_t)hip_stream));
+  return IREC_OK;
+}
+
 irec_status irec_test_decoder_sqrt(irec_context *ctx, uint64_t *out2, void *hip_stream) {
   if (!ctx || !out2) return fail(IREC_E_INVALID, "irec_test_decoder_sqrt: bad arguments");
   IREC_ON_DEVICE(ctx->device);

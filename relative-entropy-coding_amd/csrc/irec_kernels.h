@@ -102,6 +102,13 @@ constexpr size_t WS_XCH_BYTES = (size_t)2 * COOP_MAX_BLOCKS * COOP_KEYS * 4;   /
 constexpr size_t WS_HEAD_BYTES = WS_COUNTER_BYTES + WS_XCH_BYTES;
 hipError_t launch_decode(const DecArgs &A, int n_cu, hipStream_t st);   // irec_decode.hip
 int decode_tensor_waves(int n, int bs, bool table, size_t *lds_out);     // waves per workgroup of the tensor-staged decoder, 0 = does not apply
+// elementwise hand-offs of the RVAE host shim (irec_shim.hip)
+hipError_t launch_shim_stats(const float *y, const float *inf, float *out, int n_stats, int N, int Cy, int Ci, int s, int HW,
+                             const float *by, const float *bi, hipStream_t st);
+hipError_t launch_shim_cat_elu(const float *y, const float *latent, float *out, int N, int Cy, int c_off, int d, int s, int HW,
+                               const float *by, hipStream_t st);
+hipError_t launch_shim_residual_elu(const float *inp, const float *t, float alpha, float *out, float *out_elu, int64_t count,
+                                    const float *bt, int C, int HW, hipStream_t st);
 hipError_t launch_dec_sqrt_test(unsigned long long *out, hipStream_t st);
 hipError_t launch_uniform_int(int64_t seed, int64_t n, int32_t *out, hipStream_t st);
 hipError_t launch_select_test(const float *scores, int N, int Bnew, int Bcur, uint32_t *keys, int32_t *sel, hipStream_t st);

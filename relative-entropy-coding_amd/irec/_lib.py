@@ -91,6 +91,9 @@ SIGNATURES = {
     "irec_rec_encode_files": (_i64, [ctypes.c_uint32] * 6 + [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp, _i32]),
     "irec_rec_decode_files": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32]),
     "irec_device_uniform_int": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
+    "irec_shim_stats": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "irec_shim_cat_elu": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "irec_shim_residual_elu": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "irec_test_decoder_sqrt": (ctypes.c_int, [_vp, _vp, _vp]),
     "irec_test_reduce_scatter": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "irec_test_select": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),

@@ -38,6 +38,63 @@ class deterministic_transforms:
         return False
 
 
+class _HandOff:
+    """The elementwise hand-offs between the shim's convolutions and the coder as ONE launch each (csrc/irec_shim.hip:
+    irec_shim_stats / _cat_elu / _residual_elu) instead of ~10 PyTorch launches of 3-5 us per residual block and pass.
+    CUDA float32 contiguous tensors only; anything else takes the plain PyTorch ops (the coder itself has no CPU path)."""
+
+    @staticmethod
+    def ok(*tensors):
+        return all(t is not None and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in tensors)
+
+    @staticmethod
+    def _eng(t):
+        from ..engine import get_engine
+        return get_engine(t.device)
+
+    @staticmethod
+    def _p(t):
+        import ctypes
+        return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+    @staticmethod
+    def stats(y, infer_y, s, n_stats, bias_y=None, bias_infer=None):
+        """[n_stats, N, H, W, s]: prior loc, prior scale (, posterior loc, posterior scale) in the coder's NHWC order.
+        bias_*: the (not yet added) biases of the convolutions behind y / infer_y."""
+        from .. import _lib
+        n, cy, h, w = y.shape
+        out = torch.empty((n_stats, n, h, w, s), dtype=torch.float32, device=y.device)
+        eng = _HandOff._eng(y)
+        _lib.check(eng.lib.irec_shim_stats(eng.ctx, _HandOff._p(y), _HandOff._p(infer_y), _HandOff._p(out), n_stats, n, cy,
+                                           infer_y.shape[1] if infer_y is not None else 0, s, h * w, _HandOff._p(bias_y),
+                                           _HandOff._p(bias_infer), eng._stream()), "irec_shim_stats")
+        return out
+
+    @staticmethod
+    def cat_elu(y, c_off, d, latent_nhwc, bias_y=None):
+        """elu(cat(y[:, c_off:c_off + d] (+ bias), latent NHWC -> NCHW)); latent None: the ELU of the channel slice."""
+        from .. import _lib
+        n, cy, h, w = y.shape
+        s = 0 if latent_nhwc is None else latent_nhwc.shape[-1]
+        out = torch.empty((n, d + s, h, w), dtype=torch.float32, device=y.device)
+        eng = _HandOff._eng(y)
+        _lib.check(eng.lib.irec_shim_cat_elu(eng.ctx, _HandOff._p(y), _HandOff._p(latent_nhwc if s else None), _HandOff._p(out),
+                                             n, cy, c_off, d, s, h * w, _HandOff._p(bias_y), eng._stream()), "irec_shim_cat_elu")
+        return out
+
+    @staticmethod
+    def residual_elu(inp, t, alpha, bias_t=None):
+        """(inp + alpha * (t + bias), elu of it)"""
+        from .. import _lib
+        out, out_elu = torch.empty_like(inp), torch.empty_like(inp)
+        n, c, h, w = inp.shape
+        eng = _HandOff._eng(inp)
+        _lib.check(eng.lib.irec_shim_residual_elu(eng.ctx, _HandOff._p(inp), _HandOff._p(t), float(alpha), _HandOff._p(out),
+                                                  _HandOff._p(out_elu), n, c, h * w, _HandOff._p(bias_t), eng._stream()),
+                   "irec_shim_residual_elu")
+        return out, out_elu
+
+
 def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
@@ -132,35 +189,67 @@ class BidirectionalResidualBlock(nn.Module):
     def forward(self, tensor, inference_pass=True, encoder_args=None, decoder_args=None):
         """resnet_vae.py:372-497."""
         inp = tensor
-        tensor = F.elu(tensor)
+        pre = getattr(tensor, "_irec_elu", None)          # the previous block's residual kernel already formed elu(tensor)
+        tensor = pre if pre is not None else F.elu(tensor)
         indices = None
         s, d = self.stochastic_filters, self.deterministic_filters
         w_i, b_i, w_g, b_g = self._fused_weights()
+        # On the fused path the convolutions run WITHOUT their bias: the hand-off kernel that reads a convolution's output adds
+        # it first (same operation, same order, one launch fewer per convolution: 96 per image).
+        fused = _HandOff.ok(inp, tensor) and (encoder_args is not None or decoder_args is not None or inference_pass)
+        bias2 = None
         if inference_pass:
-            y = F.conv2d(tensor, w_i, b_i, padding=self._pad)                     # [N, 2s (+ d), H, W]
-            self.infer_posterior_loc, self.infer_posterior_log_scale = y[:, :s], y[:, s:2 * s]
-            self._infer_heads = y[:, :2 * s]
+            y = F.conv2d(tensor, w_i, None if fused else b_i, padding=self._pad)   # [N, 2s (+ d), H, W]
+            self._infer_y, self._infer_bias = y, (b_i if fused else None)
+            if fused:                                                             # (views of the biased heads, for callers that read them)
+                self._infer_heads = None
+                self.infer_posterior_loc = self.infer_posterior_log_scale = None
+            else:
+                self.infer_posterior_loc, self.infer_posterior_log_scale = y[:, :s], y[:, s:2 * s]
+                self._infer_heads = y[:, :2 * s]
             if not self.is_last:
-                tensor = self.infer_conv2(F.elu(y[:, 2 * s:]))
+                if fused:
+                    tensor = F.conv2d(_HandOff.cat_elu(y, 2 * s, d, None, b_i), self.infer_conv2.weight, None, padding=self._pad)
+                    bias2 = self.infer_conv2.bias
+                else:
+                    tensor = self.infer_conv2(F.elu(y[:, 2 * s:]))
         else:
             if encoder_args is None and decoder_args is None:
                 raise ModelError("training / sampling passes are outside the compression shim")
-            y = F.conv2d(tensor, w_g, b_g, padding=self._pad)                     # [N, 4s + d, H, W]
+            fused = fused and (encoder_args is None or (self._infer_y is not None and _HandOff.ok(self._infer_y)))
+            y = F.conv2d(tensor, w_g, None if fused else b_g, padding=self._pad)  # [N, 4s + d, H, W]
             n, _, h, w = y.shape
             if encoder_args is not None:                                          # :462-470
-                y[:, 2 * s:4 * s] += self._infer_heads                            # posterior loc / log-scale = inference + generative
-                st = y[:, :4 * s].view(n, 4, s, h, w).permute(1, 0, 3, 4, 2).contiguous()   # coder sees NHWC, as in the reference
-                st[1::2].exp_()                                                   # the two scales
+                if fused:
+                    st = _HandOff.stats(y, self._infer_y, s, 4, b_g, self._infer_bias)   # all four statistics, NHWC, one launch
+                else:
+                    heads = self._infer_heads if self._infer_heads is not None else \
+                        self._infer_y[:, :2 * s] + self._infer_bias[:2 * s].reshape(1, -1, 1, 1)
+                    y[:, 2 * s:4 * s] += heads                                    # posterior loc / log-scale = inference + generative
+                    st = y[:, :4 * s].view(n, 4, s, h, w).permute(1, 0, 3, 4, 2).contiguous()   # coder sees NHWC, as in the reference
+                    st[1::2].exp_()                                               # the two scales
                 self.prior, self.posterior = _Normal(st[0], st[1]), _Normal(st[2], st[3])
                 indices, latent_code = self.coder.encode(self.posterior, self.prior, **encoder_args)
             else:                                                                 # :475-476
-                st = y[:, :2 * s].view(n, 2, s, h, w).permute(1, 0, 3, 4, 2).contiguous()
-                st[1].exp_()
+                if fused:
+                    st = _HandOff.stats(y, None, s, 2, b_g)                       # the SAME kernel and exp as the encoder's prior
+                else:
+                    st = y[:, :2 * s].view(n, 2, s, h, w).permute(1, 0, 3, 4, 2).contiguous()
+                    st[1].exp_()
                 self.prior = _Normal(st[0], st[1])
                 latent_code = self.coder.decode(self.prior, **decoder_args)
-            tensor = torch.cat([y[:, 4 * s:], latent_code.permute(0, 3, 1, 2)], dim=1)
-            tensor = self.gen_conv2(F.elu(tensor, inplace=True))
-        tensor = torch.add(inp, tensor, alpha=0.1)
+            if fused and _HandOff.ok(latent_code):
+                tensor = F.conv2d(_HandOff.cat_elu(y, 4 * s, d, latent_code, b_g), self.gen_conv2.weight, None, padding=self._pad)
+                bias2 = self.gen_conv2.bias
+            else:
+                rest = y[:, 4 * s:] + b_g[4 * s:].reshape(1, -1, 1, 1) if fused else y[:, 4 * s:]
+                tensor = torch.cat([rest, latent_code.permute(0, 3, 1, 2)], dim=1)
+                tensor = self.gen_conv2(F.elu(tensor, inplace=True))
+        if _HandOff.ok(inp, tensor):
+            tensor, tensor_elu = _HandOff.residual_elu(inp, tensor, 0.1, bias2)
+            tensor._irec_elu = tensor_elu                  # (a Python attribute: the next block, or _finish, picks it up)
+        else:
+            tensor = torch.add(inp, tensor, alpha=0.1)
         if encoder_args is not None:
             return indices, tensor
         return tensor
@@ -195,7 +284,8 @@ class BidirectionalResNetVAE(nn.Module):
         return self._generative_base.reshape(1, -1, 1, 1).expand(batch_size, -1, height // 2, width // 2).contiguous()
 
     def _finish(self, tensor):
-        reconstruction = self.last_gen_conv(F.elu(tensor))
+        pre = getattr(tensor, "_irec_elu", None)
+        reconstruction = self.last_gen_conv(pre if pre is not None else F.elu(tensor))
         return torch.clamp(reconstruction, -0.5 + 1. / 512., 0.5 - 1. / 512.)
 
     @torch.no_grad()
