@@ -360,7 +360,8 @@ def run_rank(args):
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tj):
         tr = json.load(open(tj))
-        if tr.get("source_sha16") == src_hash and tr.get("kernel", "").replace(" ", "").endswith(plan["kernel"]):
+        # (the profiler prints a template's bool arguments, irec_encode_plan names only those that are set)
+        if tr.get("source_sha16") == src_hash and tr.get("kernel", "").replace(" ", "").replace(",false", "").endswith(plan["kernel"]):
             traffic = tr["hbm_bytes_per_latent"] * L
             traffic_note = tr.get("source", "")
         else:

@@ -141,7 +141,10 @@ struct TeamBarrier {
 // PASSES: a multi-team build that scores the S samples of a step in several passes and may keep its sort keys in the slab
 // (the single-team builds always can): S beyond what a team's share of the LDS holds -- the reference's sweep reaches
 // S = int(e^9) = 8103 (examples/lossless/data_aggregation.py:5-7).
-template <int NB, int TEAMS, int BS, bool PASSES = false>
+// ONE: the build of one-beam calls (B = 1 of the reference's sweep): every step takes the wide path, which is therefore the
+// pipelined form (rows a half batch ahead, two samples per v_pk_fma_f32) -- in the other builds only step 0 comes there and
+// the extra row buffers cost registers everywhere else (r03e A/B: B = 32 -14 %, B = 30 -2 %, B = 10 -3 % with it).
+template <int NB, int TEAMS, int BS, bool PASSES = false, bool ONE = false>
 __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(EncArgs A) {
   using TeamLds = TeamLdsT<NB>;
   constexpr int TEAM_MB = team_mb(NB);
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         // rounds instead of 36 (r02i: step 0 cost half a full step's instructions for a twentieth of its look-ups).
         const int n_mine = Sp > sw ? (Sp - sw + NSW - 1) / NSW : 0; // my samples of the pass: s_base + sw, + NSW, ...
         const uint32_t bet0 = bet[0];
-        if constexpr (IREC_WIDE_V2 != 0 && (!SHORT || IREC_WIDE_V2 >= 2)) {
+        if constexpr (IREC_WIDE_V2 != 0 && (ONE || IREC_WIDE_V2 >= 2)) {
         // two half batches of rows (even sizes: samples go through the fma in pairs), 20 registers as the steady state's
         constexpr int HA = ((RW / 2) + 1) & ~1, HBb = RW - HA;
         static_assert(RW % 2 == 0 && HBb >= 2 && HBb % 2 == 0, "half batches of sample pairs");
@@ -582,7 +585,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           const int m = m0 + own;                                   // own < 0: unused slot
           if (own >= 0 && (lane & 1) == 0 && m < n_mine) part_s[((size_t)g * SP + m * NSW + sw) * PS] = tot;
         }
-        } else {   // the round-2 form (the 168-VGPR builds keep it: only their first step comes here, and the wider one costs them registers)
+        } else {   // the round-2 form (builds of more than one beam: only their first step comes here)
           constexpr int HB = RW / 2;                                  // rows fetched together (20 registers, as the steady state's)
           static_assert(RW % 2 == 0, "half batches");
           for (int m0 = 0; m0 < n_mine; m0 += RW) {
@@ -1008,10 +1011,13 @@ static int team_cfg(int shape_override) {
   }
 }
 // shape of the workgroup that serves B beams: beams per build, teams per workgroup, beam stripes per team
-struct TeamShape { int nb, teams, bs; bool passes; };
+struct TeamShape { int nb, teams, bs; bool passes; bool one = false; };
 static TeamShape team_shape(int B, int S, int ovr) {
   const int cfg = team_cfg(ovr);
   // 10 beams: G is 40 registers per lane, three teams fit the register file (168 VGPRs) and, for small S, the LDS: +9 %
+  if (B == 1 && cfg == 2) {   // one beam: its own build (pipelined wide path), three teams, packed rows
+    return TeamShape{10, 3, 1, team_s_pass(10, S, 3, 1024, false, 1) != S, true};
+  }
   if (B <= 10) {
     const int ps = team_row(10, B);
     if (cfg == 3 || (cfg == 2 && team_s_pass(10, S, 3, 1024, false, ps) == S)) return TeamShape{10, 3, 1, false};
@@ -1054,7 +1060,7 @@ size_t team_ws_bytes_for(int B, int S, int ovr, int max_K) {
 const char *team_kernel_name(int B, int S, int ovr) {
   static thread_local char buf[64];
   const TeamShape sh = team_shape(B, S, ovr);
-  snprintf(buf, sizeof buf, sh.passes ? "encode_team_kernel<%d,%d,%d,passes>" : "encode_team_kernel<%d,%d,%d>", sh.nb, sh.teams, sh.bs);
+  snprintf(buf, sizeof buf, "encode_team_kernel<%d,%d,%d%s%s>", sh.nb, sh.teams, sh.bs, sh.passes ? ",passes" : "", sh.one ? ",one" : "");
   return buf;
 }
 
@@ -1070,22 +1076,24 @@ size_t team_lds_for(int B, int S, int ovr) {
   return b <= FAST_LDS_LIMIT ? b : (size_t)-1;
 }
 
-template <int NB, int TEAMS, int BS, bool PASSES = false>
+template <int NB, int TEAMS, int BS, bool PASSES = false, bool ONE = false>
 static hipError_t launch_team_t(const EncArgs &A, int grid, hipStream_t st) {
   const int ps = team_row(NB, A.B);
   const int sp = (TEAMS == 1 || PASSES) ? team_s_pass(NB, A.S, TEAMS, TEAMS == 1 ? 2048 : 1024, PASSES, ps) : A.S;
   const size_t lds = team_lds_total(NB, A.S, sp, TEAMS, PASSES, ps);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_team_kernel<NB, TEAMS, BS, PASSES>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_team_kernel<NB, TEAMS, BS, PASSES, ONE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((encode_team_kernel<NB, TEAMS, BS, PASSES>), dim3(grid), dim3(TEAMS * BS * TEAM_NT), lds, st, A);
+  hipLaunchKernelGGL((encode_team_kernel<NB, TEAMS, BS, PASSES, ONE>), dim3(grid), dim3(TEAMS * BS * TEAM_NT), lds, st, A);
   return hipGetLastError();
 }
 
 hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
   const TeamShape sh = team_shape(A.B, A.S, A.shape_override);
-  const int key = sh.nb * 100 + sh.teams * 10 + sh.bs + (sh.passes ? 10000 : 0);
+  const int key = sh.nb * 100 + sh.teams * 10 + sh.bs + (sh.passes ? 10000 : 0) + (sh.one ? 100000 : 0);
   switch (key) {
+    case 101031: return launch_team_t<10, 3, 1, false, true>(A, grid, st);
+    case 111031: return launch_team_t<10, 3, 1, true, true>(A, grid, st);
     case 11031: return launch_team_t<10, 3, 1, true>(A, grid, st);
     case 6013: return launch_team_t<60, 1, 3>(A, grid, st);
     case 1021: return launch_team_t<10, 2, 1>(A, grid, st);

@@ -1,0 +1,37 @@
+#!/bin/bash
+# Round-end evidence on the GPU box: full GPU suite, the default bench line, rocprofv3 --kernel-trace --stats of the same bench
+# command, separate --pmc passes (LDS / VALU / HBM-side traffic) of the encoder, the 60-cell sweep grid.  Everything is
+# written under gpurun_out/$TAG/ as it goes (no output held back behind a pipe).
+set -u
+export TMPDIR=/tmp
+TAG=${TAG:-r03e}
+O=gpurun_out/$TAG
+mkdir -p $O
+echo "== pytest -m gpu"; timeout -k 10 1500 python -m pytest tests -q -m gpu > $O/pytest_gpu.full.log 2>&1; grep -v amdgpu.ids $O/pytest_gpu.full.log | tail -8 > $O/pytest_gpu.log; cat $O/pytest_gpu.log
+echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+echo "== bench (default line)"; timeout -k 10 900 python bench.py --steps 20 --warmup 5 2> $O/bench_default.err > $O/bench_default.out; tail -1 $O/bench_default.out > $O/bench_default.log; grep -v amdgpu.ids $O/bench_default.err | tail -12
+echo "== kernel trace of the same command (no CPU baselines / secondary configs: the timed region is the same)"
+rm -rf $O/trace; timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/trace.log 2>&1
+f=$(find $O/trace -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && python3 - "$f" $O/kernel_stats.csv <<'PY'
+import csv, sys
+rows = list(csv.reader(open(sys.argv[1])))
+out = [rows[0]] + [[r[0][:100]] + r[1:] for r in rows[1:]]
+csv.writer(open(sys.argv[2], "w")).writerows(out)
+for r in out[:8]: print(r)
+PY
+L=8192
+for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+           "GRBM_GUI_ACTIVE FETCH_SIZE" "WRITE_SIZE GRBM_COUNT"; do
+  name=$(echo $set | tr ' ' '_' | cut -c1-40)
+  echo "== pmc $name"
+  timeout -k 10 900 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_$name -- python3 bench.py --steps 2 --warmup 1 --latents $L --no-cpu-baseline --no-secondary > $O/pmc_$name.log 2>&1
+  f=$(find $O/pmc_$name -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && python3 scripts/pmc_summary.py "$f" encode_team | tee $O/pmc_$name.summary
+  [ -n "$f" ] && python3 scripts/pmc_summary.py "$f" decode_tensor | tee -a $O/pmc_$name.summary
+done
+find $O -name "*.csv" -size +2M -delete
+python3 scripts/make_traffic_json.py $O $L encode_team > $O/traffic.json 2>&1 || true
+echo "== sweep grid"; timeout -k 10 900 python scripts/grid_bench.py > $O/grid.full.log 2>&1; grep -v amdgpu.ids $O/grid.full.log > $O/grid.log; tail -3 $O/grid.log
+echo "== decode bench"; timeout -k 10 300 python scripts/decode_bench.py 2>&1 | grep -v amdgpu.ids > $O/decode_bench.log; cat $O/decode_bench.log
+du -sh $O

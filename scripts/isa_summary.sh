@@ -25,7 +25,7 @@ for m in re.finditer(r'^(_Z\w+):\s*; @\1\n(.*?)^\.Lfunc_end\d+:', txt, re.S | re
     dem = subprocess.run(['c++filt', name], capture_output=True, text=True).stdout.strip()
     dem = re.sub(r'\(irec::\w+\)$', '', dem).replace('void irec::', '')
     cnt = lambda pat: len(re.findall(pat, body))
-    print(f"{dem} | {field('NumVgprs')} | {field('NumAgprs')} | {field('NumSgprs')} | {field('ScratchSize')} | {field('LDSByteSize')} | "
+    print(f"{dem} | {field('NumVgprs')} | {field('NumAgprs')} | {field('TotalNumSgprs')} | {field('ScratchSize')} | {field('LDSByteSize')} | "
           f"{cnt(r'scratch_(load|store)')} | {cnt(r'ds_read_b32')} | {cnt(r'v_pk_fma_f32')} | {cnt(r'v_sqrt_f32')} | {cnt(r's_barrier')} | {cnt(r'v_mfma')}")
 PY
 done

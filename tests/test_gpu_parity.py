@@ -706,8 +706,8 @@ def test_plan_names_the_kernels_that_run(engine, oracle):
     assert engine.plan(engine.params(3.0, S, 40), small, 32)["kernel"] == "encode_team_kernel<60,1,3>"   # (no one-table encoder there)
     assert engine.plan(engine.params(3.0, S, 64), big, 32)["kernel"] == "encode_generic_kernel"          # 60 < B <= 64
     assert engine.plan(engine.params(6.0, 8103, 10), big, 32)["kernel"] == "encode_team_kernel<10,3,1,passes>"
-    assert engine.plan(engine.params(6.0, 8103, 1), big, 32)["kernel"] == "encode_team_kernel<10,3,1,passes>"
-    assert engine.plan(engine.params(5.0, 403, 1), big, 32)["kernel"] == "encode_team_kernel<10,3,1>"    # one beam: 403 samples in one pass
+    assert engine.plan(engine.params(6.0, 8103, 1), big, 32)["kernel"] == "encode_team_kernel<10,3,1,passes,one>"
+    assert engine.plan(engine.params(5.0, 403, 1), big, 32)["kernel"] == "encode_team_kernel<10,3,1,one>"   # one beam: 403 samples in one pass
     info = engine.plan(p, big, 32)
     assert info["n_cu"] == 256 and info["clock_mhz"] > 1000 and info["lds_bytes"] <= 160 * 1024
 

@@ -5,6 +5,7 @@ import inspect
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 
 def _model(device="cpu", blocks=3, det=16, sto=8):
@@ -172,6 +173,43 @@ def test_batched_compress_equals_one_by_one_and_writes_rec(engine, oracle, tmp_p
     assert K.shape == (5, 4, 3) and torch.equal(recon_p, recon_batch)
     for i in range(5):
         assert [[idx[i, r, j, :K[i, r, j]].tolist() for j in range(3)] for r in range(4)] == bi_batch[i]
+
+
+@pytest.mark.gpu
+def test_handoff_kernels_against_plain_pytorch(engine):
+    """csrc/irec_shim.hip (statistics + exp in NHWC, concat + ELU, residual + ELU, each with the producing convolution's bias
+    folded in) against the plain PyTorch float32 ops they replace (rec/models/resnet_vae.py:385-496); tolerance 2e-6 relative:
+    HIP's expf / expm1f and PyTorch's differ in the last place, everything else is the same IEEE operation."""
+    from irec.models.resnet_vae import _HandOff
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    n, s, d, h, w = 3, 8, 20, 16, 16
+    y = torch.randn((n, 4 * s + d, h, w), generator=g, device="cuda")
+    yi = torch.randn((n, 2 * s + d, h, w), generator=g, device="cuda")
+    by, bi = torch.randn(4 * s + d, generator=g, device="cuda"), torch.randn(2 * s + d, generator=g, device="cuda")
+    lat = torch.randn((n, h, w, s), generator=g, device="cuda")
+    yb, yib = y + by.reshape(1, -1, 1, 1), yi + bi.reshape(1, -1, 1, 1)
+
+    def close(a, b):
+        return torch.allclose(a, b, rtol=2e-6, atol=1e-7)
+    want = yb[:, :4 * s].clone()
+    want[:, 2 * s:] += yib[:, :2 * s]
+    want = want.view(n, 4, s, h, w).permute(1, 0, 3, 4, 2).contiguous()
+    want[1::2] = want[1::2].exp()
+    got = _HandOff.stats(y, yi, s, 4, by, bi)
+    assert got.shape == (4, n, h, w, s) and close(got, want)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[2], want[2])          # the locs are exact
+    assert torch.equal(_HandOff.stats(y, None, s, 2, by), got[:2])                # the decoder's prior: the encoder's bits
+    assert close(_HandOff.stats(y, yi, s, 4), (lambda t: torch.cat([t[:1], t[1:2].exp(), t[2:3], t[3:4].exp()]))(
+        (torch.cat([y[:, :2 * s], y[:, 2 * s:4 * s] + yi[:, :2 * s]], 1)).view(n, 4, s, h, w).permute(1, 0, 3, 4, 2).contiguous()))
+    want = F.elu(torch.cat([yb[:, 4 * s:], lat.permute(0, 3, 1, 2)], dim=1))
+    assert close(_HandOff.cat_elu(y, 4 * s, d, lat, by), want)
+    assert close(_HandOff.cat_elu(yi, 2 * s, d, None, bi), F.elu(yib[:, 2 * s:]))
+    inp, t, bt = torch.randn((n, d, h, w), generator=g, device="cuda"), torch.randn((n, d, h, w), generator=g, device="cuda"), torch.randn(d, generator=g, device="cuda")
+    out, out_elu = _HandOff.residual_elu(inp, t, 0.1, bt)
+    want = torch.add(inp, t + bt.reshape(1, -1, 1, 1), alpha=0.1)
+    assert close(out, want) and close(out_elu, F.elu(want))
+    out2, _ = _HandOff.residual_elu(inp, t, 0.1)
+    assert close(out2, torch.add(inp, t, alpha=0.1))
 
 
 @pytest.mark.gpu
