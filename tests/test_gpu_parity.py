@@ -608,6 +608,18 @@ def _full_size_check(engine, oracle, n_t, n, bs, omega, eps1, B, n_oracle_blocks
         row = lay.natural[t * lay.blocks_per_tensor + b]
         assert ih[row, :Kh[row]].tolist() == ridx
         assert np.array_equal(sh[t][gsel], rs)
+    # round 3: a run of WHOLE tensors against the OpenMP oracle as well (every block of n_oracle_tensors tensors spread over
+    # the batch: VERDICT r2 found ten blocks of 64 800 thin) -- up to 256 tensors, bounded to ~6e10 proposal evaluations of oracle work
+    per_tensor = S * n * (1 + max(float(Kh.mean()) - 1, 0) * B)
+    n_oracle_tensors = int(max(1, min(n_t, 256, 6e10 // per_tensor)))
+    pick = np.unique(np.linspace(0, n_t - 1, n_oracle_tensors).astype(np.int64))
+    ridx, rsamp, _ = oracle.encode_tensors_omp(*(h[pick] for h in host), 42, omega, S, B, bs, max_K=48)
+    bpt = lay.blocks_per_tensor
+    for k, t in enumerate(pick):
+        for j in range(bpt):
+            row = lay.natural[t * bpt + j]
+            assert ih[row, :Kh[row]].tolist() == ridx[k][j], (t, j)
+        assert np.array_equal(sh[t], rsamp[k]), t
     return Kh
 
 
