@@ -34,7 +34,7 @@ def main():
     dims = lay.block_dim.cpu().numpy().astype(np.int64)
     t_start = time.time()
     print(f"# latents per call {a.latents} ({lay.n_blocks} blocks); columns: Omega 1+eps B S | kernel | ms/call | latents/s | "
-          f"G look-ups/s | look-ups/clk/CU | mean K | oracle check", flush=True)
+          f"G look-ups/s | look-ups/clk/CU | mean K | oracle check | ms/call with the tables kept | look-ups/clk/CU then", flush=True)
     worst = None
     for omega in [float(x) for x in a.omegas.split(",")]:
         for eps1 in [float(x) for x in a.eps.split(",")]:
@@ -56,10 +56,21 @@ def main():
                     ev[r + 1].record()
                 torch.cuda.synchronize()
                 ms = min(ev[r].elapsed_time(ev[r + 1]) for r in range(a.reps))
+                # the same call with the proposal tables kept across calls (IREC_FLAG_REUSE_TABLES: what the Python coder does
+                # by default -- the tables depend on (seed, S, D) only): the block kernel alone
+                keep = eng.params(omega, S, B, irec._lib.IREC_FLAG_REUSE_TABLES)
+                eng.encode_blocks(keep, lay, ql, qs, pl, ps, 42, max_K)
+                ev[0].record()
+                for r in range(a.reps):
+                    eng.encode_blocks(keep, lay, ql, qs, pl, ps, 42, max_K)
+                    ev[r + 1].record()
+                torch.cuda.synchronize()
+                ms_keep = min(ev[r].elapsed_time(ev[r + 1]) for r in range(a.reps))
                 plan = eng.plan(params, lay, max_K)
                 E = float((S * dims * (1 + np.maximum(Kh - 1, 0) * B) * (Kh > 0)).sum())
                 lps = E / (ms * 1e-3)
                 per_clk = lps / (plan["n_cu"] * plan["clock_mhz"] * 1e6)
+                per_clk_keep = E / (ms_keep * 1e-3) / (plan["n_cu"] * plan["clock_mhz"] * 1e6)
                 ok = "-"
                 if a.check:
                     ih = idx.cpu().numpy()
@@ -70,7 +81,7 @@ def main():
                         if got != ridx or not np.array_equal(sample[i].cpu().numpy(), rs):
                             ok = "MISMATCH"
                 line = (f"{omega:g} {eps1:g} {B:2d} {S:5d} | {plan['kernel']:38s} | {ms:9.3f} | {a.latents / ms * 1e3:10.1f} | "
-                        f"{lps / 1e9:8.1f} | {per_clk:6.2f} | {Kh.mean():5.2f} | {ok}")
+                        f"{lps / 1e9:8.1f} | {per_clk:6.2f} | {Kh.mean():5.2f} | {ok} | {ms_keep:9.3f} | {per_clk_keep:6.2f}")
                 print(line, flush=True)
                 if worst is None or per_clk < worst[0]:
                     worst = (per_clk, line)
