@@ -85,7 +85,10 @@ class PendingCode:
         K [N, R, bpt] int32, idx [N, R, bpt, max_K] int32 (numpy; rows are valid up to K) -- ONE gather on the device and ONE
         device-to-host copy, no per-index Python object.  irec.io.encode_files takes them as they are."""
         lay = pendings[0].lay
-        assert all(p.lay is lay for p in pendings) and lay.natural is not None
+        same = all((p.lay.n_tensors, p.lay.n, p.lay.block_size, p.lay.n_blocks) == (lay.n_tensors, lay.n, lay.block_size, lay.n_blocks)
+                   and (p.lay.block_size is None or p.lay.seed == lay.seed) for p in pendings)
+        if not same or lay.natural is None:
+            raise CodingError("gather_packed needs calls on one block layout (same tensor count, size, block_size and seed)")
         width = max(p.idx.shape[1] for p in pendings)
         rows = []
         for p in pendings:
