@@ -460,6 +460,40 @@ def test_many_beams_selection_refinement(engine):
         assert np.array_equal(sel, want), (n, nsel, bcur, ties)
 
 
+def test_new_entry_points_reject_what_they_cannot_serve(engine):
+    """Round-3 entries of include/irec.h: sizes they cannot serve are irec_status errors with text, never a crash or a
+    silent fallback -- tensors beyond the staged decoder, a decode scratch too small or misaligned, hand-off shapes that do
+    not fit their operands."""
+    from irec import _lib
+    lib, ctx = engine.lib, engine.ctx
+    params = engine.with_table_dims(engine.params(3.0, 36, 20), engine.layout(2, 8192, 1000, 42))
+    assert lib.irec_decode_tensors_supported(ctypes.byref(params), 8192, 1000) == 1
+    assert lib.irec_decode_tensors_supported(ctypes.byref(params), 301056, 1000) == 0       # does not fit the LDS
+    assert lib.irec_decode_tensors_supported(ctypes.byref(params), 700, 7) == 0             # more units than a workgroup takes
+    z = torch.zeros(64, dtype=torch.float32, device=engine.device)
+    zi = torch.zeros(64, dtype=torch.int32, device=engine.device)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = lib.irec_beam_decode_tensors(ctx, ctypes.byref(params), 1, 301056, 1000, None, None, p(z), p(z), 42, 4, p(zi), p(zi), p(z), None, 0, None)
+    assert st == _lib.IREC_E_INVALID and b"staged decoder" in lib.irec_last_error()
+    lay = engine.layout(2, 8192, 1000, 42)
+    need = lib.irec_decode_workspace_bytes(ctx, ctypes.byref(params), 8)
+    assert need > 0
+    ws = torch.empty(need + 512, dtype=torch.uint8, device=engine.device)
+    big = torch.zeros(2 * 8192, dtype=torch.float32, device=engine.device)
+    K = torch.zeros(lay.n_blocks, dtype=torch.int32, device=engine.device)
+    idx = torch.zeros((lay.n_blocks, 8), dtype=torch.int32, device=engine.device)
+    args = lambda w, nbytes: (ctx, ctypes.byref(params), lay.n_blocks, p(lay.block_base), p(lay.block_pos), p(lay.block_dim), lay.max_dim,
+                              p(lay.perm), p(big), p(big), 42, 8, p(K), p(idx), p(big), w, nbytes, None)
+    assert lib.irec_beam_decode_ws(*args(p(ws), need // 2)) == _lib.IREC_E_WORKSPACE
+    assert lib.irec_beam_decode_ws(*args(ctypes.c_void_p(ws.data_ptr() + 4), need)) == _lib.IREC_E_WORKSPACE    # not 256-byte aligned
+    assert lib.irec_beam_decode_ws(*args(p(ws), need)) == 0                                                      # K = 0 everywhere: sample = mu_p
+    torch.cuda.synchronize()
+    assert lib.irec_shim_stats(ctx, p(z), None, p(z), 4, 1, 8, 0, 2, 4, None, None, None) == _lib.IREC_E_INVALID        # four statistics need the inference heads
+    assert lib.irec_shim_stats(ctx, p(z), p(z), p(z), 3, 1, 8, 4, 2, 4, None, None, None) == _lib.IREC_E_INVALID
+    assert lib.irec_shim_cat_elu(ctx, p(z), None, p(z), 1, 4, 2, 4, 0, 4, None, None) == _lib.IREC_E_INVALID            # slice beyond the channels
+    assert lib.irec_shim_residual_elu(ctx, p(z), p(z), 0.1, p(z), None, 1, 4, 4, None, None) == _lib.IREC_E_INVALID
+
+
 def test_decoder_fast_sqrt_exhaustive(engine):
     """The decoder's 9-instruction square root (irec_decode.hip: dec_sqrt_core) returns sqrtf's bits -- the correctly rounded
     value the oracle's libm gives -- for EVERY float32 bit pattern it is allowed to see: all 2^32 patterns are run on the
