@@ -8,9 +8,13 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The product
  * (relative-entropy-coding_amd/csrc) never links, includes or calls anything in this directory.
  *
- * PARITY STATUS: "parity unpinned" against real TensorFlow.  TF 2.1 / TFP 0.9 cannot be installed in
- * this image and the reference's own tests hold no golden indices (round trip only,
+ * PARITY STATUS: partial against real TensorFlow ("parity unpinned" for everything not named below).  TF 2.1 / TFP 0.9
+ * cannot be installed in this image and the reference's own tests hold no golden indices (round trip only,
  * rec/coding/tests/test_coder.py:12-21).  What pins this file instead:
+ *   - (round 3) the eager outputs TensorFlow's public API docs print for tf.random.set_seed / uniform / normal and the RNG
+ *     guide's stateless_normal: 21 real-TF values reproduced by tf_seed_pair / philox_stream_u32_at / the MT19937 op seed /
+ *     Box-Muller / the stateless key scramble below (tests/test_tf_doc_kats.py) -- SURVEY A1, A2, A6.  NOT pinned by them:
+ *     tf.random.shuffle's Fisher-Yates loop (A5), TFP's float32 ndtri / log_prob (A4), reduce_sum's order (A7), argsort ties (A3),
  *   - Random123 Philox4x32-10 known-answer vectors,
  *   - scipy.special.ndtri over the 10006 LUT points,
  *   - CPython's own `random` module for the MT19937 seed plumbing of tf.random.shuffle,
@@ -696,7 +700,8 @@ int64_t irec_oracle_importance_n_samples(double coding_bits) { /* :50, float32 t
 
 /* tf.random.stateless_normal([count], seed=[seed0, seed1]) (rec/coding/utils.py:11): stateless_random_ops.cc GenerateKey
  * = one Philox block with key (0x3ec8f720, 0x02461e29) over counter (seed0 lo, hi, seed1 lo, hi); words 0-1 of the result are
- * the stream's key, words 2-3 its upper counter half; then the Box-Muller fill of tf.random.normal.  [TF-src, unpinned] */
+ * the stream's key, words 2-3 its upper counter half; then the Box-Muller fill of tf.random.normal.  [TF-src; pinned in round 3 by the RNG guide's
+ * stateless_normal(shape=[2,3], seed=[1,2]) values, tests/test_tf_doc_kats.py] */
 void irec_oracle_tf_stateless_normal(int64_t seed0, int64_t seed1, int64_t count, float *out) {
   const uint32_t k0[2] = {0x3ec8f720u, 0x02461e29u};
   const uint32_t c0[4] = {(uint32_t)(uint64_t)seed0, (uint32_t)((uint64_t)seed0 >> 32), (uint32_t)(uint64_t)seed1,

@@ -10,6 +10,9 @@ doctests -- produced by real TF 2.x CPU kernels, whose Philox / seed code is unc
   tf.random.uniform   : set_seed(5); uniform([], maxval=3, dtype=int32, seed=10) -> 2, again -> 0
   tf.random.normal    : set_seed(5); normal([2, 2], 0, 1, float32, seed=1) -> [[-1.3768897, -0.01258316], [-0.169515, 1.0824056]]
 
+  RNG guide           : stateless_normal(shape=[2, 3], seed=[1, 2]) -> [[0.5441101, 0.20738031, 0.07356433],
+    ("Random number generation")                                            [0.04643455, -1.30159, -0.95385665]]
+
 PROVENANCE: none of these numbers is in /root/reference or was produced in this container; they are quoted from the public
 documentation pages named above (the round-2 review supplied the first six as candidates, the other two pages were added
 here), and nothing in oracle/ was changed to make them come out.  They were first evaluated against the round-2 oracle as
@@ -24,7 +27,9 @@ philox_stream_u32_at, irec_oracle_py_randint31_nth, irec_oracle_tf_uniform_int_p
       (the normal case uses all four); `lo + u32 % range` of RandomUniformInt (three-valued, weak on its own);
       and the 256-blocks-per-element counter advance of a cached kernel (NOT on the coder's path, which calls set_seed
       before every draw -- it only shows that the second values are understood too);
-  A6  the Box-Muller layout of tf.random.normal (importance-sampler plumbing).
+  A6  the Box-Muller layout of tf.random.normal (importance-sampler plumbing); the guide's stateless_normal values pin the
+      key scramble of the stateless ops (stateless_random_ops.cc GenerateKey: one Philox block under a fixed key) that
+      stateless_gumbel_sample (rec/coding/utils.py:9-12) goes through -- oracle/irec_oracle.c had it marked "unpinned".
 What they do NOT pin: the Fisher-Yates loop of tf.random.shuffle (A5), TFP's float32 ndtri and log_prob (A4), reduce_sum's
 order (A7), argsort ties (A3).  Parity with real TF therefore stays "partial"; see DESIGN.md §7.
 """
@@ -97,3 +102,14 @@ def test_the_coders_draw_goes_through_the_pinned_plumbing(oracle, suite):
         assert np.array_equal(a, oracle.uniform_int(s, 4096))
     # tf.random.shuffle's op seed: the same call the (None-op-seed) doc values pin
     assert oracle.py_first_randint31(1234) == oracle.lib().irec_oracle_py_randint31_nth(1234, 0)
+
+
+@pytest.mark.both_suites
+def test_rng_guide_stateless_normal(oracle, suite):
+    """tf.random.stateless_normal(shape=[2, 3], seed=[1, 2]) as printed in TensorFlow's "Random number generation" guide:
+    the stateless key scramble + Box-Muller behind stateless_gumbel_sample (rec/coding/utils.py:9-12, the Gumbel branch of
+    the importance sampler, importance_sampling.py:67-71).  libm's logf / sinf / cosf stand in for Eigen's: two units in the
+    last place of slack."""
+    got = oracle.tf_stateless_normal(1, 2, 6)
+    want = np.float32([0.5441101, 0.20738031, 0.07356433, 0.04643455, -1.30159, -0.95385665])
+    assert np.all(np.abs(got - want) <= 2 * np.spacing(np.abs(want)) + 1e-9), (got, want)
