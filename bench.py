@@ -2,7 +2,7 @@
 """bench.py -- encoded latents/s of the iREC beam-search encoder on MI355X (BASELINE.json metric).
 
 One "step" = one pass of the hot path (irec_beam_encode: one persistent kernel launch) over one batch of
---latents (default 32768) synthetic RVAE latent tensors [16,16,32] (8192 dims -> 8 blocks of 1000 + 1 of 192 dims each) that are
+--latents (default 65536) synthetic RVAE latent tensors [16,16,32] (8192 dims -> 8 blocks of 1000 + 1 of 192 dims each) that are
 already resident in HBM, with B=20, Omega=3, 1+eps=1.2 (S=36): BASELINE.json configs[1].  Multi-GPU: one process per
 GPU, every rank codes its own batch (weak scaling, no data-path collective); the only collective is the final RCCL
 all_gather of the per-latent code lengths.
@@ -373,12 +373,14 @@ def run_rank(args):
     samp_dec = eng.decode_blocks(params, lay, q[2], q[3], SEED, K, out[1])
     torch.cuda.synchronize()
     round_trip_exact = bool(torch.equal(samp_dec, out[2]))
-    d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    d0.record()
-    for _ in range(3):
+    # per-call events, median: the first call after `samp_dec` is held may pay the allocator's hipMalloc of a fresh output
+    dev_ = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    dev_[0].record()
+    for i in range(5):
         eng.decode_blocks(params, lay, q[2], q[3], SEED, K, out[1])
-    d1.record(); torch.cuda.synchronize()
-    decode_ms = d0.elapsed_time(d1) / 3
+        dev_[i + 1].record()
+    torch.cuda.synchronize()
+    decode_ms = sorted(dev_[i].elapsed_time(dev_[i + 1]) for i in range(5))[2]
     assert round_trip_exact, "decode(encode) differs from the encoder's sample"
 
     result = {
@@ -464,9 +466,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--latents", type=int, default=32768, help="latent tensors per step per GPU (32 768: 294 912 blocks, "
-                    "~190 ms per step -- a timed region of almost four seconds at the driver's 20 steps, long enough for its "
-                    "5-second device samples to see the GPU busy; 8192 latents were 47 ms per step, under a second in all)")
+    ap.add_argument("--latents", type=int, default=65536, help="latent tensors per step per GPU (65 536: 589 824 blocks, "
+                    "~378 ms per step -- a timed region of 7.6 s at the driver's 20 steps, so that its 5-second device "
+                    "samples cannot miss it; the rate per latent is the same from 8192 latents up, profiles/r03g/batch_size.log)")
     ap.add_argument("--cpu-ref-latents", type=int, default=20, help="latents per CPU-ref repeat (5 repeats, median)")
     ap.add_argument("--cpu-opt-seconds", type=float, default=8.0, help="time budget of the CPU-opt (OpenMP oracle) leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
