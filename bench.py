@@ -41,7 +41,7 @@ TENSOR_SHAPE = (16, 16, 32)
 N_DIMS = 8192
 BLOCK_SIZE = 1000
 OMEGA, EPS1, BEAMS, SEED = 3.0, 1.2, 20, 42
-KERNEL_SOURCES = ("irec_team.hip", "irec_kernels.hip", "irec_fast_common.h", "irec_device.h", "irec_kernels.h",
+KERNEL_SOURCES = ("irec_team.hip", "irec_lone.hip", "irec_kernels.hip", "irec_fast_common.h", "irec_device.h", "irec_kernels.h",
                   "irec_host.cpp")
 
 

@@ -94,6 +94,7 @@ typedef struct {
 #define IREC_FLAG_SHAPE_3 (3 << IREC_FLAG_SHAPE_SHIFT)   /* three 4-wave teams (168 VGPRs)                            */
 #define IREC_FLAG_SHAPE_2X2 (4 << IREC_FLAG_SHAPE_SHIFT) /* two 8-wave beam-striped teams (128 VGPRs)                 */
 #define IREC_FLAG_SHAPE_1X2 (5 << IREC_FLAG_SHAPE_SHIFT) /* one 8-wave beam-striped team (the default of 64..n_CU blocks) */
+#define IREC_FLAG_SHAPE_TEAM (6 << IREC_FLAG_SHAPE_SHIFT) /* the team encoder's default shape also for one-beam calls (which the one-wave-per-block encoder takes otherwise) */
 
 #define IREC_TABLE_STEPS_DEFAULT 32
 #define IREC_TABLE_STEPS_MAX 4096

@@ -484,6 +484,7 @@ struct Plan {
   bool table;        // fast encoder fed by per-call proposal tables (Philox hoisted out of the block kernel)
   bool team;         // table && two-teams-per-CU encoder over three table copies (the default where it applies)
   bool team_only;    // B > 32: no one-table / fused fast encoder exists; the team encoder takes every call, the generic kernel its deferred pass
+  bool lone;         // team && one beam: the one-wave-per-block encoder (irec_lone.hip) stands in for the team encoder
   int shape;         // team-encoder workgroup shape override (IREC_FLAG_SHAPE_*; 0 = default)
   int grid_cap;      // scratch slabs = resident workgroups / teams (persistent kernels pull blocks from an atomic counter)
   int one_grid_cap;  // resident workgroups of the one-workgroup-per-block encoder of this plan (small calls of a team plan too)
@@ -510,7 +511,7 @@ irec_status check_params(const irec_params *p) {
   if (p->n_samples < 1 || p->n_samples > (1 << 24)) return fail(IREC_E_INVALID, "n_samples %d out of range", p->n_samples);
   if (p->n_beams < 1 || p->n_beams > IREC_MAX_BEAMS) return fail(IREC_E_INVALID, "n_beams %d out of range [1,%d]", p->n_beams, IREC_MAX_BEAMS);
   if (p->table_steps < 0) return fail(IREC_E_INVALID, "table_steps %d < 0", p->table_steps);
-  if (((p->flags & IREC_FLAG_SHAPE_MASK) >> IREC_FLAG_SHAPE_SHIFT) > 5) return fail(IREC_E_INVALID, "unknown IREC_FLAG_SHAPE_* value");
+  if (((p->flags & IREC_FLAG_SHAPE_MASK) >> IREC_FLAG_SHAPE_SHIFT) > 6) return fail(IREC_E_INVALID, "unknown IREC_FLAG_SHAPE_* value");
   return IREC_OK;
 }
 
@@ -523,7 +524,7 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
   pl.fast = !(p->flags & IREC_FLAG_FORCE_GENERIC) && max_dim <= irec::FAST_MAX_DIM && irec::fast_nb_for(B) != 0 &&
             irec::fast_lds_for(B, S, false) <= irec::FAST_LDS_LIMIT && (int64_t)S * B < (1 << 24);
   pl.grid_cap = 2 * n_cu; // measured residency: 2 workgroups per CU for every encoder
-  pl.table = false; pl.team = false; pl.n_tab = 0; pl.tab_bytes = 0;
+  pl.table = false; pl.team = false; pl.lone = false; pl.n_tab = 0; pl.tab_bytes = 0;
   // table window: the tables cover the first K_tab partitions; blocks with more go to the fused-Philox second pass
   const int want = p->table_steps > 0 ? p->table_steps : IREC_TABLE_STEPS_DEFAULT;
   pl.K_tab = std::max(1, std::min(std::min(want, IREC_TABLE_STEPS_MAX), max_K > 0 ? max_K : 1));
@@ -549,6 +550,7 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
     pl.team = pl.table && !(p->flags & IREC_FLAG_ONE_TABLE) && irec::team_lds_for(B, S, pl.shape) != (size_t)-1;
     if (pl.team_only && !pl.team) { pl.table = false; pl.n_tab = 0; pl.tab_bytes = 0; }
     if (pl.team) pl.grid_cap = irec::team_count_for(B, S, pl.shape) * n_cu; // one scratch slab per team
+    pl.lone = pl.team && irec::lone_applies(B, pl.shape);
   }
   if (!pl.table) pl.team_only = false;
   // resident workgroups of the one-workgroup-per-block encoders: two per CU, one for the big-LDS 8-wave configurations
@@ -560,6 +562,8 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
     pl.grid_cap = std::max(pl.grid_cap, pl.fast_grid_cap);          // both passes index the same slabs
     pl.ws_per_wg = round_up_sz(irec::fast_ws_for(B, max_K) + (pl.team ? irec::team_ws_extra_for(B, S, pl.shape) : 0), 256);
     if (pl.team) pl.ws_per_wg = std::max(pl.ws_per_wg, round_up_sz(irec::team_ws_bytes_for(B, S, pl.shape, max_K), 256));
+    // (the one-wave-per-block encoder lays its own slabs -- one workgroup per CU, a statistics slab per wave -- over the same area)
+    if (pl.lone) pl.ws_per_wg = std::max(pl.ws_per_wg, round_up_sz(((size_t)n_cu * irec::lone_ws_bytes_per_wg() + pl.grid_cap - 1) / pl.grid_cap, 256));
   } else {
     const size_t generic_ws = round_up_sz((size_t)10 * pl.dpad * 4 + (size_t)2 * B * pl.dpad * 4 +
                                           (size_t)(max_K > 0 ? max_K : 1) * B * 4 + (size_t)S * B * 4, 256);
@@ -620,7 +624,7 @@ bool team_for_call(const Plan &pl, const irec_params *p, int64_t n_blocks) {
 int shape_for_call(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks) {
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
   const int B = p->n_beams, S = p->n_samples;
-  if (pl.shape != 0 || !pl.team || n_blocks < 64 || n_blocks > 2 * (int64_t)n_cu || B > 20) return pl.shape;   // (< 64 blocks: only calls
+  if (pl.shape != 0 || !pl.team || pl.lone || n_blocks < 64 || n_blocks > 2 * (int64_t)n_cu || B > 20) return pl.shape;   // (< 64 blocks: only calls
                                                                          // that pin IREC_FLAG_TEAM get here, tests of the default shape among them)
   if (irec::team_count_for(B, S, 0) < 2) return pl.shape;                       // already one striped team
   if (n_blocks <= n_cu && B <= 10) return pl.shape;                             // (no 8-wave build for 10 beams)
@@ -659,7 +663,15 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
   const bool team = team_for_call(pl, p, n_blocks);
   std::memset(out, 0, sizeof(*out));
   const int B = p->n_beams, S = p->n_samples;
-  if (team) {
+  if (team && pl.lone) {
+    const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+    std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::lone_kernel_name());
+    std::snprintf(out->table_kernel, sizeof out->table_kernel, "alpha_choice_kernel");
+    out->grid = (int32_t)std::min<int64_t>(n_blocks, n_cu);
+    out->waves_per_wg = irec::lone_waves();
+    out->teams_per_wg = irec::lone_waves();       // every wave codes its own block
+    out->lds_bytes = (int32_t)irec::lone_lds_bytes();
+  } else if (team) {
     const int shape = shape_for_call(ctx, pl, p, n_blocks);
     const int n_teams = irec::team_count_for(B, S, shape);
     const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
@@ -801,7 +813,13 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
       else HIP_TRY(irec::launch_encode_fast(A2, false, (int)std::min<int64_t>(n_blocks, pl.fast_grid_cap), st));
       return IREC_OK;
     };
-    if (pl.team) { // grid_cap counts teams (= scratch slabs): two per workgroup, one workgroup per CU
+    if (pl.team && pl.lone) { // one workgroup per CU, a block per wave
+      HIP_TRY(irec::launch_encode_lone(A, (int)std::min<int64_t>(n_blocks, ctx->n_cu > 0 ? ctx->n_cu : 256), st));
+      if (irec_status s2 = deferred_pass()) return s2;
+#ifdef IREC_HOST_STAMPS
+      if (ctx->d_dbg) return IREC_OK;   // (no phase stamps in this kernel)
+#endif
+    } else if (pl.team) { // grid_cap counts teams (= scratch slabs): two per workgroup, one workgroup per CU
       const int n_teams = irec::team_count_for(p->n_beams, p->n_samples, pl.shape);
       // one workgroup per CU as soon as there is a block for it: team k of workgroup w starts on block k * grid + w
       const int tgrid = (int)std::min<int64_t>(n_blocks, std::min(pl.grid_cap / n_teams, ctx->n_cu > 0 ? ctx->n_cu : 256));

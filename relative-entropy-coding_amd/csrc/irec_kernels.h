@@ -88,6 +88,13 @@ const char *team_kernel_name(int B, int S, int shape_override);   // e.g. "encod
 const char *fast_kernel_name(int B, int S, bool table);
 hipError_t launch_alpha_choice(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *dlog4r, uint16_t *tab,
                                const uint32_t *keep, hipStream_t st);
+// one-beam calls: one wave per block over the team encoder's tables (irec_lone.hip)
+bool lone_applies(int B, int shape_override);           // n_beams == 1 and no diagnostic shape pinned (IREC_FLAG_SHAPE_TEAM pins the team encoder)
+int lone_waves();                                        // waves per workgroup (= blocks in flight per CU)
+size_t lone_lds_bytes();
+size_t lone_ws_bytes_per_wg();                           // scratch of one workgroup: a statistics slab per wave
+const char *lone_kernel_name();
+hipError_t launch_encode_lone(const EncArgs &A, int grid, hipStream_t st);
 // Head of the workspace, 128 uint32: [0..3] block / deferred counters and the split encoder's error flag, [8..11] "keep"
 // words of the call's proposal tables, [16..47] the stamps of the four table slots (8 words each: what the table in place
 // was built for), [64..127] arrival counters of the split encoder.  The head kernel of every call zeroes the counters,

@@ -22,7 +22,7 @@ IREC_FLAG_TABLES_PRESENT = 65536     # the previous call on this workspace / str
 IREC_FLAG_SPLIT_SAMPLES = 128      # split encoder: share samples (r02b form) instead of beams
 IREC_FLAG_REUSE_TABLES = 64        # keep a proposal table whose stamp in the workspace head matches the call's key
 IREC_FLAG_SHAPE_SHIFT = 8          # diagnostic workgroup shapes of the team encoder (include/irec.h)
-IREC_FLAG_SHAPE = {"default": 0, "1": 1 << 8, "2": 2 << 8, "3": 3 << 8, "2x2": 4 << 8, "1x2": 5 << 8}
+IREC_FLAG_SHAPE = {"default": 0, "1": 1 << 8, "2": 2 << 8, "3": 3 << 8, "2x2": 4 << 8, "1x2": 5 << 8, "team": 6 << 8}
 IREC_TABLE_STEPS_DEFAULT = 32
 IREC_TABLE_STEPS_MAX = 4096
 BIG_PRIME = 10007

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--eps", type=str, default="1.0,1.1,1.2,1.5")
     ap.add_argument("--check", type=int, default=1, help="latents per cell compared with the oracle (0: none)")
     ap.add_argument("--budget-s", type=float, default=900.0)
+    ap.add_argument("--shape", type=str, default="default", help="IREC_FLAG_SHAPE_* name (diagnostics; 'team' pins the team encoder for one-beam calls)")
     a = ap.parse_args()
     from oracle import oracle as O
     eng = irec.get_engine()
@@ -43,7 +44,7 @@ def main():
                 if time.time() - t_start > a.budget_s:
                     print("# time budget reached", flush=True)
                     return
-                params = eng.params(omega, S, B)
+                params = eng.params(omega, S, B, irec._lib.IREC_FLAG_SHAPE[a.shape])
                 max_K = 24
                 K, idx, sample = eng.encode_blocks(params, lay, ql, qs, pl, ps, 42, max_K)   # warm-up (tables, scratch)
                 torch.cuda.synchronize()
@@ -58,7 +59,7 @@ def main():
                 ms = min(ev[r].elapsed_time(ev[r + 1]) for r in range(a.reps))
                 # the same call with the proposal tables kept across calls (IREC_FLAG_REUSE_TABLES: what the Python coder does
                 # by default -- the tables depend on (seed, S, D) only): the block kernel alone
-                keep = eng.params(omega, S, B, irec._lib.IREC_FLAG_REUSE_TABLES)
+                keep = eng.params(omega, S, B, irec._lib.IREC_FLAG_REUSE_TABLES | irec._lib.IREC_FLAG_SHAPE[a.shape])
                 eng.encode_blocks(keep, lay, ql, qs, pl, ps, 42, max_K)
                 ev[0].record()
                 for r in range(a.reps):

@@ -9,8 +9,8 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -I$
 {
 echo "# ISA summary of the gfx950 kernels (hipcc $(hipcc --version | grep -m1 -o 'HIP version: [0-9.]*'), flags of csrc/Makefile)"
 echo "# kernel | VGPRs | AGPRs | SGPRs | scratch B/lane | static LDS B | scratch ops | ds_read | v_pk_fma | v_sqrt | s_barrier | MFMA"
-for f in irec_team irec_kernels irec_decode; do
-  extra=""; [ $f != irec_decode ] && extra="-mllvm -sink-insts-to-avoid-spills=true"
+for f in irec_team irec_lone irec_kernels irec_decode; do
+  extra=""; [ $f = irec_team -o $f = irec_kernels ] && extra="-mllvm -sink-insts-to-avoid-spills=true"
   hipcc $FLAGS $extra "$ROOT/relative-entropy-coding_amd/csrc/$f.hip" -o "$TMP/$f.s" 2>/dev/null
   python3 - "$TMP/$f.s" <<'PY'
 import re, subprocess, sys

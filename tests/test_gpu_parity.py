@@ -420,8 +420,9 @@ def test_reference_sweep_grid(engine, oracle, omega, B):
     """All 60 cells of the grid the reference sweeps -- kl_per_partition in 2..6 x extra_samples in {1, 1.1, 1.2, 1.5} x
     n_beams in {1, 10, 50}, S = int(exp(Omega * (1 + eps))) from 7 to 8103 (beam_search_coder.py:28-29) -- on one 1000-dim and
     one 192-dim block each: emitted indices and sample bit-exact against the oracle, once the way the library picks its
-    kernels for a call this small and once with the team encoder pinned (what a batch of such blocks runs on:
-    encode_team_kernel<10,3,1[,passes]> for B <= 10, <60,1,3> for B = 50; S * B reaches 405 150 candidates per step)."""
+    kernels for a call this small and once with the batch encoder pinned (what a batch of such blocks runs on:
+    encode_lone_kernel for B = 1, encode_team_kernel<10,3,1[,passes]> for B = 10, <60,1,3> for B = 50; S * B reaches 405 150
+    candidates per step)."""
     from irec import _lib
     n, bs = 1192, 1000
     stats = oracle.synthetic_latent(4242, n)
@@ -431,7 +432,9 @@ def test_reference_sweep_grid(engine, oracle, omega, B):
         S = oracle.n_samples(float(omega), eps1)
         ridx, rs = oracle.encode_tensor(*stats, 42, float(omega), S, B, block_size=bs)
         assert max(len(i) for i in ridx) <= 32
-        for flags in (0, _lib.IREC_FLAG_TEAM):
+        # (one beam: the pinned call runs encode_lone_kernel, one wave per block; pinning the team shape as well keeps the
+        #  team encoder's one-beam builds <10,3,1[,passes],one> under test)
+        for flags in (0, _lib.IREC_FLAG_TEAM) + ((_lib.IREC_FLAG_TEAM | _lib.IREC_FLAG_SHAPE["team"],) if B == 1 else ()):
             params = engine.params(float(omega), S, B, flags)
             K, idx, sample = engine.encode_blocks(params, lay, ql, qs, pl, ps, 42, 32)
             Kh, ih = K.cpu().numpy(), idx.cpu().numpy()
@@ -440,8 +443,52 @@ def test_reference_sweep_grid(engine, oracle, omega, B):
             assert got == ridx, (omega, eps1, S, B, flags, plan["kernel"])
             assert np.array_equal(sample.cpu().numpy()[0], rs), (omega, eps1, S, B, flags, plan["kernel"])
             if flags and B <= 60:
-                assert plan["kernel"].startswith("encode_team_kernel"), plan
+                lone = B == 1 and not (flags & _lib.IREC_FLAG_SHAPE["team"])
+                assert plan["kernel"].startswith("encode_lone_kernel" if lone else "encode_team_kernel"), plan
             assert torch.equal(engine.decode_blocks(params, lay, pl, ps, 42, K, idx), sample)
+
+
+def test_one_beam_batch_one_wave_per_block(engine, oracle):
+    """encode_lone_kernel (n_beams = 1: one wave per block) on a batch big enough that waves pull second and third blocks from
+    the counter (3 300 blocks > 12 waves x 256 CUs), with blocks of one and four dim groups, zero-KL tensors
+    (K = 0: sample = p.loc), a table window shorter than some blocks' K (those take the fused-Philox second pass) and, in a
+    second call, a max_K below the largest K (out_K reports it, nothing else is written for the block): indices and
+    samples of every tensor against the OpenMP build of the oracle, bit for bit; decode(encode) exact."""
+    from irec import _lib
+    n, bs, omega, eps1, N = 2192, 1000, 3.0, 1.0, 1100        # blocks of 1000, 1000 and 192 dims: four and one dim groups
+    S = oracle.n_samples(omega, eps1)
+    lat = [list(oracle.synthetic_latent(7000 + i, n)) for i in range(N)]
+    for i in (5, 700):                                        # q == p: K = 0 everywhere
+        lat[i][0] = lat[i][2].copy(); lat[i][1] = lat[i][3].copy()
+    for i in (9, 933):                                        # a far-off posterior: K well beyond the others'
+        lat[i][0] = (lat[i][2] + 2.5 * lat[i][3]).astype(np.float32)
+    host = [np.stack([l[j] for l in lat]) for j in range(4)]
+    dev = [torch.as_tensor(a, device="cuda") for a in host]
+    lay = engine.layout(N, n, bs, 42)
+    assert lay.n_blocks == 3 * N and lay.n_blocks > 12 * 256
+    ridx, rsamp, _ = oracle.encode_tensors_omp(*host, 42, omega, S, 1, bs, max_K=4096)
+    kmax = max(len(b) for t in ridx for b in t)
+    kbulk = int(np.percentile([len(b) for t in ridx for b in t], 90))
+    assert kmax > 2 * kbulk > 0
+    for steps in (0, kbulk):                                  # the default window (covers max_K) / a window the outliers leave
+        params = engine.params(omega, S, 1, 0, (), steps)
+        plan = engine.plan(params, lay, kmax)
+        assert plan["kernel"] == "encode_lone_kernel", plan
+        K, idx, sample = engine.encode_blocks(params, lay, *dev, 42, kmax)
+        Kh, ih = K.cpu().numpy(), idx.cpu().numpy()
+        nat = np.asarray(lay.natural).reshape(N, -1)
+        for i in range(N):
+            got = [ih[r, :Kh[r]].tolist() for r in nat[i]]
+            assert got == ridx[i], (steps, i)
+        assert np.array_equal(sample.cpu().numpy(), rsamp), steps
+        assert torch.equal(engine.decode_blocks(params, lay, dev[2], dev[3], 42, K, idx), sample)
+    # max_K below the outliers' K: their rows report K and stay uncoded, every other block is coded as before
+    params = engine.params(omega, S, 1)
+    K2, idx2, _ = engine.encode_blocks(params, lay, *dev, 42, kbulk)
+    K2h, i2h = K2.cpu().numpy(), idx2.cpu().numpy()
+    assert np.array_equal(K2h, Kh) and (K2h > kbulk).any()
+    ok = K2h <= kbulk
+    assert all(i2h[r, :K2h[r]].tolist() == ih[r, :Kh[r]].tolist() for r in np.nonzero(ok)[0])
 
 
 def test_many_beams_selection_refinement(engine):
@@ -752,8 +799,12 @@ def test_plan_names_the_kernels_that_run(engine, oracle):
     assert engine.plan(engine.params(3.0, S, 40), small, 32)["kernel"] == "encode_team_kernel<60,1,3>"   # (no one-table encoder there)
     assert engine.plan(engine.params(3.0, S, 64), big, 32)["kernel"] == "encode_generic_kernel"          # 60 < B <= 64
     assert engine.plan(engine.params(6.0, 8103, 10), big, 32)["kernel"] == "encode_team_kernel<10,3,1,passes>"
-    assert engine.plan(engine.params(6.0, 8103, 1), big, 32)["kernel"] == "encode_team_kernel<10,3,1,passes,one>"
-    assert engine.plan(engine.params(5.0, 403, 1), big, 32)["kernel"] == "encode_team_kernel<10,3,1,one>"   # one beam: 403 samples in one pass
+    # one beam: one wave per block (irec_lone.hip), 12 blocks in flight per CU; the team encoder's one-beam builds on request
+    lone = engine.plan(engine.params(6.0, 8103, 1), big, 32)
+    assert lone["kernel"] == "encode_lone_kernel" and lone["waves_per_wg"] == 12 and lone["table_kernel"] == "alpha_choice_kernel"
+    pin = irec._lib.IREC_FLAG_SHAPE["team"]
+    assert engine.plan(engine.params(6.0, 8103, 1, pin), big, 32)["kernel"] == "encode_team_kernel<10,3,1,passes,one>"
+    assert engine.plan(engine.params(5.0, 403, 1, pin), big, 32)["kernel"] == "encode_team_kernel<10,3,1,one>"   # 403 samples in one pass
     info = engine.plan(p, big, 32)
     assert info["n_cu"] == 256 and info["clock_mhz"] > 1000 and info["lds_bytes"] <= 160 * 1024
 
