@@ -338,6 +338,29 @@ def test_ragged_dims_with_idle_lanes_many_partitions(engine, oracle, D):
         assert np.array_equal(sample.cpu().numpy()[0], rs), variant
 
 
+@pytest.mark.parametrize("D", [1, 5, 65, 130, 250, 257, 600, 768, 1023, 1024])
+def test_one_beam_ragged_dims_and_tiny_sample_counts(engine, oracle, D):
+    """encode_lone_kernel on blocks of one to four dim groups with idle lanes, idle groups (600 dims: the fourth group of a
+    pair is all zero coefficients) and S = 1, 2, 3, 5, 9 -- fewer samples than a reduce-scatter holds, a sample count that is
+    not a multiple of four --, tight posteriors (tens of steps): indices and sample against the oracle."""
+    rng = np.random.default_rng(1000 + D)
+    mp = rng.normal(0, 1, D); sp = np.exp(rng.normal(0, 0.5, D))
+    mq = mp + sp * rng.normal(0, 0.7, D); sq = sp * rng.uniform(0.2, 0.7, D)
+    mq, sq, mp, sp = (a.astype(np.float32) for a in (mq, sq, mp, sp))
+    for omega, S in ((0.5, 1), (1.0, 2), (1.2, 3), (1.7, 5), (2.2, 9)):
+        c = _coder(omega, 1, 1.0, variant="table")
+        c.table_steps = 2048                      # (a window that covers every K here: nothing is left to the second pass)
+        assert c.n_samples == S
+        lay = engine.layout(1, D, None, 7)
+        plan = engine.plan(c._params(), lay, 2048)
+        assert plan["kernel"] == "encode_lone_kernel" and plan["table_steps"] == 2048, plan
+        idx, sample = c.encode(_normal(mq[None], sq[None]), _normal(mp[None], sp[None]), seed=7)
+        ridx, rs = oracle.encode_block(mq, sq, mp, sp, 7, omega, S, 1, max_K=65536)
+        assert [int(i) for i in idx] == ridx, (D, S)
+        assert np.array_equal(sample.cpu().numpy()[0], rs), (D, S)
+        assert torch.equal(c.decode(_normal(mp[None], sp[None]), idx, seed=7).cpu(), sample.cpu())
+
+
 def test_zero_kl_block(engine):
     mp = torch.tensor([[0.3, -1.0, 2.0]]); sp = torch.tensor([[1.0, 2.0, 0.5]])
     c = _coder(3.0, 10, 1.0)
