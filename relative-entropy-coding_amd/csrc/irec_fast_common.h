@@ -122,12 +122,19 @@ __device__ __forceinline__ bool rank_survivors(SM *sm, uint32_t C, int Bnew, int
   return true;
 }
 
+#ifndef IREC_SELECT_PAR_MIN
+#define IREC_SELECT_PAR_MIN 4096   // candidates per step from which every wave takes part in the streamed selection (0x7FFFFFFF: never)
+#endif
 template <int NT, class SM, class Sync, class Post = NoPost>
 __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew, int Bcur, SM *sm, const int tid, Sync &&sync,
                                                  unsigned long long *dbg = nullptr, Post &&post = Post()) {
   constexpr int NWV = NT / 64;
   int32_t *sel_s = sm->sel_s, *sel_b = sm->sel_b;
   unsigned long long t0 = dbg ? stamp_now() : 0ull;
+  // (streamed selection by every wave, below: its lane-maxima array lies over cand[], which is idle until the compaction)
+  const bool par = NWV > 1 && N > IREC_SELECT_PAR_MIN;
+  uint32_t *lane_max = reinterpret_cast<uint32_t *>(sm->cand);
+  if (par) { if (tid < 64) lane_max[tid] = 0u; if (tid == 0) sm->misc[4] = 0; }
   sync(); // keys written by all waves
   if (dbg && tid == 0) { const unsigned long long t1 = stamp_now(); dbg[8] += t1 - t0; t0 = t1; } // wait for keys
   bool done = false;
@@ -168,6 +175,79 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
     }
     sync();
     if (dbg && tid == 0) { const unsigned long long t1 = stamp_now(); dbg[10] += t1 - t0; t0 = t1; } // closing barrier
+    done = sm->misc[7] != 0;
+  }
+  else if (par) {
+    // N beyond IREC_SELECT_PAR_MIN (B = 30 / 50 with hundreds of samples; the keys may lie in the L2-resident slab): EVERY
+    // wave streams a share of the keys -- one wave alone is bound by the latency of its ~N / 256 dependent 16-byte reads per
+    // pass (r03g stamps: 5-9 % of a step at B = 50).  Same three stages: (1) lane maxima of a share, merged over the waves
+    // by LDS max (virtual lane l = the keys the lanes l of all waves read: 64 disjoint sets, so the Bnew-th largest of their
+    // maxima still leaves at least Bnew candidates); (2) every wave compacts its survivors, slots from an LDS counter (the
+    // ranking does not depend on their order); (3) wave 0 ranks.  Three barriers more, ~NWV times shorter passes.
+    const bool al = (reinterpret_cast<uintptr_t>(key) & 15) == 0;
+    const int n4 = al ? N >> 2 : 0;
+    const uint4 *key4 = reinterpret_cast<const uint4 *>(key);
+    const int lane = tid & 63;
+    {
+      uint32_t M = 0u;
+      for (int i = tid; i < n4; i += NT) {
+        const uint4 v = key4[i];
+        const uint32_t a = v.x > v.y ? v.x : v.y, b = v.z > v.w ? v.z : v.w;
+        M = M > a ? M : a;
+        M = M > b ? M : b;
+      }
+      for (int f = (n4 << 2) + tid; f < N; f += NT) M = key[f] > M ? key[f] : M;
+      if (M) __hip_atomic_fetch_max(&lane_max[lane], M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    sync();
+    uint32_t T;
+    {
+      const uint32_t M = lane_max[lane];
+      uint32_t cnt_gt = 0u;
+#pragma unroll
+      for (int l = 0; l < 64; ++l) cnt_gt += (uint32_t)__builtin_amdgcn_readlane((int)M, l) > M ? 1u : 0u;
+      T = cnt_gt < (uint32_t)Bnew ? M : 0xFFFFFFFFu;
+      T = 0xFFFFFFFFu - (uint32_t)wave_max_u64((unsigned long long)(0xFFFFFFFFu - T)); // wave min
+      T = T ? T : 1u;                                        // (0 marks a taken / empty key)
+    }
+    sync(); // every wave has read the maxima: cand[] may be written
+    {
+      auto put = [&](bool in, uint32_t k, uint32_t flat) {
+        const unsigned long long mask = __ballot(in);
+        if (mask) {                                          // wave-uniform
+          const uint32_t n_in = (uint32_t)__popcll(mask);
+          uint32_t base = 0u;
+          if (lane == 0) base = (uint32_t)__hip_atomic_fetch_add(&sm->misc[4], (int32_t)n_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+          if (in && pos < (uint32_t)SM::CANDS) sm->cand[pos] = ((unsigned long long)k << 32) | flat;
+        }
+      };
+      for (int i0 = tid - lane; i0 < n4; i0 += NT) {         // (wave-uniform trip count)
+        const int i = i0 + lane;
+        const uint4 v = i < n4 ? key4[i] : make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t a = v.x > v.y ? v.x : v.y, b = v.z > v.w ? v.z : v.w;
+        if (__ballot((a > b ? a : b) >= T)) {                // most 256-key rounds hold no survivor at all
+          put(v.x >= T, v.x, (uint32_t)(4 * i));
+          put(v.y >= T, v.y, (uint32_t)(4 * i + 1));
+          put(v.z >= T, v.z, (uint32_t)(4 * i + 2));
+          put(v.w >= T, v.w, (uint32_t)(4 * i + 3));
+        }
+      }
+      for (int f0 = (n4 << 2) + tid - lane; f0 < N; f0 += NT) {
+        const int f = f0 + lane;
+        const uint32_t k = f < N ? key[f] : 0u;
+        put(k >= T, k, (uint32_t)f);
+      }
+    }
+    sync();
+    if (tid < 64) {
+      __builtin_amdgcn_s_setprio(3);
+      const uint32_t C = (uint32_t)sm->misc[4];
+      sm->misc[7] = rank_survivors(sm, C, Bnew, Bcur, tid, post) ? 1 : 0;
+      __builtin_amdgcn_s_setprio(0);
+    }
+    sync();
     done = sm->misc[7] != 0;
   }
   else {

@@ -48,6 +48,12 @@
 #ifndef IREC_PHANTOM
 #define IREC_PHANTOM 1      // stripes at least half alive score their dead beams as phantoms in the pipelined loop (0: beam-by-beam path)
 #endif
+#ifndef IREC_PRIO_ROTATE
+#define IREC_PRIO_ROTATE 1        // beam-striped one-team builds: the stripe the SIMD arbiter favours rotates every 2^SHIFT chunks (0: off)
+#endif
+#ifndef IREC_PRIO_ROTATE_SHIFT
+#define IREC_PRIO_ROTATE_SHIFT 2
+#endif
 #ifndef IREC_STEP0_WIDE
 #define IREC_STEP0_WIDE 1   // first step (one beam): RW samples per reduce-scatter instead of one (0: the beam-wise path, A/B builds)
 #endif
@@ -453,6 +459,13 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         }
         IREC_ISSUE(zz[0], IREC_AL(0, 0), 0);
         for (int ch = 0; ch < n_chunks; ++ch) {
+          if constexpr (BS >= 2 && IREC_PRIO_ROTATE != 0) {
+            // One team, BS waves per SIMD (the stripes' waves of one dim group share a SIMD): the SIMD's arbiter favours its
+            // oldest wave, which then reaches the pass's barrier a third of the pass early and leaves the SIMD to two waves,
+            // then one (r03g stamps: 20-28 % of every wave's time is that wait).  The favoured stripe rotates instead.
+            if ((((ch >> IREC_PRIO_ROTATE_SHIFT) + bs) % BS) == 0) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+          }
           f2 acc2[SPC][NP];
 #pragma unroll
           for (int cc = 0; cc < SPC; ++cc)
@@ -505,6 +518,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           const int m = ch * SPC + cc;                              // my m-th sample
           if (own >= 0 && (lane & 1) == 0 && m < n_mine && b < nlive) part_s[((size_t)g * SP + m * NSW + sw) * PS + b_lo + b] = tot;
         }
+        if constexpr (BS >= 2 && IREC_PRIO_ROTATE != 0) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int k = 0; k < HP; ++k) asm volatile("" : "+v"(zz[0][k])); // drain the look-ups issued past the last sample
 #undef IREC_ISSUE
