@@ -215,10 +215,11 @@ __global__ __launch_bounds__(DEC_NT) __attribute__((amdgpu_waves_per_eu(6, 8))) 
 //  element by element from global memory that is one 128-byte line per 4-byte value (measured, r03a: 1.4 of the 1.9 ms of a
 //  73 728-block decode; the same arithmetic on unshuffled blocks takes 0.5 ms).  Here ONE workgroup decodes ALL blocks of a
 //  tensor: sigma_p is read coalesced into an LDS region, the waves gather their dims' variances from there and run their
-//  units (one wave x 256 dims of a block, as above; RMAX per wave, their samples waiting in registers), then the samples
-//  are scattered into the region (merge) and the region leaves coalesced with mu_p -- read coalesced -- added on the way
-//  out.  The global reads of a pass are issued a phase ahead into registers (sigma_p a whole tensor ahead), four workgroup
-//  barriers per tensor, two workgroups per CU (72 KB of LDS each at 8192 dims).
+//  units (one wave x 256 dims of a block, as above), pulled from an LDS counter, and write their samples IN PLACE over the
+//  variances -- split and merge address the same elements, each owned by one unit (r03h; until then: fixed rounds, samples
+//  waiting in registers, a zero fill and a scatter pass behind a second barrier) -- and the region leaves coalesced with
+//  mu_p -- read coalesced -- added on the way out.  The global reads of a pass are issued a phase ahead into registers
+//  (sigma_p a whole tensor ahead), two workgroup barriers per tensor, two workgroups per CU (72 KB of LDS each at 8192 dims).
 //  Blocks are Coder.split's: block j = shuffled positions [j * tbs, min((j + 1) * tbs, tn)) of tensor `tensor`; its K /
 //  index row is block_row[tensor * bpt + j] (or tensor * bpt + j).
 // ======================================================================================================
@@ -232,6 +233,10 @@ __global__ __launch_bounds__(DEC_NT) __attribute__((amdgpu_waves_per_eu(6, 8))) 
 #ifndef IREC_DEC_WMAX
 #define IREC_DEC_WMAX 12         // waves per workgroup at most
 #endif
+#ifndef IREC_DEC_DYN
+#define IREC_DEC_DYN 1           // 1: the waves pull a tensor's units from an LDS counter and write their samples IN PLACE over the
+                                 //    variances they gathered (every element has one owner); 0: r03a's fixed rounds (A/B builds)
+#endif
 #ifndef IREC_DEC_WPE
 #define IREC_DEC_WPE 6           // waves per SIMD the tensor kernel is compiled for (80 VGPRs)
 #endif
@@ -242,6 +247,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(IREC_DEC_W
   const int tid = threadIdx.x, lane = tid & 63, NT = (int)blockDim.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NW = NT >> 6;
+  (void)wave; (void)NW;
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap(); // see lds_abs_f32
   float *region = reinterpret_cast<float *>(smem + DEC_LUT_BYTES + (TABLE ? 0 : DEC_DLOG_BYTES));   // [tn]
   {
@@ -254,6 +260,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(IREC_DEC_W
   }
   const uint16_t *dlog_f = TABLE ? A.dlog4r : reinterpret_cast<const uint16_t *>(smem + DEC_LUT_BYTES);
   const int n = A.tn, bs = A.tbs, bpt = A.tbpt;
+  uint32_t *unit_next = reinterpret_cast<uint32_t *>(region + (((size_t)n + 3) & ~(size_t)3));   // 16 bytes behind the region
   const int upb = (bs + 255) >> 8;                          // units of a full block
   const int upt = bpt * upb;                                // unit slots per tensor (the short last block leaves some empty)
   // A thread's share of a tensor for the staging passes: PF = 4 * RMAX floats (RMAX 16-byte pieces when the tensor allows).
@@ -281,7 +288,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(IREC_DEC_W
   if ((int64_t)blockIdx.x < A.n_tensors && !(IREC_DEC_ABLATE & 1)) fetch16(A.p_scale + (int64_t)blockIdx.x * n, psn);
   for (int64_t tensor = blockIdx.x; tensor < A.n_tensors; tensor += gridDim.x) {
     const int64_t base = tensor * (int64_t)n;
-    __syncthreads();                                        // table fill / previous tensor's store pass: the region is free
+    // (fixed rounds: the previous tensor's store pass must be over before the region is refilled.  Pulled units: a thread
+    //  refills exactly the elements it has just stored out -- the same i = k * NT + tid in both passes --, no barrier needed;
+    //  the table fill is covered by the barrier behind the refill)
+    if (IREC_DEC_DYN == 0) __syncthreads();
     if (!(IREC_DEC_ABLATE & 1)) {
       if (vec) {
 #pragma unroll
@@ -294,7 +304,60 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(IREC_DEC_W
         for (int k = 0; k < PF; ++k) { const int i = k * NT + tid; if (i < n) region[i] = psn[k]; }
       }
     }
+    if (IREC_DEC_DYN != 0 && tid == 0) *unit_next = 0u;
     __syncthreads();
+#if IREC_DEC_DYN
+    // Units of this tensor, pulled from the counter (blocks differ in K, a tensor's 33 units do not divide by 12 waves: fixed
+    // rounds left every wave waiting for the slowest at the barrier below).  A unit gathers its variances from the region and
+    // writes its samples over them: split and merge address the SAME elements (coder.py:62-83,111-117), each owned by one
+    // unit, so nobody else reads or writes them between the two barriers -- no second barrier, no zero fill, no samples
+    // waiting in registers.  A block that cannot be decoded leaves zeros.  (Handing the blocks out longest first, K and row
+    // of a tensor's blocks fetched a tensor ahead into lanes: no further gain, profiles/r03h/ab_dec_lpt.log.)
+    for (;;) {
+      uint32_t u_ = 0u;
+      if (lane == 0) u_ = __hip_atomic_fetch_add(unit_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const int u = __builtin_amdgcn_readfirstlane((int)u_);
+      if (u >= upt) break;                                  // wave-uniform
+      const int j = u / upb, chunk = u - j * upb;
+      const int pos = j * bs;
+      const int D = n - pos < bs ? n - pos : bs;
+      if (chunk * 256 >= D) continue;
+      const int64_t row = A.block_row ? (int64_t)A.block_row[tensor * bpt + j] : tensor * bpt + j;
+      const int K = A.K[row];
+      const int32_t *idx = A.indices + row * (int64_t)A.max_K;
+      const int d0 = chunk * 256 + lane * 4;
+      int at[4];
+      float var_p[4], smp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = pos + (d0 + i < D ? d0 + i : 0);
+        at[i] = (A.perm && !(IREC_DEC_ABLATE & 4)) ? A.perm[e] : e;
+        const float sp = region[at[i]];
+        var_p[i] = sp * sp;
+      }
+      if (K >= 0 && K <= A.max_K) {                         // (else not decodable: its elements come out as mu_p)
+        const uint16_t *tab = nullptr;
+        const int Dp = (D + 3) & ~3;
+        if (TABLE && K <= A.K_tab) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (A.tab_dim[q] == D) tab = A.tab[q];
+        }
+        if (!(IREC_DEC_ABLATE & 2)) decode_unit<TABLE>(A, idx, K, D, Dp, tab, dlog_f, (uint32_t)(d0 < D ? d0 : 0), lane, var_p, smp);
+        else { smp[0] = var_p[0]; smp[1] = var_p[1]; smp[2] = var_p[2]; smp[3] = var_p[3]; }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (d0 + i < D) region[at[i]] = smp[i];             // merge (coder.py:111-117)
+    }
+    float pln[PF];
+    if (!(IREC_DEC_ABLATE & 1)) {
+      fetch16(A.p_loc + base, pln);
+      const int64_t nxt = tensor + (int64_t)gridDim.x < A.n_tensors ? tensor + (int64_t)gridDim.x : tensor;
+      fetch16(A.p_scale + nxt * n, psn);
+    }
+    __syncthreads();                                        // every unit has written its samples
+#else
     // my units of this tensor, one after the other (a rolled loop: the unit code exists once); their samples wait in registers
     // for the merge -- RMAX x 4 floats, selected by the (scalar) round number
     float keep[DEC_RMAX][4];
@@ -370,6 +433,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(IREC_DEC_W
       }
     }
     __syncthreads();
+#endif
     if (!(IREC_DEC_ABLATE & 1)) {                           // sample + coding_dist.loc (:148), leaving in natural order
       if (vec) {
 #pragma unroll
@@ -475,12 +539,16 @@ int decode_tensor_waves(int n, int bs, bool table, size_t *lds_out) {
   if (n < 1 || bs < 1) return 0;
   const int bpt = (n + bs - 1) / bs, upb = (bs + 255) / 256;
   const int64_t upt = (int64_t)bpt * upb;
-  const size_t lds = decode_lds_bytes(table) + (((size_t)n * 4 + 15) & ~(size_t)15);
+  const size_t lds = decode_lds_bytes(table) + (((size_t)n * 4 + 15) & ~(size_t)15) + 16;   // table(s), region, unit counter
   // 96 VGPRs: five waves per SIMD, so two workgroups share a CU when each has at most ten waves
   const int rounds = (int)((upt + IREC_DEC_WMAX - 1) / IREC_DEC_WMAX);
   if (rounds > DEC_RMAX_BIG || lds > FAST_LDS_LIMIT) return 0;
   if (lds_out) *lds_out = lds;
+#if IREC_DEC_DYN
+  return (int)(upt < IREC_DEC_WMAX ? upt : IREC_DEC_WMAX);   // units are pulled: the wave count need not divide them
+#else
   return (int)((upt + rounds - 1) / rounds);
+#endif
 }
 
 hipError_t launch_decode(const DecArgs &A, int n_cu, hipStream_t st) {
