@@ -210,7 +210,9 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
                              float *out_sample, void *workspace, size_t workspace_bytes, void *hip_stream);
 
 /* BeamSearchCoder.decode_block on n_blocks blocks -- beam_search_coder.py:124-148 (GaussianCoder.decode, coder.py:459-491).
- *   K [n_blocks], indices [n_blocks, max_K] in ENCODER order (idx[t] = choice at iteration t). */
+ *   K [n_blocks], indices [n_blocks, max_K] in ENCODER order (idx[t] = choice at iteration t).  A row with K < 0 or
+ *   K > max_K (what the encoder leaves for a block it did not code) is not decodable: the block's elements are returned as
+ *   p_loc -- by every decode entry point. */
 irec_status irec_beam_decode(irec_context *ctx, const irec_params *p, int64_t n_blocks, const int64_t *block_base,
                              const int32_t *block_pos, const int32_t *block_dim, const int32_t *perm,
                              const float *p_loc, const float *p_scale, int64_t seed, int32_t max_K, const int32_t *K,

@@ -173,12 +173,21 @@ __global__ __launch_bounds__(DEC_NT) __attribute__((amdgpu_waves_per_eu(6, 8))) 
     const int D = A.block_dim[blk];
     if (chunk * 256 >= D || D > upb * 256) continue;        // (a short block has fewer units than upb; one beyond the host's bound is not decoded)
     const int K = A.K[blk];
-    if (K > A.max_K || K < 0) continue;
     const int64_t base = A.block_base[blk];
     const int32_t pos = A.block_pos[blk];
     const int32_t *idx = A.indices + blk * (int64_t)A.max_K;
     const int d0 = chunk * 256 + lane * 4;
     const bool live = d0 < D;
+    if (K > A.max_K || K < 0) {                               // not decodable: its elements come out as mu_p (as the staged decoder's)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (d0 + i < D) {
+          const int e = pos + d0 + i;
+          const int64_t ixo = base + (A.perm ? A.perm[e] : e);
+          A.out_sample[ixo] = 0.f + A.p_loc[ixo];
+        }
+      continue;
+    }
     // my 4 dims: element offsets inside the tensor (Coder.split: gather through the shuffle, coder.py:62-83)
     int32_t off[4];
     float var_p[4], sample[4];
@@ -472,7 +481,13 @@ __global__ __launch_bounds__(256) void decode_kernel(DecArgs A) {
     const int32_t pos = A.block_pos[blk];
     const int K = A.K[blk];
     const int32_t *idx = A.indices + blk * (int64_t)A.max_K;
-    if (K > A.max_K || K < 0) continue;
+    if (K > A.max_K || K < 0) {                               // not decodable: its elements come out as mu_p
+      for (int d = tid; d < D; d += 256) {
+        const int64_t ixo = base + (A.perm ? (int64_t)A.perm[pos + d] : (int64_t)(pos + d));
+        A.out_sample[ixo] = 0.f + A.p_loc[ixo];
+      }
+      continue;
+    }
     // a thread decodes FOUR consecutive dims: one Philox block yields their four draws (two when the row start is not a
     // multiple of 4), instead of one block per dim with three of its four words thrown away
     for (int d0 = tid * 4; d0 < D; d0 += 256 * 4) {

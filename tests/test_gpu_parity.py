@@ -639,6 +639,32 @@ def test_decoder_variants_agree_with_the_oracle(engine, oracle, n_t, n, bs, omeg
             assert np.array_equal(sample[i].cpu().numpy(), want)
 
 
+def test_decoder_leaves_mu_p_on_rows_it_cannot_decode(engine, oracle):
+    """A K / index row with K < 0 (the encoder's mark for a block it could not serve) or K > max_K (a block that needs a
+    retry) is not decodable: every decode mode returns p.loc on that block's elements -- the staged decoder writes zeros in
+    place of the block's variances before the region leaves with mu_p added -- and the exact samples everywhere else."""
+    n_t, n, bs = 5, 8192, 1000
+    stats = [oracle.synthetic_latent(7100 + i, n) for i in range(n_t)]
+    ql, qs, pl, ps = (torch.from_numpy(np.stack([s[k] for s in stats])).cuda().contiguous() for k in range(4))
+    lay = engine.layout(n_t, n, bs, 42)
+    params = engine.params(3.0, 36, 20)
+    K, idx, sample = engine.encode_blocks(params, lay, ql, qs, pl, ps, 42, 40)
+    bpt = lay.blocks_per_tensor
+    bad = [(0, 0, -1), (1, 8, 41), (3, 4, -1), (4, 7, 1000)]          # (tensor, block, K written into its row)
+    K2 = K.clone()
+    for i, j, k in bad:
+        K2[int(lay.natural[i * bpt + j])] = k
+    want = sample.clone()
+    perm = torch.from_numpy(oracle.tf_shuffle_perm(42, n).astype(np.int64)).cuda()
+    for i, j, _ in bad:
+        lo, hi = oracle.split_blocks(n, bs)[j]
+        g = perm[lo:hi]
+        want[i, g] = pl[i, g]
+    for mode in ("auto", "tensors", "tensors_fused", "tables", "fused", "legacy"):
+        rec = engine.decode_blocks(params, lay, pl, ps, 42, K2, idx, mode=mode)
+        assert torch.equal(rec, want), mode
+
+
 @pytest.mark.parametrize("flags", [8, 0, 4, 2], ids=["table", "auto", "one_table", "fused"])
 def test_full_size_properties(engine, oracle, flags):
     """BASELINE config 2 at bench size: properties that need no oracle run (round trip, ranges), plus a sampled
