@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <thread>
 #include <vector>
@@ -92,7 +93,7 @@ const char *irec_io_last_error(void) { return g_io_error.c_str(); }
 // ArithmeticCoder(P, precision).encode(message) -- entropy_coding.pyx:51-121.  out_bits receives one ASCII '0'/'1' per
 // code bit (the reference returns a list of such characters); *n_bits is the code length even when it exceeds cap.
 irec_status irec_ac_encode(const int64_t *counts, int32_t n_symbols, const int64_t *message, int64_t n_message,
-                           int32_t precision, uint8_t *out_bits, int64_t cap, int64_t *n_bits) {
+                           int32_t precision, uint8_t *out_bits, int64_t cap, int64_t *n_bits) try {
   Cdf cdf;
   if (!cdf.build(counts, n_symbols)) return io_fail("irec_ac_encode: counts must be >= 1");
   if (precision < 8 || precision > 40 || !n_bits || (n_message > 0 && !message) || (cap > 0 && !out_bits))
@@ -119,14 +120,14 @@ irec_status irec_ac_encode(const int64_t *counts, int32_t n_symbols, const int64
   *n_bits = sink.n;
   if (sink.overflow) return io_fail("irec_ac_encode: output buffer too small");
   return IREC_OK;
-}
+} catch (const std::exception &e) { g_io_error = std::string("irec_ac_encode: ") + e.what(); return IREC_E_INVALID; }
 
 // ArithmeticCoder.decode_fast(code) -- entropy_coding.pyx:213-302: decodes until the terminator symbol 0.
 // The reference finds the symbol with an AVL tree over C (data_structures.py:186-213, the tightest lower bound
 // (width*C[j])//R <= z - low); here the same j comes from a binary search.  *n_message is the decoded length
 // (terminator included) even when it exceeds cap.
 irec_status irec_ac_decode(const int64_t *counts, int32_t n_symbols, const uint8_t *bits, int64_t n_bits,
-                           int32_t precision, int64_t *out_message, int64_t cap, int64_t *n_message) {
+                           int32_t precision, int64_t *out_message, int64_t cap, int64_t *n_message) try {
   Cdf cdf;
   if (!cdf.build(counts, n_symbols)) return io_fail("irec_ac_decode: counts must be >= 1");
   if (precision < 8 || precision > 40 || !n_message || (n_bits > 0 && !bits) || (cap > 0 && !out_message))
@@ -136,7 +137,7 @@ irec_status irec_ac_decode(const int64_t *counts, int32_t n_symbols, const uint8
   *n_message = n;
   if (n > cap) return io_fail("irec_ac_decode: output buffer too small");
   return IREC_OK;
-}
+} catch (const std::exception &e) { g_io_error = std::string("irec_ac_decode: ") + e.what(); return IREC_E_INVALID; }
 
 // int('1' + code, 2).to_bytes(ceil((len+1)/8), 'big') -- rec/io/utils.py:66-72,100-106: a leading 1 bit, then the code,
 // right-aligned in big-endian bytes.  Returns the byte count (or -1 if cap is too small).
@@ -219,7 +220,7 @@ uint16_t get_u16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 // Returns the file's byte count (also when it exceeds cap: call again), or -1 on invalid input (irec_io_last_error()).
 int64_t irec_rec_encode_file(uint32_t seed, uint32_t block_size, uint32_t max_index, uint32_t height, uint32_t width,
                              uint32_t channels, int32_t n_res_blocks, const int32_t *blocks_per_res, const int32_t *K,
-                             const int32_t *indices, uint8_t *out, int64_t cap) {
+                             const int32_t *indices, uint8_t *out, int64_t cap) try {
   if (n_res_blocks < 0 || n_res_blocks > 65535 || (n_res_blocks > 0 && (!blocks_per_res || !K)) || height > 65535 ||
       width > 65535 || channels > 65535) { io_fail("irec_rec_encode_file: bad arguments"); return -1; }
   std::vector<std::vector<uint8_t>> cs((size_t)n_res_blocks), xs((size_t)n_res_blocks);
@@ -248,7 +249,7 @@ int64_t irec_rec_encode_file(uint32_t seed, uint32_t block_size, uint32_t max_in
   for (auto &v : xs) f.insert(f.end(), v.begin(), v.end());
   if (out && cap >= (int64_t)f.size()) std::memcpy(out, f.data(), f.size());
   return (int64_t)f.size();
-}
+} catch (const std::exception &e) { g_io_error = std::string("irec_rec_encode_file: ") + e.what(); return -1; }
 
 // read_compressed_code (rec/io/utils.py:109-216) for files written with the default models.  header_out[9] = seed, block_size,
 // max_index, height, width, channels, uses_count_file, uses_index_file, R.  Two-call protocol: with null / short outputs it
@@ -256,13 +257,17 @@ int64_t irec_rec_encode_file(uint32_t seed, uint32_t block_size, uint32_t max_in
 // blocks_per_res [R], K [blocks], indices [total].
 irec_status irec_rec_decode_file(const uint8_t *bytes, int64_t n_bytes, uint32_t *header_out, int64_t *sizes_out,
                                  int32_t *blocks_per_res, int64_t cap_res, int32_t *K, int64_t cap_blocks, int32_t *indices,
-                                 int64_t cap_indices) {
+                                 int64_t cap_indices) try {
   if (!bytes || n_bytes < 28 || !header_out || !sizes_out) return io_fail("irec_rec_decode_file: bad arguments");
   for (int k = 0; k < 5; ++k) header_out[k] = get_u32(bytes + 4 * k);
   for (int k = 0; k < 4; ++k) header_out[5 + k] = get_u16(bytes + 20 + 2 * k);
   const int64_t R = header_out[8];
   if (header_out[6] || header_out[7]) return io_fail("irec_rec_decode_file: file uses empirical count tables (not the default models)");
   if (n_bytes < 28 + 16 * R) return io_fail("irec_rec_decode_file: truncated header");
+  // a damaged header must come back as an error, not as a symbol table of 2^32 entries: max_index is a sample count
+  // (n_samples <= 2^24, irec_params), a residual block's largest partition count at most IREC_MAX_PARTITIONS, and a coded
+  // block costs at least one bit of its count stream
+  if (header_out[2] < 1u || header_out[2] > (1u << 24)) return io_fail("irec_rec_decode_file: max_index out of range (damaged header?)");
   const uint8_t *dyn = bytes + 28;
   int64_t pos = 28 + 16 * R, n_blocks = 0, n_idx = 0;
   std::vector<std::vector<int32_t>> counts((size_t)R), vals((size_t)R);
@@ -270,7 +275,10 @@ irec_status irec_rec_decode_file(const uint8_t *bytes, int64_t n_bytes, uint32_t
   for (int64_t r = 0; r < R; ++r) off_x += get_u32(dyn + 4 * (R + r));
   for (int64_t r = 0; r < R; ++r) {
     const int64_t nc = get_u32(dyn + 4 * (R + r)), nx = get_u32(dyn + 4 * (2 * R + r));
-    const int32_t mx = (int32_t)get_u32(dyn + 4 * (3 * R + r));
+    const int64_t mx64 = get_u32(dyn + 4 * (3 * R + r));
+    if (mx64 > IREC_MAX_PARTITIONS || (int64_t)get_u32(dyn + 4 * r) > 8 * nc + 8)
+      return io_fail("irec_rec_decode_file: partition / block counts out of range (damaged header?)");
+    const int32_t mx = (int32_t)mx64;
     if (pos + nc > n_bytes || off_x + nx > n_bytes) return io_fail("irec_rec_decode_file: truncated streams");
     if (!decode_stream(bytes + pos, nc, mx + 1, 100, counts[(size_t)r])) return io_fail("irec_rec_decode_file: corrupt count stream");
     if (!decode_stream(bytes + off_x, nx, (int32_t)header_out[2], 1000, vals[(size_t)r])) return io_fail("irec_rec_decode_file: corrupt index stream");
@@ -292,7 +300,7 @@ irec_status irec_rec_decode_file(const uint8_t *bytes, int64_t n_bytes, uint32_t
     for (int32_t v : vals[(size_t)r]) indices[ib++] = v;
   }
   return IREC_OK;
-}
+} catch (const std::exception &e) { g_io_error = std::string("irec_rec_decode_file: ") + e.what(); return IREC_E_INVALID; }
 
 // ---- many containers at once (round 3) --------------------------------------------------------------------------------------
 // The per-image loop of the reference's evaluation script writes one .rec per image (compression_performance.py:350-365) and
@@ -312,7 +320,7 @@ void for_each_image(int32_t n_images, int32_t n_threads, F &&body) {
   if (T > n_images) T = n_images;
   if (T <= 1) { for (int32_t i = 0; i < n_images; ++i) body(i); return; }
   std::vector<std::thread> pool;
-  for (int t = 0; t < T; ++t)
+  for (int t = 0; t < T; ++t)   // (body() reports through its own error slot and must not throw: an exception leaving a thread ends the process)
     pool.emplace_back([&, t]() { for (int32_t i = t; i < n_images; i += T) body(i); });
   for (auto &th : pool) th.join();
 }
@@ -321,14 +329,14 @@ extern "C" {
 
 int64_t irec_rec_encode_files(uint32_t seed, uint32_t block_size, uint32_t max_index, uint32_t height, uint32_t width,
                               uint32_t channels, int32_t n_images, int32_t n_res_blocks, int32_t blocks_per_res, int32_t max_K,
-                              const int32_t *K, const int32_t *idx, uint8_t *out, int64_t cap, int64_t *offsets, int32_t n_threads) {
+                              const int32_t *K, const int32_t *idx, uint8_t *out, int64_t cap, int64_t *offsets, int32_t n_threads) try {
   if (n_images < 0 || n_res_blocks < 1 || blocks_per_res < 1 || max_K < 0 || !K || (max_K > 0 && !idx) || !offsets) {
     io_fail("irec_rec_encode_files: bad arguments"); return -1; }
   std::vector<std::vector<uint8_t>> files((size_t)n_images);
   std::vector<std::string> errs((size_t)n_images);
   const int64_t per_img = (int64_t)n_res_blocks * blocks_per_res;
   const std::vector<int32_t> bpr((size_t)n_res_blocks, blocks_per_res);
-  for_each_image(n_images, n_threads, [&](int32_t i) {
+  for_each_image(n_images, n_threads, [&](int32_t i) { try {
     const int32_t *Ki = K + (int64_t)i * per_img;
     std::vector<int32_t> flat;
     flat.reserve((size_t)per_img * 8);
@@ -349,7 +357,7 @@ int64_t irec_rec_encode_files(uint32_t seed, uint32_t block_size, uint32_t max_i
     }
     if (n < 0) { errs[(size_t)i] = g_io_error; return; }
     f.resize((size_t)n);
-  });
+  } catch (const std::exception &e) { errs[(size_t)i] = std::string("irec_rec_encode_files: ") + e.what(); } });
   int64_t total = 0;
   for (int32_t i = 0; i < n_images; ++i) {
     if (!errs[(size_t)i].empty()) { g_io_error = errs[(size_t)i] + " (image " + std::to_string(i) + ")"; return -1; }
@@ -359,19 +367,19 @@ int64_t irec_rec_encode_files(uint32_t seed, uint32_t block_size, uint32_t max_i
   if (out && cap >= total)
     for (int32_t i = 0; i < n_images; ++i) std::memcpy(out + offsets[i], files[(size_t)i].data(), files[(size_t)i].size());
   return total;
-}
+} catch (const std::exception &e) { g_io_error = std::string("irec_rec_encode_files: ") + e.what(); return -1; }
 
 // The inverse: n_images containers (bytes at offsets[i] .. offsets[i + 1]) decoded on host threads into the packed layout
 // above (rows zero-filled past K).  headers [n_images][9] as irec_rec_decode_file's; every file must hold n_res_blocks
 // residual blocks of blocks_per_res coded blocks with at most max_K partitions, else the call fails naming the image.
 irec_status irec_rec_decode_files(const uint8_t *bytes, const int64_t *offsets, int32_t n_images, int32_t n_res_blocks,
                                   int32_t blocks_per_res, int32_t max_K, uint32_t *headers, int32_t *K, int32_t *idx,
-                                  int32_t n_threads) {
+                                  int32_t n_threads) try {
   if (!bytes || !offsets || n_images < 0 || n_res_blocks < 1 || blocks_per_res < 1 || max_K < 0 || !headers || !K || (max_K > 0 && !idx))
     return io_fail("irec_rec_decode_files: bad arguments");
   std::vector<std::string> errs((size_t)n_images);
   const int64_t per_img = (int64_t)n_res_blocks * blocks_per_res;
-  for_each_image(n_images, n_threads, [&](int32_t i) {
+  for_each_image(n_images, n_threads, [&](int32_t i) { try {
     std::vector<int32_t> bpr((size_t)n_res_blocks), flat;
     int64_t sizes[3] = {0, 0, 0};
     int32_t *Ki = K + (int64_t)i * per_img;
@@ -404,10 +412,10 @@ irec_status irec_rec_decode_files(const uint8_t *bytes, const int64_t *offsets, 
       }
     }
     if (st != IREC_OK) errs[(size_t)i] = g_io_error.empty() ? std::string("irec_rec_decode_files: failed") : g_io_error;
-  });
+  } catch (const std::exception &e) { errs[(size_t)i] = std::string("irec_rec_decode_files: ") + e.what(); } });
   for (int32_t i = 0; i < n_images; ++i)
     if (!errs[(size_t)i].empty()) { g_io_error = errs[(size_t)i] + " (image " + std::to_string(i) + ")"; return IREC_E_INVALID; }
   return IREC_OK;
-}
+} catch (const std::exception &e) { g_io_error = std::string("irec_rec_decode_files: ") + e.what(); return IREC_E_INVALID; }
 
 } // extern "C"

@@ -120,6 +120,7 @@ def _native_decode(data):
     # max_index is tiny); the library reports the exact sizes if they were short, and only then is the file decoded twice
     n_res = int(np.frombuffer(data[26:28], dtype="<u2")[0]) if len(data) >= 28 else 0
     n_blk = int(np.frombuffer(data[28:28 + 4 * n_res], dtype="<u4").sum()) if len(data) >= 28 + 4 * n_res else 0
+    n_blk = min(n_blk, 8 * len(data) + 8)            # (a damaged header: a coded block costs at least a bit of its count stream)
     sizes[:] = (n_res, n_blk, 4 * len(data) + 1024)
     for _attempt in range(2):
         bpr = np.empty(max(int(sizes[0]), 1), dtype=np.int32)

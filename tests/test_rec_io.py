@@ -201,3 +201,45 @@ def test_batched_container_calls_equal_the_per_image_writer(tmp_path):
     blob, off = U.encode_files(1, (8, 8, 3), 10, K, idx, 36)
     with pytest.raises(ValueError, match="structure"):
         U.decode_files(blob, off, 2, 3, 2)
+
+
+def test_damaged_containers_are_errors_not_crashes(tmp_path):
+    """The native reader on damaged files: every prefix of a valid container and 800 copies with one to three random bytes
+    replaced either decode to some structure or raise ValueError with the library's message -- never an uncaught C++
+    exception (a header claiming 2^32 symbols used to end the process with std::length_error), never an allocation sized by
+    a damaged header.  The batched reader names the damaged member of a blob."""
+    from irec.io import utils as U
+    rng = np.random.default_rng(11)
+    blocks = [[rng.integers(0, 36, int(k)).tolist() for k in rng.integers(0, 30, 9)] for _ in range(6)]
+    path = tmp_path / "a.rec"
+    U.write_compressed_code(str(path), 42, (32, 32, 3), 1000, blocks, 36)
+    data = path.read_bytes()
+    assert U._native_decode(data) == (42, (32, 32, 3), 1000, blocks)
+    ok = err = 0
+    for n in range(len(data)):
+        with pytest.raises(ValueError):
+            U._native_decode(data[:n])
+    for _ in range(800):
+        b = bytearray(data)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        try:
+            U._native_decode(bytes(b)); ok += 1
+        except ValueError:
+            err += 1
+    assert ok + err == 800 and err > 400
+    # a batch whose second member has a damaged static header (max_index = 2^32 - 1)
+    K = np.array([[len(ix) for ix in rb] for rb in blocks], dtype=np.int32)[None].repeat(3, axis=0)
+    mk = int(K.max())
+    idx = np.zeros((3, 6, 9, mk), dtype=np.int32)
+    for i in range(3):
+        for r, rb in enumerate(blocks):
+            for j, ix in enumerate(rb):
+                idx[i, r, j, :len(ix)] = ix
+    blob, off = U.encode_files(42, (32, 32, 3), 1000, K, idx, 36)
+    hdr, K2, idx2 = U.decode_files(blob, off, 6, 9, mk)
+    assert np.array_equal(K2, K) and np.array_equal(idx2, idx)
+    bad = blob.copy()
+    bad[int(off[1]) + 8:int(off[1]) + 12] = 255
+    with pytest.raises(ValueError, match="image 1"):
+        U.decode_files(bad, off, 6, 9, mk)
