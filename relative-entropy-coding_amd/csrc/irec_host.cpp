@@ -290,7 +290,9 @@ const char *irec_last_error(void) { return g_last_error.c_str(); }
 const char *irec_version(void) { return "irec-hip 0.1 (gfx950)"; }
 
 int32_t irec_n_samples(double kl_per_partition, double extra_samples) {
-  return (int32_t)std::exp(kl_per_partition * extra_samples);
+  const double s = std::exp(kl_per_partition * extra_samples);   // int(np.exp(.)), beam_search_coder.py:28-29
+  if (!(s >= 0.0)) return 0;                                       // NaN
+  return s >= 2147483647.0 ? INT32_MAX : (int32_t)s;               // (saturates; irec_params takes at most 2^24 samples anyway)
 }
 
 double irec_codelength(int64_t n_indices, int32_t n_samples) { return (double)n_indices * std::log((double)n_samples); }

@@ -26,7 +26,9 @@ struct Cdf {
     int64_t c = 0;
     for (int32_t i = 0; i < n; ++i) {
       if (counts[i] < 1) return false; // strictly increasing C is what the reference's interval tree assumes
+      if (counts[i] > ((int64_t)1 << 40)) return false;            // (the sum below must not overflow)
       C[i] = c; c += counts[i]; D[i] = c;
+      if (c > ((int64_t)1 << 40)) return false;
     }
     R = c;
     return true;
@@ -47,6 +49,9 @@ template <class Emit>
 irec_status ac_decode_impl(const Cdf &cdf, const uint8_t *bits, int64_t n_bits, int32_t precision, Emit &&emit) {
   const int32_t n_symbols = (int32_t)cdf.C.size();
   const int64_t whole = (int64_t)1 << precision, half = whole >> 1, quarter = whole >> 2;
+  // a model whose total exceeds a quarter of the code range can give a symbol an empty interval (the reference's coder then
+  // never terminates): an error here
+  if (cdf.R > quarter) return io_fail("irec_ac_decode: the model's total count exceeds 2^(precision - 2)");
   int64_t low = 0, high = whole, z = 0, i = 0, n = 0;
   auto bit = [&](int64_t p) { return p < n_bits && bits[p] == '1'; };
   while (i < precision && i < n_bits) { if (bit(i)) z += (int64_t)1 << (precision - i - 1); ++i; }
@@ -99,6 +104,7 @@ irec_status irec_ac_encode(const int64_t *counts, int32_t n_symbols, const int64
   if (precision < 8 || precision > 40 || !n_bits || (n_message > 0 && !message) || (cap > 0 && !out_bits))
     return io_fail("irec_ac_encode: bad arguments");
   const int64_t whole = (int64_t)1 << precision, half = whole >> 1, quarter = whole >> 2;
+  if (cdf.R > quarter) return io_fail("irec_ac_encode: the model's total count exceeds 2^(precision - 2)");
   int64_t low = 0, high = whole, s = 0;
   BitSink sink{out_bits, cap};
   for (int64_t k = 0; k < n_message; ++k) {
@@ -235,7 +241,8 @@ int64_t irec_rec_encode_file(uint32_t seed, uint32_t block_size, uint32_t max_in
     max_part[(size_t)r] = (uint32_t)mx;
     if (!encode_stream(K + kb, nb, mx + 1, 100, cs[(size_t)r])) { io_fail("irec_rec_encode_file: count stream"); return -1; }
     if (!encode_stream(indices + ib, tot, (int32_t)max_index, 1000, xs[(size_t)r])) {
-      io_fail("irec_rec_encode_file: an index does not fit max_index"); return -1; }   // (the reference overruns its table here)
+      io_fail("irec_rec_encode_file: an index does not fit max_index (or max_index exceeds what the 32-bit coder's range holds, ~1.07 million)");
+      return -1; }   // (the reference overruns its table here)
     kb += nb; ib += tot;
   }
   std::vector<uint8_t> f;

@@ -243,3 +243,42 @@ def test_damaged_containers_are_errors_not_crashes(tmp_path):
     bad[int(off[1]) + 8:int(off[1]) + 12] = 255
     with pytest.raises(ValueError, match="image 1"):
         U.decode_files(bad, off, 6, 9, mk)
+
+
+@pytest.mark.timeout(120)
+def test_arithmetic_coder_rejects_models_it_cannot_code():
+    """irec_ac_encode / irec_ac_decode with hostile arguments return an error with text: counts below 1, counts whose total
+    exceeds a quarter of the code range (a symbol could get an empty interval: the reference's coder then never terminates,
+    this one used to as well), precisions outside 8..40, symbols outside the model -- and random bit strings decode or fail,
+    in bounded time."""
+    import ctypes
+    from irec import _lib
+    lib = _lib.load()
+    msg = np.array([1, 2, 1, 0], dtype=np.int64)
+    bits = np.zeros(256, dtype=np.uint8)
+    nb = ctypes.c_int64(0)
+
+    def enc(counts, precision=32, m=msg):
+        c = np.array(counts, dtype=np.int64)
+        return lib.irec_ac_encode(ctypes.c_void_p(c.ctypes.data), len(counts), ctypes.c_void_p(m.ctypes.data), len(m), precision,
+                                  ctypes.c_void_p(bits.ctypes.data), bits.size, ctypes.byref(nb))
+    assert enc([1, 5, 5]) == 0 and nb.value > 0
+    for bad in ([0, 0, 0], [-1, 5, 5], [2 ** 62, 2 ** 62, 5], [1, 2 ** 29, 2 ** 29 + 1], [1]):
+        assert enc(bad) != 0 and b"irec_ac_encode" in lib.irec_io_last_error(), bad
+    assert enc([1, 2 ** 29, 2 ** 29 - 1]) == 0                   # total = 2^30 = a quarter of the 32-bit range: still fine
+    for precision in (0, -5, 1, 7, 41, 63, 64, 1000):
+        assert enc([1, 5, 5], precision) != 0, precision
+    counts = np.array([1, 5, 5], dtype=np.int64)
+    out, nm = np.zeros(64, dtype=np.int64), ctypes.c_int64(0)
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        rb = (rng.integers(0, 2, int(rng.integers(1, 200))) + ord("0")).astype(np.uint8)
+        lib.irec_ac_decode(ctypes.c_void_p(counts.ctypes.data), 3, ctypes.c_void_p(rb.ctypes.data), rb.size, 32,
+                           ctypes.c_void_p(out.ctypes.data), out.size, ctypes.byref(nm))
+    big = np.array([1, 2 ** 31, 5], dtype=np.int64)
+    assert lib.irec_ac_decode(ctypes.c_void_p(big.ctypes.data), 3, ctypes.c_void_p(bits.ctypes.data), 8, 32,
+                              ctypes.c_void_p(out.ctypes.data), out.size, ctypes.byref(nm)) != 0
+    # int(np.exp(Omega * (1 + eps))) saturates instead of wrapping (beam_search_coder.py:28-29)
+    assert lib.irec_n_samples(ctypes.c_double(3.0), ctypes.c_double(1.2)) == 36
+    assert lib.irec_n_samples(ctypes.c_double(50.0), ctypes.c_double(2.0)) == 2 ** 31 - 1
+    assert lib.irec_n_samples(ctypes.c_double(float("nan")), ctypes.c_double(1.0)) == 0
