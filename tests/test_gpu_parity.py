@@ -514,6 +514,45 @@ def test_one_beam_batch_one_wave_per_block(engine, oracle):
     assert all(i2h[r, :K2h[r]].tolist() == ih[r, :Kh[r]].tolist() for r in np.nonzero(ok)[0])
 
 
+def test_scalar_parameters_out_of_range_are_errors(engine, oracle):
+    """400 random combinations of kl_per_partition (0, negative, NaN, inf, denormal, huge), n_samples (0 .. 2^31 - 1), n_beams
+    (0 .. 1000), flag words (every diagnostic bit), table_steps and max_K (negative .. 2^31 - 1) on a two-block call: each one
+    either codes the blocks or comes back as an irec error with text -- no crash, no hang, no silent wrap."""
+    import irec
+    n = 1192
+    stats = oracle.synthetic_latent(4242, n)
+    ql, qs, pl, ps = (torch.from_numpy(a[None]).cuda().contiguous() for a in stats)
+    lay = engine.layout(1, n, 1000, 42)
+    rng = np.random.default_rng(3)
+    ran = failed = 0
+    for _ in range(400):
+        om = float(rng.choice([0.0, -1.0, float("nan"), float("inf"), 1e-30, 1e30, 3.0]))
+        S = int(rng.choice([0, -1, 1, 2, 36, 2 ** 24, 2 ** 24 + 1, 2 ** 31 - 1]))
+        B = int(rng.choice([0, -3, 1, 2, 64, 65, 1000]))
+        fl = int(rng.choice([0, 1, 2, 4, 8, 16, 128, 0xF00, 0x700, 1 << 12, 0xF << 12, 0x7FFFFFFF]))
+        mk = int(rng.choice([-1, 0, 1, 32, 65536, 65537, 2 ** 31 - 1]))
+        ts = int(rng.choice([0, -1, 1, 4096, 2 ** 31 - 1]))
+        try:
+            params = engine.params(om, S, B, fl, (), ts)
+            if S > 200 or mk > 4096:                               # (sizes only: no launch of that size in a test)
+                ws = engine.lib.irec_encode_workspace_bytes(engine.ctx, ctypes.byref(params), 1000, mk if 0 <= mk < 2 ** 31 else 0)
+                assert ws >= 0
+            else:
+                K, idx, sample = engine.encode_blocks(params, lay, ql, qs, pl, ps, 42, mk)
+                torch.cuda.synchronize()
+                assert K.shape[0] == lay.n_blocks
+            ran += 1
+        except (irec.CodingError, ValueError, AssertionError, OverflowError, ctypes.ArgumentError):
+            failed += 1
+    assert ran > 50 and failed > 50, (ran, failed)
+    # and the library still codes afterwards
+    params = engine.params(3.0, 36, 20)
+    K, idx, sample = engine.encode_blocks(params, lay, ql, qs, pl, ps, 42, 32)
+    ridx, rs = oracle.encode_tensor(*stats, 42, 3.0, 36, 20, block_size=1000)
+    Kh, ih = K.cpu().numpy(), idx.cpu().numpy()
+    assert [ih[lay.natural[j], :Kh[lay.natural[j]]].tolist() for j in range(2)] == ridx
+
+
 def test_many_beams_selection_refinement(engine):
     """top-B with B up to 64 (irec_fast_common.h: rank_survivors): the B-th largest of the 64 lane maxima leaves more than 64
     candidates above it, which are cut down to the exact B best by a bitwise search for the B-th largest key; against
