@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <exception>
 #include <cfloat>
 #include <cmath>
 #include <cstdarg>
@@ -352,7 +353,7 @@ irec_status irec_tf_stateless_normal(int64_t seed0, int64_t seed1, int64_t count
 
 irec_status irec_importance_encode(const float *t_loc, const float *t_scale, const float *p_loc, const float *p_scale,
                                    int64_t n, double coding_bits, double alpha, int64_t seed, int64_t *out_index,
-                                   float *out_sample) {
+                                   float *out_sample) try {
   if (!t_loc || !t_scale || !p_loc || !p_scale || !out_index || !out_sample || n < 1)
     return fail(IREC_E_INVALID, "irec_importance_encode: bad arguments");
   if (!(alpha >= 1.0)) return fail(IREC_E_INVALID, "Alpha must be in the range [1, inf), but %g was given!", alpha); // :33-34
@@ -391,7 +392,7 @@ irec_status irec_importance_encode(const float *t_loc, const float *t_scale, con
   *out_index = best_s;
   for (int64_t d = 0; d < n; ++d) out_sample[d] = p_scale[d] * st.element((uint64_t)(best_s * n + d)) + p_loc[d];
   return IREC_OK;
-}
+} catch (const std::exception &e) { return fail(IREC_E_INVALID, "irec_importance_encode: %s", e.what()); }
 
 irec_status irec_importance_decode(const float *p_loc, const float *p_scale, int64_t n, int64_t index, int64_t seed,
                                    float *out_sample) {
@@ -402,7 +403,7 @@ irec_status irec_importance_decode(const float *p_loc, const float *p_scale, int
   return IREC_OK;
 }
 
-irec_status irec_create(int device, irec_context **out) {
+irec_status irec_create(int device, irec_context **out) try {
   if (!out) return fail(IREC_E_INVALID, "irec_create: null output");
   *out = nullptr;
   int count = 0;
@@ -466,7 +467,7 @@ irec_status irec_create(int device, irec_context **out) {
   if (st != IREC_OK) { irec_destroy(ctx); return st; }
   *out = ctx;
   return IREC_OK;
-}
+} catch (const std::exception &e) { return fail(IREC_E_INVALID, "irec_create: %s", e.what()); }
 
 void irec_destroy(irec_context *ctx) {
   if (!ctx) return;
