@@ -5,23 +5,12 @@
 set -u
 export TMPDIR=/tmp
 TAG=${TAG:-r03g}
-STAGES=${STAGES:-ab}    # a: GPU suite, smoke, bench line, kernel trace;  b: PMC passes, sweep grid, decoder bench
+STAGES=${STAGES:-ab}    # a: GPU suite, smoke;  b: PMC passes -> traffic.json, bench line, kernel trace of the same command, sweep grid, decoder bench
 O=gpurun_out/$TAG
 mkdir -p $O
 if [[ $STAGES == *a* ]]; then
 echo "== pytest -m gpu"; timeout -k 10 1500 python -m pytest tests -q -m gpu > $O/pytest_gpu.full.log 2>&1; grep -v amdgpu.ids $O/pytest_gpu.full.log | tail -8 > $O/pytest_gpu.log; cat $O/pytest_gpu.log
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
-echo "== bench (default line)"; timeout -k 10 900 python bench.py --steps 20 --warmup 5 2> $O/bench_default.err > $O/bench_default.out; tail -1 $O/bench_default.out > $O/bench_default.log; grep -v amdgpu.ids $O/bench_default.err | tail -12
-echo "== kernel trace of the same command (no CPU baselines / secondary configs: the timed region is the same)"
-rm -rf $O/trace; timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/trace.log 2>&1
-f=$(find $O/trace -name "*kernel_stats.csv" | head -1)
-[ -n "$f" ] && python3 - "$f" $O/kernel_stats.csv <<'PY'
-import csv, sys
-rows = list(csv.reader(open(sys.argv[1])))
-out = [rows[0]] + [[r[0][:100]] + r[1:] for r in rows[1:]]
-csv.writer(open(sys.argv[2], "w")).writerows(out)
-for r in out[:8]: print(r)
-PY
 fi
 if [[ $STAGES == *b* ]]; then
 L=8192
@@ -36,6 +25,19 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ
 done
 find $O -name "*.csv" -size +2M -delete
 python3 scripts/make_traffic_json.py $O $L encode_team > $O/traffic.json 2>&1 || true
+# the bench line is taken AFTER the PMC passes so that it carries roofline.traffic of exactly these sources (on the box's scratch copy)
+grep -q source_sha16 $O/traffic.json && cp $O/traffic.json profiles/traffic.json
+echo "== bench (default line)"; timeout -k 10 900 python bench.py --steps 20 --warmup 5 2> $O/bench_default.err > $O/bench_default.out; tail -1 $O/bench_default.out > $O/bench_default.log; grep -v amdgpu.ids $O/bench_default.err | tail -12
+echo "== kernel trace of the same command (no CPU baselines / secondary configs: the timed region is the same)"
+rm -rf $O/trace; timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/trace.log 2>&1
+f=$(find $O/trace -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && python3 - "$f" $O/kernel_stats.csv <<'PY'
+import csv, sys
+rows = list(csv.reader(open(sys.argv[1])))
+out = [rows[0]] + [[r[0][:100]] + r[1:] for r in rows[1:]]
+csv.writer(open(sys.argv[2], "w")).writerows(out)
+for r in out[:8]: print(r)
+PY
 echo "== sweep grid"; timeout -k 10 900 python scripts/grid_bench.py > $O/grid.full.log 2>&1; grep -v amdgpu.ids $O/grid.full.log > $O/grid.log; tail -3 $O/grid.log
 echo "== decode bench"; timeout -k 10 300 python scripts/decode_bench.py 2>&1 | grep -v amdgpu.ids > $O/decode_bench.log; cat $O/decode_bench.log
 fi
