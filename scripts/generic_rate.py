@@ -1,0 +1,20 @@
+"""Diagnostic: rate of encode_generic_kernel (blocks of more than 1024 dims, 60 < B <= 64) next to the team encoder's on the
+same latents -- what a caller pays for block_size > 1024.  Usage: python scripts/generic_rate.py"""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "relative-entropy-coding_amd")]
+import bench, irec
+eng = irec.get_engine()
+L = 512
+q = bench.synthetic_batch(L, eng.device, 0)
+for bs, B in ((1000, 20), (2048, 20), (4096, 20), (1000, 64)):
+    lay = eng.layout(L, bench.N_DIMS, bs, bench.SEED)
+    params = eng.params(3.0, 36, B)
+    plan = eng.plan(params, lay, 64)
+    eng.encode_blocks(params, lay, *q, bench.SEED, 64)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(3):
+        K, idx, s = eng.encode_blocks(params, lay, *q, bench.SEED, 64)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+    print(f"block_size {bs:5d} B {B:2d}: {plan['kernel']:28s} {dt * 1e3:9.2f} ms for {L} latents -> {L / dt:9.0f} latents/s, max K {int(K.max())}", flush=True)
