@@ -568,7 +568,7 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
     // (the one-wave-per-block encoder lays its own slabs -- one workgroup per CU, a statistics slab per wave -- over the same area)
     if (pl.lone) pl.ws_per_wg = std::max(pl.ws_per_wg, round_up_sz(((size_t)n_cu * irec::lone_ws_bytes_per_wg() + pl.grid_cap - 1) / pl.grid_cap, 256));
   } else {
-    const size_t generic_ws = round_up_sz((size_t)10 * pl.dpad * 4 + (size_t)2 * B * pl.dpad * 4 +
+    const size_t generic_ws = round_up_sz((size_t)10 * pl.dpad * 4 + (size_t)3 * B * pl.dpad * 4 +   // (beams [2][B], G [B])
                                           (size_t)(max_K > 0 ? max_K : 1) * B * 4 + (size_t)S * B * 4, 256);
     if (pl.team_only) {   // slabs serve the team encoder and, for blocks beyond the table window, the generic kernel
       pl.one_grid_cap = 0;

@@ -90,9 +90,10 @@ __global__ __launch_bounds__(256) void block_kl_kernel(EncArgs A, float *out_kl)
 
 // ======================================================================================================
 //  generic encoder: any D, B <= 64.  Scratch slab per workgroup:
-//    float dmu,vq,vp,mp,c,sa,m,A,Bv,H [10][Dpad] | float beams[2][B][Dpad] | int32 bp[max_K][B] | uint32 key[S*B]
+//    float dmu,vq,vp,mp,c,sa,m,A,Bv,H [10][Dpad] | float beams[2][B][Dpad] | float G[B][Dpad] | int32 bp[max_K][B] | uint32 key[S*B]
 // ======================================================================================================
 constexpr int GEN_NT = 256;
+constexpr int GEN_CH = 16;    // beams scored together against one sample's draw (one reduce-scatter per dim group; 32: spills, slower)
 constexpr int GEN_NSC = 8192; // score/key entries kept in LDS; larger candidate sets go to the scratch slab
 
 __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
@@ -118,7 +119,8 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
   float *f_vq = f_dmu + Dpad, *f_vp = f_vq + Dpad, *f_mp = f_vp + Dpad, *f_c = f_mp + Dpad;
   float *f_sa = f_c + Dpad, *f_m = f_sa + Dpad, *f_A = f_m + Dpad, *f_Bv = f_A + Dpad, *f_H = f_Bv + Dpad;
   float *beams = f_H + Dpad;                                                  // [2][B][Dpad]
-  int32_t *bp = reinterpret_cast<int32_t *>(beams + (size_t)2 * B * Dpad);    // [max_K][B]
+  float *G_s = beams + (size_t)2 * B * Dpad;                                  // [B][Dpad] G of the live beams, rebuilt every step
+  int32_t *bp = reinterpret_cast<int32_t *>(G_s + (size_t)B * Dpad);          // [max_K][B]
   uint32_t *key_glb = reinterpret_cast<uint32_t *>(bp + (size_t)A.max_K * B); // [S*B]
 
   for (;;) {
@@ -209,34 +211,61 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
         if (lane == 0) Cb_s[b] = cb;
       }
       __syncthreads();
-      // phase 2: score every candidate (s, b); one wave per candidate, canonical tree over dims
+      // phase 1c: G of every live beam (it used to be rebuilt for every candidate, four scratch loads and three operations per
+      // proposal; r03i: once per step)
+      for (int b = wave; b < Bcur; b += GEN_NT / 64)
+        for (int d = lane; d < ((D + 3) & ~3); d += 64)   // (the tail of the last quad is read with it: keep it a number)
+          G_s[(size_t)b * Dpad + d] = d < D ? beam_G(t ? bcur[(size_t)b * Dpad + d] : 0.f, f_m[d], f_A[d], f_Bv[d], f_sa[d]) : 0.f;
+      __syncthreads();
+      // phase 2: scores, canonical tree over dims.  A wave takes SAMPLES (s = wave, wave + 4, ...) and scores up to GEN_CH beams at a
+      // time against the sample's draw: the Philox block of a dim quad is evaluated once per GEN_CH candidates (r03i; once per
+      // candidate until then: one wave per candidate), the group partials leave one reduce-scatter instead of a wave sum each.
       const int N = S * Bcur;
       uint32_t *key = (N <= GEN_NSC) ? key_lds : key_glb;
-      for (int f = wave; f < N; f += GEN_NT / 64) {
-        const int s = f / Bcur, b = f - s * Bcur;
-        const uint32_t h = hash_from_sum(hsum[cur * 64 + b]);
-        float sc = 0.f;
-        for (int g = 0; g < NG; ++g) {
-          const int d0 = g * 256 + lane * 4;
-          float acc = 0.f;
-          if (d0 < D) {
-            uint32_t rm1[4];
-            draw_rm1_x4(ss, (uint64_t)s * (uint64_t)D + (uint64_t)d0, rm1);
+      const int ownc = rsn_owner<GEN_CH>(lane);
+      for (int s = wave; s < S; s += GEN_NT / 64) {
+        for (int b0 = 0; b0 < Bcur; b0 += GEN_CH) {
+          uint32_t hb[GEN_CH];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int d = d0 + i;
-              if (d < D) {
-                const uint32_t k = ((rm1[i] + 1u) * h) % IREC_P; // floormod(r * hash, 10007), :45-47
-                const float z = lut_s[k];                        // ndtri(k / 10007): dist.quantile / scale, :48-49
-                const float bv = t ? bcur[(size_t)b * Dpad + d] : 0.f;
-                acc = proposal_term(acc, z, f_H[d], beam_G(bv, f_m[d], f_A[d], f_Bv[d], f_sa[d]));
+          for (int j = 0; j < GEN_CH; ++j) hb[j] = hash_from_sum(hsum[cur * 64 + (b0 + j < Bcur ? b0 + j : 0)]);
+          float sc = 0.f;
+          for (int g = 0; g < NG; ++g) {
+            const int d0 = g * 256 + lane * 4;
+            float acc[GEN_CH];
+#pragma unroll
+            for (int j = 0; j < GEN_CH; ++j) acc[j] = 0.f;
+            if (d0 < D) {
+              uint32_t rm1[4];
+              draw_rm1_x4(ss, (uint64_t)s * (uint64_t)D + (uint64_t)d0, rm1);
+              float Hd[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) Hd[i] = d0 + i < D ? f_H[d0 + i] : 0.f;
+              // the beams' G quads in one batch (one scratch round trip per chunk, not one per beam); Dpad is a
+              // multiple of 256 and d0 of 4: the quads are aligned and inside the slab row also where d0 + 3 >= D
+              float4 Gq[GEN_CH];
+#pragma unroll
+              for (int j = 0; j < GEN_CH; ++j)
+                Gq[j] = *reinterpret_cast<const float4 *>(G_s + (size_t)(b0 + j < Bcur ? b0 + j : b0) * Dpad + d0);
+#pragma unroll
+              for (int j = 0; j < GEN_CH; ++j) {
+                if (b0 + j < Bcur) { // wave-uniform
+                  const float Gj[4] = {Gq[j].x, Gq[j].y, Gq[j].z, Gq[j].w};
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) {
+                    if (d0 + i < D) {
+                      const uint32_t k = ((rm1[i] + 1u) * hb[j]) % IREC_P;   // floormod(r * hash, 10007), :45-47
+                      const float z = lut_s[k];                              // ndtri(k / 10007): dist.quantile / scale, :48-49
+                      acc[j] = proposal_term(acc[j], z, Hd[i], Gj[i]);
+                    }
+                  }
+                }
               }
             }
+            const float gs = reduce_scatter<GEN_CH>(acc, lane);   // lane: total of beam b0 + ownc over this dim group's lanes
+            sc = g == 0 ? gs : sc + gs;
           }
-          const float gs = wave_tree_sum(acc);
-          sc = g == 0 ? gs : sc + gs;
+          if ((lane & (64 / GEN_CH - 1)) == 0 && b0 + ownc < Bcur) key[s * Bcur + b0 + ownc] = __float_as_uint(sc + Cb_s[b0 + ownc]);
         }
-        if (lane == 0) key[f] = __float_as_uint(sc + Cb_s[b]);
       }
       __syncthreads();
       // phase 3: top-B (beam_search_coder.py:85-89 / :104)
@@ -250,16 +279,25 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
         bp[(size_t)t * B + tid] = (sp_ << 6) | bp_;
       }
       float *bnext = beams + (size_t)(cur ^ 1) * B * Dpad;
-      for (int d = tid; d < D; d += GEN_NT) {
-        const float sa = f_sa[d];
+      for (int d0 = tid * 4; d0 < D; d0 += GEN_NT * 4) {   // a thread forms FOUR consecutive dims of every new beam: one Philox block
+        float sa4[4];                                       // yields their four draws (r03i: one block per dim until then)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sa4[i] = d0 + i < D ? f_sa[d0 + i] : 0.f;
         for (int j = 0; j < Bnew; ++j) {
           const int32_t sp_ = sel_s[j], bp_ = sel_b[j];
           const uint32_t h = hash_from_sum(hsum[cur * 64 + bp_]);
-          const uint32_t rm1 = draw_rm1(ss, (uint64_t)sp_ * (uint64_t)D + (uint64_t)d);
-          const uint32_t k = ((rm1 + 1u) * h) % IREC_P;
-          const float y = sa * lut_s[k];
-          const float ob = t ? bcur[(size_t)bp_ * Dpad + d] : 0.f;
-          bnext[(size_t)j * Dpad + d] = ob + y; // combined_samples = beams + samples, :81
+          uint32_t rm1[4];
+          draw_rm1_x4(ss, (uint64_t)sp_ * (uint64_t)D + (uint64_t)d0, rm1);   // ((sp_ * D + d0) & 3 is uniform: d0 % 4 == 0)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int d = d0 + i;
+            if (d < D) {
+              const uint32_t k = ((rm1[i] + 1u) * h) % IREC_P;
+              const float y = sa4[i] * lut_s[k];
+              const float ob = t ? bcur[(size_t)bp_ * Dpad + d] : 0.f;
+              bnext[(size_t)j * Dpad + d] = ob + y; // combined_samples = beams + samples, :81
+            }
+          }
         }
       }
       __syncthreads();
