@@ -226,6 +226,8 @@ class BeamSearchCoder(GaussianCoder):
         indices and sample still on the device, NO host synchronisation.  The caller reads the indices when it needs
         them (`PendingCode.to_lists`, one device-to-host copy; `PendingCode.gather` for many calls at once)."""
         src = torch.as_tensor(q_loc)
+        if src.ndim < 2 or src.shape[0] < 1 or src[0].numel() < 1:
+            raise CodingError(f"nothing to encode: distributions of shape {tuple(src.shape)} (need [batch >= 1, dims >= 1 ...])")
         eng = self._engine_for(src)
         params = self._params(table_steps)   # (a model passes ONE window to all its coders: equal keys, tables built once)
         n_tensors = src.shape[0]
@@ -255,6 +257,8 @@ class BeamSearchCoder(GaussianCoder):
                 self.no_split = True
     def decode_tensors(self, p_loc, p_scale, indices, seed, block_size):
         src = torch.as_tensor(p_loc)
+        if src.ndim < 2 or src.shape[0] < 1 or src[0].numel() < 1:
+            raise CodingError(f"nothing to decode: coding distribution of shape {tuple(src.shape)} (need [batch >= 1, dims >= 1 ...])")
         eng = self._engine_for(src)
         params = self._params()
         n_tensors = src.shape[0]

@@ -102,6 +102,13 @@ def test_coder_api_mirrors_reference():
         c.encode(q, q, seed=1)
     with pytest.raises(CodingError, match="batch size must be 1"):
         c.encode_block(q, q, seed=1)
+    # empty inputs are coding errors with text, before anything touches a device
+    for shape in ((1, 0), (0, 8)):
+        e = torch.distributions.Normal(torch.zeros(shape), torch.ones(shape))
+        with pytest.raises(CodingError, match="nothing to encode"):
+            c.encode(e, e, seed=1, batched=True)
+        with pytest.raises(CodingError, match="nothing to decode"):
+            c.decode(e, [], seed=1, batched=True)
 
 
 def test_simple_hash_mirror(oracle):
