@@ -149,7 +149,7 @@ irec_status irec_ac_decode(const int64_t *counts, int32_t n_symbols, const uint8
 // right-aligned in big-endian bytes.  Returns the byte count (or -1 if cap is too small).
 int64_t irec_rec_pack_bits(const uint8_t *bits, int64_t n_bits, uint8_t *out_bytes, int64_t cap) {
   const int64_t total = n_bits + 1, nbytes = (total + 7) / 8;
-  if (!out_bytes || cap < nbytes || (n_bits > 0 && !bits)) return -1;
+  if (n_bits < 0 || !out_bytes || cap < nbytes || (n_bits > 0 && !bits)) return -1;
   std::memset(out_bytes, 0, (size_t)nbytes);
   const int64_t pad = nbytes * 8 - total; // leading zero bits
   for (int64_t p = 0; p < total; ++p) {
