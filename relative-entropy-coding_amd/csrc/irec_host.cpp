@@ -820,7 +820,19 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
       HIP_TRY(irec::launch_encode_lone(A, (int)std::min<int64_t>(n_blocks, ctx->n_cu > 0 ? ctx->n_cu : 256), st));
       if (irec_status s2 = deferred_pass()) return s2;
 #ifdef IREC_HOST_STAMPS
-      if (ctx->d_dbg) return IREC_OK;   // (no phase stamps in this kernel)
+      if (ctx->d_dbg) {   // diagnostic build (-DIREC_LONE_STAMPS): per-wave phase cycles of the one-beam encoder
+        const int lgrid = (int)std::min<int64_t>(n_blocks, ctx->n_cu > 0 ? ctx->n_cu : 256), nwv = irec::lone_waves();
+        std::vector<unsigned long long> h((size_t)lgrid * nwv * 16);
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(h.data(), ctx->d_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        static const char *nm[6] = {"prologue (fetch, KL)", "step constants", "scoring", "selection", "update", "epilogue"};
+        double sum[6] = {0}, tot = 0;
+        for (size_t w = 0; w < (size_t)lgrid * nwv; ++w) for (int k = 0; k < 6; ++k) { sum[k] += (double)h[w * 16 + k]; tot += (double)h[w * 16 + k]; }
+        fprintf(stderr, "[irec lone stamps] share of wave time:\n");
+        for (int k = 0; k < 6; ++k) fprintf(stderr, "  %-22s %5.1f%%\n", nm[k], 100 * sum[k] / tot);
+        fprintf(stderr, "  cycles per wave: %.0f\n", tot / (lgrid * nwv));
+        return IREC_OK;
+      }
 #endif
     } else if (pl.team) { // grid_cap counts teams (= scratch slabs): two per workgroup, one workgroup per CU
       const int n_teams = irec::team_count_for(p->n_beams, p->n_samples, pl.shape);

@@ -31,6 +31,11 @@ constexpr int LONE_NWV = 12;                                        // waves per
 constexpr size_t LONE_T3_BYTES = (((size_t)3 * IREC_PM1) * 4 + 15) & ~(size_t)15;
 constexpr size_t LONE_SLAB_BYTES = (size_t)3 * FAST_MAX_DIM * 4;    // per wave: mq - mp, sq^2, sp^2 of its block, [3][1024] f32
 
+#ifdef IREC_LONE_STAMPS   // diagnostic build: per-wave cycle sums per phase (0 prologue, 1 constants, 2 scoring, 3 selection, 4 update, 5 epilogue)
+#define LSTAMP(slot) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (A.dbg && (threadIdx.x & 63) == 0) A.dbg[((size_t)blockIdx.x * LONE_NWV + (threadIdx.x >> 6)) * 16 + (slot)] += now_ - *lst_prev; *lst_prev = now_; } while (0)
+#else
+#define LSTAMP(slot) do { } while (0)
+#endif
 typedef float lone_f2 __attribute__((ext_vector_type(2)));
 typedef unsigned int lone_u2 __attribute__((ext_vector_type(2)));
 
@@ -44,7 +49,8 @@ __device__ __forceinline__ float row_ahead(float v) {
 // pairs of groups share a v_pk_fma_f32, so a block of one or three groups carries a zero-coefficient partner).
 template <int NGX>
 __device__ __forceinline__ void lone_code_block(const EncArgs &A, const int64_t blk, const int D, const int64_t base, const int32_t pos,
-                                                const int K, const uint16_t *tab, float *stats_g, const int lane) {
+                                                const int K, const uint16_t *tab, float *stats_g, const int lane, unsigned long long *lst_prev) {
+  (void)lst_prev;
   constexpr int NP = NGX / 2;
   const int S = A.S;
   const int Dp = (D + 3) & ~3;            // row stride of the proposal table
@@ -72,6 +78,7 @@ __device__ __forceinline__ void lone_code_block(const EncArgs &A, const int64_t 
                           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tab_u)),
       (short)0, (int)0x7FFFFFFF, 0x00020000);
 
+  LSTAMP(0);
   for (int t = 0; t < K; ++t) {
     // ---- step constants of my dims (beam_search_coder.py:67-77), G / H / C_b of the one beam ----
     const float rho = A.rho[K - 1 - t];
@@ -120,6 +127,7 @@ __device__ __forceinline__ void lone_code_block(const EncArgs &A, const int64_t 
         if (g < NG) cb = cb + __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(mine), g * LSTEP));
     }
 
+    LSTAMP(1);
     // ---- scoring (beam_search_coder.py:80-84): S candidates, four per reduce-scatter ----
     // rows through a buffer descriptor: the wave-uniform row offset travels in soffset, my quad's offset in voffset -- no vector
     // address arithmetic per row (the flat form costs two VALU operations per load here)
@@ -208,11 +216,13 @@ __device__ __forceinline__ void lone_code_block(const EncArgs &A, const int64_t 
       const uint32_t s_mine = (uint32_t)(s0 + my_cc);
       if (score_lane && s_mine < (uint32_t)S && key > best_k) { best_k = key; best_s = s_mine; }   // (earlier sample wins a tie)
     }
+    LSTAMP(2);
     // ---- top-1 (beam_search_coder.py:85-89): value descending, ties to the lower index ----
     const unsigned long long win = wave_max_u64(cand_pack(best_k, best_s));
     const uint32_t s_star = 0xFFFFFFFFu - (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)win);
     if (lane == 0) A.out_indices[blk * (int64_t)A.max_K + t] = (int32_t)s_star;
 
+    LSTAMP(3);
     // ---- the surviving beam (:92-93): beam += sa * z of the chosen sample ----
     {
       uint2 r[NGX];
@@ -228,18 +238,27 @@ __device__ __forceinline__ void lone_code_block(const EncArgs &A, const int64_t 
     }
     hsum += s_star * (uint32_t)(69 + t);                          // simple_hash's running int32 sum (:33-35, :94-95)
     bet = (uint32_t)A.dlog4r[hash_from_sum((int32_t)hsum) - 1u];
+    LSTAMP(4);
   }
-  // ---- beams[0] + coding_dist.loc (:118-122), merge == scatter through perm ----
+  // ---- beams[0] + coding_dist.loc (:118-122), merge == scatter through perm: positions, then mu_p, in one batch each ----
+  int64_t ixo[NGX][4];
 #pragma unroll
   for (int g = 0; g < NGX; ++g)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int d = g * 256 + lane * 4 + i;
-      if (d < D) {
-        const int64_t ixo = src_index(A, base, pos, d);
-        A.out_sample[ixo] = beam[g][i] + A.p_loc[ixo];
-      }
+      ixo[g][i] = src_index(A, base, pos, d < D ? d : 0);
     }
+  float plv[NGX][4];
+#pragma unroll
+  for (int g = 0; g < NGX; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) plv[g][i] = A.p_loc[ixo[g][i]];
+#pragma unroll
+  for (int g = 0; g < NGX; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (g * 256 + lane * 4 + i < D) A.out_sample[ixo[g][i]] = beam[g][i] + plv[g][i];
 }
 
 __global__ __launch_bounds__(LONE_NWV * 64, 1) void encode_lone_kernel(EncArgs A) {
@@ -257,6 +276,8 @@ __global__ __launch_bounds__(LONE_NWV * 64, 1) void encode_lone_kernel(EncArgs A
   __syncthreads();   // the only barrier: from here on the waves never wait for each other
 
   float *stats_g = reinterpret_cast<float *>(A.ws + ((size_t)blockIdx.x * LONE_NWV + wave) * LONE_SLAB_BYTES);
+  unsigned long long lst_t = __builtin_amdgcn_s_memtime();
+  (void)lst_t;
   bool first_block = true;
   for (;;) {
     int64_t blk;
@@ -281,27 +302,49 @@ __global__ __launch_bounds__(LONE_NWV * 64, 1) void encode_lone_kernel(EncArgs A
     }
     const int NG = (D + 255) >> 8;          // 1..4 dim groups
 
-    // ---- the block's statistics (split == gather through perm) and its KL, one dim group at a time ----
+    // ---- the block's statistics (split == gather through perm) and its KL ----
+    // All dim groups' loads in two batches -- the 16 positions through perm, then the 64 statistics -- instead of a dependent
+    // pair per group: a wave owns the whole block here, and eight dependent random-access round trips in front of every block
+    // were 29 % of a wave's time at S = 7 (profiles/r03j/stamps_lone.log).
     double tot = 0.0;
-    for (int g = 0; g < NG; ++g) {
-      const int d0 = g * 256 + lane * 4;
-      double klacc = 0.0;
-      float st[3][4];
+    {
+      int64_t ixs[4][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        st[0][i] = 0.f; st[1][i] = 1.f; st[2][i] = 1.f;
-        if (d0 + i < D) {
-          const int64_t ixi = src_index(A, base, pos, d0 + i);
-          const float mq_ = A.q_loc[ixi], sq_ = A.q_scale[ixi], mp_ = A.p_loc[ixi], sp_ = A.p_scale[ixi];
-          klacc = klacc + kl_dim(mq_, sq_, mp_, sp_);
-          st[0][i] = mq_ - mp_; st[1][i] = sq_ * sq_; st[2][i] = sp_ * sp_;
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int d = g * 256 + lane * 4 + i;
+          ixs[g][i] = src_index(A, base, pos, d < D ? d : 0);
+        }
+      float mqv[4][4], sqv[4][4], mpv[4][4], spv[4][4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          mqv[g][i] = A.q_loc[ixs[g][i]]; sqv[g][i] = A.q_scale[ixs[g][i]];
+          mpv[g][i] = A.p_loc[ixs[g][i]]; spv[g][i] = A.p_scale[ixs[g][i]];
+        }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (g < NG) { // wave-uniform
+          const int d0 = g * 256 + lane * 4;
+          double klacc = 0.0;
+          float st[3][4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            st[0][i] = 0.f; st[1][i] = 1.f; st[2][i] = 1.f;
+            if (d0 + i < D) {
+              klacc = klacc + kl_dim(mqv[g][i], sqv[g][i], mpv[g][i], spv[g][i]);
+              st[0][i] = mqv[g][i] - mpv[g][i]; st[1][i] = sqv[g][i] * sqv[g][i]; st[2][i] = spv[g][i] * spv[g][i];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            *reinterpret_cast<float4 *>(stats_g + k * FAST_MAX_DIM + d0) = make_float4(st[k][0], st[k][1], st[k][2], st[k][3]);
+          const double gs = wave_tree_sum(klacc);
+          tot = g == 0 ? gs : tot + gs;         // dim-group sums in increasing order
         }
       }
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-        *reinterpret_cast<float4 *>(stats_g + k * FAST_MAX_DIM + d0) = make_float4(st[k][0], st[k][1], st[k][2], st[k][3]);
-      const double gs = wave_tree_sum(klacc);
-      tot = g == 0 ? gs : tot + gs;         // dim-group sums in increasing order
     }
     const int32_t K = __builtin_amdgcn_readfirstlane(num_aux((float)tot, A.omega));
     if (lane == 0) A.out_K[blk] = K;
@@ -319,8 +362,9 @@ __global__ __launch_bounds__(LONE_NWV * 64, 1) void encode_lone_kernel(EncArgs A
         }
       continue;
     }
-    if (NG > 2) lone_code_block<4>(A, blk, D, base, pos, K, tab, stats_g, lane);
-    else lone_code_block<2>(A, blk, D, base, pos, K, tab, stats_g, lane);
+    if (NG > 2) lone_code_block<4>(A, blk, D, base, pos, K, tab, stats_g, lane, &lst_t);
+    else lone_code_block<2>(A, blk, D, base, pos, K, tab, stats_g, lane, &lst_t);
+    { unsigned long long *lst_prev = &lst_t; (void)lst_prev; LSTAMP(5); }
   }
 }
 
