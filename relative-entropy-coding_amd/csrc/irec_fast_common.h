@@ -122,6 +122,53 @@ __device__ __forceinline__ bool rank_survivors(SM *sm, uint32_t C, int Bnew, int
   return true;
 }
 
+// ---- XCD-aware block hand-out of the persistent batch encoders (encode_team_kernel, encode_lone_kernel) ----
+// Workgroups go to the eight XCDs round-robin (workgroup w runs on XCD w mod 8) and each XCD has its own L2.  The rows of one
+// latent tensor lie next to each other (eight 1000-dim blocks of an 8192-dim tensor) and gather their statistics out of the
+// same 4 x 32 KB through the shuffle, a line of 32 floats feeding all eight blocks.  Handing consecutive rows to consecutive
+// workgroups makes every XCD fetch every line of every tensor (a one-beam call of 256 latents: 0.26 ms; XCD-aware: 0.19 ms,
+// profiles/r03l/ab_lone_xcd.log).  So rows are dealt in groups of 64 = 8 x 8: the rows 8 x .. 8 x + 7 of a group go to XCD x.
+//   * static first round (slot u = k * gridDim.x + w for the k-th block stream of workgroup w, one block per CU before any
+//     CU gets a second): each aligned group of 64 slots is transposed as an 8 x 8 when gridDim.x is a multiple of 8 (then
+//     u mod 8 == w mod 8); a bijection on every full group below n_static, the tail and other grids keep u -> u;
+//   * later blocks: one counter per XCD, value c of XCD x -> row first + 64 (c / 8) + 8 x + c mod 8; an XCD whose share has
+//     run out takes from the next one's (rows of a counter only grow, so "past the end" is final; this is also what codes
+//     the shares of XCDs that have no workgroup of the launch).  The counters lie 256 bytes apart.
+#ifndef IREC_XCD_HANDOUT
+#define IREC_XCD_HANDOUT 1
+#endif
+__device__ __forceinline__ int64_t xcd_static_row(int64_t u, int64_t n_static, int grid) {
+#if IREC_XCD_HANDOUT
+  const int64_t m = u & ~(int64_t)63;
+  if ((grid & 7) != 0 || m + 64 > n_static) return u;
+  const int v = (int)(u & 63);
+  return m + ((v & 7) << 3) + (v >> 3);
+#else
+  (void)n_static; (void)grid;
+  return u;
+#endif
+}
+// One lane calls this.  `steal` (0 at kernel start, kept by the caller) counts the XCD shares this caller found exhausted.
+// Returns n when nothing is left.
+__device__ __forceinline__ int64_t xcd_pull_row(const EncArgs &A, int64_t first, int64_t n, int &steal) {
+#if IREC_XCD_HANDOUT
+  if (first >= n) return n;                       // the static round dealt every row: no counter is touched
+  const uint32_t span = (uint32_t)(n - first);    // (n < 2^31: irec_beam_encode)
+  for (; steal < 8; ++steal) {
+    const uint32_t x = ((uint32_t)blockIdx.x + (uint32_t)steal) & 7u;
+    const uint32_t rem = span & 63u;
+    const uint32_t share = (span >> 6) * 8u + (rem > 8u * x ? (rem - 8u * x < 8u ? rem - 8u * x : 8u) : 0u);   // rows of XCD x
+    const uint32_t c = atomicAdd(A.xcd_counter + WS_XCD_STRIDE * x, 1u);
+    if (c < share) return first + (int64_t)(c >> 3) * 64 + (int64_t)(8u * x + (c & 7u));
+  }
+  return n;
+#else
+  (void)steal;
+  const int64_t row = first + (int64_t)atomicAdd(A.counter, 1u);
+  return row < n ? row : n;
+#endif
+}
+
 #ifndef IREC_SELECT_PAR_MIN
 #define IREC_SELECT_PAR_MIN 4096   // candidates per step from which every wave takes part in the streamed selection (0x7FFFFFFF: never)
 #endif

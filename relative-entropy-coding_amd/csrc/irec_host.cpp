@@ -584,6 +584,14 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
   return pl;
 }
 
+// Workgroups of a persistent batch encoder (team / one-beam): one per CU, not more than blocks -- rounded up to a multiple of
+// 8 where that fits, so that hand-out slot u runs on XCD u mod 8 (irec_fast_common.h: xcd_static_row); the extra workgroups
+// find no row and leave.
+static int batch_grid(int64_t n_blocks, int cap) {
+  const int64_t g = std::min<int64_t>(n_blocks, cap), r = (g + 7) & ~(int64_t)7;
+  return (int)(r <= cap ? r : g);
+}
+
 // Split encoder for calls of so few blocks that most CUs would idle (one image's residual block: 9 blocks): W workgroups
 // per block, each scoring a stripe of the samples (irec_kernels.hip).  All n_blocks * W workgroups must be resident at once
 // (they wait for each other every step), so the grid stays within HALF the CUs -- room for a second such call on another
@@ -670,7 +678,7 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
     const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
     std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::lone_kernel_name());
     std::snprintf(out->table_kernel, sizeof out->table_kernel, "alpha_choice_kernel");
-    out->grid = (int32_t)std::min<int64_t>(n_blocks, n_cu);
+    out->grid = batch_grid(n_blocks, n_cu);
     out->waves_per_wg = irec::lone_waves();
     out->teams_per_wg = irec::lone_waves();       // every wave codes its own block
     out->lds_bytes = (int32_t)irec::lone_lds_bytes();
@@ -680,7 +688,7 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
     const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
     std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::team_kernel_name(B, S, shape));
     std::snprintf(out->table_kernel, sizeof out->table_kernel, "alpha_choice_kernel");
-    out->grid = (int32_t)std::min<int64_t>(n_blocks, std::min(pl.grid_cap / n_teams, n_cu));
+    out->grid = batch_grid(n_blocks, std::min(pl.grid_cap / n_teams, n_cu));
     out->waves_per_wg = irec::team_waves_for(B, S, shape);
     out->teams_per_wg = n_teams;
     out->lds_bytes = (int32_t)irec::team_lds_for(B, S, shape);
@@ -738,6 +746,7 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   if (!ctx) return fail(IREC_E_INVALID, "irec_beam_encode: null context");
   if (irec_status s = check_params(p)) return s;
   if (n_blocks < 0) return fail(IREC_E_INVALID, "irec_beam_encode: n_blocks < 0");
+  if (n_blocks > 0x7FFF0000ll) return fail(IREC_E_INVALID, "irec_beam_encode: more than 2^31 - 65536 blocks in one call");   // (block rows are int32 in the kernels)
   if (n_blocks == 0) return IREC_OK;
   if (!block_base || !block_pos || !block_dim || !q_loc || !q_scale || !p_loc || !p_scale || !out_K || !out_sample)
     return fail(IREC_E_INVALID, "irec_beam_encode: null pointer argument");
@@ -759,10 +768,11 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   A.omega = p->kl_per_partition; A.S = p->n_samples; A.B = p->n_beams; A.max_K = max_K;
   A.out_K = out_K; A.out_indices = out_indices; A.out_sample = out_sample;
   A.lut = ctx->d_lut; A.lut2 = ctx->d_lut2; A.dlog4r = ctx->d_dlog4r; A.rho = ctx->d_rho;
-  // workspace head: counter block (512 bytes, zeroed per call: [0] block counter of the first pass, [1] deferred-block
-  // count, [2] block counter of the deferred pass, [3] split-encoder error flag, [64..127] its per-block arrival counters),
-  // then the candidate exchange of the split encoder
+  // workspace head: counter block (WS_COUNTER_BYTES, zeroed per call: [0] block counter of the first pass, [1] deferred-block
+  // count, [2] block counter of the deferred pass, [3] split-encoder error flag, [64..127] its per-block arrival counters,
+  // [128 + 64 x] the block counter of XCD x), then the candidate exchange of the split encoder
   A.counter = (unsigned int *)workspace;
+  A.xcd_counter = (unsigned int *)workspace + irec::WS_XCD_WORD;
   A.defer_count = (unsigned int *)workspace + 1;
   if (pl.team) pl.shape = shape_for_call(ctx, pl, p, n_blocks);
   A.K_tab = pl.K_tab; A.deferred_pass = 0; A.shape_override = pl.shape;
@@ -817,11 +827,11 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
       return IREC_OK;
     };
     if (pl.team && pl.lone) { // one workgroup per CU, a block per wave
-      HIP_TRY(irec::launch_encode_lone(A, (int)std::min<int64_t>(n_blocks, ctx->n_cu > 0 ? ctx->n_cu : 256), st));
+      HIP_TRY(irec::launch_encode_lone(A, batch_grid(n_blocks, ctx->n_cu > 0 ? ctx->n_cu : 256), st));
       if (irec_status s2 = deferred_pass()) return s2;
 #ifdef IREC_HOST_STAMPS
       if (ctx->d_dbg) {   // diagnostic build (-DIREC_LONE_STAMPS): per-wave phase cycles of the one-beam encoder
-        const int lgrid = (int)std::min<int64_t>(n_blocks, ctx->n_cu > 0 ? ctx->n_cu : 256), nwv = irec::lone_waves();
+        const int lgrid = batch_grid(n_blocks, ctx->n_cu > 0 ? ctx->n_cu : 256), nwv = irec::lone_waves();
         std::vector<unsigned long long> h((size_t)lgrid * nwv * 16);
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(h.data(), ctx->d_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -837,7 +847,7 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
     } else if (pl.team) { // grid_cap counts teams (= scratch slabs): two per workgroup, one workgroup per CU
       const int n_teams = irec::team_count_for(p->n_beams, p->n_samples, pl.shape);
       // one workgroup per CU as soon as there is a block for it: team k of workgroup w starts on block k * grid + w
-      const int tgrid = (int)std::min<int64_t>(n_blocks, std::min(pl.grid_cap / n_teams, ctx->n_cu > 0 ? ctx->n_cu : 256));
+      const int tgrid = batch_grid(n_blocks, std::min(pl.grid_cap / n_teams, ctx->n_cu > 0 ? ctx->n_cu : 256));
       HIP_TRY(irec::launch_encode_team(A, tgrid, st));
 #ifndef IREC_HOST_STAMPS
       if (irec_status s2 = deferred_pass()) return s2;

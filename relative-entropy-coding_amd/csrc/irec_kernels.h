@@ -27,6 +27,7 @@ struct EncArgs {
   const float *rho;        // [IREC_MAX_PARTITIONS_DEV] rho[i] = float32((i+1)^-0.7864636765648174)
   // scratch
   unsigned int *counter; char *ws; size_t ws_per_wg; int32_t max_dim_pad;
+  unsigned int *xcd_counter;   // [8] block counters of the XCD-aware hand-out (irec_fast_common.h: xcd_static_row / xcd_pull_row)
   // shared proposal tables (beam-striped encoder): tab[q] serves blocks with block_dim == tab_dim[q]
   const uint16_t *tab[4]; int32_t tab_dim[4];
   // The tables hold the first K_tab steps only (bounded workspace: O(K_tab * S * D), not O(max_K * S * D)).  A table-fed
@@ -96,14 +97,16 @@ size_t lone_ws_bytes_per_wg();                           // scratch of one workg
 const char *lone_kernel_name();
 hipError_t launch_encode_lone(const EncArgs &A, int grid, hipStream_t st);
 // Head of the workspace, 128 uint32: [0..3] block / deferred counters and the split encoder's error flag, [8..11] "keep"
+// and behind them the eight per-XCD block counters of the batch encoders' first pass, [128 + 64 x]: 256 bytes apart, so that the
+// adds of different XCDs do not queue on one line.
 // words of the call's proposal tables, [16..47] the stamps of the four table slots (8 words each: what the table in place
 // was built for), [64..127] arrival counters of the split encoder.  The head kernel of every call zeroes the counters,
 // compares each slot's stamp with the call's key (IREC_FLAG_REUSE_TABLES; keep = 1 on a match, else 0) and stamps the key:
 // the table kernels that follow on the stream read `keep`, nobody writes it again before the next call's head kernel.
-constexpr int WS_KEEP_WORD = 8, WS_STAMP_WORD = 16, WS_STAMP_WORDS = 8;
+constexpr int WS_KEEP_WORD = 8, WS_STAMP_WORD = 16, WS_STAMP_WORDS = 8, WS_XCD_WORD = 128, WS_XCD_STRIDE = 64;
 struct TableStamps { uint32_t w[4][WS_STAMP_WORDS]; int32_t reuse; };   // all-zero key = slot unused (never matches)
 hipError_t launch_zero_counters(void *p, const TableStamps &stamps, hipStream_t st);
-constexpr size_t WS_COUNTER_BYTES = 512;                  // [0,256): counters, keep words, table stamps; [256,512): 64 arrival counters
+constexpr size_t WS_COUNTER_BYTES = 512 + 8 * 256;        // [0,256): counters, keep words, table stamps; [256,512): 64 arrival counters; [512,2560): XCD counters
 constexpr int COOP_MAX_BLOCKS = 64, COOP_KEYS = 1024;      // split encoder: blocks per call, sort keys per step (S * NB, aliased-key builds)
 constexpr size_t WS_XCH_BYTES = (size_t)2 * COOP_MAX_BLOCKS * COOP_KEYS * 4;   // key exchange of the split encoder, double buffered
 constexpr size_t WS_HEAD_BYTES = WS_COUNTER_BYTES + WS_XCH_BYTES;

@@ -278,14 +278,20 @@ __global__ __launch_bounds__(LONE_NWV * 64, 1) void encode_lone_kernel(EncArgs A
   float *stats_g = reinterpret_cast<float *>(A.ws + ((size_t)blockIdx.x * LONE_NWV + wave) * LONE_SLAB_BYTES);
   unsigned long long lst_t = __builtin_amdgcn_s_memtime();
   (void)lst_t;
+  // Block hand-out (irec_fast_common.h): the first block of wave k of workgroup w is slot k * gridDim.x + w -- one block per
+  // CU before any CU gets a second -- with the rows of a tensor dealt to one XCD; later blocks from the XCD's counter.
+  const int64_t n_static = (int64_t)LONE_NWV * (int64_t)gridDim.x < A.n_blocks ? (int64_t)LONE_NWV * (int64_t)gridDim.x : A.n_blocks;
   bool first_block = true;
+  int steal = 0;
   for (;;) {
     int64_t blk;
-    if (first_block) blk = (int64_t)wave * (int64_t)gridDim.x + (int64_t)blockIdx.x;   // one block per CU before any CU gets a second
-    else {
-      unsigned int v = 0u;
-      if (lane == 0) v = atomicAdd(A.counter, 1u);
-      blk = (int64_t)LONE_NWV * (int64_t)gridDim.x + (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+    if (first_block) {
+      blk = (int64_t)wave * (int64_t)gridDim.x + (int64_t)blockIdx.x;
+      if (blk < n_static) blk = xcd_static_row(blk, n_static, (int)gridDim.x);
+    } else {
+      int64_t v = 0;
+      if (lane == 0) v = xcd_pull_row(A, n_static, A.n_blocks, steal);
+      blk = ((int64_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)v);
     }
     first_block = false;
     if (blk >= A.n_blocks) break;

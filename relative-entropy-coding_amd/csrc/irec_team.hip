@@ -234,11 +234,20 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   // Block hand-out: the first block of team k of workgroup w is k * gridDim.x + w -- a call of fewer blocks than resident
   // teams (a mid-size batch: 38 images x 9 blocks) puts ONE block on every CU before any CU gets a second one, instead of
   // three on the first third of the CUs; later blocks come from the atomic counter, which starts behind the static ones.
+  // Both rounds deal the rows of a tensor to one XCD (irec_fast_common.h: xcd_static_row / xcd_pull_row).
+  const int64_t n_static = (int64_t)TEAMS * (int64_t)gridDim.x < A.n_blocks ? (int64_t)TEAMS * (int64_t)gridDim.x : A.n_blocks;
   bool first_block = true;
+  int steal = 0;
   for (;;) {
     tsync();
-    if (tid == 0) misc[0] = first_block ? (int32_t)(team * (int)gridDim.x + (int)blockIdx.x)
-                                        : (int32_t)(TEAMS * (int)gridDim.x) + (int32_t)atomicAdd(A.counter, 1u);
+    if (tid == 0) {
+      int64_t r;
+      if (first_block) {
+        r = (int64_t)team * (int64_t)gridDim.x + (int64_t)blockIdx.x;
+        r = r < n_static ? xcd_static_row(r, n_static, (int)gridDim.x) : A.n_blocks;
+      } else r = xcd_pull_row(A, n_static, A.n_blocks, steal);
+      misc[0] = (int32_t)r;
+    }
     first_block = false;
     tsync();
     const int64_t blk = misc[0];

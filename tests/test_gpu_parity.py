@@ -944,7 +944,7 @@ def test_mid_size_calls_take_the_eight_wave_team(engine, oracle, B, n_latents):
     lay = engine.layout(n_latents, 8192, 1000, 42)
     plan = engine.plan(c._params(), lay, 32)
     assert 64 <= lay.n_blocks <= plan["n_cu"] and plan["kernel"] == "encode_team_kernel<20,1,2>" and plan["teams_per_wg"] == 1, plan
-    assert plan["grid"] == lay.n_blocks and plan["waves_per_wg"] == 8
+    assert plan["grid"] == -(-lay.n_blocks // 8) * 8 and plan["waves_per_wg"] == 8   # (a multiple of 8: slot u on XCD u mod 8)
     big = engine.plan(c._params(), engine.layout(64, 8192, 1000, 42), 32)
     assert big["kernel"] != plan["kernel"] and big["teams_per_wg"] >= 2, big
     idx, sample = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)
