@@ -361,6 +361,26 @@ def test_one_beam_ragged_dims_and_tiny_sample_counts(engine, oracle, D):
         assert torch.equal(c.decode(_normal(mp[None], sp[None]), idx, seed=7).cpu(), sample.cpu())
 
 
+@pytest.mark.parametrize("B,n_tensors", [(1, 383), (1, 384), (1, 385), (1, 421), (20, 95), (20, 97), (20, 131), (10, 104)])
+def test_block_hand_out_codes_every_block_once(engine, oracle, B, n_tensors):
+    """The XCD-aware hand-out of the batch encoders (irec_fast_common.h: xcd_static_row / xcd_pull_row): calls of many tiny
+    blocks (tensors of 64 dims in 8 blocks of 8) whose block counts sit on either side of what the static first round deals
+    (12 x n_CU one-beam blocks, 3 x n_CU team blocks), are not multiples of 64 and leave the per-XCD counters ragged shares --
+    every tensor against the oracle, so a block coded twice, skipped or coded from another block's row would show."""
+    n, bs = 64, 8
+    q = [np.stack([oracle.synthetic_latent(4000 + i, n)[j] for i in range(n_tensors)]) for j in range(4)]
+    c = _coder(2.0, B, 1.0, block_size=bs)
+    S = oracle.n_samples(2.0, 1.0)
+    lay = engine.layout(n_tensors, n, bs, 42)
+    plan = engine.plan(c._params(), lay, 32)
+    assert plan["kernel"].startswith("encode_lone_kernel" if B == 1 else "encode_team_kernel"), plan
+    assert lay.n_blocks == 8 * n_tensors and plan["grid"] % 8 == 0
+    idx, sample = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)
+    for i in range(n_tensors):
+        ridx, rs = oracle.encode_tensor(q[0][i], q[1][i], q[2][i], q[3][i], 42, 2.0, S, B, block_size=bs)
+        assert idx[i] == ridx and np.array_equal(sample[i].cpu().numpy(), rs), i
+
+
 def test_zero_kl_block(engine):
     mp = torch.tensor([[0.3, -1.0, 2.0]]); sp = torch.tensor([[1.0, 2.0, 0.5]])
     c = _coder(3.0, 10, 1.0)
