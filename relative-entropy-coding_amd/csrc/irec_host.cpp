@@ -796,7 +796,9 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
       w[7] = ~(w[1] ^ w[2] ^ w[3] ^ w[4] ^ w[5] ^ w[6]);
     }
   stamps.reuse = (p->flags & IREC_FLAG_REUSE_TABLES) ? 1 : 0;
-  HIP_TRY(irec::launch_zero_counters(workspace, stamps, st));
+  int split_blocks = 0;   // a split call: the head kernel also zeroes the exchange granules of its blocks
+  if (pl.table && !pl.team && split_width(ctx, pl, p, n_blocks) >= 2) split_blocks = (int)n_blocks;   // (pl.team: of THIS call, above)
+  HIP_TRY(irec::launch_zero_counters(workspace, stamps, split_blocks, st));
   int grid = (int)std::min<int64_t>(n_blocks, pl.one_grid_cap);
   A.dbg = nullptr;
 #ifdef IREC_HOST_STAMPS

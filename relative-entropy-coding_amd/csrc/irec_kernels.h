@@ -105,10 +105,14 @@ hipError_t launch_encode_lone(const EncArgs &A, int grid, hipStream_t st);
 // the table kernels that follow on the stream read `keep`, nobody writes it again before the next call's head kernel.
 constexpr int WS_KEEP_WORD = 8, WS_STAMP_WORD = 16, WS_STAMP_WORDS = 8, WS_XCD_WORD = 128, WS_XCD_STRIDE = 64;
 struct TableStamps { uint32_t w[4][WS_STAMP_WORDS]; int32_t reuse; };   // all-zero key = slot unused (never matches)
-hipError_t launch_zero_counters(void *p, const TableStamps &stamps, hipStream_t st);
+hipError_t launch_zero_counters(void *p, const TableStamps &stamps, int split_blocks, hipStream_t st);   // split_blocks > 0: also zeroes the exchange granules of that many blocks
 constexpr size_t WS_COUNTER_BYTES = 512 + 8 * 256;        // [0,256): counters, keep words, table stamps; [256,512): 64 arrival counters; [512,2560): XCD counters
 constexpr int COOP_MAX_BLOCKS = 64, COOP_KEYS = 1024;      // split encoder: blocks per call, sort keys per step (S * NB, aliased-key builds)
-constexpr size_t WS_XCH_BYTES = (size_t)2 * COOP_MAX_BLOCKS * COOP_KEYS * 4;   // key exchange of the split encoder, double buffered
+#ifndef IREC_COOP_GRANULES
+#define IREC_COOP_GRANULES 1   // split encoder: sort keys travel as 8-byte {key, step tag} granules that the partners sweep directly
+                               // (0: 4-byte keys behind an arrival counter, r02-r03l)
+#endif
+constexpr size_t WS_XCH_BYTES = (size_t)2 * COOP_MAX_BLOCKS * COOP_KEYS * 8;   // key exchange of the split encoder, double buffered: {key, tag} granules
 constexpr size_t WS_HEAD_BYTES = WS_COUNTER_BYTES + WS_XCH_BYTES;
 hipError_t launch_decode(const DecArgs &A, int n_cu, hipStream_t st);   // irec_decode.hip
 int decode_tensor_waves(int n, int bs, bool table, size_t *lds_out);     // waves per workgroup of the tensor-staged decoder, 0 = does not apply

@@ -618,17 +618,31 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
             if (m < n_mine && b < Bcur && (RW == 64 || (lane & 1) == 0)) part_s[((size_t)g * SP + (m * NSW + sw)) * NB + b] = tot;
           }
         }
+#if IREC_COOP_GRANULES
+        // (granules: a partner that has seen ALL my keys of this step goes on to load the beams I stored in the last update --
+        //  every wave's beam stores are drained before the barrier that precedes the first key store)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         __syncthreads();
         IREC_STAMP(1);
         // ---------------- my candidates' keys go straight into the exchange (flat f = s * Bcur + b) ----------------
         {
+#if IREC_COOP_GRANULES
+          unsigned long long *xg = reinterpret_cast<unsigned long long *>(A.coop_xch) + ((size_t)(t & 1) * COOP_MAX_BLOCKS + (size_t)blk) * COOP_KEYS;
+          const unsigned long long tag = (unsigned long long)(uint32_t)(t + 1) << 32;
+#else
           uint32_t *xk = A.coop_xch + ((size_t)(t & 1) * COOP_MAX_BLOCKS + (size_t)blk) * COOP_KEYS;
+#endif
           for (int idx = tid; idx < S * NOWN; idx += NT) {
             const int s_ = idx / NOWN, o = idx - s_ * NOWN, b = coop_w + o * coop_W;
             if (b < Bcur) {
               float sc = part_s[((size_t)0 * SP + s_) * NB + b];
               for (int gg = 1; gg < NG; ++gg) sc = sc + part_s[((size_t)gg * SP + s_) * NB + b];
+#if IREC_COOP_GRANULES
+              __hip_atomic_store(&xg[s_ * Bcur + b], tag | (unsigned long long)score_key(sc + Cb_s[b]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
               __hip_atomic_store(&xk[s_ * Bcur + b], score_key(sc + Cb_s[b]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
             }
           }
         }
@@ -763,6 +777,63 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
         // loaded `sc1` (relaxed agent-scope atomics: L2-bypassing, never a stale line), the storing waves drain their stores
         // (s_waitcnt vmcnt(0)) before ONE lane behind the workgroup barrier adds to the block's arrival counter, the polling
         // lane reads that counter `sc1`, and the payload loads sit behind the next workgroup barrier.
+#if IREC_COOP_GRANULES
+        // Granules (MI355X_MICROARCH.md, handoff-1to1): a key travels as ONE naturally aligned 8-byte {key, step tag} `sc1` store
+        // and every partner sweeps the step's granules with `sc1` loads until each carries this step's tag -- no drain, no
+        // arrival counter, no second round trip for the payload (r03l: ≈ 3 µs of a 12 µs step were the three serial round trips
+        // of the counter form).  Tags: t + 1 >= 1; the head kernel zeroed this block's granules, buffer t & 1 last held tag
+        // t - 1.  A thread gives up like the counter form did: sticky error flag, 2 s.
+        unsigned long long *xg = reinterpret_cast<unsigned long long *>(A.coop_xch) + ((size_t)(t & 1) * COOP_MAX_BLOCKS + (size_t)blk) * COOP_KEYS;
+        const uint32_t tag = (uint32_t)(t + 1);
+        unsigned long long sub_prev = A.dbg ? stamp_now() : 0ull;   // diagnostics: [12] publish, [13] sweep (wait + read back)
+        auto sub_stamp = [&](int slot) {
+          if (A.dbg && tid == 0) { const unsigned long long now_ = stamp_now(); A.dbg[(size_t)blockIdx.x * 16 + slot] += now_ - sub_prev; sub_prev = now_; }
+        };
+        __syncthreads();   // (aliased keys: all of them written; beam mode: every partial read before key_s is refilled)
+        if (!beam_mode)
+          for (int f = tid; f < N; f += NT)
+            __hip_atomic_store(&xg[s_lo * Bcur + f], ((unsigned long long)tag << 32) | (unsigned long long)key_s[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sub_stamp(12);
+        int32_t bad = 0;
+        {
+          constexpr int MKX = (1024 + NT - 1) / NT;
+          uint32_t kk[MKX];
+          uint32_t pending = 0u;
+#pragma unroll
+          for (int q = 0; q < MKX; ++q) { kk[q] = 0u; if (q * NT + tid < Ng) pending |= 1u << q; }
+          const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
+          for (uint32_t turn = 1; pending != 0u; ++turn) {
+            unsigned long long gq[MKX];
+#pragma unroll
+            for (int q = 0; q < MKX; ++q)                                           // all of a thread's loads in flight together
+              gq[q] = (pending >> q) & 1u ? __hip_atomic_load(&xg[q * NT + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+            for (int q = 0; q < MKX; ++q)
+              if (((pending >> q) & 1u) && (uint32_t)(gq[q] >> 32) == tag) { kk[q] = (uint32_t)gq[q]; pending &= ~(1u << q); }
+            if (pending == 0u || (turn & 63u) != 0u) continue;
+            if (__hip_atomic_load(A.coop_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bad = 1; break; }
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { // 2 s: the partners are not resident -- give up, loudly
+              __hip_atomic_store(A.coop_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              bad = 1; break;
+            }
+          }
+          // (key_s of the sample mode holds my own keys at [0, N): every thread has read its own before the barrier above and
+          //  nobody reads key_s again before the barrier below)
+          // (no __syncthreads_or: it brings a static LDS word with it, and the table must stay at LDS address 0 -- lds_abs_f32)
+          if (bad) misc[6] = 1;
+          __syncthreads();
+          if (misc[6]) { // every workgroup of the block sees the flag (it is sticky): nobody waits for anybody any more
+            if (tid == 0 && coop_w == 0) A.out_K[blk] = -2;
+            break;
+          }
+#pragma unroll
+          for (int q = 0; q < MKX; ++q) {
+            const int f = q * NT + tid;
+            if (f < Ng) key_s[f] = kk[q];
+          }
+        }
+        sub_stamp(13);
+#else
         uint32_t *xk = A.coop_xch + ((size_t)(t & 1) * COOP_MAX_BLOCKS + (size_t)blk) * COOP_KEYS;
         unsigned long long sub_prev = A.dbg ? stamp_now() : 0ull;   // diagnostics: [12] publish, [13] wait for partners, [14] read back
         auto sub_stamp = [&](int slot) {
@@ -812,6 +883,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
           }
         }
         sub_stamp(14);
+#endif
       }
       select_topB<NT>(key_s, Ng, Bnew, Bcur, sm, A.dbg ? A.dbg + (size_t)blockIdx.x * 16 : nullptr); // first barrier inside orders key_s writes
       IREC_STAMP(2);
@@ -1158,8 +1230,20 @@ hipError_t launch_alpha_table(int64_t seed, int32_t S, int32_t D, int32_t K_tab,
 // that held the memset node faulted on the second replay).
 // Since r02i it also keeps the books of the proposal tables (irec_kernels.h, "Head of the workspace"): thread q < 4 compares
 // the stamp of table slot q with this call's key, publishes keep[q] and stamps the key -- one thread owns a slot's words.
+// Workgroups 1 .. n of a split call zero the exchange granules of block blockIdx.x - 1 (both parities, 16 KB): the step tags
+// of the split encoder start at 1, so no granule of an earlier call on this workspace -- or whatever the memory held before --
+// can pass for one of this call's.
 __global__ void zero_counters_kernel(uint32_t *p, TableStamps ts) {
   const int t = (int)threadIdx.x;
+  if (blockIdx.x != 0) {
+    uint4 *x = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(p) + WS_COUNTER_BYTES);
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      uint4 *xb = x + ((size_t)par * COOP_MAX_BLOCKS + (size_t)(blockIdx.x - 1)) * (COOP_KEYS * 8 / 16);
+      for (int k = t; k < COOP_KEYS * 8 / 16; k += (int)blockDim.x) xb[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    return;
+  }
   const bool book = (t >= WS_KEEP_WORD && t < WS_KEEP_WORD + 4) || (t >= WS_STAMP_WORD && t < WS_STAMP_WORD + 4 * WS_STAMP_WORDS);
   if (!book) p[t] = 0u;
   if (t < 4) {
@@ -1172,8 +1256,9 @@ __global__ void zero_counters_kernel(uint32_t *p, TableStamps ts) {
     for (int k = 0; k < WS_STAMP_WORDS; ++k) stamp[k] = ts.w[t][k];
   }
 }
-hipError_t launch_zero_counters(void *p, const TableStamps &stamps, hipStream_t st) {
-  hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(WS_COUNTER_BYTES / 4), 0, st, reinterpret_cast<uint32_t *>(p), stamps);
+hipError_t launch_zero_counters(void *p, const TableStamps &stamps, int split_blocks, hipStream_t st) {
+  const int extra = IREC_COOP_GRANULES && split_blocks > 0 ? (split_blocks < COOP_MAX_BLOCKS ? split_blocks : COOP_MAX_BLOCKS) : 0;
+  hipLaunchKernelGGL(zero_counters_kernel, dim3(1 + extra), dim3(WS_COUNTER_BYTES / 4), 0, st, reinterpret_cast<uint32_t *>(p), stamps);
   return hipGetLastError();
 }
 
