@@ -352,7 +352,10 @@ __host__ __device__ inline FastPlan fast_plan(int NB, int S, bool table) {
 }
 
 
-template <int NB, int NW, bool TABLE>
+// SPLIT: 0 = one workgroup per block; 1 = split encoder sharing a block's samples; 2 = split encoder sharing its beams.  Builds
+// of their own since r03n: the beam-sharing form holds G of its two beam slots only (201 VGPRs and no scratch at NB = 20,
+// against 256 + 512 B when all three forms were one kernel), and the plain form carries no exchange code.
+template <int NB, int NW, bool TABLE, int SPLIT = 0>
 __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
   using Cfg = FastCfg<NB, TABLE>;
   constexpr int NT = NW * 64;
@@ -394,7 +397,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
   unsigned long long stamp_prev = A.dbg ? stamp_now() : 0ull;
   // Split mode (A.coop_W > 1, TABLE kernels of 4 waves with aliased keys only): this workgroup serves ONE block together
   // with coop_W - 1 partners and scores sample stripe coop_w of it; no block counter, one trip through the loop.
-  const int coop_W = TABLE && NW == 4 ? A.coop_W : 1;
+  const int coop_W = SPLIT != 0 ? (A.coop_W > 1 ? A.coop_W : 2) : 1;   // (the split builds are launched with coop_W >= 2: launch_fast_nw)
   const int coop_w = coop_W > 1 ? (int)(blockIdx.x % (unsigned)coop_W) : 0;
   bool coop_done = false;
   // Beam mode of the split encoder (r02i): the workgroups of a block share its BEAMS instead of its samples -- workgroup w
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
   // same per-step arrival counter (a workgroup reads step t - 1's beams behind step t's counter wait, and nobody can be
   // more than one step ahead, so the double buffer suffices).
   constexpr int NOWN = 2;
-  const bool beam_mode = coop_W > 1 && A.coop_beams != 0;
+  constexpr bool beam_mode = SPLIT == 2;
   // the block's beams: the slab of its first workgroup (beam mode), or my own
   float *beams_blk = reinterpret_cast<float *>(A.ws + (size_t)(blockIdx.x - (unsigned)(beam_mode ? coop_w : 0)) * A.ws_per_wg +
                                                A.ws_per_wg - (size_t)2 * NB * FAST_MAX_DIM * 4);
@@ -1173,13 +1176,13 @@ hipError_t launch_encode_generic(const EncArgs &A, int grid, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int NB, int NW, bool TABLE>
+template <int NB, int NW, bool TABLE, int SPLIT = 0>
 static hipError_t launch_fast_t(const EncArgs &A, int grid, hipStream_t st) {
   const size_t lds = fast_plan(NB, A.S, TABLE).bytes;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_fast_kernel<NB, NW, TABLE>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_fast_kernel<NB, NW, TABLE, SPLIT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((encode_fast_kernel<NB, NW, TABLE>), dim3(grid), dim3(NW * 64), lds, st, A);
+  hipLaunchKernelGGL((encode_fast_kernel<NB, NW, TABLE, SPLIT>), dim3(grid), dim3(NW * 64), lds, st, A);
   return hipGetLastError();
 }
 
@@ -1205,6 +1208,11 @@ size_t fast_ws_bytes_nb(int NB, int max_K) { return fast_ws_bytes(NB, max_K); }
 
 template <int NB, bool TABLE>
 static hipError_t launch_fast_nw(const EncArgs &A, int grid, hipStream_t st) {
+  if constexpr (TABLE)
+    if (A.coop_W > 1) {   // split call (host: split_width / split_beam_width; aliased-key plans only, four waves)
+      if (fast_plan(NB, A.S, TABLE).nw != 4) return hipErrorInvalidValue;
+      return A.coop_beams != 0 ? launch_fast_t<NB, 4, true, 2>(A, grid, st) : launch_fast_t<NB, 4, true, 1>(A, grid, st);
+    }
   return fast_plan(NB, A.S, TABLE).nw == 8 ? launch_fast_t<NB, 8, TABLE>(A, grid, st) : launch_fast_t<NB, 4, TABLE>(A, grid, st);
 }
 
