@@ -23,6 +23,7 @@
 //
 // Compiled with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (no implicit fma: see irec_device.h).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -582,20 +583,21 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
             float acc[RW];
 #pragma unroll
             for (int p = 0; p < RW; ++p) acc[p] = 0.f;
+            // one sub-batch of NH rows: rows m0 + h .. + NH - 1 (past my last sample: entry 0, the total is dropped)
+            auto sub_batch = [&](auto nh_tag, const int h) {
+              constexpr int NH = decltype(nh_tag)::value;
+              uint2 ap[NH];
 #pragma unroll
-            for (int h = 0; h < SPB; h += HB) {
-              uint2 ap[HB];
-#pragma unroll
-              for (int k = 0; k < HB; ++k) {
-                const int m = m0 + h + k;                          // past my last sample: entry 0, the total is dropped
+              for (int k = 0; k < NH; ++k) {
+                const int m = m0 + h + k;
                 ap[k] = make_uint2(0u, 0u);
                 if (m < n_mine) ap[k] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)(m * NSW + sw) * Dp);
               }
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
-                float z[HB][NOWN];
+                float z[NH][NOWN];
 #pragma unroll
-                for (int k = 0; k < HB; ++k) {
+                for (int k = 0; k < NH; ++k) {
                   const uint32_t w = (i & 2) ? ap[k].y : ap[k].x;
                   const uint32_t al = (i & 1) ? (w >> 16) : (w & 0xFFFFu);
 #pragma unroll
@@ -607,12 +609,23 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
                   }
                 }
 #pragma unroll
-                for (int k = 0; k < HB; ++k)
+                for (int k = 0; k < NH; ++k)
 #pragma unroll
                   for (int o = 0; o < NOWN; ++o)
                     acc[(h + k) * NOWN + o] = proposal_term(acc[(h + k) * NOWN + o], z[k][o], cH[i], G[o][i]);
                 __builtin_amdgcn_sched_barrier(0);
               }
+            };
+            // the last reduce-scatter of a step is rarely full (S = 36: 16 + 16 + 4): sub-batches past my last sample are
+            // skipped, one that holds at most half its rows runs at half width -- 36 sample slots instead of 48
+#pragma unroll
+            for (int h = 0; h < SPB; h += HB) {
+              const int left = n_mine - (m0 + h);                  // wave-uniform
+              if (left <= 0) continue;
+              if constexpr (HB >= 8) {
+                if (left <= HB / 2) { sub_batch(std::integral_constant<int, HB / 2>{}, h); continue; }
+              }
+              sub_batch(std::integral_constant<int, HB>{}, h);
             }
             const float tot = reduce_scatter<RW>(acc, lane);
             const int p = RW == 64 ? lane : (lane >> 1);
