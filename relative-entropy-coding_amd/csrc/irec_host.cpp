@@ -705,7 +705,7 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
     }
     out->waves_per_wg = irec::fast_waves_for(B, S, pl.table);
     out->teams_per_wg = 1;
-    out->lds_bytes = (int32_t)irec::fast_lds_for(B, S, pl.table);
+    out->lds_bytes = (int32_t)irec::fast_lds_for(B, S, pl.table) + (out->split >= 2 && out->split_beams ? 40024 : 0);   // (beam split: two table copies of 10 006 floats)
   } else {
     std::snprintf(out->kernel, sizeof out->kernel, "encode_generic_kernel");
     out->grid = (int32_t)std::min<int64_t>(n_blocks, pl.grid_cap);

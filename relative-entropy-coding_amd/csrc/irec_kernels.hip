@@ -328,14 +328,17 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
 // scores S in ceil(S / S_pass) passes, each followed by the group combine into the sort keys.  With one pass and at
 // most 1024 candidates the keys are written over group 0 of the partials; otherwise they get their own array.
 struct FastPlan { int s_pass; bool alias; int nw; size_t off_part, off_key, off_small, bytes; };
-__host__ __device__ inline FastPlan fast_plan(int NB, int S, bool table) {
+// two_tables (the beam-split build): a second copy of the quantile table right behind the first, so that entry offset +
+// beam rotation (both < 40 024 bytes) addresses the pair without the wrap -- ONE v_mad_u32_u16 per look-up instead of an
+// extract, an add and a conditional subtract; its workgroups have a CU each, the 40 KB are there.
+__host__ __device__ inline FastPlan fast_plan(int NB, int S, bool table, bool two_tables = false) {
   FastPlan p;
-  const size_t head = (table ? 40032 - 8 : 40032 + 20016);
+  const size_t head = (table ? 40032 - 8 : 40032 + 20016) + (two_tables ? (size_t)IREC_PM1 * 4 : 0);
   const size_t row = (size_t)4 * NB * 4;                       // partial-score bytes per sample
   const size_t keys = (((size_t)S * NB * 4) + 15) & ~(size_t)15;
   auto total = [&](int s_pass, bool alias) { return head + (((size_t)s_pass * row + 15) & ~(size_t)15) + (alias ? 0 : keys) + SMALL_LDS_BYTES; };
   const size_t two_per_cu = 80 * 1024 - 256, one_per_cu = 160 * 1024 - 1024;
-  p.alias = S * NB <= 1024 && total(S, true) <= two_per_cu;
+  p.alias = S * NB <= 1024 && total(S, true) <= (two_tables ? one_per_cu : two_per_cu);   // (two_tables: one workgroup per CU anyway)
   if (p.alias) { p.s_pass = S; p.nw = 4; }
   else {
     // largest pass that still lets two workgroups share a CU, if that leaves passes of >= 16 samples
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
   constexpr int RW = Cfg::RW, SPC = Cfg::SPC;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int S = A.S, B = A.B;
-  const FastPlan plan = fast_plan(NB, S, TABLE);
+  const FastPlan plan = fast_plan(NB, S, TABLE, SPLIT == 2);
   const int SP = plan.s_pass;                                                 // samples scored per pass
   const bool keys_alias = plan.alias;
   char *lut2_b = smem;                                                        // float [10006], dlog order
@@ -384,7 +387,11 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap(); // see lds_abs_f32
   {
     float *l2 = reinterpret_cast<float *>(lut2_b);
-    for (int k = tid; k < (int)IREC_PM1; k += NT) l2[k] = A.lut2[k];
+    for (int k = tid; k < (int)IREC_PM1; k += NT) {
+      const float v = A.lut2[k];
+      l2[k] = v;
+      if (SPLIT == 2) l2[k + (int)IREC_PM1] = v;   // (fast_plan: two_tables)
+    }
     if (!TABLE) {
       uint16_t *dl = reinterpret_cast<uint16_t *>(smem + 40032);
       for (int k = tid; k < (int)IREC_PM1; k += NT) dl[k] = A.dlog4r[k];
@@ -599,12 +606,11 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
 #pragma unroll
                 for (int k = 0; k < NH; ++k) {
                   const uint32_t w = (i & 2) ? ap[k].y : ap[k].x;
-                  const uint32_t al = (i & 1) ? (w >> 16) : (w & 0xFFFFu);
 #pragma unroll
                   for (int o = 0; o < NOWN; ++o) {
-                    uint32_t ad = al + own_bet[o];
-                    const uint32_t ad2 = ad - IREC_LUT2_BYTES;
-                    ad = ad2 < ad ? ad2 : ad;
+                    uint32_t ad;                                   // 16-bit half x 1 + rotation: into the table pair, no wrap
+                    if (i & 1) asm("v_mad_u32_u16 %0, %1, 1, %2 op_sel:[1,0,0,0]" : "=v"(ad) : "v"(w), "s"(own_bet[o]));
+                    else asm("v_mad_u32_u16 %0, %1, 1, %2" : "=v"(ad) : "v"(w), "s"(own_bet[o]));
                     z[k][o] = lds_abs_f32(ad);
                   }
                 }
@@ -953,9 +959,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
             float nb[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              uint32_t ad = al[i] + bet_old[o];
-              const uint32_t ad2 = ad - IREC_LUT2_BYTES;
-              ad = ad2 < ad ? ad2 : ad;
+              const uint32_t ad = al[i] + bet_old[o];      // (beam-split build: the table pair, no wrap)
               const float y = sa_t[i] * lds_abs_f32(ad); // dist.quantile(.), :48-49
               nb[i] = obv[o][i] + y;                       // combined_samples[best_ind_aux, best_ind_beam], :81,92-93
             }
@@ -1191,7 +1195,7 @@ hipError_t launch_encode_generic(const EncArgs &A, int grid, hipStream_t st) {
 
 template <int NB, int NW, bool TABLE, int SPLIT = 0>
 static hipError_t launch_fast_t(const EncArgs &A, int grid, hipStream_t st) {
-  const size_t lds = fast_plan(NB, A.S, TABLE).bytes;
+  const size_t lds = fast_plan(NB, A.S, TABLE, SPLIT == 2).bytes;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_fast_kernel<NB, NW, TABLE, SPLIT>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
