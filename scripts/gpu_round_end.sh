@@ -4,7 +4,7 @@
 # written under gpurun_out/$TAG/ as it goes (no output held back behind a pipe).
 set -u
 export TMPDIR=/tmp
-TAG=${TAG:-r03o}
+TAG=${TAG:-r03p}
 STAGES=${STAGES:-ab}    # a: GPU suite, smoke;  b: PMC passes -> traffic.json, bench line, kernel trace of the same command, sweep grid, decoder bench
 O=gpurun_out/$TAG
 mkdir -p $O
