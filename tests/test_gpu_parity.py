@@ -1025,9 +1025,15 @@ def test_split_encoder_small_calls(engine, oracle, n_tensors, n, bs, omega, eps1
     plan = engine.plan(c._params(), lay, 32)
     assert plan["split"] >= 2 and plan["grid"] == lay.n_blocks * plan["split"], plan
     assert plan["split_beams"] == (1 if mode == "beams" and -(-B // plan["split"]) <= 2 else 0), plan
+    # the split forms are builds of their own (r03n): <NB,4,true,1> shares samples, <NB,4,true,2> beams -- the latter with
+    # two table copies in its LDS
+    nb = 10 if B <= 10 else 20
+    assert plan["kernel"] == f"encode_fast_kernel<{nb},4,true,{2 if plan['split_beams'] else 1}>" and plan["waves_per_wg"] == 4, plan
     idx, sample = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)
     c2 = _coder(omega, B, eps1, block_size=bs, variant="one_table_nosplit")
-    assert engine.plan(c2._params(), lay, 32)["split"] == 0
+    plain = engine.plan(c2._params(), lay, 32)
+    assert plain["split"] == 0 and plain["kernel"] == f"encode_fast_kernel<{nb},4,true>", plain
+    assert plan["lds_bytes"] == plain["lds_bytes"] + (40024 if plan["split_beams"] else 0), (plan, plain)
     idx2, sample2 = c2.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)
     assert idx == idx2 and torch.equal(sample, sample2)
     for i in range(n_tensors):
