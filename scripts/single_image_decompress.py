@@ -1,0 +1,20 @@
+"""Diagnostic: latency of ONE 32x32 image through the 24-block RVAE shim, compress and decompress (eager, N = 1), and whether
+the decompressed reconstruction equals the compress pass's.  Same model as scripts/config3_harness.py."""
+import os, sys, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "relative-entropy-coding_amd"), os.path.join(ROOT, "scripts")]
+from config3_harness import build_model
+m = build_model(torch.device("cuda"))
+g = torch.Generator().manual_seed(7)
+images = (torch.rand(10, 3, 32, 32, generator=g) - 0.5).cuda()
+tc, td, same = [], [], True
+for i in range(10):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    idx, rec = m.compress(images[i:i + 1], seed=42)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    out = m.decompress(idx, 42, images[i:i + 1].shape)
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    tc.append(t1 - t0); td.append(t2 - t1)
+    same = same and torch.equal(out, rec)
+med = lambda v: sorted(v)[len(v) // 2]
+print(f"single image, eager: compress {1e3 * med(tc[2:]):.2f} ms, decompress {1e3 * med(td[2:]):.2f} ms (median of 8), reconstruction identical: {same}")
