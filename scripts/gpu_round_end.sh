@@ -5,7 +5,7 @@
 set -u
 export TMPDIR=/tmp
 TAG=${TAG:-r03p}
-STAGES=${STAGES:-ab}    # a: GPU suite, smoke;  b: PMC passes -> traffic.json, bench line, kernel trace of the same command, sweep grid, decoder bench
+STAGES=${STAGES:-ab}    # a: GPU suite, smoke;  b: PMC passes -> traffic.json, bench line, kernel trace of the same command, sweep grid, decoder bench;  c: end-to-end shim
 O=gpurun_out/$TAG
 mkdir -p $O
 if [[ $STAGES == *a* ]]; then
@@ -40,5 +40,12 @@ for r in out[:8]: print(r)
 PY
 echo "== sweep grid"; timeout -k 10 900 python scripts/grid_bench.py > $O/grid.full.log 2>&1; grep -v amdgpu.ids $O/grid.full.log > $O/grid.log; tail -3 $O/grid.log
 echo "== decode bench"; timeout -k 10 300 python scripts/decode_bench.py 2>&1 | grep -v amdgpu.ids > $O/decode_bench.log; cat $O/decode_bench.log
+fi
+if [[ $STAGES == *c* ]]; then   # c: the end-to-end shim: 38-image share and single image (eager / one HIP graph), kernel trace of the single-image pass
+echo "== config 3 harness (38 images, 12 singles)"; timeout -k 10 300 python scripts/config3_harness.py --images 38 --singles 12 2>&1 | grep -v amdgpu.ids > $O/config3.log; tail -1 $O/config3.log | cut -c1-300
+echo "== single image: compress / decompress eager"; timeout -k 10 300 python scripts/single_image_decompress.py 2>&1 | grep -v amdgpu.ids > $O/single_image_decompress.log; tail -1 $O/single_image_decompress.log
+echo "== kernel trace of the single-image pass"
+rm -rf /tmp/si_trace; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/si_trace -- python3 scripts/single_image_profile.py > $O/single_image_trace.log 2>&1
+f=$(find /tmp/si_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/single_image_kernel_stats.csv && grep -h "encode_fast_kernel\|decode_tensor_kernel" $O/single_image_kernel_stats.csv | cut -c1-160
 fi
 du -sh $O
