@@ -175,6 +175,18 @@ irec_status irec_philox_uniform_int(int64_t seed, int64_t n, int32_t *out);
  * get_auxiliary_ratio, coder.py:16,218-220) and uploads them to HIP device `device`.
  * Fails with IREC_E_NO_DEVICE when there is no GPU: there is no CPU fallback. */
 irec_status irec_create(int device, irec_context **out);
+/* irec_create with the path's TF-dependent primitive supplied by the caller.
+ *   lut10007  host float [10007], may be NULL (= irec_build_lut): lut10007[k] = the float32 that
+ *             tfd.Normal(0, 1).quantile(float32(k) / 10007) returns in the CALLER's TensorFlow, k = 1..10006 (entry 0 is never
+ *             indexed) -- the 10006 values `dist.quantile` can take at beam_search_coder.py:48-49 before the scale is applied.
+ *             Every kernel of the context (encoders, decoders) reads its quantiles from this table and from nothing else.
+ * Why: irec_build_lut restates TFP 0.9's float32 ndtri with a correctly rounded log; TensorFlow evaluates it over Eigen's
+ * vectorised log, and a 1-ulp difference in one entry can move an emitted index.  A maintainer with a TF 2.1 machine dumps
+ * the table once (scripts/make_tf_vectors.py writes it as `quantile` in tf_primitives.npz) and creates the context with it:
+ * the stream then decodes on the TensorFlow side, no recompile.  (The other TF-dependent input, the tf.random.shuffle
+ * permutation of Coder.split, is a caller argument already: `perm` of irec_beam_encode / irec_beam_decode.)
+ * All entries 1..10006 must be finite (IREC_E_INVALID otherwise). */
+irec_status irec_create_ex(int device, const float *lut10007, irec_context **out);
 void irec_destroy(irec_context *ctx);
 
 /* Bytes of device scratch irec_beam_encode needs for blocks of at most max_dim dims and max_K partitions. */

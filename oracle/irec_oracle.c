@@ -204,6 +204,23 @@ void irec_oracle_build_lut(float *lut) {
   for (int k = 1; k < IREC_P; ++k) lut[k] = irec_oracle_ndtri_f32((float)k / (float)IREC_P);
 }
 
+/* The quantile table the coder functions below read.  irec_oracle_set_lut(lut10007) injects a caller's table -- the
+ * counterpart of the product's irec_create_ex(): the 10006 values dist.quantile returns at beam_search_coder.py:48-49 are
+ * the one TF-dependent primitive of the path whose float32 bits (TFP's ndtri over Eigen's vectorised log) this repo can
+ * only restate; a TF-side maintainer feeds TF's own values into both sides.  NULL restores the restated table.
+ * Not thread-safe against concurrent coder calls: set it before any parallel region. */
+static float g_lut[IREC_P];
+static int g_lut_ready = 0;
+static const float *oracle_lut(void) {
+  if (!g_lut_ready) { irec_oracle_build_lut(g_lut); g_lut_ready = 1; }
+  return g_lut;
+}
+void irec_oracle_set_lut(const float *lut10007) {
+  if (lut10007) memcpy(g_lut, lut10007, sizeof(g_lut));
+  else irec_oracle_build_lut(g_lut);
+  g_lut_ready = 1;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * tf.random.set_seed(seed); tf.random.shuffle(tf.range(n))   (coder.py:62-64, 111-113)
  * CPython MT19937 (random.Random(seed).randint(0, 2^31-1)) supplies the op seed.
@@ -425,9 +442,7 @@ static int cand_before(float va, int32_t fa, float vb, int32_t fb) {
 int32_t irec_oracle_encode_block(int mode, float omega, int S, int B, int D, const float *mq, const float *sq,
                                  const float *mp, const float *sp, int64_t seed, int32_t max_K,
                                  int32_t *out_indices, float *out_sample, int32_t *trace_sel, float *trace_score) {
-  static float lut[IREC_P];
-  static int lut_ready = 0;
-  if (!lut_ready) { irec_oracle_build_lut(lut); lut_ready = 1; }
+  const float *lut = oracle_lut();
 
   float kl = irec_oracle_block_kl(mode, D, mq, sq, mp, sp);
   int32_t K = irec_oracle_num_aux(kl, omega);
@@ -621,9 +636,7 @@ int irec_oracle_encode_blocks_omp(int mode, float omega, int S, int B, int64_t n
  * the reference's in-place list reversal (:127) is an implementation detail of its loop direction. */
 void irec_oracle_decode_block(int mode, int S, int D, const float *mp, const float *sp, const int32_t *indices,
                               int32_t K, int64_t seed, float *out_sample) {
-  static float lut[IREC_P];
-  static int lut_ready = 0;
-  if (!lut_ready) { irec_oracle_build_lut(lut); lut_ready = 1; }
+  const float *lut = oracle_lut();
   float *c = (float *)calloc((size_t)D, sizeof(float));
   float *sample = (float *)calloc((size_t)D, sizeof(float));
   int32_t *r = (int32_t *)malloc((size_t)S * D * sizeof(int32_t));

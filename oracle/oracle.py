@@ -55,6 +55,7 @@ def lib():
         L.irec_oracle_ndtri_f32.argtypes = [ctypes.c_float]
         L.irec_oracle_ndtri_f32.restype = ctypes.c_float
         L.irec_oracle_build_lut.argtypes = [f32p]
+        L.irec_oracle_set_lut.argtypes = [f32p]
         L.irec_oracle_py_first_randint31.argtypes = [ctypes.c_int64]
         L.irec_oracle_py_first_randint31.restype = ctypes.c_int64
         L.irec_oracle_py_randint31_nth.argtypes = [ctypes.c_int64, ctypes.c_int64]
@@ -133,6 +134,17 @@ def build_lut():
     o = np.zeros(P, dtype=np.float32)
     lib().irec_oracle_build_lut(_p(o, ctypes.c_float))
     return o
+
+
+def set_lut(lut=None):
+    """Injects a quantile table into the coder functions (the oracle-side twin of the product's irec_create_ex): float32
+    [10007], lut[k] = Normal(0,1).quantile(float32(k)/10007), entry 0 unused.  None restores the restated table."""
+    if lut is None:
+        lib().irec_oracle_set_lut(None)
+        return
+    a = np.ascontiguousarray(lut, dtype=np.float32)
+    assert a.shape == (P,), a.shape
+    lib().irec_oracle_set_lut(_p(a, ctypes.c_float))
 
 
 def py_first_randint31(seed):

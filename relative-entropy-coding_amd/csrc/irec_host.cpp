@@ -403,9 +403,14 @@ irec_status irec_importance_decode(const float *p_loc, const float *p_scale, int
   return IREC_OK;
 }
 
-irec_status irec_create(int device, irec_context **out) try {
+irec_status irec_create(int device, irec_context **out) { return irec_create_ex(device, nullptr, out); }
+
+irec_status irec_create_ex(int device, const float *lut10007, irec_context **out) try {
   if (!out) return fail(IREC_E_INVALID, "irec_create: null output");
   *out = nullptr;
+  if (lut10007)   // an injected quantile table must hold numbers: one NaN / inf entry would poison every score it touches
+    for (int k = 1; k < IREC_BIG_PRIME; ++k)
+      if (!std::isfinite(lut10007[k])) return fail(IREC_E_INVALID, "irec_create_ex: lut10007[%d] is not finite", k);
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
     return fail(IREC_E_NO_DEVICE, "irec_create: no HIP device visible (this library has no CPU fallback)");
@@ -418,7 +423,8 @@ irec_status irec_create(int device, irec_context **out) try {
 
   const int P = IREC_BIG_PRIME;
   std::vector<float> lut(P);
-  irec_build_lut(lut.data());
+  if (lut10007) { std::memcpy(lut.data(), lut10007, (size_t)P * sizeof(float)); lut[0] = 0.0f; }
+  else irec_build_lut(lut.data());
   // smallest primitive root of 10007 and the discrete-log tables
   auto mulmod = [&](uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) % P); };
   uint32_t g = 0;
@@ -866,12 +872,20 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
         HIP_TRY(hipMemcpy(h.data(), ctx->d_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         static const char *nm[12] = {"fetch", "prologue", "scoring", "wait-score", "combine", "select", "update-tail", "wait-update", "epilogue",
                                      "upd:sel+issue+consts", "upd:batches", "-"};
+        // (waves of teams that coded no block -- a mid-size call leaves team slots empty -- are left out of the averages)
+        const int nwt = nwv / n_teams;   // waves per team
         double w0[12] = {0}, wo[12] = {0}, t0 = 0, to = 0;
-        for (int w = 0; w < tgrid * nwv; ++w)
-          for (int k = 0; k < 12; ++k) { const double v = (double)h[(size_t)w * 16 + k]; if ((w & 3) == 0) { w0[k] += v; t0 += v; } else { wo[k] += v; to += v; } }
-        fprintf(stderr, "[irec team stamps] share of wave time, wave 0 of a team | waves 1-3:\n");
-        for (int k = 0; k < 11; ++k) fprintf(stderr, "  %-20s %5.1f%% | %5.1f%%\n", nm[k], 100 * w0[k] / t0, 100 * wo[k] / to);
-        fprintf(stderr, "  cycles per wave: %.0f | %.0f\n", t0 / (tgrid * nwv / 4), to / (tgrid * nwv * 3 / 4));
+        int n0 = 0, no = 0;
+        for (int w = 0; w < tgrid * nwv; ++w) {
+          if (h[(size_t)w * 16 + 1] == 0ull) continue;   // no prologue: no block
+          if ((w % nwt) == 0) ++n0; else ++no;
+          for (int k = 0; k < 12; ++k) { const double v = (double)h[(size_t)w * 16 + k]; if ((w % nwt) == 0) { w0[k] += v; t0 += v; } else { wo[k] += v; to += v; } }
+        }
+        fprintf(stderr, "[irec team stamps] %d of %d teams coded blocks; share of wave time (cycles per wave), wave 0 of a team | the others:\n", n0, tgrid * n_teams);
+        t0 -= w0[11]; to -= wo[11];   // (slot 11 counts block-steps, not cycles)
+        for (int k = 0; k < 11; ++k) fprintf(stderr, "  %-20s %5.1f%% (%8.0f) | %5.1f%% (%8.0f)\n", nm[k], 100 * w0[k] / t0, w0[k] / (n0 ? n0 : 1), 100 * wo[k] / to, wo[k] / (no ? no : 1));
+        fprintf(stderr, "  cycles per wave: %.0f | %.0f;  block-steps per wave: %.2f;  cycles per block-step: %.0f\n", t0 / (n0 ? n0 : 1), to / (no ? no : 1),
+                w0[11] / (n0 ? n0 : 1), w0[11] > 0 ? t0 / w0[11] : 0.0);
         if (h[13]) fprintf(stderr, "  shader clock of workgroup 0, wave 0: %.0f MHz over %.3f ms (s_memtime / s_memrealtime)\n",
                            100.0 * (double)h[12] / (double)h[13], (double)h[13] / 1e5);
         return IREC_OK;

@@ -283,7 +283,11 @@ irec_status irec_rec_decode_file(const uint8_t *bytes, int64_t n_bytes, uint32_t
   for (int64_t r = 0; r < R; ++r) {
     const int64_t nc = get_u32(dyn + 4 * (R + r)), nx = get_u32(dyn + 4 * (2 * R + r));
     const int64_t mx64 = get_u32(dyn + 4 * (3 * R + r));
-    if (mx64 > IREC_MAX_PARTITIONS || (int64_t)get_u32(dyn + 4 * r) > 8 * nc + 8)
+    // (count model [1, 101, 101, ...] over mx + 2 symbols: with mx >= 1 a block's count costs >= log2(203 / 101) > 1 bit; a
+    //  residual block whose K are ALL zero -- mx = 0, model [1, 101] -- costs log2(102 / 101) = 0.0142 bit per block, i.e. up
+    //  to 71 blocks per bit of its count stream: the reference writes and reads such files)
+    const int64_t blocks_cap = (mx64 >= 1 ? 1 : 72) * (8 * nc + 8);
+    if (mx64 > IREC_MAX_PARTITIONS || (int64_t)get_u32(dyn + 4 * r) > blocks_cap)
       return io_fail("irec_rec_decode_file: partition / block counts out of range (damaged header?)");
     const int32_t mx = (int32_t)mx64;
     if (pos + nc > n_bytes || off_x + nx > n_bytes) return io_fail("irec_rec_decode_file: truncated streams");

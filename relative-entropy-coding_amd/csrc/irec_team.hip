@@ -391,6 +391,9 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
     TSTAMP(1);
     int cur = 0, Bcur = 1;
     for (int t = 0; t < K; ++t) {
+#ifdef IREC_TEAM_STAMPS
+      st_acc[11] += 1ull;                                            // (diagnostic build: block-steps of this wave)
+#endif
       const uint16_t *tab_tu = tab + (size_t)t * S * Dp;             // uniform base of this step's rows
       // my quad inside a row (32-bit offsets: one VGPR).  Lanes past the padded row end (all their dims invalid, zero
       // coefficients) read the row's LAST quad: finite z, and the same addresses as the last real lane of their 32-lane
@@ -917,10 +920,10 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   }
 #ifdef IREC_TEAM_STAMPS
   if (A.dbg && lane == 0)
-    for (int k = 0; k < 12; ++k) A.dbg[((size_t)blockIdx.x * (TEAMS * 4) + wave_wg) * 16 + k] = st_acc[k];
+    for (int k = 0; k < 12; ++k) A.dbg[((size_t)blockIdx.x * (TEAMS * BS * 4) + wave_wg) * 16 + k] = st_acc[k];
   if (A.dbg && lane == 0) {
-    A.dbg[((size_t)blockIdx.x * (TEAMS * 4) + wave_wg) * 16 + 12] = __builtin_amdgcn_s_memtime() - st_t0;
-    A.dbg[((size_t)blockIdx.x * (TEAMS * 4) + wave_wg) * 16 + 13] = __builtin_amdgcn_s_memrealtime() - st_r0;
+    A.dbg[((size_t)blockIdx.x * (TEAMS * BS * 4) + wave_wg) * 16 + 12] = __builtin_amdgcn_s_memtime() - st_t0;
+    A.dbg[((size_t)blockIdx.x * (TEAMS * BS * 4) + wave_wg) * 16 + 13] = __builtin_amdgcn_s_memrealtime() - st_r0;
   }
 #endif
 }

@@ -68,6 +68,7 @@ SIGNATURES = {
     "irec_importance_n_samples": (_i64, [ctypes.c_double]),
     "irec_tf_random_normal": (ctypes.c_int, [_i64, _i64, _vp]),
     "irec_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
+    "irec_create_ex": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.POINTER(_vp)]),
     "irec_destroy": (None, [_vp]),
     "irec_encode_workspace_bytes": (ctypes.c_size_t, [_vp, _PP, _i32, _i32]),
     "irec_encode_plan": (ctypes.c_int, [_vp, _PP, _i64, _i32, _i32, ctypes.POINTER(IrecPlanInfo)]),

@@ -12,7 +12,7 @@ import torch
 from .coder import GaussianCoder
 from .utils import CodingError
 from .. import _lib
-from ..engine import get_engine
+from ..engine import Engine, get_engine
 
 
 class MorePartitionsNeeded(CodingError):
@@ -152,7 +152,9 @@ class PendingCode:
 class BeamSearchCoder(GaussianCoder):
     def __init__(self, kl_per_partition, n_beams, extra_samples=1., extrapolate_auxiliary_ratios=True,
                  name="gaussian_encoder", **kwargs):
-        """beam_search_coder.py:15-30."""
+        """beam_search_coder.py:15-30.  Extension: `engine=` (an `irec.Engine` built with the caller's own quantile table,
+        irec_create_ex) instead of the device's default engine."""
+        self.engine = kwargs.pop("engine", None)
         super().__init__(name=name, kl_per_partition=kl_per_partition, sampler=None,
                          extrapolate_auxiliary_ratios=extrapolate_auxiliary_ratios, **kwargs)
         self.n_beams = n_beams
@@ -210,7 +212,7 @@ class BeamSearchCoder(GaussianCoder):
                 (_lib.IREC_FLAG_SPLIT_SAMPLES if self.split_samples else 0) | _lib.IREC_FLAG_SHAPE[self.team_shape] | \
                 (32 if self._test_split_orphan and not self.no_split else 0)
         steps = int(table_steps) if table_steps else self.table_window()
-        return get_engine().params(self.kl_per_partition, self.n_samples, self.n_beams, flags, table_steps=steps)
+        return Engine.params(self.kl_per_partition, self.n_samples, self.n_beams, flags, table_steps=steps)
 
     @staticmethod
     def _dev(t, device):
@@ -218,6 +220,8 @@ class BeamSearchCoder(GaussianCoder):
         return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
     def _engine_for(self, tensor):
+        if self.engine is not None:
+            return self.engine
         t = torch.as_tensor(tensor)
         return get_engine(t.device if t.device.type == "cuda" else None)
 

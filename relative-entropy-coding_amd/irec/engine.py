@@ -124,7 +124,12 @@ class BlockLayout:
 
 
 class Engine:
-    def __init__(self, device):
+    """`lut` (optional, float32 [10007]): the caller's own table of Normal(0,1).quantile(float32(k)/10007) -- the values
+    `dist.quantile` takes at beam_search_coder.py:48-49 -- instead of the library's restatement of TFP's float32 ndtri
+    (irec_create_ex, include/irec.h).  An engine built this way is private to its creator: pass it to a coder as
+    `BeamSearchCoder(..., engine=...)`; `get_engine()` keeps handing out the default-table engine of the device."""
+
+    def __init__(self, device, lut=None):
         if not torch.cuda.is_available():
             raise _lib.IrecLibraryError("irec needs a HIP device (MI355X / gfx950); there is no CPU fallback")
         self.device = torch.device(device)
@@ -134,7 +139,13 @@ class Engine:
         self.device = torch.device("cuda", self.index)
         self.lib = _lib.load()
         ctx = ctypes.c_void_p()
-        _lib.check(self.lib.irec_create(self.index, ctypes.byref(ctx)), "irec_create")
+        if lut is None:
+            _lib.check(self.lib.irec_create(self.index, ctypes.byref(ctx)), "irec_create")
+        else:
+            table = np.ascontiguousarray(np.asarray(lut), dtype=np.float32)
+            if table.shape != (_lib.BIG_PRIME,):
+                raise ValueError(f"lut must hold {_lib.BIG_PRIME} float32 values (entry k = quantile(k / 10007)), got shape {table.shape}")
+            _lib.check(self.lib.irec_create_ex(self.index, table.ctypes.data_as(ctypes.c_void_p), ctypes.byref(ctx)), "irec_create_ex")
         self.ctx = ctx
         self._layouts = {}
         self._ws = {}      # one scratch buffer per HIP stream: calls on different streams never share counters / slabs

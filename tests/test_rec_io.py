@@ -158,6 +158,36 @@ def test_native_container_equals_the_per_stream_writer(tmp_path):
         U._native_decode(b"\x00" * 26 + b"\x05\x00" + b"\x00" * 12)            # R = 5 but the dynamic header is truncated
 
 
+def test_residual_blocks_whose_partition_counts_are_all_zero(tmp_path):
+    """A residual block whose coded blocks all have K = 0 (posterior == prior: nothing to send) is coded with the count model
+    [1, 101]: 0.014 bit per block, so hundreds of blocks fit a few bytes of count stream.  The reader's damaged-header bound
+    must not take such a file for a damaged one (round 3's bound assumed one bit per block); byte-identical to the
+    reference-shaped writer, and through the batched calls."""
+    from irec.io import utils as U
+    for name, blocks in (("thousand", [[[] for _ in range(1000)]]),
+                         ("mixed", [[[] for _ in range(200)], [[3, 1, 4], [], [1]] + [[] for _ in range(7)]]),
+                         ("sixty_four", [[[] for _ in range(64)], [[] for _ in range(64)]])):
+        a, b = tmp_path / f"{name}.rec", tmp_path / f"{name}_py.rec"
+        U.write_compressed_code(str(a), 11, (32, 32, 3), 1000, blocks, 36)
+        U._write_compressed_code_py(str(b), 11, (32, 32, 3), 1000, blocks, 36)
+        assert a.read_bytes() == b.read_bytes()
+        assert U.read_compressed_code(str(a)) == (11, (32, 32, 3), 1000, blocks)
+        assert U._read_compressed_code_py(str(a)) == (11, (32, 32, 3), 1000, blocks)
+    assert (tmp_path / "thousand.rec").stat().st_size < 100          # 1000 blocks in a handful of bytes
+    # the packed form: one image whose second residual block is all zero, 64 blocks per residual block
+    K = np.zeros((2, 2, 64), dtype=np.int32)
+    K[:, 0, :] = 2
+    idx = np.random.default_rng(3).integers(0, 36, (2, 2, 64, 2)).astype(np.int32)
+    blob, off = U.encode_files(5, (32, 32, 3), 1000, K, idx, 36)
+    hdr, K2, idx2 = U.decode_files(blob, off, 2, 64, 2)
+    assert (K2 == K).all() and (idx2[:, 0] == idx[:, 0]).all() and (idx2[:, 1] == 0).all()
+    # the bound still refuses a header that claims more blocks than any count stream of that length can hold
+    data = bytearray((tmp_path / "thousand.rec").read_bytes())
+    data[28:32] = (10 ** 6).to_bytes(4, "little")
+    with pytest.raises(ValueError):
+        U._native_decode(bytes(data))
+
+
 def test_batched_container_calls_equal_the_per_image_writer(tmp_path):
     """irec_rec_encode_files / irec_rec_decode_files (round 3: the files of a whole batch from ONE packed read-back, on host
     threads) against the per-image writer that the golden tests above pin to the real reference: byte-identical files, for the

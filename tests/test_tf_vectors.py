@@ -91,18 +91,31 @@ def test_tf_kl_and_partition_count(oracle):
     assert abs(kl - float(g["kl_sum"])) <= 1e-5 * abs(float(g["kl_sum"]))
 
 
+def _tf_lut():
+    """TensorFlow's own quantile table as the [10007] array irec_create_ex / oracle.set_lut take (entry 0 unused)."""
+    q = _prim()["quantile"].astype(np.float32).reshape(-1)
+    assert q.shape == (10006,)
+    return np.concatenate([np.zeros(1, np.float32), q])
+
+
 def test_tf_encode_block_indices_oracle(oracle):
+    """TensorFlow's quantile table is INJECTED (oracle.set_lut, the twin of irec_create_ex): whether the restated table equals
+    it is test_tfp_quantile_table's question, not this one's."""
     g = _enc()
-    for name in g["names"]:
-        name = str(name)
-        f = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
-        S = int(f["n_samples"])
-        for mode in (oracle.LITERAL, oracle.CANONICAL):
-            idx, sample = oracle.encode_block(f["q_loc"], f["q_scale"], f["p_loc"], f["p_scale"], int(f["seed"]),
-                                              float(f["kl_per_partition"]), S, int(f["n_beams"]), mode=mode)
-            assert idx == g[f"{name}_indices"].tolist(), (name, mode)
-        assert np.allclose(sample, g[f"{name}_sample"], rtol=0, atol=1e-5), name          # north_star: 1e-5 on reconstructions
-        assert np.allclose(g[f"{name}_decoded"], g[f"{name}_sample"], rtol=0, atol=1e-5), name
+    oracle.set_lut(_tf_lut())
+    try:
+        for name in g["names"]:
+            name = str(name)
+            f = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+            S = int(f["n_samples"])
+            for mode in (oracle.LITERAL, oracle.CANONICAL):
+                idx, sample = oracle.encode_block(f["q_loc"], f["q_scale"], f["p_loc"], f["p_scale"], int(f["seed"]),
+                                                  float(f["kl_per_partition"]), S, int(f["n_beams"]), mode=mode)
+                assert idx == g[f"{name}_indices"].tolist(), (name, mode)
+            assert np.allclose(sample, g[f"{name}_sample"], rtol=0, atol=1e-5), name          # north_star: 1e-5 on reconstructions
+            assert np.allclose(g[f"{name}_decoded"], g[f"{name}_sample"], rtol=0, atol=1e-5), name
+    finally:
+        oracle.set_lut(None)
 
 
 @pytest.mark.gpu
@@ -110,11 +123,12 @@ def test_tf_encode_block_indices_hip(engine):
     import irec
     import torch
     g = _enc()
+    eng = irec.Engine(engine.device, lut=_tf_lut())      # TensorFlow's own quantile table at the boundary (irec_create_ex)
     for name in g["names"]:
         name = str(name)
         f = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
         c = irec.BeamSearchCoder(kl_per_partition=float(f["kl_per_partition"]), n_beams=int(f["n_beams"]),
-                                 extra_samples=float(f["extra_samples"]))
+                                 extra_samples=float(f["extra_samples"]), engine=eng)
         q = torch.distributions.Normal(torch.as_tensor(f["q_loc"][None]).cuda(), torch.as_tensor(f["q_scale"][None]).cuda(), validate_args=False)
         p = torch.distributions.Normal(torch.as_tensor(f["p_loc"][None]).cuda(), torch.as_tensor(f["p_scale"][None]).cuda(), validate_args=False)
         idx, sample = c.encode(q, p, seed=int(f["seed"]))
