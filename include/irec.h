@@ -223,8 +223,10 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
 
 /* BeamSearchCoder.decode_block on n_blocks blocks -- beam_search_coder.py:124-148 (GaussianCoder.decode, coder.py:459-491).
  *   K [n_blocks], indices [n_blocks, max_K] in ENCODER order (idx[t] = choice at iteration t).  A row with K < 0 or
- *   K > max_K (what the encoder leaves for a block it did not code) is not decodable: the block's elements are returned as
- *   p_loc -- by every decode entry point. */
+ *   K > max_K (what the encoder leaves for a block it did not code), or one that holds an index outside [0, n_samples) (a
+ *   damaged or foreign stream; the reference fails in tf.gather), is not decodable: the block's elements are returned as
+ *   p_loc -- by every decode entry point, and no table row outside the call's tables is ever addressed.  So is a block whose
+ *   dim exceeds the call's bound (max_block_dim, or the largest listed table dim when there is none). */
 irec_status irec_beam_decode(irec_context *ctx, const irec_params *p, int64_t n_blocks, const int64_t *block_base,
                              const int32_t *block_pos, const int32_t *block_dim, const int32_t *perm,
                              const float *p_loc, const float *p_scale, int64_t seed, int32_t max_K, const int32_t *K,

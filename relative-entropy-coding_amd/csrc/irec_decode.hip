@@ -62,11 +62,15 @@ __device__ __forceinline__ float dec_sqrt_core(float x) {
 __device__ __forceinline__ bool dec_sqrt_core_ok(float x) {   // inputs the core handles as sqrtf does
   return !(x < 0x1.0p-96f) || x == 0.0f;                       // (NaN compares false: allowed; negatives: sqrtf's NaN either way, but keep them on the slow path)
 }
+// `bad` (wave-uniform on return): an index of the row is not a sample index (>= S: a damaged or foreign stream).  The reference
+// would fail in tf.gather (beam_search_coder.py:141-146); here the block is "not decodable" like a row with K out of range --
+// and the proposal-table row it would have addressed is never read (the fused draw is memory-safe for any index).
 template <bool TABLE, bool FAST>
 __device__ __forceinline__ float decode_unit_run(const DecArgs &A, const int32_t *idx, int K, int D, int Dp, const uint16_t *tab,
                                                 const uint16_t *dlog_f, uint32_t row_off, int lane, const float (&var_p)[4],
-                                                float (&sample)[4]) {
+                                                float (&sample)[4], bool &bad) {
   float c[4];
+  bad = false;
   float amin = 1.0f;                                      // smallest auxiliary variance seen (FAST: what the short sqrt was fed)
 #pragma unroll
   for (int i = 0; i < 4; ++i) { c[i] = 0.f; sample[i] = 0.f; }
@@ -75,6 +79,7 @@ __device__ __forceinline__ float decode_unit_run(const DecArgs &A, const int32_t
     const int nt = K - t0 < 64 ? K - t0 : 64;
     // lane j: step t0 + j
     const uint32_t idxv = lane < nt ? (uint32_t)idx[t0 + lane] : 0u;
+    if (__ballot(idxv >= (uint32_t)A.S)) { bad = true; return amin; }   // (wave-uniform; before any row of this chunk is addressed)
     uint32_t incl = idxv * (uint32_t)(69 + t0 + lane);
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -139,11 +144,18 @@ template <bool TABLE>
 __device__ __forceinline__ void decode_unit(const DecArgs &A, const int32_t *idx, int K, int D, int Dp, const uint16_t *tab,
                                             const uint16_t *dlog_f, uint32_t row_off, int lane, const float (&var_p)[4],
                                             float (&sample)[4]) {
+  bool bad = false;
+  auto undecodable = [&]() {          // the block's elements come out as mu_p, as for a row with K out of range
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sample[i] = 0.f;
+  };
   if constexpr (IREC_DEC_FAST_SQRT != 0) {
-    const float amin = decode_unit_run<TABLE, true>(A, idx, K, D, Dp, tab, dlog_f, row_off, lane, var_p, sample);
+    const float amin = decode_unit_run<TABLE, true>(A, idx, K, D, Dp, tab, dlog_f, row_off, lane, var_p, sample, bad);
+    if (bad) { undecodable(); return; }
     if (__builtin_expect(__ballot(!dec_sqrt_core_ok(amin)) == 0ull, 1)) return;   // wave-uniform
   }
-  decode_unit_run<TABLE, false>(A, idx, K, D, Dp, tab, dlog_f, row_off, lane, var_p, sample);
+  decode_unit_run<TABLE, false>(A, idx, K, D, Dp, tab, dlog_f, row_off, lane, var_p, sample, bad);
+  if (bad) undecodable();
 }
 
 template <bool TABLE>
@@ -171,10 +183,18 @@ __global__ __launch_bounds__(DEC_NT) __attribute__((amdgpu_waves_per_eu(6, 8))) 
     const int64_t blk = u / upb;
     const int chunk = (int)(u - blk * upb);
     const int D = A.block_dim[blk];
-    if (chunk * 256 >= D || D > upb * 256) continue;        // (a short block has fewer units than upb; one beyond the host's bound is not decoded)
-    const int K = A.K[blk];
     const int64_t base = A.block_base[blk];
     const int32_t pos = A.block_pos[blk];
+    if (D > upb * 256) {                                    // beyond the host's bound (a call without max_block_dim whose dim hints
+      if (chunk == 0)                                       // do not list this block): not decodable -- mu_p, as every such block
+        for (int d = lane; d < D; d += 64) {
+          const int64_t ixo = base + (A.perm ? A.perm[pos + d] : pos + d);
+          A.out_sample[ixo] = 0.f + A.p_loc[ixo];
+        }
+      continue;
+    }
+    if (chunk * 256 >= D) continue;                         // (a short block has fewer units than upb)
+    const int K = A.K[blk];
     const int32_t *idx = A.indices + blk * (int64_t)A.max_K;
     const int d0 = chunk * 256 + lane * 4;
     const bool live = d0 < D;
@@ -341,7 +361,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(IREC_DEC_W
       for (int i = 0; i < 4; ++i) {
         const int e = pos + (d0 + i < D ? d0 + i : 0);
         at[i] = (A.perm && !(IREC_DEC_ABLATE & 4)) ? A.perm[e] : e;
-        const float sp = region[at[i]];
+        // (a padding lane owns no element: position `pos` belongs to the block's chunk-0 unit, which may already have written
+        //  its sample there -- a zero variance keeps the lane's chain at zero and out of the slow-sqrt test)
+        const float sp = d0 + i < D ? region[at[i]] : 0.f;
         var_p[i] = sp * sp;
       }
       if (K >= 0 && K <= A.max_K) {                         // (else not decodable: its elements come out as mu_p)
@@ -481,7 +503,10 @@ __global__ __launch_bounds__(256) void decode_kernel(DecArgs A) {
     const int32_t pos = A.block_pos[blk];
     const int K = A.K[blk];
     const int32_t *idx = A.indices + blk * (int64_t)A.max_K;
-    if (K > A.max_K || K < 0) {                               // not decodable: its elements come out as mu_p
+    bool bad_idx = false;                                     // (every thread reads the same row: uniform over the workgroup)
+    if (K >= 0 && K <= A.max_K)
+      for (int t = 0; t < K; ++t) bad_idx |= (uint32_t)idx[t] >= (uint32_t)A.S;
+    if (K > A.max_K || K < 0 || bad_idx) {                    // not decodable: its elements come out as mu_p
       for (int d = tid; d < D; d += 256) {
         const int64_t ixo = base + (A.perm ? (int64_t)A.perm[pos + d] : (int64_t)(pos + d));
         A.out_sample[ixo] = 0.f + A.p_loc[ixo];

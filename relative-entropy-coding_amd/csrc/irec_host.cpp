@@ -886,6 +886,17 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
         for (int k = 0; k < 11; ++k) fprintf(stderr, "  %-20s %5.1f%% (%8.0f) | %5.1f%% (%8.0f)\n", nm[k], 100 * w0[k] / t0, w0[k] / (n0 ? n0 : 1), 100 * wo[k] / to, wo[k] / (no ? no : 1));
         fprintf(stderr, "  cycles per wave: %.0f | %.0f;  block-steps per wave: %.2f;  cycles per block-step: %.0f\n", t0 / (n0 ? n0 : 1), to / (no ? no : 1),
                 w0[11] / (n0 ? n0 : 1), w0[11] > 0 ? t0 / w0[11] : 0.0);
+        {   // idle tail of the persistent grid: wave-time between a wave's exit and the last wave's (slot 12 = a wave's lifetime)
+          double life_max = 0, life_sum = 0, life_min = 1e300;
+          int nlife = 0;
+          for (int w = 0; w < tgrid * nwv; ++w) {
+            const double v = (double)h[(size_t)w * 16 + 12];
+            if (v <= 0) continue;
+            life_max = std::max(life_max, v); life_min = std::min(life_min, v); life_sum += v; ++nlife;
+          }
+          if (nlife) fprintf(stderr, "  idle tail: %.1f%% of the grid's wave-time lies behind a wave's exit (first exit at %.1f%% of the longest lifetime)\n",
+                             100.0 * (1.0 - life_sum / (nlife * life_max)), 100.0 * life_min / life_max);
+        }
         if (h[13]) fprintf(stderr, "  shader clock of workgroup 0, wave 0: %.0f MHz over %.3f ms (s_memtime / s_memrealtime)\n",
                            100.0 * (double)h[12] / (double)h[13], (double)h[13] / 1e5);
         return IREC_OK;

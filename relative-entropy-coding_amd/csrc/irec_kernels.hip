@@ -791,6 +791,16 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
       } // sample passes
       const int Ng = S * Bcur;                                  // candidates of the step over all workgroups
       const int Bnew = B < Ng ? B : Ng;
+      const bool last = (t == K - 1);
+      // Beam-split build (r04): this step's sample scale is copied and the NEXT step's IEEE constants (six divisions and a
+      // square root per dim: ~3 k cycles of one wave per SIMD) are formed HERE, between publishing my keys and sweeping the
+      // partners' -- they depend on t only, not on the selection -- instead of in the update behind it: the wait for the
+      // partners (4.3 k cycles per step, profiles/r04a/stamps.log) absorbs them.
+      float sa_now[4] = {sa[0], sa[1], sa[2], sa[3]};
+      float m_nx[4] = {0.f, 0.f, 0.f, 0.f}, cA_nx[4] = {0.f, 0.f, 0.f, 0.f}, cBv_nx[4] = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (beam_mode) {
+        if (active && !last) step_consts(t + 1, m_nx, cA_nx, cBv_nx);
+      }
       if (A.dbg && tid == 0) { const unsigned long long now_ = stamp_now(); A.dbg[(size_t)blockIdx.x * 16 + 11] += now_ - stamp_prev; } // combine
       if (coop_W > 1) {
         // ---- split encoder: every workgroup of the block publishes the sort keys of ITS candidates at their global flat
@@ -910,19 +920,22 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
       select_topB<NT>(key_s, Ng, Bnew, Bcur, sm, A.dbg ? A.dbg + (size_t)blockIdx.x * 16 : nullptr); // first barrier inside orders key_s writes
       IREC_STAMP(2);
       // ---------------- new hashes / back-pointers (beam_search_coder.py:94-95) ----------------
+      // (the discrete log of the new hash is a load from the global table when the proposals come from tables: it is issued
+      //  here and stored into the LDS behind the update, whose own loads it then waits under -- nobody reads the next step's
+      //  offsets before the barrier that closes the update)
+      uint32_t beta_new = 0u;
       if (tid < Bnew) {
         const int32_t sp_ = sel_s[tid], bp_ = sel_b[tid];
         const int32_t nh = (int32_t)((uint32_t)hsum[cur * 64 + bp_] + (uint32_t)sp_ * (uint32_t)(69 + t));
         hsum[(cur ^ 1) * 64 + tid] = nh;
-        beta4[(cur ^ 1) * 64 + tid] = dlog_s[hash_from_sum(nh) - 1u];
+        beta_new = dlog_s[hash_from_sum(nh) - 1u];
         bp[(size_t)t * NB + tid] = (sp_ << 6) | bp_;
       }
       // ---------------- gather the surviving beams (beam_search_coder.py:92-93), prepare the next step ----------------
-      const bool last = (t == K - 1);
       __builtin_amdgcn_s_setprio(2); // serial phase: ahead of the co-resident workgroup's scoring waves
       if (active && beam_mode) {
         // beam mode: only the new beams that land in my slots; parents come from (and new beams go to) the block's shared slab
-        const float sa_t[4] = {sa[0], sa[1], sa[2], sa[3]};
+        const float sa_t[4] = {sa_now[0], sa_now[1], sa_now[2], sa_now[3]};
         const float *bold = beams_blk + ((size_t)cur * NB) * FAST_MAX_DIM + d0;
         float *bnew = beams_blk + ((size_t)(cur ^ 1) * NB) * FAST_MAX_DIM + d0;
         uint2 apv[NOWN];
@@ -946,8 +959,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
             }
           }
         }
-        float m[4] = {0.f, 0.f, 0.f, 0.f}, cA[4] = {0.f, 0.f, 0.f, 0.f}, cBv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (!last) step_consts(t + 1, m, cA, cBv); // next step's constants, under the loads' latency
+        const float (&m)[4] = m_nx, (&cA)[4] = cA_nx, (&cBv)[4] = cBv_nx;   // next step's constants: formed under the partners' wait
 #pragma unroll
         for (int o = 0; o < NOWN; ++o) {
           const int j = coop_w + o * coop_W;
@@ -1072,6 +1084,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
           if (sw == 0 && (lane & 1) == 0 && j < Bnew) cpart_s[g * 32 + j] = ctot;
         }
       }
+      if (tid < Bnew) beta4[(cur ^ 1) * 64 + tid] = beta_new;
       __syncthreads();
       __builtin_amdgcn_s_setprio(0);
       IREC_STAMP(3);

@@ -390,6 +390,10 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 
     TSTAMP(1);
     int cur = 0, Bcur = 1;
+    // 4 * dlog(hash) of the live beams, lane j = beam j: every wave carries its own copy from the update into the next step's
+    // scoring (r04: the table look-up behind it is a GLOBAL load; it used to sit inside the one-wave selection, a round trip
+    // to the L2 on the path every wave of the team waits on)
+    uint32_t bv_cur = 0u;                                            // hash of the empty path is 1 = g^0
     for (int t = 0; t < K; ++t) {
 #ifdef IREC_TEAM_STAMPS
       st_acc[11] += 1ull;                                            // (diagnostic build: block-steps of this wave)
@@ -402,9 +406,8 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
       const uint16_t *tab_t = tab_tu + tab_lo;
       uint32_t bet[NBW];
       {
-        const uint32_t bv = beta4[cur * TEAM_MB + (lane < Bcur ? lane : 0)]; // one LDS round trip, then cross-lane reads
 #pragma unroll
-        for (int b = 0; b < NBW; ++b) bet[b] = (uint32_t)__builtin_amdgcn_readlane((int)bv, b_lo + b);
+        for (int b = 0; b < NBW; ++b) bet[b] = (uint32_t)__builtin_amdgcn_readlane((int)bv_cur, b_lo + b);
       }
       const int nlive = Bcur - b_lo < 0 ? 0 : (Bcur - b_lo < NBW ? Bcur - b_lo : NBW);   // live beams of my stripe
 
@@ -762,8 +765,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
       // (:94-95) and notes its parent's table offset, so one barrier publishes everything the update needs
       select_topB_sync<NT>(key_s, N, Bnew, Bcur, sm, tid, tsync, nullptr, [&](int j, int32_t sp_, int32_t bp_, uint32_t) {
         const int32_t nh = (int32_t)((uint32_t)hsum[cur * TEAM_MB + bp_] + (uint32_t)sp_ * (uint32_t)(69 + t));
-        hsum[(cur ^ 1) * TEAM_MB + j] = nh;
-        beta4[(cur ^ 1) * TEAM_MB + j] = dlog_s[hash_from_sum(nh) - 1u];
+        hsum[(cur ^ 1) * TEAM_MB + j] = nh;                    // (its discrete log: looked up by every wave in the update, below)
         sm->sel_bo[j] = beta4[cur * TEAM_MB + bp_];
         bp[(size_t)t * NB + j] = (sp_ << 6) | bp_;
       });
@@ -772,6 +774,12 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
       // ---------------- gather the surviving beams (beam_search_coder.py:92-93), prepare the next step ----------------
       const bool last = (t == K - 1);
       __builtin_amdgcn_s_setprio(2); // serial phase: ahead of the other team's scoring waves
+      // new beams' table offsets: lane j looks up dlog(hash(path_j)) -- a global load, consumed at the end of the update
+      uint32_t bv_new;
+      {
+        const int32_t nh = hsum[(cur ^ 1) * TEAM_MB + (lane < Bnew ? lane : 0)];
+        bv_new = dlog_s[hash_from_sum(nh) - 1u];
+      }
 #ifdef IREC_ABLATE_UPDATE
       if (false) {
 #else
@@ -902,6 +910,9 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
       }
       TSTAMP(6);
       __builtin_amdgcn_s_setprio(0);
+      // (wave 0 keeps the LDS copy for the parent look-up of the next selection, which it runs itself: same wave, program order)
+      if (tid < Bnew) beta4[(cur ^ 1) * TEAM_MB + tid] = bv_new;
+      bv_cur = bv_new;
       // no barrier here: the new C_b partials, hashes and beams are first read behind the next step's barriers
       cur ^= 1;
       Bcur = Bnew;

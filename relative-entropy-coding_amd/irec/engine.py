@@ -242,12 +242,31 @@ class Engine:
                                           self._stream()), "irec_block_kl")
         return out_kl, out_K
 
-    def encode_blocks(self, params, lay, q_loc, q_scale, p_loc, p_scale, seed, max_K, out=None):
+    def encode_blocks(self, params, lay, q_loc, q_scale, p_loc, p_scale, seed, max_K, out=None, order_by_K=False):
         """Asynchronous.  Returns device tensors (K [n_blocks], indices [n_blocks, max_K], sample [like q_loc]),
-        rows in `lay` order."""
+        rows in `lay` order.
+        order_by_K: hand the blocks to the persistent kernel LONGEST FIRST -- K = ceil(KL / Omega) of every block from
+        irec_block_kl (beam_search_coder.py:57-59; an HBM-bound pre-pass, ~0.5 % of a batch call), rows sorted by K x dims on
+        the device, outputs scattered back to `lay` order -- instead of largest-dim first only: posteriors whose KL differs by
+        orders of magnitude between tensors otherwise leave the call waiting for a few long blocks that were handed out late."""
         for t in (q_loc, q_scale, p_loc, p_scale):
             assert t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device
             assert t.numel() == lay.n_tensors * lay.n
+        if order_by_K and lay.n_blocks > 1:
+            _, K0 = self.block_kl(params, lay, q_loc, q_scale, p_loc, p_scale)
+            work = K0.to(torch.int64).clamp_(min=0) * lay.block_dim.to(torch.int64)
+            order = torch.argsort(work, descending=True, stable=True)
+            sub = object.__new__(BlockLayout)
+            sub.__dict__.update(lay.__dict__)
+            sub.block_base, sub.block_pos, sub.block_dim = lay.block_base[order], lay.block_pos[order], lay.block_dim[order]
+            sub.natural, sub._natural_dev = None, None
+            K2, idx2, sample = self.encode_blocks(params, sub, q_loc, q_scale, p_loc, p_scale, seed, max_K,
+                                                  out=None if out is None else (torch.empty_like(out[0]), torch.empty_like(out[1]), out[2]))
+            if out is None:
+                out = (torch.empty_like(K2), torch.empty_like(idx2), sample)
+            out[0][order] = K2
+            out[1][order] = idx2
+            return out[0], out[1], sample
         params = self.with_table_dims(params, lay)
         if out is None:
             out_K = torch.empty(lay.n_blocks, dtype=torch.int32, device=self.device)

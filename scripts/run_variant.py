@@ -14,8 +14,11 @@ flags |= irec._lib.IREC_FLAG_SHAPE[os.environ.get("SHAPE", "default")]   # team-
 flags |= int(os.environ.get("SPLIT_W", "0")) << 12                         # split-encoder width (diagnostics)
 if os.environ.get("NO_SPLIT"): flags |= 16
 if os.environ.get("SPLIT_SAMPLES"): flags |= 128                                      # split encoder: samples, not beams
-params = eng.params(omega, S, B, flags)
-q = bench.synthetic_batch(L, eng.device, 0)
+max_K = int(os.environ.get("MAXK", "32"))
+params = eng.params(omega, S, B, flags, table_steps=int(os.environ.get("TABLE_STEPS", "0")))
+# SKEW=1: per-tensor log-normal scale on delta (bench.skewed_batch): K from 1 to 60 inside one call
+q = bench.skewed_batch(L, eng.device, 0) if os.environ.get("SKEW") else bench.synthetic_batch(L, eng.device, 0)
+by_K = bool(os.environ.get("ORDER_BY_K"))
 lay = eng.layout(L, bench.N_DIMS, bench.BLOCK_SIZE, bench.SEED)
 order = os.environ.get("ORDER", "")   # diagnostic: the order in which the persistent kernel meets the blocks
 if order:
@@ -43,9 +46,9 @@ if order:
     assert sorted(rows.tolist()) == list(range(lay.n_blocks))
     lay = lay.subset(rows)
 out = None
-print("plan:", eng.plan(params, lay, 32)["kernel"], flush=True)
+print("plan:", eng.plan(params, lay, max_K)["kernel"], flush=True)
 for i in range(int(os.environ.get("REPS", "3"))):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    out = eng.encode_blocks(params, lay, *q, bench.SEED, 32)
+    out = eng.encode_blocks(params, lay, *q, bench.SEED, max_K, order_by_K=by_K)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"{variant} B={B} S={S}: {dt * 1e3:.2f} ms for {L} latents -> {L / dt:.0f} latents/s", flush=True)

@@ -30,6 +30,36 @@ def test_launcher_starts_n_ranks_cpu_rig(n):
     assert res["steps"] == 2 and res["warmup"] == 1
 
 
+def test_driver_command_rehearsal_eight_ranks():
+    """The driver's own N = 8 command line, rehearsed on the CPU (gloo, launch-only: rendezvous, sharding exchange, max-over-ranks
+    timing and the JSON contract -- no GPU work): `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 8 --steps K --warmup W`.  One JSON line from rank 0 with n_gpus = world_size = 8,
+    eight per-rank entries, weak scaling, and neither the secondary configurations nor the CPU baselines (they run at N = 1 only)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"IREC_BENCH_LAUNCH_ONLY": "1", "OMP_NUM_THREADS": "1"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), BENCH, "--gpus", "8", "--steps", "3", "--warmup", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["world_size"] == 8 and res["ranks_timed"] == 8
+    assert len(res["per_rank_latents_per_s"]) == 8 and all(v > 0 for v in res["per_rank_latents_per_s"])
+    assert res["scaling"] == "weak" and res["steps"] == 3 and res["warmup"] == 2 and res["higher_is_better"] is True
+    assert "cpu_baseline" not in res and "cpu_baseline_opt" not in res and "secondary" not in res
+    assert res["metric"] == "encoded latents/sec" and res["unit"] == "latents/s" and res["value"] is None   # never a measurement
+    # the launcher form of the same job (`python bench.py --gpus 8`: the parent starts the ranks itself)
+    r2 = _run(["--gpus", "8", "--steps", "1", "--warmup", "1"], {"IREC_BENCH_LAUNCH_ONLY": "1", "OMP_NUM_THREADS": "1"}, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    res2 = json.loads([ln for ln in r2.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res2["n_gpus"] == 8 and res2["world_size"] == 8 and len(res2["per_rank_latents_per_s"]) == 8
+
+
 def test_world_size_mismatch_is_an_error():
     r = _run(["--gpus", "2"], {"IREC_BENCH_LAUNCH_ONLY": "1", "WORLD_SIZE": "3", "RANK": "0"}, timeout=60)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
@@ -47,7 +77,7 @@ def test_a_failing_rank_fails_the_job():
 
 @pytest.mark.gpu
 def test_two_ranks_on_one_gpu_over_gloo():
-    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--latents", "128", "--no-cpu-baseline"],
+    r = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--latents", "4096", "--no-cpu-baseline"],
              {"IREC_DIST_BACKEND": "gloo"}, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])

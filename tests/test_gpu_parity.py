@@ -724,6 +724,95 @@ def test_decoder_leaves_mu_p_on_rows_it_cannot_decode(engine, oracle):
         assert torch.equal(rec, want), mode
 
 
+def test_skewed_partition_counts_match_the_oracle(engine, oracle):
+    """Heavy-tailed K inside one call (per-tensor log-normal scale on delta: K from 1 to 60 and more; real posteriors differ by
+    orders of magnitude in KL between residual blocks, resnet_vae.py:462-476): blocks beyond the default table window take the
+    second pass, long and short blocks share teams.  Indices, K and samples against the oracle on 12 tensors, as listed and
+    with the blocks handed out longest first (Engine.encode_blocks(order_by_K=True)); both orders bit-identical everywhere;
+    decode(encode) exact."""
+    import bench
+    n_t = 96
+    q = bench.skewed_batch(n_t, engine.device, 0)
+    lay = engine.layout(n_t, 8192, 1000, 42)
+    S = 36
+    for table_steps in (0, 128):                       # default window (32 steps: the long blocks are deferred) / everything from tables
+        params = engine.params(3.0, S, 20, table_steps=table_steps)
+        K, idx, sample = engine.encode_blocks(params, lay, *q, 42, 128)
+        K2, idx2, sample2 = engine.encode_blocks(params, lay, *q, 42, 128, order_by_K=True)
+        Kh = K.cpu().numpy()
+        assert Kh.min() >= 0 and Kh.max() >= 40 and Kh.max() <= 128, (int(Kh.min()), int(Kh.max()))
+        assert torch.equal(K, K2) and torch.equal(sample, sample2)
+        ih, ih2 = idx.cpu().numpy(), idx2.cpu().numpy()
+        for r in range(lay.n_blocks):
+            assert np.array_equal(ih[r, :Kh[r]], ih2[r, :Kh[r]]), r
+        assert torch.equal(engine.decode_blocks(params, lay, q[2], q[3], 42, K, idx), sample)
+    c = 12
+    hb = [t[:c].cpu().numpy() for t in q]
+    ridx, rsamp, _ = oracle.encode_tensors_omp(*hb, 42, 3.0, S, 20, 1000, max_K=128)
+    bpt = lay.blocks_per_tensor
+    sh = sample[:c].cpu().numpy()
+    for i in range(c):
+        for j in range(bpt):
+            row = lay.natural[i * bpt + j]
+            assert ih[row, :Kh[row]].tolist() == ridx[i][j], (i, j)
+        assert np.array_equal(sh[i], rsamp[i]), i
+
+
+def test_decoder_refuses_indices_that_are_no_sample_index(engine, oracle):
+    """An index row holding a value outside [0, S) -- a .rec file written with another max_index, a corrupt stream -- must not
+    become an out-of-bounds read of the proposal tables (round 3's table path addressed row `index` unchecked): the block is
+    not decodable, its elements come out as p.loc in every decode mode, every other block exactly."""
+    n_t, n, bs, S = 4, 8192, 1000, 36
+    stats = [oracle.synthetic_latent(7300 + i, n) for i in range(n_t)]
+    ql, qs, pl, ps = (torch.from_numpy(np.stack([s[k] for s in stats])).cuda().contiguous() for k in range(4))
+    lay = engine.layout(n_t, n, bs, 42)
+    params = engine.params(3.0, S, 20)
+    K, idx, sample = engine.encode_blocks(params, lay, ql, qs, pl, ps, 42, 40)
+    bpt = lay.blocks_per_tensor
+    bad = [(0, 0, 0, S), (1, 8, 1, 10 ** 6), (2, 3, 2, -1), (3, 5, 0, 2 ** 31 - 1)]     # (tensor, block, step, value)
+    idx2 = idx.clone()
+    Kh = K.cpu().numpy()
+    want = sample.clone()
+    perm = torch.from_numpy(oracle.tf_shuffle_perm(42, n).astype(np.int64)).cuda()
+    for i, j, t, v in bad:
+        row = int(lay.natural[i * bpt + j])
+        idx2[row, min(t, int(Kh[row]) - 1)] = v
+        lo, hi = oracle.split_blocks(n, bs)[j]
+        g = perm[lo:hi]
+        want[i, g] = pl[i, g]
+    for mode in ("auto", "tensors", "tensors_fused", "tables", "fused", "legacy"):
+        rec = engine.decode_blocks(params, lay, pl, ps, 42, K, idx2, mode=mode)
+        assert torch.equal(rec, want), mode
+    # values past the block's K are not part of the row: they may hold anything
+    idx3 = idx.clone()
+    for r in range(lay.n_blocks):
+        idx3[r, int(Kh[r]):] = 10 ** 6
+    for mode in ("auto", "tables", "fused", "legacy"):
+        assert torch.equal(engine.decode_blocks(params, lay, pl, ps, 42, K, idx3, mode=mode), sample), mode
+
+
+def test_decoder_without_a_dim_bound_leaves_mu_p_on_unlisted_blocks(engine, oracle):
+    """irec_beam_decode (no workspace, no max_block_dim) sizes its units from the listed table dims; a block with more dims
+    than they cover used to be skipped with its output elements left uninitialised.  It is 'not decodable': p.loc."""
+    n = 3000
+    mq, sq, mp, sp = oracle.synthetic_latent(7400, n)
+    ql, qs, pl, ps = (torch.from_numpy(a[None]).cuda().contiguous() for a in (mq, sq, mp, sp))
+    lay = engine.layout(1, n, 1000, 42)
+    params = engine.params(3.0, 36, 20)
+    K, idx, sample = engine.encode_blocks(params, lay, ql, qs, pl, ps, 42, 40)
+    hinted = engine.params(3.0, 36, 20, table_dims=(200,))           # lists 200-dim blocks only: one 256-dim unit per block
+    out = torch.full_like(pl, float("nan"))
+    irec_lib = engine.lib
+    import irec
+    irec._lib.check(irec_lib.irec_beam_decode(engine.ctx, ctypes.byref(hinted), lay.n_blocks, ctypes.c_void_p(lay.block_base.data_ptr()),
+                                              ctypes.c_void_p(lay.block_pos.data_ptr()), ctypes.c_void_p(lay.block_dim.data_ptr()),
+                                              ctypes.c_void_p(lay.perm.data_ptr()), ctypes.c_void_p(pl.data_ptr()), ctypes.c_void_p(ps.data_ptr()),
+                                              42, 40, ctypes.c_void_p(K.data_ptr()), ctypes.c_void_p(idx.data_ptr()),
+                                              ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                    "irec_beam_decode")
+    assert torch.equal(out, pl)                                        # every block has 1000 dims: none is decodable, none is garbage
+
+
 @pytest.mark.parametrize("flags", [8, 0, 4, 2], ids=["table", "auto", "one_table", "fused"])
 def test_full_size_properties(engine, oracle, flags):
     """BASELINE config 2 at bench size: properties that need no oracle run (round trip, ranges), plus a sampled
