@@ -494,6 +494,7 @@ struct Plan {
   bool team;         // table && two-teams-per-CU encoder over three table copies (the default where it applies)
   bool team_only;    // B > 32: no one-table / fused fast encoder exists; the team encoder takes every call, the generic kernel its deferred pass
   bool lone;         // team && one beam: the one-wave-per-block encoder (irec_lone.hip) stands in for the team encoder
+  bool chunk;        // blocks of more than 1024 dims (block_size = None, 2048, ...): encode_chunk_kernel over the team encoder's tables
   int shape;         // team-encoder workgroup shape override (IREC_FLAG_SHAPE_*; 0 = default)
   int grid_cap;      // scratch slabs = resident workgroups / teams (persistent kernels pull blocks from an atomic counter)
   int one_grid_cap;  // resident workgroups of the one-workgroup-per-block encoder of this plan (small calls of a team plan too)
@@ -533,7 +534,7 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
   pl.fast = !(p->flags & IREC_FLAG_FORCE_GENERIC) && max_dim <= irec::FAST_MAX_DIM && irec::fast_nb_for(B) != 0 &&
             irec::fast_lds_for(B, S, false) <= irec::FAST_LDS_LIMIT && (int64_t)S * B < (1 << 24);
   pl.grid_cap = 2 * n_cu; // measured residency: 2 workgroups per CU for every encoder
-  pl.table = false; pl.team = false; pl.lone = false; pl.n_tab = 0; pl.tab_bytes = 0;
+  pl.table = false; pl.team = false; pl.lone = false; pl.chunk = false; pl.n_tab = 0; pl.tab_bytes = 0;
   // table window: the tables cover the first K_tab partitions; blocks with more go to the fused-Philox second pass
   const int want = p->table_steps > 0 ? p->table_steps : IREC_TABLE_STEPS_DEFAULT;
   pl.K_tab = std::max(1, std::min(std::min(want, IREC_TABLE_STEPS_MAX), max_K > 0 ? max_K : 1));
@@ -562,6 +563,22 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
     pl.lone = pl.team && irec::lone_applies(B, pl.shape);
   }
   if (!pl.table) pl.team_only = false;
+  // Blocks of more than 1024 dims -- Coder.__init__ takes any block_size, None (the whole tensor as one block) included,
+  // coder.py:29-36,415-419 -- are walked in chunks of 1024 by encode_chunk_kernel (irec_team.hip); its second pass and
+  // everything it does not serve (B > 20, more samples than one pass holds, no dim hints) is the generic kernel's.
+  pl.chunk = !pl.fast && !pl.team_only && !(p->flags & (IREC_FLAG_FORCE_GENERIC | IREC_FLAG_FUSED_PHILOX | IREC_FLAG_ONE_TABLE)) &&
+             p->table_dims[0] > 0 && irec::chunk_applies(B, S, max_dim);
+  if (pl.chunk) {
+    pl.table = true;
+    for (int q = 0; q < 4 && p->table_dims[q] > 0; ++q) {
+      if (p->table_dims[q] > max_dim) { pl.table = false; break; }
+      pl.tab_dim[pl.n_tab] = p->table_dims[q];
+      pl.tab_off[pl.n_tab] = pl.tab_bytes;
+      pl.tab_bytes += round_up_sz((size_t)pl.K_tab * S * round_up(p->table_dims[q], 4) * 2, 256);
+      ++pl.n_tab;
+    }
+    if (!pl.table) { pl.chunk = false; pl.n_tab = 0; pl.tab_bytes = 0; }
+  }
   // resident workgroups of the one-workgroup-per-block encoders: two per CU, one for the big-LDS 8-wave configurations
   auto one_cap = [&](bool table) { return (irec::fast_waves_for(B, S, table) == 8 ? 1 : 2) * n_cu; };
   if (pl.fast) {
@@ -581,6 +598,11 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
       pl.fast_grid_cap = 2 * n_cu;
       pl.grid_cap = std::max(pl.grid_cap, pl.fast_grid_cap);
       pl.ws_per_wg = std::max(generic_ws, round_up_sz(irec::team_ws_bytes_for(B, S, pl.shape, max_K), 256));
+    } else if (pl.chunk) {   // one slab per team of the chunked encoder; the generic kernel's second pass lies over the same slabs
+      pl.one_grid_cap = 0;
+      pl.fast_grid_cap = 2 * n_cu;
+      pl.grid_cap = std::max(irec::chunk_teams() * n_cu, pl.fast_grid_cap);
+      pl.ws_per_wg = std::max(generic_ws, round_up_sz(irec::chunk_ws_for(B, pl.dpad, max_K), 256));
     } else {
       pl.one_grid_cap = pl.grid_cap; pl.fast_grid_cap = 0;
       pl.ws_per_wg = generic_ws;
@@ -603,7 +625,7 @@ static int batch_grid(int64_t n_blocks, int cap) {
 // (they wait for each other every step), so the grid stays within HALF the CUs -- room for a second such call on another
 // stream -- and W within what the exchange buffers hold.  0 = not split.
 int split_width(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks) {
-  if (!pl.table || (p->flags & IREC_FLAG_NO_SPLIT)) return 0;
+  if (!pl.table || pl.chunk || (p->flags & IREC_FLAG_NO_SPLIT)) return 0;
   const int B = p->n_beams, S = p->n_samples, nb = irec::fast_nb_for(B);
   if (!nb || irec::fast_waves_for(B, S, true) != 4 || (int64_t)S * nb > 1024) return 0;   // aliased-key 4-wave builds only
   if (n_blocks < 1 || n_blocks > irec::COOP_MAX_BLOCKS) return 0;
@@ -680,7 +702,15 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
   const bool team = team_for_call(pl, p, n_blocks);
   std::memset(out, 0, sizeof(*out));
   const int B = p->n_beams, S = p->n_samples;
-  if (team && pl.lone) {
+  if (pl.chunk) {
+    const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+    std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::chunk_kernel_name(B));
+    std::snprintf(out->table_kernel, sizeof out->table_kernel, "alpha_choice_kernel");
+    out->grid = batch_grid(n_blocks, n_cu);
+    out->waves_per_wg = irec::chunk_teams() * 4;
+    out->teams_per_wg = irec::chunk_teams();
+    out->lds_bytes = (int32_t)irec::chunk_lds_for(B, S);
+  } else if (team && pl.lone) {
     const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
     std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::lone_kernel_name());
     std::snprintf(out->table_kernel, sizeof out->table_kernel, "alpha_choice_kernel");
@@ -799,7 +829,7 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   if (pl.table)
     for (int q = 0; q < pl.n_tab; ++q) {
       uint32_t *w = stamps.w[q];
-      w[0] = 0x7ab1e000u | (pl.team ? 1u : 2u);
+      w[0] = 0x7ab1e000u | ((pl.team || pl.chunk) ? 1u : 2u);   // (rows with copy bits / plain byte offsets)
       w[1] = (uint32_t)(uint64_t)seed; w[2] = (uint32_t)((uint64_t)seed >> 32);
       w[3] = (uint32_t)p->n_samples; w[4] = (uint32_t)pl.tab_dim[q]; w[5] = (uint32_t)pl.K_tab;
       w[6] = (uint32_t)pl.tab_off[q];
@@ -822,7 +852,7 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
       const uint32_t *keep = (const uint32_t *)workspace + irec::WS_KEEP_WORD + q;
       A.tab[q] = tab; A.tab_dim[q] = pl.tab_dim[q];
       if (p->flags & IREC_FLAG_TABLES_PRESENT) continue;   // the caller's previous call on this workspace built exactly these
-      if (pl.team) HIP_TRY(irec::launch_alpha_choice(seed, p->n_samples, pl.tab_dim[q], pl.K_tab, ctx->d_dlog4r, tab, keep, st));
+      if (pl.team || pl.chunk) HIP_TRY(irec::launch_alpha_choice(seed, p->n_samples, pl.tab_dim[q], pl.K_tab, ctx->d_dlog4r, tab, keep, st));
       else HIP_TRY(irec::launch_alpha_table(seed, p->n_samples, pl.tab_dim[q], pl.K_tab, ctx->d_dlog4r, tab, keep, st));
       A.tab[q] = tab; A.tab_dim[q] = pl.tab_dim[q];
     }
@@ -834,11 +864,14 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
       A2.deferred_pass = 1; A2.coop_W = 1;
       A2.counter = (unsigned int *)workspace + 2;
       for (int q = 0; q < 4; ++q) { A2.tab[q] = nullptr; A2.tab_dim[q] = -1; }
-      if (pl.team_only) HIP_TRY(irec::launch_encode_generic(A2, (int)std::min<int64_t>(n_blocks, pl.fast_grid_cap), st));
+      if (pl.team_only || pl.chunk) HIP_TRY(irec::launch_encode_generic(A2, (int)std::min<int64_t>(n_blocks, pl.fast_grid_cap), st));
       else HIP_TRY(irec::launch_encode_fast(A2, false, (int)std::min<int64_t>(n_blocks, pl.fast_grid_cap), st));
       return IREC_OK;
     };
-    if (pl.team && pl.lone) { // one workgroup per CU, a block per wave
+    if (pl.chunk) {   // one workgroup per CU, two teams, a block of any dim count per team
+      HIP_TRY(irec::launch_encode_chunk(A, batch_grid(n_blocks, ctx->n_cu > 0 ? ctx->n_cu : 256), st));
+      if (irec_status s2 = deferred_pass()) return s2;
+    } else if (pl.team && pl.lone) { // one workgroup per CU, a block per wave
       HIP_TRY(irec::launch_encode_lone(A, batch_grid(n_blocks, ctx->n_cu > 0 ? ctx->n_cu : 256), st));
       if (irec_status s2 = deferred_pass()) return s2;
 #ifdef IREC_HOST_STAMPS

@@ -89,6 +89,13 @@ const char *team_kernel_name(int B, int S, int shape_override);   // e.g. "encod
 const char *fast_kernel_name(int B, int S, bool table);
 hipError_t launch_alpha_choice(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *dlog4r, uint16_t *tab,
                                const uint32_t *keep, hipStream_t st);
+// blocks of more than 1024 dims: a team walks the block in chunks of 1024 over the team encoder's tables (irec_team.hip, encode_chunk_kernel)
+bool chunk_applies(int B, int S, int max_dim);          // B <= 20, 1024 < max_dim <= 16384, one scoring pass fits the LDS next to the tables
+int chunk_teams();                                       // teams (= scratch slabs) per workgroup
+size_t chunk_lds_for(int B, int S);
+size_t chunk_ws_for(int B, int dpad, int max_K);         // scratch slab of one team
+const char *chunk_kernel_name(int B);
+hipError_t launch_encode_chunk(const EncArgs &A, int grid, hipStream_t st);
 // one-beam calls: one wave per block over the team encoder's tables (irec_lone.hip)
 bool lone_applies(int B, int shape_override);           // n_beams == 1 and no diagnostic shape pinned (IREC_FLAG_SHAPE_TEAM pins the team encoder)
 int lone_waves();                                        // waves per workgroup (= blocks in flight per CU)

@@ -33,6 +33,13 @@
 
 namespace irec {
 
+#ifndef IREC_SPLIT_CONSTS_EARLY
+#define IREC_SPLIT_CONSTS_EARLY 0   // beam-split build: 1 = next step's constants between publishing the keys and sweeping the partners'
+                                    // (r04 A/B, profiles/r04d: neutral -- the wait is skew between the partners, not hand-off latency); 0: in the update
+#endif
+#ifndef IREC_SPLIT_NW
+#define IREC_SPLIT_NW 4             // waves per workgroup of the beam-split build (8: two sample stripes per dim group, A/B)
+#endif
 #define IREC_STAMP(slot)                                                    \
   do {                                                                      \
     if (A.dbg && tid == 0) {                                                \
@@ -798,7 +805,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
       // partners (4.3 k cycles per step, profiles/r04a/stamps.log) absorbs them.
       float sa_now[4] = {sa[0], sa[1], sa[2], sa[3]};
       float m_nx[4] = {0.f, 0.f, 0.f, 0.f}, cA_nx[4] = {0.f, 0.f, 0.f, 0.f}, cBv_nx[4] = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (beam_mode) {
+      if constexpr (beam_mode && IREC_SPLIT_CONSTS_EARLY != 0) {
         if (active && !last) step_consts(t + 1, m_nx, cA_nx, cBv_nx);
       }
       if (A.dbg && tid == 0) { const unsigned long long now_ = stamp_now(); A.dbg[(size_t)blockIdx.x * 16 + 11] += now_ - stamp_prev; } // combine
@@ -958,6 +965,9 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
                 obv[o][i] = __hip_atomic_load(bold + (size_t)bp_ * FAST_MAX_DIM + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
+        }
+        if constexpr (IREC_SPLIT_CONSTS_EARLY == 0) {
+          if (!last) step_consts(t + 1, m_nx, cA_nx, cBv_nx);               // (A/B build: in the update, under its loads' latency)
         }
         const float (&m)[4] = m_nx, (&cA)[4] = cA_nx, (&cBv)[4] = cBv_nx;   // next step's constants: formed under the partners' wait
 #pragma unroll
@@ -1241,7 +1251,7 @@ static hipError_t launch_fast_nw(const EncArgs &A, int grid, hipStream_t st) {
   if constexpr (TABLE)
     if (A.coop_W > 1) {   // split call (host: split_width / split_beam_width; aliased-key plans only, four waves)
       if (fast_plan(NB, A.S, TABLE).nw != 4) return hipErrorInvalidValue;
-      return A.coop_beams != 0 ? launch_fast_t<NB, 4, true, 2>(A, grid, st) : launch_fast_t<NB, 4, true, 1>(A, grid, st);
+      return A.coop_beams != 0 ? launch_fast_t<NB, IREC_SPLIT_NW, true, 2>(A, grid, st) : launch_fast_t<NB, 4, true, 1>(A, grid, st);
     }
   return fast_plan(NB, A.S, TABLE).nw == 8 ? launch_fast_t<NB, 8, TABLE>(A, grid, st) : launch_fast_t<NB, 4, TABLE>(A, grid, st);
 }

@@ -940,6 +940,390 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 }
 
 // ======================================================================================================
+//  encode_chunk_kernel: blocks of MORE than 1024 dims on the team encoder's tables (round 4).
+//
+//  Coder.__init__ takes any block_size, None included (rec/coding/coder.py:29-36,415-419: the whole latent tensor as ONE
+//  block -- the reference's default), and the register-resident encoders above hold 1024 dims per block.  Until now such
+//  blocks went to encode_generic_kernel (5-10 k latents/s).  Here a team walks the block in CHUNKS of 1024 dims (four dim
+//  groups, one per wave, exactly the lane ownership of the canonical tree) twice per step:
+//    scoring   per chunk: the step's constants from the slab's statistics and cumulative variance (the IEEE chain of
+//              coder.py:141-154), G and the C_b terms of the live beams from the beams in the slab, then every sample x beam
+//              over the chunk -- three table copies, copy bits of alpha_choice_kernel, as in encode_team_kernel -- into the
+//              per-group partials; a combine adds the chunk's group sums to the RUNNING score of every candidate in
+//              increasing group order, which is the specification's order ("group sums are added in increasing
+//              group order"), so the bits are encode_generic_kernel's;
+//    update    per chunk: the selected parents and proposal rows -> new beams into the slab's other buffer.
+//  A (chunk, dim group) is read and written by ONE wave in both phases: no cross-wave traffic through global memory, the
+//  only shared state is the team's LDS (partials, running scores / keys, selection).  Scoring is the plain form (a dim
+//  slot's look-ups issued together, then consumed); two teams per CU at 256 VGPRs.
+//  Slab of a team: stats [3][Dpad] | cvar [2][Dpad] (by step parity) | sa [Dpad] | beams [2][NB][Dpad] | bp [max_K][NB].
+// ======================================================================================================
+constexpr int CHUNK_MAX_DIM = 16384;
+__host__ __device__ inline size_t chunk_ws_bytes(int NB, int dpad, int max_K) {
+  return (size_t)(6 + 2 * NB) * dpad * 4 + ((((size_t)(max_K > 0 ? max_K : 1) * NB * 4) + 255) & ~(size_t)255);
+}
+__host__ __device__ inline size_t chunk_lds_one(int NB, int S) {   // part [4][S][NB] | run / keys [S][NB] | TeamLds | barrier
+  return team_part_bytes(NB, S) + team_key_bytes(NB, S) + team_small_bytes(NB) + 16;
+}
+__host__ __device__ inline size_t chunk_lds_total(int NB, int S, int teams) { return T3_BYTES + (size_t)teams * chunk_lds_one(NB, S); }
+
+template <int NB, int TEAMS>
+__global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArgs A) {
+  using TeamLds = TeamLdsT<NB>;
+  constexpr int TEAM_MB = team_mb(NB);
+  constexpr size_t TEAM_SMALL_BYTES = (sizeof(TeamLds) + 15) & ~(size_t)15;
+  constexpr int NT = TEAM_NT;
+  constexpr int SPC = 20 / NB;                     // samples per reduce-scatter (20 accumulators)
+  constexpr int RW = NB * SPC;
+  static_assert(NB == 10 || NB == 20, "chunked encoder: 10 or 20 beams");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int S = A.S, B = A.B;
+  const int lane = threadIdx.x & 63;
+  const int wave_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int team = wave_wg / TEAM_NW, g = wave_wg % TEAM_NW;                    // wave g of a team owns dim group g of every chunk
+  const int tid = (int)threadIdx.x - team * NT;
+  char *tbase = smem + T3_BYTES + (size_t)team * chunk_lds_one(NB, S);
+  float *part_s = reinterpret_cast<float *>(tbase);                             // [4][S][NB]
+  float *run_s = reinterpret_cast<float *>(tbase + team_part_bytes(NB, S));     // [S * Bcur] running scores, then the sort keys
+  uint32_t *key_s = reinterpret_cast<uint32_t *>(run_s);
+  TeamLds *sm = reinterpret_cast<TeamLds *>(tbase + team_part_bytes(NB, S) + team_key_bytes(NB, S));
+  uint32_t *bar_word = reinterpret_cast<uint32_t *>(tbase + team_part_bytes(NB, S) + team_key_bytes(NB, S) + TEAM_SMALL_BYTES);
+  double *gpart = sm->gpart;
+  int32_t *sel_s = sm->sel_s, *sel_b = sm->sel_b;
+  int32_t *hsum = &sm->hsum[0][0];
+  uint32_t *beta4 = &sm->beta4[0][0];
+  int32_t *misc = sm->misc;
+  float *cpart_s = &sm->cpart[0][0];
+  float *Cb_s = sm->Cb;
+  const uint16_t *dlog_s = A.dlog4r;
+  const int rs_p = rsn_owner<RW>(lane), rs_c = rsn_owner<NB>(lane);
+  double *kl_tot = reinterpret_cast<double *>(sm->wb);                          // running KL total of the prologue (wb is idle then)
+
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap(); // see lds_abs_f32
+  {
+    float *l3 = reinterpret_cast<float *>(smem);
+    for (int k = (int)threadIdx.x; k < (int)IREC_PM1; k += TEAMS * NT) {
+      const float v = A.lut2[k];
+      l3[k] = v; l3[k + IREC_PM1] = v; l3[k + 2 * IREC_PM1] = v;
+    }
+    if (tid == 0) *bar_word = 0u;
+  }
+  __syncthreads();
+  TeamBarrier tsync{bar_word, 0u, (uint32_t)TEAM_NW};
+
+  const int Dpad = A.max_dim_pad;
+  char *slab = A.ws + ((size_t)blockIdx.x * TEAMS + team) * A.ws_per_wg;
+  float *stats_g = reinterpret_cast<float *>(slab);                 // [3][Dpad]: mq - mp, sq^2, sp^2
+  float *cvar_g = stats_g + (size_t)3 * Dpad;                       // [2][Dpad]: cumulative variance, by step parity
+  float *sa_g = cvar_g + (size_t)2 * Dpad;                          // [Dpad]: this step's sample scale
+  float *beams_g = sa_g + Dpad;                                     // [2][NB][Dpad]
+  int32_t *bp = reinterpret_cast<int32_t *>(beams_g + (size_t)2 * NB * Dpad);   // [max_K][NB]
+
+  const int64_t n_static = (int64_t)TEAMS * (int64_t)gridDim.x < A.n_blocks ? (int64_t)TEAMS * (int64_t)gridDim.x : A.n_blocks;
+  bool first_block = true;
+  int steal = 0;
+  for (;;) {
+    tsync();
+    if (tid == 0) {
+      int64_t r;
+      if (first_block) {
+        r = (int64_t)team * (int64_t)gridDim.x + (int64_t)blockIdx.x;
+        r = r < n_static ? xcd_static_row(r, n_static, (int)gridDim.x) : A.n_blocks;
+      } else r = xcd_pull_row(A, n_static, A.n_blocks, steal);
+      misc[0] = (int32_t)r;
+    }
+    first_block = false;
+    tsync();
+    const int64_t blk = misc[0];
+    if (blk >= A.n_blocks) break; // every wave of the team reaches this
+    const int D = A.block_dim[blk];
+    const int64_t base = A.block_base[blk];
+    const int32_t pos = A.block_pos[blk];
+    const uint16_t *tab = nullptr;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (A.tab_dim[q] == D) tab = A.tab[q];
+    if (D < 1 || D > Dpad || tab == nullptr) { // host promised D <= max_block_dim and listed dims
+      if (tid == 0) A.out_K[blk] = -1;
+      continue;
+    }
+    const int Dp = (D + 3) & ~3;            // row stride of the proposal table
+    const int NC = (D + 1023) >> 10;        // chunks of 1024 dims
+    auto groups_of = [&](int c) { const int left = D - (c << 10); return left >= 1024 ? 4 : (left + 255) >> 8; };
+
+    // ---- statistics (split == gather through perm) and the block's KL, groups in increasing order ----
+    for (int c = 0; c < NC; ++c) {
+      const int ngc = groups_of(c);
+      const int d0 = (c << 10) + g * 256 + lane * 4;
+      double klacc = 0.0;
+      if (g < ngc) {
+        float st3[3][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          st3[0][i] = 0.f; st3[1][i] = 1.f; st3[2][i] = 1.f;
+          if (d0 + i < D) {
+            const int64_t ixi = src_index(A, base, pos, d0 + i);
+            const float mq_ = A.q_loc[ixi], sq_ = A.q_scale[ixi], mp_ = A.p_loc[ixi], sp_ = A.p_scale[ixi];
+            klacc = klacc + kl_dim(mq_, sq_, mp_, sp_);
+            st3[0][i] = mq_ - mp_; st3[1][i] = sq_ * sq_; st3[2][i] = sp_ * sp_;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          *reinterpret_cast<float4 *>(stats_g + (size_t)k * Dpad + d0) = make_float4(st3[k][0], st3[k][1], st3[k][2], st3[k][3]);
+        *reinterpret_cast<float4 *>(cvar_g + d0) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const double gs = wave_tree_sum(klacc);
+      if (g < ngc && lane == 0) gpart[g] = gs;
+      tsync();
+      if (tid == 0) {
+        double tot = c == 0 ? gpart[0] : *kl_tot + gpart[0];
+        for (int gg = 1; gg < ngc; ++gg) tot = tot + gpart[gg];
+        *kl_tot = tot;
+      }
+      tsync();
+    }
+    if (tid == 0) {
+      const int32_t K = num_aux((float)*kl_tot, A.omega);
+      misc[1] = K;
+      A.out_K[blk] = K;
+      hsum[0] = 0;
+      beta4[0] = 0u; // hash of the empty path is 1 = g^0
+    }
+    tsync();
+    const int K = misc[1];
+    if (K > A.max_K || K > IREC_MAX_PARTITIONS_DEV) continue;
+    if (K > A.K_tab) { // beyond the table window: the second pass (generic kernel) codes it
+      if (tid == 0) atomicAdd(A.defer_count, 1u);
+      continue;
+    }
+    if (K == 0) { // nothing to code: sample = p.loc
+      for (int c = 0; c < NC; ++c) {
+        const int d0 = (c << 10) + g * 256 + lane * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (g < groups_of(c) && d0 + i < D) { const int64_t ixo = src_index(A, base, pos, d0 + i); A.out_sample[ixo] = 0.f + A.p_loc[ixo]; }
+      }
+      continue;
+    }
+
+    int cur = 0, Bcur = 1;
+    uint32_t bv_cur = 0u;                                            // lane j: 4 * dlog(hash(path of beam j))
+    for (int t = 0; t < K; ++t) {
+      const uint16_t *tab_tu = tab + (size_t)t * S * Dp;             // this step's rows
+      const float rho = A.rho[K - 1 - t];
+      uint32_t bet[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) bet[b] = (uint32_t)__builtin_amdgcn_readlane((int)bv_cur, b < Bcur ? b : 0);
+      const int N = S * Bcur;
+      // ---------------- scoring, chunk by chunk (beam_search_coder.py:67-84) ----------------
+      for (int c = 0; c < NC; ++c) {
+        const int ngc = groups_of(c);
+        const int d0 = (c << 10) + g * 256 + lane * 4;
+        if (g < ngc) {
+          // the step's constants of my four dims (coder.py:141-154), from the statistics and the cumulative variance in the slab
+          float sa[4], cH[4], m[4], cA[4], cBv[4], cn[4];
+          {
+            const float4 q0 = *reinterpret_cast<const float4 *>(stats_g + d0);
+            const float4 q1 = *reinterpret_cast<const float4 *>(stats_g + (size_t)Dpad + d0);
+            const float4 q2 = *reinterpret_cast<const float4 *>(stats_g + (size_t)2 * Dpad + d0);
+            const float4 qc = *reinterpret_cast<const float4 *>(cvar_g + (size_t)(t & 1) * Dpad + d0);
+            const float dmu_[4] = {q0.x, q0.y, q0.z, q0.w}, vq_[4] = {q1.x, q1.y, q1.z, q1.w}, vp_[4] = {q2.x, q2.y, q2.z, q2.w};
+            const float c_[4] = {qc.x, qc.y, qc.z, qc.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const bool ok = d0 + i < D;
+              const StepConst sc = step_constants(rho, dmu_[i], vq_[i], vp_[i], c_[i]);
+              sa[i] = ok ? sc.sa : 0.f; cH[i] = ok ? sc.H : 0.f;
+              m[i] = ok ? sc.m : 0.f; cA[i] = ok ? sc.A : 0.f; cBv[i] = ok ? sc.Bv : 0.f;
+              cn[i] = c_[i] + sc.a;                                    // cumulative_auxiliary_variance += auxiliary_var (:109)
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            *reinterpret_cast<float4 *>(cvar_g + (size_t)((t + 1) & 1) * Dpad + d0) = make_float4(cn[0], cn[1], cn[2], cn[3]);
+            *reinterpret_cast<float4 *>(sa_g + d0) = make_float4(sa[0], sa[1], sa[2], sa[3]);
+          }
+          // G and the C_b terms of the live beams (dead slots: G = 0, never read)
+          float G[NB][4];
+          float cacc[rsn_room(NB)];
+#pragma unroll
+          for (int b = 0; b < rsn_room(NB); ++b) cacc[b] = 0.f;
+          {
+            const float *bold = beams_g + (size_t)cur * NB * Dpad + d0;
+            float4 bq[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              bq[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (t && b < Bcur) bq[b] = *reinterpret_cast<const float4 *>(bold + (size_t)b * Dpad);   // (wave-uniform)
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              const float bv4[4] = {bq[b].x, bq[b].y, bq[b].z, bq[b].w};
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                G[b][i] = b < Bcur ? beam_G(bv4[i], m[i], cA[i], cBv[i], sa[i]) : 0.f;
+                if (b < Bcur) cacc[b] = beam_C_term(cacc[b], bv4[i], m[i], cA[i], cBv[i]);
+              }
+            }
+          }
+          {
+            const float ctot = reduce_scatter_n<NB>(cacc, lane);
+            if ((lane & 1) == 0 && rs_c >= 0 && rs_c < Bcur) cpart_s[g * TEAM_MB + rs_c] = ctot;
+          }
+          // every sample x beam over my four dims; rows one chunk of samples ahead
+          const uint32_t tab_lo = (uint32_t)(d0 < Dp ? d0 : Dp - 4);   // lanes past the row's end: its last quad (zero coefficients)
+          const uint16_t *tab_t = tab_tu + tab_lo;
+          const int nchunks = (S + SPC - 1) / SPC;
+          uint2 alp_next[SPC];
+#pragma unroll
+          for (int cc = 0; cc < SPC; ++cc) {
+            alp_next[cc] = make_uint2(0u, 0u);
+            if (cc < S) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)cc * Dp);
+          }
+          for (int ch = 0; ch < nchunks; ++ch) {
+            float acc[rsn_room(RW)];
+#pragma unroll
+            for (int p = 0; p < rsn_room(RW); ++p) acc[p] = 0.f;
+            uint2 alp[SPC];
+#pragma unroll
+            for (int cc = 0; cc < SPC; ++cc) {
+              alp[cc] = alp_next[cc];
+              const int sn = (ch + 1) * SPC + cc;
+              if (sn < S) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sn * Dp);
+            }
+#pragma unroll
+            for (int cc = 0; cc < SPC; ++cc) {
+              const int s = ch * SPC + cc;
+              if (s < S) { // wave-uniform
+                const uint2 ap = alp[cc];
+                const uint32_t al[4] = {(ap.x & 0xFFFFu) << 2, (ap.x >> 16) << 2, (ap.y & 0xFFFFu) << 2, (ap.y >> 16) << 2};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  float z[NB];
+#pragma unroll
+                  for (int b = 0; b < NB; ++b) z[b] = lds_abs_f32(al[i] + bet[b]);   // 4 * (dlog r + 10006 c + dlog h): no wrap
+#pragma unroll
+                  for (int b = 0; b < NB; ++b) acc[cc * NB + b] = proposal_term(acc[cc * NB + b], z[b], cH[i], G[b][i]);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              }
+            }
+            const float tot = reduce_scatter_n<RW>(acc, lane);
+            const int cc = rs_p / NB, b = rs_p - cc * NB;               // rs_p < 0: unused slot
+            const int s = ch * SPC + cc;
+            if (rs_p >= 0 && (lane & 1) == 0 && s < S && b < Bcur) part_s[((size_t)g * S + s) * NB + b] = tot;
+          }
+        }
+        tsync();
+        // the chunk's group sums onto the running scores / C_b, increasing group order
+        for (int f = tid; f < N; f += NT) {
+          const int s = f / Bcur, b = f - s * Bcur;
+          float v = part_s[((size_t)0 * S + s) * NB + b];
+          if (c > 0) v = run_s[f] + v;
+          for (int gg = 1; gg < ngc; ++gg) v = v + part_s[((size_t)gg * S + s) * NB + b];
+          run_s[f] = v;
+        }
+        if (tid < Bcur) {
+          float cb = cpart_s[tid];
+          if (c > 0) cb = Cb_s[tid] + cb;
+          for (int gg = 1; gg < ngc; ++gg) cb = cb + cpart_s[gg * TEAM_MB + tid];
+          Cb_s[tid] = cb;
+        }
+        tsync();   // partials free for the next chunk; running sums and C_b published
+      }
+      for (int f = tid; f < N; f += NT) {
+        const int s = f / Bcur, b = f - s * Bcur;
+        key_s[f] = score_key(run_s[f] + Cb_s[b]);
+      }
+      const int Bnew = B < N ? B : N;
+      // top-B (beam_search_coder.py:85-89); the selection's first barrier orders the key writes
+      select_topB_sync<NT>(key_s, N, Bnew, Bcur, sm, tid, tsync, nullptr, [&](int j, int32_t sp_, int32_t bp_, uint32_t) {
+        const int32_t nh = (int32_t)((uint32_t)hsum[cur * TEAM_MB + bp_] + (uint32_t)sp_ * (uint32_t)(69 + t));
+        hsum[(cur ^ 1) * TEAM_MB + j] = nh;
+        sm->sel_bo[j] = beta4[cur * TEAM_MB + bp_];
+        bp[(size_t)t * NB + j] = (sp_ << 6) | bp_;
+      });
+      // ---------------- new beams, chunk by chunk (beam_search_coder.py:92-93) ----------------
+      const bool last = (t == K - 1);
+      uint32_t bv_new;
+      {
+        const int32_t nh = hsum[(cur ^ 1) * TEAM_MB + (lane < Bnew ? lane : 0)];
+        bv_new = dlog_s[hash_from_sum(nh) - 1u];
+      }
+      const int Bupd = last ? 1 : Bnew;     // beams[0] is all that leaves the block (:118-122)
+      const int32_t v_sp = sel_s[lane < Bnew ? lane : 0], v_bp = sel_b[lane < Bnew ? lane : 0];
+      const uint32_t v_bo = sm->sel_bo[lane < Bnew ? lane : 0];
+      for (int c = 0; c < NC; ++c) {
+        const int d0 = (c << 10) + g * 256 + lane * 4;
+        if (g >= groups_of(c)) continue;     // wave-uniform
+        const uint32_t tab_lo = (uint32_t)(d0 < Dp ? d0 : Dp - 4);
+        const uint16_t *tab_t = tab_tu + tab_lo;
+        const float4 sq = *reinterpret_cast<const float4 *>(sa_g + d0);
+        const float sa_t[4] = {sq.x, sq.y, sq.z, sq.w};
+        const float *bold = beams_g + (size_t)cur * NB * Dpad + d0;
+        float *bnew = beams_g + (size_t)(cur ^ 1) * NB * Dpad + d0;
+        constexpr int UB = 5;                // beams per load batch
+#pragma unroll 1
+        for (int j0 = 0; j0 < Bupd; j0 += UB) {
+          uint2 apv[UB];
+          float4 obv4[UB];
+          uint32_t bet_old[UB];
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            const int j = j0 + u;
+            apv[u] = make_uint2(0u, 0u); obv4[u] = make_float4(0.f, 0.f, 0.f, 0.f); bet_old[u] = 0u;
+            if (j < Bupd) { // wave-uniform
+              const int32_t sp_ = __builtin_amdgcn_readlane(v_sp, j);
+              const int32_t bp_ = __builtin_amdgcn_readlane(v_bp, j);
+              bet_old[u] = (uint32_t)__builtin_amdgcn_readlane((int)v_bo, j);
+              apv[u] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sp_ * Dp);
+              if (t) obv4[u] = *reinterpret_cast<const float4 *>(bold + (size_t)bp_ * Dpad);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+            const int j = j0 + u;
+            if (j < Bupd) { // wave-uniform
+              const uint32_t al[4] = {(apv[u].x & 0xFFFFu) << 2, (apv[u].x >> 16) << 2, (apv[u].y & 0xFFFFu) << 2, (apv[u].y >> 16) << 2};
+              const float obv[4] = {obv4[u].x, obv4[u].y, obv4[u].z, obv4[u].w};
+              float nb[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const float y = sa_t[i] * lds_abs_f32(al[i] + bet_old[u]);   // dist.quantile(.), :48-49
+                nb[i] = obv[i] + y;                                          // combined_samples[best_ind_aux, best_ind_beam], :81,92-93
+              }
+              if (last) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                  if (d0 + i < D) { // beams[0] + coding_dist.loc, :122
+                    const int64_t ixo = src_index(A, base, pos, d0 + i);
+                    A.out_sample[ixo] = nb[i] + A.p_loc[ixo];
+                  }
+              } else {
+                *reinterpret_cast<float4 *>(bnew + (size_t)j * Dpad) = make_float4(nb[0], nb[1], nb[2], nb[3]);
+              }
+            }
+          }
+        }
+      }
+      if (tid < Bnew) beta4[(cur ^ 1) * TEAM_MB + tid] = bv_new;   // (wave 0: read by its own next selection)
+      bv_cur = bv_new;
+      cur ^= 1;
+      Bcur = Bnew;
+    }
+    // ---- index path of beam 0 (beam_search_coder.py:118-121) ----
+    tsync();
+    if (tid == 0) {
+      int j = 0;
+      for (int t = K - 1; t >= 0; --t) {
+        const int32_t v = __builtin_nontemporal_load(&bp[(size_t)t * NB + j]);
+        A.out_indices[blk * (int64_t)A.max_K + t] = v >> 6;
+        j = v & 63;
+      }
+    }
+  }
+}
+
+// ======================================================================================================
 //  proposal table with copy bits: tab[t][s][d] = dlog_g(r[s, d]) + 10006 * c   (uint16, row stride = D rounded up to 4)
 //
 //  The int32 draw of get_pseudo_random_sample (beam_search_coder.py:38-43) depends only on (seed + t, S, D): it is
@@ -1144,6 +1528,32 @@ hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
     case 3212: return launch_team_t<32, 1, 2>(A, grid, st);
     default: return hipErrorInvalidValue;
   }
+}
+
+// ---- chunked encoder (blocks of more than 1024 dims) ----
+constexpr int CHUNK_TEAMS = 2;
+static int chunk_nb_for(int B) { return B <= 10 ? 10 : B <= 20 ? 20 : 0; }
+bool chunk_applies(int B, int S, int max_dim) {
+  const int nb = chunk_nb_for(B);
+  return nb != 0 && max_dim > FAST_MAX_DIM && max_dim <= CHUNK_MAX_DIM && (int64_t)S * nb <= 2048 &&
+         chunk_lds_total(nb, S, CHUNK_TEAMS) <= FAST_LDS_LIMIT;
+}
+int chunk_teams() { return CHUNK_TEAMS; }
+size_t chunk_lds_for(int B, int S) { return chunk_lds_total(chunk_nb_for(B), S, CHUNK_TEAMS); }
+size_t chunk_ws_for(int B, int dpad, int max_K) { return chunk_ws_bytes(chunk_nb_for(B), dpad, max_K); }
+const char *chunk_kernel_name(int B) { return chunk_nb_for(B) == 10 ? "encode_chunk_kernel<10,2>" : "encode_chunk_kernel<20,2>"; }
+template <int NB>
+static hipError_t launch_chunk_t(const EncArgs &A, int grid, hipStream_t st) {
+  const size_t lds = chunk_lds_total(NB, A.S, CHUNK_TEAMS);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_chunk_kernel<NB, CHUNK_TEAMS>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((encode_chunk_kernel<NB, CHUNK_TEAMS>), dim3(grid), dim3(CHUNK_TEAMS * TEAM_NT), lds, st, A);
+  return hipGetLastError();
+}
+hipError_t launch_encode_chunk(const EncArgs &A, int grid, hipStream_t st) {
+  if (!chunk_applies(A.B, A.S, A.max_dim_pad)) return hipErrorInvalidValue;
+  return chunk_nb_for(A.B) == 10 ? launch_chunk_t<10>(A, grid, st) : launch_chunk_t<20>(A, grid, st);
 }
 
 hipError_t launch_alpha_choice(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *dlog4r, uint16_t *tab,

@@ -137,7 +137,13 @@ class BidirectionalResidualBlock(nn.Module):
         self.gen_conv1, self.gen_conv2 = conv(d, d), conv(d + s, d)
         self.prior_loc_head, self.prior_log_scale_head = conv(d, s), conv(d, s)
         self.gen_posterior_loc_head, self.gen_posterior_log_scale_head = conv(d, s), conv(d, s)
-        self.infer_posterior_loc = self.infer_posterior_log_scale = 0.
+        self._infer_y = self._infer_bias = self._infer_heads = None   # inference pass's head convolution (and its pending bias)
+        # Hand-off kernels (csrc/irec_shim.hip) or plain torch ops between the convolutions and the coder: decided ONCE per block --
+        # None: by where the block lives (a float32 CUDA block takes the kernels) -- and identically in compress and decompress,
+        # never per tensor: the kernels' expf / expm1f and torch.exp / F.elu differ in the last ulp, so an encoder and a decoder
+        # that chose differently would rebuild different prior scales and the reconstruction would silently diverge.  Inputs
+        # the kernels cannot take as they are (non-contiguous, channels_last) are made contiguous, not routed around them.
+        self.use_handoff_kernels = None
         self.posterior = self.prior = None
         self._pad = pad
         self._fused = None   # (parameter versions, inference-side weight / bias, generative-side weight / bias)
@@ -152,6 +158,30 @@ class BidirectionalResidualBlock(nn.Module):
         else:
             raise ModelError("Sampler must be one of ['rejection', 'importance', 'beam_search'],"
                              f"but got {sampler}!")
+
+    @property
+    def infer_posterior_loc(self):
+        """Inference-side posterior loc head (resnet_vae.py: infer_posterior_loc; 0. before an inference pass, as there).  On the
+        kernel path the head convolution runs without its bias (the hand-off kernel adds it): the view is biased lazily."""
+        return self._infer_head(0)
+
+    @property
+    def infer_posterior_log_scale(self):
+        return self._infer_head(1)
+
+    def _infer_head(self, k):
+        if self._infer_y is None:
+            return 0.
+        s = self.stochastic_filters
+        v = self._infer_y[:, k * s:(k + 1) * s]
+        return v if self._infer_bias is None else v + self._infer_bias[k * s:(k + 1) * s].reshape(1, -1, 1, 1)
+
+    def _handoff(self, *tensors):
+        """Whether this block's passes take the hand-off kernels: the explicit flag, else float32-on-CUDA of the block itself."""
+        if self.use_handoff_kernels is not None:
+            return bool(self.use_handoff_kernels)
+        w = self.gen_conv1.weight
+        return w.is_cuda and w.dtype == torch.float32 and all(t is None or (t.is_cuda and t.dtype == torch.float32) for t in tensors)
 
     @property
     def posterior_loc(self):
@@ -196,17 +226,16 @@ class BidirectionalResidualBlock(nn.Module):
         w_i, b_i, w_g, b_g = self._fused_weights()
         # On the fused path the convolutions run WITHOUT their bias: the hand-off kernel that reads a convolution's output adds
         # it first (same operation, same order, one launch fewer per convolution: 96 per image).
-        fused = _HandOff.ok(inp, tensor) and (encoder_args is not None or decoder_args is not None or inference_pass)
+        fused = self._handoff(inp, tensor)                 # one decision per block: the same in compress and decompress
+        if fused:
+            inp, tensor = inp.contiguous(), tensor.contiguous()
         bias2 = None
         if inference_pass:
             y = F.conv2d(tensor, w_i, None if fused else b_i, padding=self._pad)   # [N, 2s (+ d), H, W]
+            if fused:
+                y = y.contiguous()
             self._infer_y, self._infer_bias = y, (b_i if fused else None)
-            if fused:                                                             # (views of the biased heads, for callers that read them)
-                self._infer_heads = None
-                self.infer_posterior_loc = self.infer_posterior_log_scale = None
-            else:
-                self.infer_posterior_loc, self.infer_posterior_log_scale = y[:, :s], y[:, s:2 * s]
-                self._infer_heads = y[:, :2 * s]
+            self._infer_heads = None if fused else y[:, :2 * s]     # (infer_posterior_loc / _log_scale: lazily biased views)
             if not self.is_last:
                 if fused:
                     tensor = F.conv2d(_HandOff.cat_elu(y, 2 * s, d, None, b_i), self.infer_conv2.weight, None, padding=self._pad)
@@ -216,16 +245,19 @@ class BidirectionalResidualBlock(nn.Module):
         else:
             if encoder_args is None and decoder_args is None:
                 raise ModelError("training / sampling passes are outside the compression shim")
-            fused = fused and (encoder_args is None or (self._infer_y is not None and _HandOff.ok(self._infer_y)))
+            if encoder_args is not None and self._infer_y is None:
+                raise ModelError(f"{self.name}: a compression pass needs the statistics of an inference pass over the same input first")
+            if encoder_args is not None and fused != (self._infer_bias is not None):
+                raise ModelError(f"{self.name}: use_handoff_kernels changed between the inference and the generative pass")
             y = F.conv2d(tensor, w_g, None if fused else b_g, padding=self._pad)  # [N, 4s + d, H, W]
+            if fused:
+                y = y.contiguous()
             n, _, h, w = y.shape
             if encoder_args is not None:                                          # :462-470
                 if fused:
                     st = _HandOff.stats(y, self._infer_y, s, 4, b_g, self._infer_bias)   # all four statistics, NHWC, one launch
                 else:
-                    heads = self._infer_heads if self._infer_heads is not None else \
-                        self._infer_y[:, :2 * s] + self._infer_bias[:2 * s].reshape(1, -1, 1, 1)
-                    y[:, 2 * s:4 * s] += heads                                    # posterior loc / log-scale = inference + generative
+                    y[:, 2 * s:4 * s] += self._infer_heads                                   # posterior loc / log-scale = inference + generative
                     st = y[:, :4 * s].view(n, 4, s, h, w).permute(1, 0, 3, 4, 2).contiguous()   # coder sees NHWC, as in the reference
                     st[1::2].exp_()                                               # the two scales
                 self.prior, self.posterior = _Normal(st[0], st[1]), _Normal(st[2], st[3])
@@ -238,15 +270,15 @@ class BidirectionalResidualBlock(nn.Module):
                     st[1].exp_()
                 self.prior = _Normal(st[0], st[1])
                 latent_code = self.coder.decode(self.prior, **decoder_args)
-            if fused and _HandOff.ok(latent_code):
+            if fused:
+                latent_code = latent_code.to(dtype=torch.float32).contiguous()
                 tensor = F.conv2d(_HandOff.cat_elu(y, 4 * s, d, latent_code, b_g), self.gen_conv2.weight, None, padding=self._pad)
                 bias2 = self.gen_conv2.bias
             else:
-                rest = y[:, 4 * s:] + b_g[4 * s:].reshape(1, -1, 1, 1) if fused else y[:, 4 * s:]
-                tensor = torch.cat([rest, latent_code.permute(0, 3, 1, 2)], dim=1)
+                tensor = torch.cat([y[:, 4 * s:], latent_code.permute(0, 3, 1, 2)], dim=1)
                 tensor = self.gen_conv2(F.elu(tensor, inplace=True))
-        if _HandOff.ok(inp, tensor):
-            tensor, tensor_elu = _HandOff.residual_elu(inp, tensor, 0.1, bias2)
+        if fused:
+            tensor, tensor_elu = _HandOff.residual_elu(inp, tensor.contiguous(), 0.1, bias2)
             tensor._irec_elu = tensor_elu                  # (a Python attribute: the next block, or _finish, picks it up)
         else:
             tensor = torch.add(inp, tensor, alpha=0.1)

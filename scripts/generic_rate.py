@@ -8,13 +8,15 @@ import bench, irec
 eng = irec.get_engine()
 L = 512
 q = bench.synthetic_batch(L, eng.device, 0)
-for bs, B in ((1000, 20), (2048, 20), (4096, 20), (1000, 64)):
+# (round 4: block sizes above 1024 take encode_chunk_kernel; FORCE_GENERIC pins the generic kernel for the comparison)
+for bs, B, flags in ((1000, 20, 0), (2048, 20, 0), (2048, 20, 1), (4096, 20, 0), (4096, 20, 1), (None, 20, 0), (None, 20, 1), (2048, 10, 0),
+                     (None, 10, 0), (1000, 64, 0)):
     lay = eng.layout(L, bench.N_DIMS, bs, bench.SEED)
-    params = eng.params(3.0, 36, B)
-    plan = eng.plan(params, lay, 64)
-    eng.encode_blocks(params, lay, *q, bench.SEED, 64)
+    params = eng.params(3.0, 36, B, flags, table_steps=128)
+    plan = eng.plan(params, lay, 128)
+    eng.encode_blocks(params, lay, *q, bench.SEED, 128)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(3):
-        K, idx, s = eng.encode_blocks(params, lay, *q, bench.SEED, 64)
+        K, idx, s = eng.encode_blocks(params, lay, *q, bench.SEED, 128)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
-    print(f"block_size {bs:5d} B {B:2d}: {plan['kernel']:28s} {dt * 1e3:9.2f} ms for {L} latents -> {L / dt:9.0f} latents/s, max K {int(K.max())}", flush=True)
+    print(f"block_size {str(bs):>5s} B {B:2d}: {plan['kernel']:28s} {dt * 1e3:9.2f} ms for {L} latents -> {L / dt:9.0f} latents/s, max K {int(K.max())}", flush=True)

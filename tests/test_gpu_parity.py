@@ -268,13 +268,87 @@ def test_batched_latents_match_oracle(engine, oracle, variant):
 
 
 def test_large_block_uses_generic_path(engine, oracle):
-    # block_size=None on a 3000-dim tensor: D > 1024 -> generic kernel
+    # block_size=None on a 3000-dim tensor: D > 1024 -> the chunked encoder (round 4), and the generic kernel when pinned
     mq, sq, mp, sp = oracle.synthetic_latent(77, 3000)
-    c = _coder(3.0, 10, 1.0)
-    idx, sample = c.encode(_normal(mq[None], sq[None]), _normal(mp[None], sp[None]), seed=3)
     ridx, rs = oracle.encode_block(mq, sq, mp, sp, 3, 3.0, 20, 10)
-    assert [int(i) for i in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
-    assert torch.equal(c.decode(_normal(mp[None], sp[None]), idx, seed=3), sample)
+    for generic in (False, True):
+        c = _coder(3.0, 10, 1.0)
+        c.force_generic = generic
+        idx, sample = c.encode(_normal(mq[None], sq[None]), _normal(mp[None], sp[None]), seed=3)
+        assert [int(i) for i in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs), generic
+        assert torch.equal(c.decode(_normal(mp[None], sp[None]), idx, seed=3), sample)
+
+
+@pytest.mark.parametrize("n,bs,omega,eps1,B,n_t", [(8192, 2048, 3.0, 1.2, 20, 6), (8192, 4096, 3.0, 1.2, 20, 4), (8192, None, 3.0, 1.2, 20, 5),
+                                                   (8192, None, 3.0, 1.0, 10, 3), (5000, 2048, 3.0, 1.0, 7, 3), (3001, None, 2.0, 1.5, 1, 4),
+                                                   (1025, None, 3.0, 1.2, 20, 3), (2500, 2048, 3.0, 1.2, 13, 3), (12288, None, 3.0, 1.0, 10, 2),
+                                                   (4099, 1100, 3.5, 1.0, 20, 2)])
+def test_blocks_beyond_1024_dims_take_the_chunked_encoder(engine, oracle, n, bs, omega, eps1, B, n_t):
+    """Coder.__init__ takes any block_size, None included (coder.py:29-36,415-419: the whole tensor as ONE block -- the
+    reference's default).  Round 4: such blocks are walked in chunks of 1024 dims by encode_chunk_kernel over the team
+    encoder's tables instead of falling to the generic kernel.  Indices, K and samples against the oracle, bit for bit:
+    block_size 2048 / 4096 / None on 8192-dim tensors, ragged chunks and dim groups (5000, 3001, 1025, 4099 dims), a call that
+    mixes blocks above and below 1024 dims (2500 = 2048 + 452), one beam, beam counts that are not a build's, a 12 288-dim
+    block; decode(encode) exact; the generic kernel pinned gives the same bits; irec_encode_plan names the kernel."""
+    S = oracle.n_samples(omega, eps1)
+    stats = [oracle.synthetic_latent(8100 + i, n) for i in range(n_t)]
+    ql, qs, pl, ps = (torch.from_numpy(np.stack([s[k] for s in stats])).cuda().contiguous() for k in range(4))
+    lay = engine.layout(n_t, n, bs, 42)
+    max_K = 160
+    params = engine.params(omega, S, B, table_steps=max_K)      # (tables over every partition: nothing is left to the second pass)
+    plan = engine.plan(params, lay, max_K)
+    assert plan["kernel"] == ("encode_chunk_kernel<10,2>" if B <= 10 else "encode_chunk_kernel<20,2>"), plan["kernel"]
+    assert plan["table_kernel"] == "alpha_choice_kernel" and plan["lds_bytes"] <= 160 * 1024
+    K, idx, sample = engine.encode_blocks(params, lay, ql, qs, pl, ps, 42, max_K)
+    Kh, ih = K.cpu().numpy(), idx.cpu().numpy()
+    assert Kh.min() >= 0 and Kh.max() <= max_K, (int(Kh.min()), int(Kh.max()))
+    import irec
+    gen = engine.params(omega, S, B, irec._lib.IREC_FLAG_FORCE_GENERIC)
+    K2, idx2, sample2 = engine.encode_blocks(gen, lay, ql, qs, pl, ps, 42, max_K)
+    assert torch.equal(K, K2) and torch.equal(sample, sample2)
+    ih2 = idx2.cpu().numpy()
+    for r in range(lay.n_blocks):
+        assert np.array_equal(ih[r, :Kh[r]], ih2[r, :Kh[r]]), r
+    assert torch.equal(engine.decode_blocks(params, lay, pl, ps, 42, K, idx), sample)
+    bpt = lay.blocks_per_tensor
+    for i in sorted({0, n_t - 1}):
+        ridx, rs = oracle.encode_tensor(*stats[i], 42, omega, S, B, block_size=bs)
+        got = [ih[lay.natural[i * bpt + j], :Kh[lay.natural[i * bpt + j]]].tolist() for j in range(bpt)]
+        if bs is None:
+            assert got[0] == ridx, i
+        else:
+            assert got == ridx, i
+        assert np.array_equal(sample[i].cpu().numpy(), rs), i
+
+
+def test_chunked_encoder_second_pass_and_batches(engine, oracle):
+    """Blocks whose K exceeds the proposal-table window are left by the chunked encoder and coded by the generic kernel in
+    the call's second pass; K = 0 blocks return p.loc; a batch of more blocks than resident teams pulls from the counters."""
+    n, bs, S, B = 4096, 2048, 36, 20
+    n_t = 300                                              # 600 blocks > 512 resident teams
+    stats = [oracle.synthetic_latent(8200 + i, n) for i in range(n_t)]
+    ql, qs, pl, ps = (torch.from_numpy(np.stack([s[k] for s in stats])).cuda().contiguous() for k in range(4))
+    ql[5] = pl[5]; qs[5] = ps[5]                           # posterior == prior: KL = 0, K = 0
+    lay = engine.layout(n_t, n, bs, 42)
+    full = engine.params(3.0, S, B)
+    short = engine.params(3.0, S, B, table_steps=8)        # K ~ 15 per 2048-dim block: everything takes the second pass
+    K, idx, sample = engine.encode_blocks(full, lay, ql, qs, pl, ps, 42, 64)
+    K2, idx2, sample2 = engine.encode_blocks(short, lay, ql, qs, pl, ps, 42, 64)
+    Kh = K.cpu().numpy()
+    assert Kh.max() > 8 and torch.equal(K, K2) and torch.equal(sample, sample2)
+    ih, ih2 = idx.cpu().numpy(), idx2.cpu().numpy()
+    for r in range(lay.n_blocks):
+        assert np.array_equal(ih[r, :Kh[r]], ih2[r, :Kh[r]]), r
+    bpt = lay.blocks_per_tensor
+    assert all(Kh[lay.natural[5 * bpt + j]] == 0 for j in range(bpt)) and torch.equal(sample[5], pl[5])
+    assert torch.equal(engine.decode_blocks(full, lay, pl, ps, 42, K, idx), sample)
+    for i in (0, 5, 150, n_t - 1):
+        mq, sq, mp, sp = (t[i].cpu().numpy() for t in (ql, qs, pl, ps))
+        if i == 5:
+            continue
+        ridx, rs = oracle.encode_tensor(mq, sq, mp, sp, 42, 3.0, S, B, block_size=bs)
+        assert [ih[lay.natural[i * bpt + j], :Kh[lay.natural[i * bpt + j]]].tolist() for j in range(bpt)] == ridx, i
+        assert np.array_equal(sample[i].cpu().numpy(), rs), i
 
 
 def test_wide_beam_uses_generic_path(engine, oracle):
