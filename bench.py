@@ -251,17 +251,16 @@ def cpu_baselines(q, n_ref, n_opt_budget_s):
             "opt_lps": done / max(t_opt, 1e-9), "opt_threads": used, "opt_latents": done, "opt_first": first}
 
 
-def secondary_config(eng, device, name, omega, eps1, beams, n_tensors, n_dims, reps, check, ref_line):
+def secondary_config(eng, device, name, omega, eps1, beams, n_tensors, n_dims, reps, check, ref_line, block_size=BLOCK_SIZE, max_K=48):
     """One further BASELINE configuration, outside the timed headline: `reps` calls of irec_beam_encode on `n_tensors`
     synthetic tensors of `n_dims` dims (blocks of 1000) by HIP events; kernel from irec_encode_plan; look-ups per clock per
     CU; the first `check` tensors compared with the oracle (indices and sample, bit for bit)."""
     import torch
     from oracle import oracle as O
     S = int(np.exp(omega * eps1))
-    params = eng.params(omega, S, beams)
+    params = eng.params(omega, S, beams, table_steps=max_K if max_K > 48 else 0)
     q = synthetic_batch(n_tensors, device, 77, n_dims)
-    lay = eng.layout(n_tensors, n_dims, BLOCK_SIZE, SEED)
-    max_K = 48
+    lay = eng.layout(n_tensors, n_dims, block_size, SEED)
     out = (torch.empty(lay.n_blocks, dtype=torch.int32, device=device),
            torch.empty((lay.n_blocks, max_K), dtype=torch.int32, device=device), torch.empty_like(q[0]))
     plan = eng.plan(params, lay, max_K)
@@ -284,7 +283,11 @@ def secondary_config(eng, device, name, omega, eps1, beams, n_tensors, n_dims, r
     if check:
         c = min(check, n_tensors)
         hb = [t[:c].cpu().numpy() for t in q]
-        ridx, rsamp, _ = O.encode_tensors_omp(*hb, SEED, omega, S, beams, BLOCK_SIZE, max_K=max_K, n_threads=host_cores())
+        if block_size is None:   # (no shuffle without a block size, coder.py:415-419: the per-tensor entry of the checker)
+            per = [O.encode_tensor(*(h[i] for h in hb), SEED, omega, S, beams, block_size=None) for i in range(c)]
+            ridx, rsamp = [[p_[0]] for p_ in per], np.stack([p_[1].reshape(-1) for p_ in per])
+        else:
+            ridx, rsamp, _ = O.encode_tensors_omp(*hb, SEED, omega, S, beams, block_size, max_K=max_K, n_threads=host_cores())
         ih, sh = out[1].cpu().numpy(), out[2][:c].cpu().numpy()
         bpt = lay.blocks_per_tensor
         for i in range(c):
@@ -294,7 +297,7 @@ def secondary_config(eng, device, name, omega, eps1, beams, n_tensors, n_dims, r
             assert np.array_equal(sh[i], rsamp[i]), f"{name}: parity, tensor {i} sample"
         checked = c
     res = {"name": name, "reference": ref_line, "omega": omega, "extra_samples": eps1, "n_beams": beams, "n_samples": S,
-           "tensors_per_call": n_tensors, "dims_per_tensor": n_dims, "blocks_per_call": int(lay.n_blocks), "kernel": plan["kernel"],
+           "tensors_per_call": n_tensors, "dims_per_tensor": n_dims, "block_size": block_size, "blocks_per_call": int(lay.n_blocks), "kernel": plan["kernel"],
            "grid": plan["grid"], "ms_per_call": ms, "tensors_per_s": n_tensors / (ms * 1e-3),
            "lookups_per_clk_per_cu": lookups, "mean_K": float(Kh.mean()), "oracle_checked_tensors": checked}
     log(f"secondary {name}: {plan['kernel']} {ms:.3f} ms/call, {res['tensors_per_s']:.0f} tensors/s, {lookups:.2f} look-ups/clk/CU, "
@@ -510,6 +513,17 @@ def run_rank(args):
         sec.append(secondary_config(eng, device, "configs[4] S = 148, 1024 latents of 8192 dims", 5.0, 1.0, 30, 1024, N_DIMS, 5, 16, stress))
         sec.append(secondary_config(eng, device, "configs[4] S = 403 (eps = 0.2), 1024 latents of 8192 dims", 5.0, 1.2, 30, 1024, N_DIMS, 3, 16, stress))
         result["secondary"]["configs"] = sec
+        # calls of fewer blocks than team slots: the literal per-call shapes of configs[2] (one image's residual block: 9 blocks; one
+        # GPU's share of 300 images: 38 latents = 342 blocks per call), compression_performance.py:305-347, resnet_vae.py:821-826
+        rvae = "BASELINE.json configs[1]/[2] settings (B = 20, Omega = 3, S = 36)"
+        result["secondary"]["midsize"] = [
+            secondary_config(eng, device, "one GPU's share of config 3: 38 latents = 342 blocks per call", OMEGA, EPS1, BEAMS, 38, N_DIMS, 30, 2, rvae),
+            secondary_config(eng, device, "one image's residual block: 1 latent = 9 blocks per call", OMEGA, EPS1, BEAMS, 1, N_DIMS, 30, 1, rvae)]
+        # blocks of more than 1024 dims (coder.py:29-36,415-419: block_size is the caller's, None = the whole tensor as one block)
+        big = "Coder.__init__(block_size=...) beyond 1024 dims (rec/coding/coder.py:29-36,415-419), headline settings"
+        result["secondary"]["large_blocks"] = [
+            secondary_config(eng, device, "block_size = 2048, 512 latents of 8192 dims", OMEGA, EPS1, BEAMS, 512, N_DIMS, 5, 2, big, block_size=2048, max_K=128),
+            secondary_config(eng, device, "block_size = None (one 8192-dim block per latent), 512 latents", OMEGA, EPS1, BEAMS, 512, N_DIMS, 3, 2, big, block_size=None, max_K=128)]
         result["secondary"]["skewed_K"] = skewed_K_leg(eng, device, 8192, 5, 16)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   static_assert(NB % BS == 0, "beam stripes must divide the beam count");
   // 20 accumulators are reduced together (one sample x 20 beams, or two samples x 10 beams) by the 20-value
   // reduce-scatter: 22 exchange+add pairs instead of the 31 of a zero-padded 32-wide one, and 12 registers fewer
-  static_assert(NBW == 10 || NBW == 16 || NBW == 20, "the team encoder is built for 10, 16 or 20 beams per wave");
+  static_assert(NBW == 10 || NBW == 16 || NBW == 18 || NBW == 20, "the team encoder is built for 10, 16, 18 or 20 beams per wave");
   static_assert(NB <= TEAM_MB && NB <= 64, "beam indices are lane indices and 6-bit back-pointers");
   constexpr int CMAX = TEAMS == 1 ? 2048 : 1024;    // candidates one combine round covers (host: SP * NB <= CMAX)
   constexpr int SPC = BS >= 2 ? 1 : 20 / NBW;   // samples per chunk (beam-striped builds: one, to fit 128 VGPRs)
@@ -1464,6 +1464,12 @@ static TeamShape team_shape(int B, int S, int ovr) {
   // round 3: B = 50 of the reference's sweep (examples/lossless/data_aggregation.py:7).  One 12-wave team, three stripes of
   // 20 beams at 168 VGPRs (the three-team build's register diet: half-slot pipeline, parked state); a stripe that is at least
   // half alive scores its missing beams as phantoms
+  // round 4: stripes of 18 beams for 48 < B <= 54 at S >= 128 -- B = 50 of the sweep then scores 54 beam slots instead of 60
+  // (its third stripe holds 14 live beams and 4 phantoms instead of 10 and 10): -3 % time from S = 148 on (10.06 against
+  // 9.71 look-ups/clk/CU at S = 1808), but its full-slot look-up pipeline at 168 VGPRs (416 B of scratch) loses 10-26 % to the
+  // 60-beam build's half-slot diet below S ~ 100; stripes of 16 for B <= 48 lose at every S (B = 40 on the 60-beam build
+  // leaves its third stripe idle anyway) and are not built (profiles/r04g/).
+  if (cfg != 3 && B > 48 && B <= 54 && S >= 128) return TeamShape{54, 1, 3, false};
   if (B <= 60) return TeamShape{60, 1, 3, false};
   return TeamShape{0, 0, 0, false};
 }
@@ -1517,6 +1523,7 @@ hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
     case 111031: return launch_team_t<10, 3, 1, true, true>(A, grid, st);
     case 11031: return launch_team_t<10, 3, 1, true>(A, grid, st);
     case 6013: return launch_team_t<60, 1, 3>(A, grid, st);
+    case 5413: return launch_team_t<54, 1, 3>(A, grid, st);
     case 1021: return launch_team_t<10, 2, 1>(A, grid, st);
     case 1031: return launch_team_t<10, 3, 1>(A, grid, st);
     case 2011: return launch_team_t<20, 1, 1>(A, grid, st);

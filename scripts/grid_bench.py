@@ -15,6 +15,31 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "relative-entropy-coding_amd")]
 import irec  # noqa: E402
 
 
+GATHER_PEAK = 13.70   # look-ups/clk/CU: random addresses, 2-choice bank assignment (profiles/r01j/gather_rates.log)
+
+
+def arithmetic_floor(kernel, S, B, D=1000):
+    """Look-ups per clock per CU that the ARITHMETIC of one block-step allows (DESIGN.md §4 "The sweep grid"), a ceiling in
+    the unit of the measured column: live look-ups S * B * D of a steady-state step over the larger of
+      * the gather pipe:  S * B' * D / 13.70 cycles, B' = beam SLOTS the build scores (phantoms included),
+      * VALU issue of the busiest SIMD (it hosts one wave per beam stripe of the team, plus wave 0's selection): 2 cycles per
+        wave instruction; per wave and step  480 (IEEE step constants of four dims: six divisions, a square root) + 45 per beam
+        of the update + 60 (combine, barriers), wave 0 another 650 (selection); per wave and sample 8 per beam (address add,
+        packed fma; the look-up itself issues on the LDS port) + 45 (20-value reduce-scatter, row handling);
+      * for the one-wave-per-block encoder: 1 900 cycles of step constants + 75 S of the gather pipe per block-step.
+    Latency is NOT in it: what a cell loses to its dependent phases with few teams in flight is the gap to this number."""
+    if kernel.startswith("encode_lone"):
+        return S * D / (1900.0 + 75.0 * S)
+    nb, teams, bs = (int(x) for x in kernel.split("<")[1].split(">")[0].split(",")[:3])
+    per_stripe = nb // bs
+    live_stripes = max(1, min(bs, -(-B // per_stripe)))                       # stripes holding at least one live beam
+    slots = sum(per_stripe if 2 * min(per_stripe, max(0, B - k * per_stripe)) >= per_stripe else min(per_stripe, max(0, B - k * per_stripe))
+                for k in range(live_stripes)) if B > 1 else 1
+    lds = S * slots * D / GATHER_PEAK
+    valu = 2.0 * (live_stripes * (480 + 60) + 45 * min(B, slots) + 650 + (8 * slots + 45 * live_stripes) * S)
+    return S * B * D / max(lds, valu)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--latents", type=int, default=256)
@@ -35,7 +60,8 @@ def main():
     dims = lay.block_dim.cpu().numpy().astype(np.int64)
     t_start = time.time()
     print(f"# latents per call {a.latents} ({lay.n_blocks} blocks); columns: Omega 1+eps B S | kernel | ms/call | latents/s | "
-          f"G look-ups/s | look-ups/clk/CU | mean K | oracle check | ms/call with the tables kept | look-ups/clk/CU then", flush=True)
+          f"G look-ups/s | look-ups/clk/CU | mean K | oracle check | ms/call with the tables kept | look-ups/clk/CU then | "
+          f"arithmetic floor (look-ups/clk/CU) | tables-kept rate / floor", flush=True)
     worst = None
     for omega in [float(x) for x in a.omegas.split(",")]:
         for eps1 in [float(x) for x in a.eps.split(",")]:
@@ -82,7 +108,8 @@ def main():
                         if got != ridx or not np.array_equal(sample[i].cpu().numpy(), rs):
                             ok = "MISMATCH"
                 line = (f"{omega:g} {eps1:g} {B:2d} {S:5d} | {plan['kernel']:38s} | {ms:9.3f} | {a.latents / ms * 1e3:10.1f} | "
-                        f"{lps / 1e9:8.1f} | {per_clk:6.2f} | {Kh.mean():5.2f} | {ok} | {ms_keep:9.3f} | {per_clk_keep:6.2f}")
+                        f"{lps / 1e9:8.1f} | {per_clk:6.2f} | {Kh.mean():5.2f} | {ok} | {ms_keep:9.3f} | {per_clk_keep:6.2f} | "
+                        f"{arithmetic_floor(plan['kernel'], S, B):6.2f} | {per_clk_keep / arithmetic_floor(plan['kernel'], S, B):5.2f}")
                 print(line, flush=True)
                 if worst is None or per_clk < worst[0]:
                     worst = (per_clk, line)

@@ -538,7 +538,7 @@ def test_reference_sweep_grid(engine, oracle, omega, B):
     n_beams in {1, 10, 50}, S = int(exp(Omega * (1 + eps))) from 7 to 8103 (beam_search_coder.py:28-29) -- on one 1000-dim and
     one 192-dim block each: emitted indices and sample bit-exact against the oracle, once the way the library picks its
     kernels for a call this small and once with the batch encoder pinned (what a batch of such blocks runs on:
-    encode_lone_kernel for B = 1, encode_team_kernel<10,3,1[,passes]> for B = 10, <60,1,3> for B = 50; S * B reaches 405 150
+    encode_lone_kernel for B = 1, encode_team_kernel<10,3,1[,passes]> for B = 10, <60,1,3> / <54,1,3> (S >= 128) for B = 50; S * B reaches 405 150
     candidates per step)."""
     from irec import _lib
     n, bs = 1192, 1000
@@ -1068,6 +1068,9 @@ def test_plan_names_the_kernels_that_run(engine, oracle):
     assert engine.plan(engine.params(5.0, 148, 30), big, 32)["kernel"] == "encode_team_kernel<30,1,3>"
     assert engine.plan(engine.params(3.0, S, 40), big, 32)["kernel"] == "encode_team_kernel<60,1,3>"     # round 3: 32 < B <= 60
     assert engine.plan(engine.params(3.0, S, 40), small, 32)["kernel"] == "encode_team_kernel<60,1,3>"   # (no one-table encoder there)
+    assert engine.plan(engine.params(3.0, S, 50), big, 32)["kernel"] == "encode_team_kernel<60,1,3>"     # B = 50 below S = 128
+    assert engine.plan(engine.params(5.0, 148, 50), big, 32)["kernel"] == "encode_team_kernel<54,1,3>"   # round 4: stripes of 18 from S = 128 on
+    assert engine.plan(engine.params(5.0, 148, 57), big, 32)["kernel"] == "encode_team_kernel<60,1,3>"
     assert engine.plan(engine.params(3.0, S, 64), big, 32)["kernel"] == "encode_generic_kernel"          # 60 < B <= 64
     assert engine.plan(engine.params(6.0, 8103, 10), big, 32)["kernel"] == "encode_team_kernel<10,3,1,passes>"
     # one beam: one wave per block (irec_lone.hip), 12 blocks in flight per CU; the team encoder's one-beam builds on request
