@@ -84,6 +84,8 @@ typedef struct {
                                   /* stamp -- checked on the device, so also inside a replayed HIP graph -- keeps the table   */
                                   /* instead of rebuilding it (the 24 residual blocks of an image share seed, S and dims:     */
                                   /* beam_search_coder.py:38-43, resnet_vae.py:822-824).  Same outputs, bit for bit.          */
+#define IREC_FLAG_SHARE_ALL 131072 /* team encoder, calls that leave team slots idle: share EVERY row of the call between teams instead of only */
+                                  /* the rows beyond one per CU (diagnostics, r04j: slower than the default at every size; same outputs)     */
 #define IREC_FLAG_SPLIT_SHIFT 12  /* bits 12-15: workgroups per block of the split encoder, 0 = chosen by the library (diagnostics) */
 #define IREC_FLAG_SPLIT_MASK (0xF << IREC_FLAG_SPLIT_SHIFT)
 /* Diagnostic workgroup shapes of the team encoder for B <= 20 (bits 8-11 of flags; 0 = the default shape).  Same outputs. */

@@ -628,7 +628,7 @@ int split_width(const irec_context *ctx, const Plan &pl, const irec_params *p, i
   if (!pl.table || pl.chunk || (p->flags & IREC_FLAG_NO_SPLIT)) return 0;
   const int B = p->n_beams, S = p->n_samples, nb = irec::fast_nb_for(B);
   if (!nb || irec::fast_waves_for(B, S, true) != 4 || (int64_t)S * nb > 1024) return 0;   // aliased-key 4-wave builds only
-  if (n_blocks < 1 || n_blocks > irec::COOP_MAX_BLOCKS) return 0;
+  if (n_blocks < 1 || n_blocks > irec::COOP_SPLIT_MAX_BLOCKS) return 0;
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
   int64_t W = (n_cu / 2) / n_blocks;
   W = std::min<int64_t>(W, S);                                             // at least one sample per workgroup
@@ -650,6 +650,43 @@ int split_beam_width(const irec_params *p, int W) {
   return W;
 }
 
+// Shared rows of the team encoder (irec_team.hip) for calls of one to one-and-a-half blocks per CU with more than ten beams (one
+// GPU's share of config 3: 342 blocks).  Every CU gets ONE whole block; each of the n_blocks - n_cu rows beyond that is coded by W
+// teams in the idle team slots of W CUs, which split its samples and exchange sort keys, so a CU carries one block and a fraction
+// instead of two -- the call is as long as its most loaded CU (r04i: 342 blocks 0.59 -> 0.555 ms, 297 blocks 0.575 -> 0.54 ms).
+// Not for B <= 10 (302 blocks of a Kodak level: 0.26 ms either way) and not beyond 1.5 blocks per CU (W = 1).
+// IREC_FLAG_SHARE_ALL (diagnostics): every row of a call of 64 .. 384 blocks is shared, W = slots / blocks -- slower than the
+// default at every size (r04j: 252 blocks 0.49 against 0.44 ms on the 8-wave team; the partners of a row wait for the slowest).
+// Returns W (0: no sharing) for the shape the call runs; *first = first shared row, *grid = workgroups the static round needs.
+int team_share_width(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks, int shape, int64_t *first, int *grid) {
+  if (!pl.team || pl.lone || pl.team_only || (p->flags & IREC_FLAG_NO_SPLIT)) return 0;
+  const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+  const int teams = irec::team_shareable(p->n_beams, p->n_samples, shape);
+  if (teams < 2) return 0;
+  const int want = (p->flags & IREC_FLAG_SPLIT_MASK) >> IREC_FLAG_SPLIT_SHIFT;
+  const int64_t cap = std::min<int64_t>(8, p->n_samples);
+  const int64_t slots = (int64_t)teams * n_cu;
+  int64_t W = 0, f = 0;
+  if (p->flags & IREC_FLAG_SHARE_ALL) {
+    if (n_blocks < 64 || n_blocks > irec::COOP_MAX_BLOCKS || 2 * n_blocks > slots) return 0;
+    W = slots / n_blocks;
+  } else {
+    if (p->n_beams <= 10 || n_blocks <= n_cu || n_blocks >= slots || n_blocks - n_cu > irec::COOP_MAX_BLOCKS) return 0;
+    f = n_cu;
+    W = (slots - n_cu) / (n_blocks - n_cu);        // every slot in the static round: all partners resident at once
+  }
+  W = std::min(W, cap);
+  if (want >= 2) W = std::min<int64_t>(W, want);
+  if (W < 2) return 0;
+  const int64_t n_slots = f + (n_blocks - f) * W;
+  int64_t g = n_cu;                                  // (whole rows: hand-out slots 0 .. n_cu - 1 = team 0 of every workgroup)
+  if (f == 0) { g = (n_slots + teams - 1) / teams; g = std::min<int64_t>(n_cu, (g + 7) & ~(int64_t)7); }
+  if (g * teams < n_slots) return 0;
+  if (first) *first = f;
+  if (grid) *grid = (int)g;
+  return (int)W;
+}
+
 // small calls (a single image's res-block: 9 blocks) are latency-bound: the one-table encoder's set-up (a 6 us proposal
 // table, 40 KB of LDS to fill) beats the team encoder's (38 us per table for the bank assignment, 120 KB); the scratch
 // sized for the team plan covers both
@@ -663,6 +700,8 @@ bool team_for_call(const Plan &pl, const irec_params *p, int64_t n_blocks) {
 int shape_for_call(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks) {
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
   const int B = p->n_beams, S = p->n_samples;
+  if ((p->flags & IREC_FLAG_SHARE_ALL) && !(p->flags & IREC_FLAG_NO_SPLIT) && pl.shape == 0 &&
+      team_share_width(ctx, pl, p, n_blocks, 0, nullptr, nullptr) >= 2) return pl.shape;   // (diagnostics) every row shared between teams: the three-team shape
   if (pl.shape != 0 || !pl.team || pl.lone || n_blocks < 64 || n_blocks > 2 * (int64_t)n_cu || B > 20) return pl.shape;   // (< 64 blocks: only calls
                                                                          // that pin IREC_FLAG_TEAM get here, tests of the default shape among them)
   if (irec::team_count_for(B, S, 0) < 2) return pl.shape;                       // already one striped team
@@ -725,6 +764,11 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
     std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::team_kernel_name(B, S, shape));
     std::snprintf(out->table_kernel, sizeof out->table_kernel, "alpha_choice_kernel");
     out->grid = batch_grid(n_blocks, std::min(pl.grid_cap / n_teams, n_cu));
+    {
+      int sgrid = 0;
+      out->split = team_share_width(ctx, pl, p, n_blocks, shape, nullptr, &sgrid);   // teams that code each shared row
+      if (out->split >= 2) out->grid = sgrid;
+    }
     out->waves_per_wg = irec::team_waves_for(B, S, shape);
     out->teams_per_wg = n_teams;
     out->lds_bytes = (int32_t)irec::team_lds_for(B, S, shape);
@@ -838,6 +882,10 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   stamps.reuse = (p->flags & IREC_FLAG_REUSE_TABLES) ? 1 : 0;
   int split_blocks = 0;   // a split call: the head kernel also zeroes the exchange granules of its blocks
   if (pl.table && !pl.team && split_width(ctx, pl, p, n_blocks) >= 2) split_blocks = (int)n_blocks;   // (pl.team: of THIS call, above)
+  int64_t share_first = 0;
+  int share_grid = 0;
+  const int share_W = (pl.table && pl.team) ? team_share_width(ctx, pl, p, n_blocks, pl.shape, &share_first, &share_grid) : 0;
+  if (share_W >= 2) split_blocks = (int)(n_blocks - share_first);
   HIP_TRY(irec::launch_zero_counters(workspace, stamps, split_blocks, st));
   int grid = (int)std::min<int64_t>(n_blocks, pl.one_grid_cap);
   A.dbg = nullptr;
@@ -892,7 +940,11 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
     } else if (pl.team) { // grid_cap counts teams (= scratch slabs): two per workgroup, one workgroup per CU
       const int n_teams = irec::team_count_for(p->n_beams, p->n_samples, pl.shape);
       // one workgroup per CU as soon as there is a block for it: team k of workgroup w starts on block k * grid + w
-      const int tgrid = batch_grid(n_blocks, std::min(pl.grid_cap / n_teams, ctx->n_cu > 0 ? ctx->n_cu : 256));
+      int tgrid = batch_grid(n_blocks, std::min(pl.grid_cap / n_teams, ctx->n_cu > 0 ? ctx->n_cu : 256));
+      if (share_W >= 2) {   // rows [share_first, n_blocks) are coded by share_W teams each; the static round deals every slot
+        A.coop_W = share_W; A.tsplit_first = share_first; tgrid = share_grid;
+        A.coop_test_orphan = (p->flags & IREC_FLAG_TEST_SPLIT_ORPHAN) ? 1 : 0;
+      }
       HIP_TRY(irec::launch_encode_team(A, tgrid, st));
 #ifndef IREC_HOST_STAMPS
       if (irec_status s2 = deferred_pass()) return s2;

@@ -41,6 +41,9 @@ struct EncArgs {
   // the step's keys back and run the same selection.  *coop_err != 0: a workgroup gave up waiting (partners not resident):
   // block not coded.
   int32_t coop_W; unsigned int *coop_arrive; uint32_t *coop_xch; unsigned int *coop_err;
+  // Shared rows of the team encoder (irec_team.hip, round 4): rows [tsplit_first, n_blocks) are coded by coop_W teams each, which
+  // split the row's samples and exchange their sort keys through coop_xch (row r uses exchange slot r - tsplit_first).
+  int64_t tsplit_first;
   int32_t coop_beams;         // 1: the workgroups of a block share its beams (slots w, w + coop_W) instead of its samples
   int32_t coop_test_orphan;   // IREC_FLAG_TEST_SPLIT_ORPHAN: partners leave at once (exercises the give-up exit)
   // diagnostics (IREC_STAMPS=1): per-workgroup cycle sums [grid][8]; nullptr in normal runs
@@ -80,6 +83,7 @@ hipError_t launch_alpha_table(int64_t seed, int32_t S, int32_t D, int32_t K_tab,
 // two-teams-per-CU encoder over three table copies (irec_team.hip)
 // (shape_override: 0 = default shape, 1..4 = the diagnostic shapes of IREC_FLAG_SHAPE_*, see team_cfg() in irec_team.hip)
 int team_count_for(int B, int S, int shape_override);   // teams per workgroup (= scratch slabs per workgroup) of the build that serves B beams
+int team_shareable(int B, int S, int shape_override);   // teams per workgroup when that build can share rows between teams (several 4-wave teams, one pass, keys within the exchange), else 0
 int team_waves_for(int B, int S, int shape_override);   // waves per workgroup of that build
 size_t team_ws_extra_for(int B, int S, int shape_override); // extra scratch-slab bytes of that build
 size_t team_ws_bytes_for(int B, int S, int shape_override, int max_K);   // whole scratch slab of one team of that build
@@ -114,7 +118,9 @@ constexpr int WS_KEEP_WORD = 8, WS_STAMP_WORD = 16, WS_STAMP_WORDS = 8, WS_XCD_W
 struct TableStamps { uint32_t w[4][WS_STAMP_WORDS]; int32_t reuse; };   // all-zero key = slot unused (never matches)
 hipError_t launch_zero_counters(void *p, const TableStamps &stamps, int split_blocks, hipStream_t st);   // split_blocks > 0: also zeroes the exchange granules of that many blocks
 constexpr size_t WS_COUNTER_BYTES = 512 + 8 * 256;        // [0,256): counters, keep words, table stamps; [256,512): 64 arrival counters; [512,2560): XCD counters
-constexpr int COOP_MAX_BLOCKS = 64, COOP_KEYS = 1024;      // split encoder: blocks per call, sort keys per step (S * NB, aliased-key builds)
+constexpr int COOP_MAX_BLOCKS = 384, COOP_KEYS = 1024;     // key exchange: blocks per call that are shared (split encoder: <= 64 blocks of a small call; team encoder:
+                                                           // the rows beyond one per CU of a mid-size call), sort keys per step (S * NB)
+constexpr int COOP_SPLIT_MAX_BLOCKS = 64;                  // the split encoder takes calls of at most this many blocks
 #ifndef IREC_COOP_GRANULES
 #define IREC_COOP_GRANULES 1   // split encoder: sort keys travel as 8-byte {key, step tag} granules that the partners sweep directly
                                // (0: 4-byte keys behind an arrival counter, r02-r03l)

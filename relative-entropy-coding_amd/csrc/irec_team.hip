@@ -150,7 +150,9 @@ struct TeamBarrier {
 // ONE: the build of one-beam calls (B = 1 of the reference's sweep): every step takes the wide path, which is therefore the
 // pipelined form (rows a half batch ahead, two samples per v_pk_fma_f32) -- in the other builds only step 0 comes there and
 // the extra row buffers cost registers everywhere else (r03e A/B: B = 32 -14 %, B = 30 -2 %, B = 10 -3 % with it).
-template <int NB, int TEAMS, int BS, bool PASSES = false, bool ONE = false>
+// SHARE: the build of calls whose rows beyond one per CU are shared between teams (A.coop_W > 1, below) -- its own instantiation:
+// the exchange code costs the two-team builds their spill-free register allocation (r04: <20,2,1> 80 -> 400 B of scratch with it).
+template <int NB, int TEAMS, int BS, bool PASSES = false, bool ONE = false, bool SHARE = false>
 __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(EncArgs A) {
   using TeamLds = TeamLdsT<NB>;
   constexpr int TEAM_MB = team_mb(NB);
@@ -235,7 +237,17 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   // teams (a mid-size batch: 38 images x 9 blocks) puts ONE block on every CU before any CU gets a second one, instead of
   // three on the first third of the CUs; later blocks come from the atomic counter, which starts behind the static ones.
   // Both rounds deal the rows of a tensor to one XCD (irec_fast_common.h: xcd_static_row / xcd_pull_row).
-  const int64_t n_static = (int64_t)TEAMS * (int64_t)gridDim.x < A.n_blocks ? (int64_t)TEAMS * (int64_t)gridDim.x : A.n_blocks;
+  // Shared blocks (round 4; calls of one to two blocks per CU): the rows from A.tsplit_first on are coded by A.coop_W teams EACH --
+  // anywhere on the chip -- that split the row's SAMPLES: team q of a row scores the samples of stripe q, publishes their sort
+  // keys as tagged granules (the split encoder's exchange, irec_kernels.hip), sweeps its partners' and then runs the same
+  // selection and the same update as they do, on its own slab: nothing but keys is shared.  A 342-block call then loads a CU
+  // with one whole block and a fraction of another instead of two whole ones.  Hand-out slots: one per whole row, coop_W per
+  // shared row; the host sizes coop_W so that the static round deals every slot (all partners resident at once).
+  constexpr bool CAN_SHARE = SHARE && TEAMS >= 2 && BS == 1 && !PASSES && !ONE;
+  const int Wsh = (CAN_SHARE && A.coop_W > 1) ? A.coop_W : 1;
+  const int64_t n_whole = Wsh > 1 ? (A.tsplit_first < A.n_blocks ? A.tsplit_first : A.n_blocks) : A.n_blocks;
+  const int64_t n_slots = n_whole + (A.n_blocks - n_whole) * Wsh;
+  const int64_t n_static = (int64_t)TEAMS * (int64_t)gridDim.x < n_slots ? (int64_t)TEAMS * (int64_t)gridDim.x : n_slots;
   bool first_block = true;
   int steal = 0;
   for (;;) {
@@ -244,15 +256,20 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
       int64_t r;
       if (first_block) {
         r = (int64_t)team * (int64_t)gridDim.x + (int64_t)blockIdx.x;
-        r = r < n_static ? xcd_static_row(r, n_static, (int)gridDim.x) : A.n_blocks;
-      } else r = xcd_pull_row(A, n_static, A.n_blocks, steal);
+        r = r < n_static ? xcd_static_row(r, n_static, (int)gridDim.x) : n_slots;
+      } else r = xcd_pull_row(A, n_static, n_slots, steal);
       misc[0] = (int32_t)r;
+      misc[6] = 0;                          // (shared rows: a partner gave up)
     }
     first_block = false;
     tsync();
-    const int64_t blk = misc[0];
+    const int64_t slot = misc[0];
     TSTAMP(0);
-    if (blk >= A.n_blocks) break; // every wave of the team reaches this; the other team drains on its own
+    if (slot >= n_slots) break; // every wave of the team reaches this; the other team drains on its own
+    const int64_t blk = slot < n_whole ? slot : n_whole + (slot - n_whole) / Wsh;
+    const int qsh = slot < n_whole ? 0 : (int)((slot - n_whole) % Wsh);      // my sample stripe of a shared row
+    const int Wrow = slot < n_whole ? 1 : Wsh;                               // teams that code this row
+    if (Wrow > 1 && A.coop_test_orphan && qsh != 0) continue;                // test hook: team 0 of a shared row is left waiting
     const int D = A.block_dim[blk];
     const int64_t base = A.block_base[blk];
     const int32_t pos = A.block_pos[blk];
@@ -261,7 +278,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
     for (int q = 0; q < 4; ++q)
       if (A.tab_dim[q] == D) tab = A.tab[q];
     if (D < 1 || D > FAST_MAX_DIM || tab == nullptr) { // host promised D <= 1024 and listed dims
-      if (tid == 0) A.out_K[blk] = -1;
+      if (tid == 0 && qsh == 0) A.out_K[blk] = -1;
       continue;
     }
     const int Dp = (D + 3) & ~3;            // row stride of the proposal table
@@ -269,6 +286,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
     const int NSW = NW / NG;                // sample stripes
     const bool active = wave < NG * NSW;
     const int g = wave % NG, sw = wave / NG;
+    const int NSWe = NSW * Wrow, swe = sw * Wrow + qsh;   // ... of the row over all the teams that code it: my samples are swe, swe + NSWe, ...
     const int d0 = g * 256 + lane * 4;
 
     // ---- my 4 dims (split == gather through perm) and the block's KL ----
@@ -307,7 +325,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         for (int gg = 1; gg < NG; ++gg) tot = tot + gpart[gg];
         const int32_t K = num_aux((float)tot, A.omega);
         misc[1] = K;
-        A.out_K[blk] = K;
+        if (qsh == 0) A.out_K[blk] = K;
         hsum[0] = 0;
         beta4[0] = 0u; // hash of the empty path is 1 = g^0
       }
@@ -316,11 +334,11 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
     const int K = misc[1];
     if (K > A.max_K || K > IREC_MAX_PARTITIONS_DEV) continue;
     if (K > A.K_tab) { // beyond the table window: the fused-Philox pass codes it
-      if (tid == 0) atomicAdd(A.defer_count, 1u);
+      if (tid == 0 && qsh == 0) atomicAdd(A.defer_count, 1u);
       continue;
     }
     if (K == 0) { // nothing to code: sample = p.loc
-      if (active && sw == 0 && bs == 0) {
+      if (active && sw == 0 && bs == 0 && qsh == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           if (valid[i]) { const int64_t ixo = src_index(A, base, pos, d0 + i); A.out_sample[ixo] = 0.f + A.p_loc[ixo]; }
@@ -389,6 +407,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
     }
 
     TSTAMP(1);
+    bool abandoned = false;
     int cur = 0, Bcur = 1;
     // 4 * dlog(hash) of the live beams, lane j = beam j: every wave carries its own copy from the update into the next step's
     // scoring (r04: the table look-up behind it is a GLOBAL load; it used to sit inside the one-wave selection, a round trip
@@ -429,11 +448,11 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         // most 15 LDS operations outstanding, so by the time the next slot's are issued the current slot's have landed
         // (or the compiler's wait counts see to it).  Empty volatile asm statements pin the order (pure arithmetic would
         // otherwise drift across the scheduling barriers).  A chunk is SPC samples (20 accumulators, one reduce-scatter).
-        const int n_mine = Sp > sw ? (Sp - sw + NSW - 1) / NSW : 0; // my samples of the pass: s_base + sw, + NSW, ...
+        const int n_mine = Sp > swe ? (Sp - swe + NSWe - 1) / NSWe : 0; // my samples of the pass: s_base + swe, + NSWe, ...
         const int n_chunks = (n_mine + SPC - 1) / SPC;
         auto row = [&](int m) {                                     // proposal row of my m-th sample; zero row past the end:
           uint2 r = make_uint2(0u, 0u);                             // entry 0 is a valid address, its results are dropped
-          if (m < n_mine) r = *reinterpret_cast<const uint2 *>(tab_tu + ((uint32_t)(s_base + m * NSW + sw) * (uint32_t)Dp + tab_lo));
+          if (m < n_mine) r = *reinterpret_cast<const uint2 *>(tab_tu + ((uint32_t)(s_base + m * NSWe + swe) * (uint32_t)Dp + tab_lo));
           return r;
         };
         // proposal rows stay packed (4 x uint16 per sample in two registers); the byte address of a dim slot's entry in copy 0
@@ -531,7 +550,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           }
           const int cc = own / NBW, b = own - cc * NBW;            // own < 0: unused slot
           const int m = ch * SPC + cc;                              // my m-th sample
-          if (own >= 0 && (lane & 1) == 0 && m < n_mine && b < nlive) part_s[((size_t)g * SP + m * NSW + sw) * PS + b_lo + b] = tot;
+          if (own >= 0 && (lane & 1) == 0 && m < n_mine && b < nlive) part_s[((size_t)g * SP + m * NSWe + swe) * PS + b_lo + b] = tot;
         }
         if constexpr (BS >= 2 && IREC_PRIO_ROTATE != 0) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
@@ -544,7 +563,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         // pay a whole reduce-scatter (86 instructions) for 4 look-ups; here RW SAMPLES share one -- a sample sits where a
         // beam sits in the steady state, every total still comes out of the same lane chain and lane tree.  36 samples: two
         // rounds instead of 36 (r02i: step 0 cost half a full step's instructions for a twentieth of its look-ups).
-        const int n_mine = Sp > sw ? (Sp - sw + NSW - 1) / NSW : 0; // my samples of the pass: s_base + sw, + NSW, ...
+        const int n_mine = Sp > swe ? (Sp - swe + NSWe - 1) / NSWe : 0; // my samples of the pass: s_base + swe, + NSWe, ...
         const uint32_t bet0 = bet[0];
         if constexpr (IREC_WIDE_V2 != 0 && (ONE || IREC_WIDE_V2 >= 2)) {
         // two half batches of rows (even sizes: samples go through the fma in pairs), 20 registers as the steady state's
@@ -562,7 +581,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           for (int k = 0; k < H; ++k) {
             int m = m_first + k;
             m = m < n_mine ? m : n_mine - 1;
-            const char *rowp = reinterpret_cast<const char *>(tab_tu) + (size_t)((uint32_t)(s_base + m * NSW + sw) * (uint32_t)Dp) * 2u;
+            const char *rowp = reinterpret_cast<const char *>(tab_tu) + (size_t)((uint32_t)(s_base + m * NSWe + swe) * (uint32_t)Dp) * 2u;
             ap[k] = *reinterpret_cast<const uint2 *>(rowp + lane_off);
           }
         };
@@ -612,7 +631,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
             own = rs_p;
           }
           const int m = m0 + own;                                   // own < 0: unused slot
-          if (own >= 0 && (lane & 1) == 0 && m < n_mine) part_s[((size_t)g * SP + m * NSW + sw) * PS] = tot;
+          if (own >= 0 && (lane & 1) == 0 && m < n_mine) part_s[((size_t)g * SP + m * NSWe + swe) * PS] = tot;
         }
         } else {   // the round-2 form (builds of more than one beam: only their first step comes here)
           constexpr int HB = RW / 2;                                  // rows fetched together (20 registers, as the steady state's)
@@ -628,7 +647,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
               for (int k = 0; k < HB; ++k) {
                 const int m = m0 + h * HB + k;                        // past my last sample: entry 0, the total is dropped
                 ap[k] = make_uint2(0u, 0u);
-                if (m < n_mine) ap[k] = *reinterpret_cast<const uint2 *>(tab_tu + ((uint32_t)(s_base + m * NSW + sw) * (uint32_t)Dp + tab_lo));
+                if (m < n_mine) ap[k] = *reinterpret_cast<const uint2 *>(tab_tu + ((uint32_t)(s_base + m * NSWe + swe) * (uint32_t)Dp + tab_lo));
               }
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
@@ -645,18 +664,18 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
             }
             const float tot = reduce_scatter_n<RW>(acc, lane);
             const int m = m0 + rs_p;                                  // rs_p < 0: unused slot
-            if (rs_p >= 0 && (lane & 1) == 0 && m < n_mine) part_s[((size_t)g * SP + m * NSW + sw) * PS] = tot;
+            if (rs_p >= 0 && (lane & 1) == 0 && m < n_mine) part_s[((size_t)g * SP + m * NSWe + swe) * PS] = tot;
           }
         }
       } else if (active && nlive > 0) {
 #endif
-        const int s_per_stripe = (Sp + NSW - 1) / NSW;
+        const int s_per_stripe = (Sp + NSWe - 1) / NSWe;
         const int nchunks = (s_per_stripe + SPC - 1) / SPC;
         // proposal rows (4 x uint16: dlog(r) + 10006 c of my dims) are fetched one chunk ahead
         uint2 alp_next[SPC];
 #pragma unroll
         for (int cc = 0; cc < SPC; ++cc) {
-          const int s0 = cc * NSW + sw;   // sample index inside the pass
+          const int s0 = cc * NSWe + swe;   // sample index inside the pass
           alp_next[cc] = make_uint2(0u, 0u);
           if (s0 < Sp) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)(s_base + s0) * Dp);
         }
@@ -668,12 +687,12 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 #pragma unroll
           for (int cc = 0; cc < SPC; ++cc) {
             alp[cc] = alp_next[cc];
-            const int sn = ((ch + 1) * SPC + cc) * NSW + sw;
+            const int sn = ((ch + 1) * SPC + cc) * NSWe + swe;
             if (sn < Sp) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)(s_base + sn) * Dp);
           }
 #pragma unroll
           for (int cc = 0; cc < SPC; ++cc) {
-            const int s = (ch * SPC + cc) * NSW + sw;   // sample index inside the pass
+            const int s = (ch * SPC + cc) * NSWe + swe;   // sample index inside the pass
             if (s < Sp) { // wave-uniform
               const uint2 ap = alp[cc];
               // byte address of entry alpha' in copy 0 (the table starts at LDS address 0)
@@ -705,7 +724,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           }
           const float tot = reduce_scatter_n<RW>(acc, lane);
           const int cc = rs_p / NBW, b = rs_p - cc * NBW;   // rs_p < 0: unused slot
-          const int s = (ch * SPC + cc) * NSW + sw;
+          const int s = (ch * SPC + cc) * NSWe + swe;
           if (rs_p >= 0 && (lane & 1) == 0 && s < Sp && b < nlive) part_s[((size_t)g * SP + s) * PS + b_lo + b] = tot;
         }
       }
@@ -737,6 +756,12 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
               for (int gg = 0; gg < 4; ++gg) asm volatile("" : "+v"(pr[q][gg]));
             tsync();
           }
+          // shared rows: a candidate is MINE when its sample lies in my stripe; the others' keys come out of the exchange
+          unsigned long long *xg = nullptr;
+          if (CAN_SHARE && Wrow > 1)
+            xg = reinterpret_cast<unsigned long long *>(A.coop_xch) + ((size_t)(t & 1) * COOP_MAX_BLOCKS + (size_t)(blk - n_whole)) * COOP_KEYS;
+          const unsigned long long tag64 = (unsigned long long)(uint32_t)(t + 1) << 32;
+          uint32_t foreign = 0u;                        // bit q: candidate q * NT + tid is a partner's
 #pragma unroll
           for (int q = 0; q < MK; ++q) {
             float sc = pr[q][0];
@@ -747,12 +772,51 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
             if (NG > 1) cb = cb + cbv[q][1];
             if (NG > 2) cb = cb + cbv[q][2];
             if (NG > 3) cb = cb + cbv[q][3];
-            if (q * NT + tid < Np) key_s[f_base + q * NT + tid] = score_key(sc + cb);
+            const int f = q * NT + tid;
+            if (f < Np) {
+              bool mine = true;
+              if (CAN_SHARE && Wrow > 1) {
+                const int s_ = Bcur == NB ? f / NB : f / Bcur;
+                mine = ((s_ % NSWe) % Wrow) == qsh;
+              }
+              if (mine) {
+                const uint32_t key = score_key(sc + cb);
+                key_s[f_base + f] = key;
+                if (CAN_SHARE && Wrow > 1) __hip_atomic_store(&xg[f], tag64 | (unsigned long long)key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              } else foreign |= 1u << q;
+            }
+          }
+          if (CAN_SHARE && Wrow > 1) {
+            // sweep the partners' granules until each carries this step's tag (tags start at 1; the head kernel zeroed the row's
+            // granules; buffer t & 1 last held tag t - 1).  Give-up as in the split encoder: sticky error flag, 2 s.
+            const uint32_t tag = (uint32_t)(t + 1);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
+            int32_t bad = 0;
+            for (uint32_t turn = 1; foreign != 0u; ++turn) {
+              unsigned long long gq[MK];
+#pragma unroll
+              for (int q = 0; q < MK; ++q)
+                gq[q] = (foreign >> q) & 1u ? __hip_atomic_load(&xg[q * NT + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+#pragma unroll
+              for (int q = 0; q < MK; ++q)
+                if (((foreign >> q) & 1u) && (uint32_t)(gq[q] >> 32) == tag) { key_s[f_base + q * NT + tid] = (uint32_t)gq[q]; foreign &= ~(1u << q); }
+              if (foreign == 0u || (turn & 63u) != 0u) continue;
+              if (__hip_atomic_load(A.coop_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bad = 1; break; }
+              if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { // 2 s: the partners are not resident -- give up, loudly
+                __hip_atomic_store(A.coop_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bad = 1; break;
+              }
+            }
+            if (bad) misc[6] = 1;
           }
         }
       }
       if (s_end < S) tsync(); // the next pass overwrites the partials
       } // sample passes
+      if (CAN_SHARE && Wrow > 1) {   // every team of the row sees the (sticky) flag: nobody waits for anybody any more
+        tsync();
+        if (misc[6]) { abandoned = true; break; }
+      }
       const int Bnew = B < N ? B : N;
       TSTAMP(4);
 #ifdef IREC_ABLATE_SELECT
@@ -857,7 +921,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
                 nb[i] = obv[i] + y;                                         // combined_samples[best_ind_aux, best_ind_beam], :81,92-93
               }
               if (last) {
-                if (j == 0 && sw == 0) {
+                if (j == 0 && sw == 0 && qsh == 0) {
 #pragma unroll
                   for (int i = 0; i < 4; ++i)
                     if (valid[i]) { // beams[0] + coding_dist.loc, :122
@@ -919,7 +983,11 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
     }
     // ---- index path of beam 0 (beam_search_coder.py:118-121) ----
     tsync();
-    if (tid == 0) {
+    if (abandoned) {                          // a shared row whose partners were not all resident: not coded (the host codes the call again)
+      if (tid == 0 && qsh == 0) A.out_K[blk] = -2;
+      continue;
+    }
+    if (tid == 0 && qsh == 0) {
       int j = 0;
       for (int t = K - 1; t >= 0; --t) {
         const int32_t v = __builtin_nontemporal_load(&bp[(size_t)t * NB + j]);
@@ -1474,6 +1542,10 @@ static TeamShape team_shape(int B, int S, int ovr) {
   return TeamShape{0, 0, 0, false};
 }
 int team_count_for(int B, int S, int ovr) { return team_shape(B, S, ovr).teams; }
+int team_shareable(int B, int S, int ovr) {
+  const TeamShape sh = team_shape(B, S, ovr);
+  return (sh.nb && sh.teams >= 2 && sh.bs == 1 && !sh.passes && !sh.one && (int64_t)S * sh.nb <= COOP_KEYS) ? sh.teams : 0;
+}
 int team_waves_for(int B, int S, int ovr) { const TeamShape sh = team_shape(B, S, ovr); return sh.teams * sh.bs * TEAM_NW; }
 size_t team_ws_extra_for(int B, int S, int ovr) { // scratch-slab bytes on top of fast_ws_for(): the sort keys when they do not fit the LDS
   const TeamShape sh = team_shape(B, S, ovr);
@@ -1503,21 +1575,30 @@ size_t team_lds_for(int B, int S, int ovr) {
   return b <= FAST_LDS_LIMIT ? b : (size_t)-1;
 }
 
-template <int NB, int TEAMS, int BS, bool PASSES = false, bool ONE = false>
+template <int NB, int TEAMS, int BS, bool PASSES = false, bool ONE = false, bool SHARE = false>
 static hipError_t launch_team_t(const EncArgs &A, int grid, hipStream_t st) {
   const int ps = team_row(NB, A.B);
   const int sp = (TEAMS == 1 || PASSES) ? team_s_pass(NB, A.S, TEAMS, TEAMS == 1 ? 2048 : 1024, PASSES, ps) : A.S;
   const size_t lds = team_lds_total(NB, A.S, sp, TEAMS, PASSES, ps);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_team_kernel<NB, TEAMS, BS, PASSES, ONE>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_team_kernel<NB, TEAMS, BS, PASSES, ONE, SHARE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((encode_team_kernel<NB, TEAMS, BS, PASSES, ONE>), dim3(grid), dim3(TEAMS * BS * TEAM_NT), lds, st, A);
+  hipLaunchKernelGGL((encode_team_kernel<NB, TEAMS, BS, PASSES, ONE, SHARE>), dim3(grid), dim3(TEAMS * BS * TEAM_NT), lds, st, A);
   return hipGetLastError();
 }
 
 hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
   const TeamShape sh = team_shape(A.B, A.S, A.shape_override);
   const int key = sh.nb * 100 + sh.teams * 10 + sh.bs + (sh.passes ? 10000 : 0) + (sh.one ? 100000 : 0);
+  if (A.coop_W > 1) {   // rows shared between teams (host: team_share_width -> team_shareable builds only)
+    switch (key) {
+      case 1021: return launch_team_t<10, 2, 1, false, false, true>(A, grid, st);
+      case 1031: return launch_team_t<10, 3, 1, false, false, true>(A, grid, st);
+      case 2021: return launch_team_t<20, 2, 1, false, false, true>(A, grid, st);
+      case 2031: return launch_team_t<20, 3, 1, false, false, true>(A, grid, st);
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (key) {
     case 101031: return launch_team_t<10, 3, 1, false, true>(A, grid, st);
     case 111031: return launch_team_t<10, 3, 1, true, true>(A, grid, st);

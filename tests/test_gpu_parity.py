@@ -1158,6 +1158,70 @@ def test_one_to_two_blocks_per_cu_take_the_two_team_shape(engine, oracle, B, eps
         assert idx[i] == ridx and np.array_equal(sample[i].cpu().numpy(), rs), i
 
 
+@pytest.mark.parametrize("B,eps1,n_latents,shape,extra,want_W", [(20, 1.2, 38, "default", 0, 2), (20, 1.2, 38, "3", 0, 5), (20, 1.2, 29, "default", 0, 8),
+                                                                (13, 1.2, 45, "3", 0, 3), (10, 1.0, 34, "default", 131072, 2),
+                                                                (7, 1.0, 14, "default", 131072, 6), (20, 1.2, 38, "default", 131072, 2)])
+def test_calls_of_one_to_two_blocks_per_cu_share_rows_between_teams(engine, oracle, B, eps1, n_latents, shape, extra, want_W):
+    """Round 4: in a call of n_CU < blocks < teams * n_CU every CU gets ONE whole block; each row beyond that is coded by W teams
+    in the idle team slots of W CUs, which split its samples, exchange their sort keys as tagged granules and then run the same
+    selection and update (irec_team.hip, "Shared blocks").  Same outputs as the call with IREC_FLAG_NO_SPLIT (every block on one
+    team) bit for bit -- K, index rows, samples of EVERY block --, the oracle's on three tensors; irec_encode_plan reports W;
+    a K = 0 tensor and rows beyond the table window among the shared rows; decode(encode) exact."""
+    import irec
+    S = oracle.n_samples(3.0, eps1)
+    stats = [list(oracle.synthetic_latent(900 + i, 8192)) for i in range(n_latents)]
+    stats[-1][0], stats[-1][1] = stats[-1][2].copy(), stats[-1][3].copy()        # the last tensor (its rows are shared ones): KL = 0
+    ql, qs, pl, ps = (torch.from_numpy(np.stack([s[k] for s in stats])).cuda().contiguous() for k in range(4))
+    lay = engine.layout(n_latents, 8192, 1000, 42)
+    fl = irec._lib.IREC_FLAG_SHAPE[shape] | extra      # (extra = IREC_FLAG_SHARE_ALL: every row of the call shared, the diagnostic policy)
+    for steps in (0, 6):                               # tables over every partition / a window that the longer rows leave (second pass)
+        share = engine.params(3.0, S, B, fl, table_steps=steps)
+        whole = engine.params(3.0, S, B, fl | irec._lib.IREC_FLAG_NO_SPLIT, table_steps=steps)
+        plan = engine.plan(share, lay, 32)
+        assert plan["split"] == want_W and plan["grid"] <= plan["n_cu"] and plan["kernel"].startswith("encode_team_kernel"), plan
+        assert engine.plan(whole, lay, 32)["split"] == 0
+        K, idx, sample = engine.encode_blocks(share, lay, ql, qs, pl, ps, 42, 32)
+        K2, idx2, sample2 = engine.encode_blocks(whole, lay, ql, qs, pl, ps, 42, 32)
+        Kh = K.cpu().numpy()
+        assert Kh.min() >= 0 and Kh.max() <= 32 and torch.equal(K, K2) and torch.equal(sample, sample2)
+        ih, ih2 = idx.cpu().numpy(), idx2.cpu().numpy()
+        for r in range(lay.n_blocks):
+            assert np.array_equal(ih[r, :Kh[r]], ih2[r, :Kh[r]]), r
+        assert torch.equal(engine.decode_blocks(share, lay, pl, ps, 42, K, idx), sample)
+    bpt = lay.blocks_per_tensor
+    assert all(Kh[lay.natural[(n_latents - 1) * bpt + j]] == 0 for j in range(bpt)) and torch.equal(sample[-1], pl[-1])
+    if B <= 10 and not extra:
+        return
+    for i in (0, n_latents // 2, n_latents - 2):
+        ridx, rs = oracle.encode_tensor(*stats[i], 42, 3.0, S, B, block_size=1000)
+        assert [ih[lay.natural[i * bpt + j], :Kh[lay.natural[i * bpt + j]]].tolist() for j in range(bpt)] == ridx, i
+        assert np.array_equal(sample[i].cpu().numpy(), rs), i
+
+
+def test_shared_rows_give_up_instead_of_hanging(engine, oracle):
+    """Test hook (IREC_FLAG_TEST_SPLIT_ORPHAN): the partner teams of every shared row leave at once, so team 0 of each must take the
+    2-second give-up exit: out_K = -2 on the shared rows, every whole row coded as ever; the Python coder codes the call again
+    without sharing (SplitNotResident -> no_split) and returns the oracle's outputs."""
+    import irec
+    n_latents, S, B = 29, 36, 20                       # 261 blocks: five shared rows
+    stats = [oracle.synthetic_latent(950 + i, 8192) for i in range(n_latents)]
+    ql, qs, pl, ps = (torch.from_numpy(np.stack([s[k] for s in stats])).cuda().contiguous() for k in range(4))
+    lay = engine.layout(n_latents, 8192, 1000, 42)
+    orphan = engine.params(3.0, S, B, irec._lib.IREC_FLAG_TEST_SPLIT_ORPHAN)
+    whole = engine.params(3.0, S, B, irec._lib.IREC_FLAG_NO_SPLIT)
+    K, idx, sample = engine.encode_blocks(orphan, lay, ql, qs, pl, ps, 42, 32)
+    K2, idx2, sample2 = engine.encode_blocks(whole, lay, ql, qs, pl, ps, 42, 32)
+    Kh, K2h = K.cpu().numpy(), K2.cpu().numpy()
+    assert (Kh == -2).sum() == lay.n_blocks - 256 and (Kh[Kh != -2] == K2h[Kh != -2]).all()
+    c = _coder(3.0, B, 1.2, block_size=1000, variant="auto")
+    c._test_split_orphan = True
+    idx_l, smp = c.encode(_normal(ql, qs), _normal(pl, ps), seed=42, batched=True)
+    assert c.no_split
+    for i in (0, n_latents - 1):
+        ridx, rs = oracle.encode_tensor(*stats[i], 42, 3.0, S, B, block_size=1000)
+        assert idx_l[i] == ridx and np.array_equal(smp[i].cpu().numpy(), rs), i
+
+
 def test_library_errors_are_coding_errors(engine):
     import irec
     c = irec.BeamSearchCoder(kl_per_partition=3., n_beams=100, extra_samples=1.)
