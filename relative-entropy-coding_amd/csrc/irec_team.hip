@@ -1404,7 +1404,10 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
 //  node p still takes (x_p = min(n_p, L - n_{p-1} + x_{p-1})) and test the closing node.
 //  One half-wave per (t, s, m); choice bits never change any emitted value (all three table copies are identical).
 // ======================================================================================================
-__global__ __launch_bounds__(256) void alpha_choice_kernel(int64_t seed, int32_t S, int32_t D, int32_t K_tab,
+#ifndef IREC_CHOICE_WPE
+#define IREC_CHOICE_WPE 1   // waves per SIMD alpha_choice_kernel is compiled for (1: 256 VGPRs, one workgroup per CU at a time)
+#endif
+__global__ __launch_bounds__(256, IREC_CHOICE_WPE) void alpha_choice_kernel(int64_t seed, int32_t S, int32_t D, int32_t K_tab,
                                                            const uint16_t *__restrict__ dlog4r, uint16_t *__restrict__ tab,
                                                            const uint32_t *__restrict__ keep) {
   if (keep && *keep) return;   // the table in place was built for exactly this key (head kernel of this call): uniform exit
