@@ -33,7 +33,8 @@ extern "C" {
 #endif
 
 #define IREC_BIG_PRIME 10007     /* beam_search_coder.py:30 */
-#define IREC_MAX_BEAMS 64        /* hard limit of this build (reference: unbounded python int) */
+#define IREC_MAX_BEAMS 256       /* hard limit of this build (reference: any python int, beam_search_coder.py:28); B <= 60 takes the */
+                                 /* register-resident encoders, anything above the generic kernel                                    */
 #define IREC_MAX_PARTITIONS 65536 /* hard limit on K = ceil(KL / kl_per_partition) */
 
 typedef enum {

@@ -1206,7 +1206,7 @@ irec_status irec_test_reduce_scatter(irec_context *ctx, const float *in, float *
 
 irec_status irec_test_select(irec_context *ctx, const float *scores, int32_t n, int32_t n_select, int32_t n_beams_cur,
                              uint32_t *scratch_keys, int32_t *out_sel, void *hip_stream) {
-  if (!ctx || !scores || !scratch_keys || !out_sel || n < 1 || n_select < 1 || n_select > n || n_select > IREC_MAX_BEAMS ||
+  if (!ctx || !scores || !scratch_keys || !out_sel || n < 1 || n_select < 1 || n_select > n || n_select > 64 ||
       n_beams_cur < 1)
     return fail(IREC_E_INVALID, "irec_test_select: bad arguments");
   IREC_ON_DEVICE(ctx->device);

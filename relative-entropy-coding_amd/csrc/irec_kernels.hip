@@ -19,7 +19,7 @@
 //                              through L2 every step) the workgroups share the block's beams (A.coop_beams: each owns at most
 //                              two beam slots, scores every sample for them and forms only its own new beams in the block's
 //                              shared slab) or, in the older form, its samples.
-//   encode_generic_kernel      any D, B <= 64: beams in a global scratch slab; correctness fallback.
+//   encode_generic_kernel      any D, B <= 256: beams in a global scratch slab; correctness fallback.
 //
 // Compiled with: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (no implicit fma: see irec_device.h).
 #include <hip/hip_runtime.h>
@@ -97,24 +97,30 @@ __global__ __launch_bounds__(256) void block_kl_kernel(EncArgs A, float *out_kl)
 }
 
 // ======================================================================================================
-//  generic encoder: any D, B <= 64.  Scratch slab per workgroup:
+//  generic encoder: any D, B <= 256 (round 4; 64 until then: the reference's n_beams is any Python int, beam_search_coder.py:28).
+//  Scratch slab per workgroup:
 //    float dmu,vq,vp,mp,c,sa,m,A,Bv,H [10][Dpad] | float beams[2][B][Dpad] | float G[B][Dpad] | int32 bp[max_K][B] | uint32 key[S*B]
 // ======================================================================================================
 constexpr int GEN_NT = 256;
 constexpr int GEN_CH = 16;    // beams scored together against one sample's draw (one reduce-scatter per dim group; 32: spills, slower)
 constexpr int GEN_NSC = 8192; // score/key entries kept in LDS; larger candidate sets go to the scratch slab
+constexpr int GEN_MB = 256;   // beams at most (selected beam = thread index: GEN_NT; back-pointers hold the parent in 8 bits)
+using GenLds = SmallLdsT<GEN_MB, 32, 512>;   // (more than 64 beams: the threshold selection always leaves more than 64 survivors and falls
+                                             //  to the scan, one barrier per selected beam -- slow and correct, as a fallback may be)
+constexpr size_t GEN_SMALL_BYTES = (sizeof(GenLds) + 15) & ~(size_t)15;
+static_assert(GEN_MB <= GEN_NT, "new beam j is recorded by thread j");
 
 __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *lut_s = reinterpret_cast<float *>(smem);                              // [10008]
   uint32_t *key_lds = reinterpret_cast<uint32_t *>(smem + 40032);              // [GEN_NSC]
-  SmallLds *sm = reinterpret_cast<SmallLds *>(smem + 40032 + GEN_NSC * 4);
+  GenLds *sm = reinterpret_cast<GenLds *>(smem + 40032 + GEN_NSC * 4);
   double *gpart = sm->gpart;                                                   // [4]
-  double *total_s = reinterpret_cast<double *>(smem + 40032 + GEN_NSC * 4 + SMALL_LDS_BYTES); // [1]
-  int32_t *sel_s = sm->sel_s, *sel_b = sm->sel_b;                              // [64]
-  int32_t *hsum = &sm->hsum[0][0];                                             // [2][64]
+  double *total_s = reinterpret_cast<double *>(smem + 40032 + GEN_NSC * 4 + GEN_SMALL_BYTES); // [1]
+  int32_t *sel_s = sm->sel_s, *sel_b = sm->sel_b;                              // [GEN_MB]
+  int32_t *hsum = &sm->hsum[0][0];                                             // [2][GEN_MB]
   int32_t *misc = sm->misc;
-  float *Cb_s = reinterpret_cast<float *>(total_s + 1);                        // [64] C_b of the live beams
+  float *Cb_s = reinterpret_cast<float *>(total_s + 1);                        // [GEN_MB] C_b of the live beams
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform by construction: keep it in an SGPR
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
         for (int b0 = 0; b0 < Bcur; b0 += GEN_CH) {
           uint32_t hb[GEN_CH];
 #pragma unroll
-          for (int j = 0; j < GEN_CH; ++j) hb[j] = hash_from_sum(hsum[cur * 64 + (b0 + j < Bcur ? b0 + j : 0)]);
+          for (int j = 0; j < GEN_CH; ++j) hb[j] = hash_from_sum(hsum[cur * GEN_MB + (b0 + j < Bcur ? b0 + j : 0)]);
           float sc = 0.f;
           for (int g = 0; g < NG; ++g) {
             const int d0 = g * 256 + lane * 4;
@@ -279,12 +285,12 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
       // phase 3: top-B (beam_search_coder.py:85-89 / :104)
       const int Bnew = B < N ? B : N;
       for (int f = tid; f < N; f += GEN_NT) key[f] = score_key(__uint_as_float(key[f]));
-      select_topB<GEN_NT>(key, N, Bnew, Bcur, sm);
+      select_topB_sync<GEN_NT>(key, N, Bnew, Bcur, sm, tid, WorkgroupSync());
       // phase 4: gather the surviving beams, extend their index paths (:92-95 / :105-106)
       if (tid < Bnew) {
         const int32_t sp_ = sel_s[tid], bp_ = sel_b[tid];
-        hsum[(cur ^ 1) * 64 + tid] = (int32_t)((uint32_t)hsum[cur * 64 + bp_] + (uint32_t)sp_ * (uint32_t)(69 + t));
-        bp[(size_t)t * B + tid] = (sp_ << 6) | bp_;
+        hsum[(cur ^ 1) * GEN_MB + tid] = (int32_t)((uint32_t)hsum[cur * GEN_MB + bp_] + (uint32_t)sp_ * (uint32_t)(69 + t));
+        bp[(size_t)t * B + tid] = (int32_t)(((uint32_t)sp_ << 8) | (uint32_t)bp_);   // (S <= 2^24, irec_params)
       }
       float *bnext = beams + (size_t)(cur ^ 1) * B * Dpad;
       for (int d0 = tid * 4; d0 < D; d0 += GEN_NT * 4) {   // a thread forms FOUR consecutive dims of every new beam: one Philox block
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
         for (int i = 0; i < 4; ++i) sa4[i] = d0 + i < D ? f_sa[d0 + i] : 0.f;
         for (int j = 0; j < Bnew; ++j) {
           const int32_t sp_ = sel_s[j], bp_ = sel_b[j];
-          const uint32_t h = hash_from_sum(hsum[cur * 64 + bp_]);
+          const uint32_t h = hash_from_sum(hsum[cur * GEN_MB + bp_]);
           uint32_t rm1[4];
           draw_rm1_x4(ss, (uint64_t)sp_ * (uint64_t)D + (uint64_t)d0, rm1);   // ((sp_ * D + d0) & 3 is uniform: d0 % 4 == 0)
 #pragma unroll
@@ -321,9 +327,9 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
     if (tid == 0) {
       int j = 0;
       for (int t = K - 1; t >= 0; --t) {
-        const int32_t v = bp[(size_t)t * B + j];
-        A.out_indices[blk * (int64_t)A.max_K + t] = v >> 6;
-        j = v & 63;
+        const uint32_t v = (uint32_t)bp[(size_t)t * B + j];
+        A.out_indices[blk * (int64_t)A.max_K + t] = (int32_t)(v >> 8);
+        j = (int)(v & 255u);
       }
     }
   }
@@ -1205,7 +1211,7 @@ hipError_t launch_block_kl(const EncArgs &A, float *out_kl, int grid, hipStream_
   return hipGetLastError();
 }
 
-size_t generic_lds_bytes() { return 40032 + (size_t)GEN_NSC * 4 + SMALL_LDS_BYTES + 8 + 256 + 64; }
+size_t generic_lds_bytes() { return 40032 + (size_t)GEN_NSC * 4 + GEN_SMALL_BYTES + 8 + (size_t)GEN_MB * 4 + 64; }
 
 hipError_t launch_encode_generic(const EncArgs &A, int grid, hipStream_t st) {
   const size_t lds = generic_lds_bytes();

@@ -28,7 +28,7 @@ IREC_FLAG_SHAPE = {"default": 0, "1": 1 << 8, "2": 2 << 8, "3": 3 << 8, "2x2": 4
 IREC_TABLE_STEPS_DEFAULT = 32
 IREC_TABLE_STEPS_MAX = 4096
 BIG_PRIME = 10007
-MAX_BEAMS = 64
+MAX_BEAMS = 256
 MAX_PARTITIONS = 65536
 
 

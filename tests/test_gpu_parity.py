@@ -365,6 +365,22 @@ def test_wide_beam_uses_generic_path(engine, oracle):
     assert [int(i) for i in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
 
 
+@pytest.mark.parametrize("B,omega,eps1,n", [(100, 3.0, 1.2, 900), (256, 2.0, 1.0, 700), (65, 5.0, 1.0, 700), (200, 3.0, 1.0, 1500)])
+def test_more_than_64_beams_take_the_generic_kernel(engine, oracle, B, omega, eps1, n):
+    """n_beams is any Python int in the reference (beam_search_coder.py:28); round 4 lifts this build's limit from 64 to 256 (the
+    generic kernel: beams in its slab, parents in 8 bits of the back-pointers, selection by the scan once more than 64 survive the
+    threshold).  S < B on the first steps (S = 7 at Omega = 2: 7, 49, 256 beams), blocks of more than 1024 dims, decode(encode) exact."""
+    S = oracle.n_samples(omega, eps1)
+    mq, sq, mp, sp = oracle.synthetic_latent(600 + B, n)
+    ridx, rs = oracle.encode_block(mq, sq, mp, sp, 11, omega, S, B)
+    c = _coder(omega, B, eps1)
+    idx, sample = c.encode(_normal(mq[None], sq[None]), _normal(mp[None], sp[None]), seed=11)
+    assert [int(i) for i in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
+    assert torch.equal(c.decode(_normal(mp[None], sp[None]), idx, seed=11), sample)
+    lay = engine.layout(1, n, None, 11)
+    assert engine.plan(engine.params(omega, S, B), lay, 32)["kernel"] == "encode_generic_kernel"
+
+
 def test_wide_beam_blocks_beyond_the_table_window_take_the_generic_kernel(engine, oracle):
     """B = 50 has no fused-Philox fast encoder: blocks with more partitions than the proposal tables cover are coded by the
     generic kernel in the call's second pass (irec_host.cpp: team_only plans) -- same outputs as the oracle's."""
@@ -1224,7 +1240,7 @@ def test_shared_rows_give_up_instead_of_hanging(engine, oracle):
 
 def test_library_errors_are_coding_errors(engine):
     import irec
-    c = irec.BeamSearchCoder(kl_per_partition=3., n_beams=100, extra_samples=1.)
+    c = irec.BeamSearchCoder(kl_per_partition=3., n_beams=300, extra_samples=1.)     # beyond IREC_MAX_BEAMS = 256
     with pytest.raises(irec.CodingError):
         c.encode(_normal(np.zeros((1, 4), np.float32), np.ones((1, 4), np.float32)),
                  _normal(np.zeros((1, 4), np.float32), np.ones((1, 4), np.float32)), seed=1)
