@@ -20,8 +20,12 @@ for case in range(n_cases):
     if os.environ.get("SOAK_BIG"):   # bias towards more than 1024 candidates per step (streamed top-B, sample passes, keys in the slab)
         B = int(rng.choice([1, 10, 11, 16, 20, 21, 30, 31, 32, 40, 50, 60])); omega = float(rng.choice([4.0, 5.0, 5.5, 6.0])); eps1 = float(rng.choice([1.0, 1.1, 1.2]))
         D = int(rng.choice([192, 777, 1000, 1024]))
+    if os.environ.get("SOAK_LARGE"):   # round 4: blocks of more than 1024 dims (chunked encoder for B <= 20, generic beyond) and up to 256 beams
+        D = int(rng.choice([1025, 1279, 1500, 2048, 2049, 2500, 3000, 4096, int(rng.integers(1025, 4200))]))
+        B = int(rng.choice([1, 2, 7, 10, 11, 20, 20, 10, 33, 100, 256])); omega = float(rng.choice([2.0, 3.0, 3.5, float(rng.uniform(1.0, 3.6))]))
+        eps1 = float(rng.choice([1.0, 1.2]))
     S = int(np.exp(omega * eps1))
-    if S * B * D > (1.3e7 if os.environ.get("SOAK_BIG") else 6e6):          # keep the oracle fast
+    if S * B * D > (1.3e7 if (os.environ.get("SOAK_BIG") or os.environ.get("SOAK_LARGE")) else 6e6):          # keep the oracle fast
         continue
     NT = int(rng.choice([1, 2, 3, 5, 8]))   # tensors per call (= blocks per call: both teams of a CU get work)
     def draw():
@@ -43,7 +47,7 @@ for case in range(n_cases):
         for _try in range(20):
             t4, style = draw()
             K = O.num_aux(O.block_kl(*t4), omega)
-            if K <= 300 and K * S * B * D <= 4e8:
+            if K <= 300 and K * S * B * D <= (1.5e9 if os.environ.get("SOAK_LARGE") else 4e8):
                 break
         else:
             continue
@@ -55,7 +59,7 @@ for case in range(n_cases):
     mq, sq, mp, sp = (np.stack([t4[k] for t4 in tens]) for k in range(4))
     q = torch.distributions.Normal(torch.from_numpy(mq).cuda(), torch.from_numpy(sq).cuda(), validate_args=False)
     p = torch.distributions.Normal(torch.from_numpy(mp).cuda(), torch.from_numpy(sp).cuda(), validate_args=False)
-    for variant in ("table", "one_table", "fused", "generic"):
+    for variant in (("table", "generic") if os.environ.get("SOAK_LARGE") else ("table", "one_table", "fused", "generic")):
         c = irec.BeamSearchCoder(kl_per_partition=omega, n_beams=B, extra_samples=eps1)
         c.n_samples = S
         c.force_generic = variant == "generic"; c.fused_philox = variant == "fused"; c.one_table = variant == "one_table"; c.team = variant == "table"
@@ -72,7 +76,7 @@ for case in range(n_cases):
     done += len(tens); stats["K"].append(K)
     if case % 100 == 99:   # a long run must keep writing: the GPU box takes minutes of silence for a hang
         print(f"[soak] case {case + 1}/{n_cases}: {done} blocks, {len(bad)} mismatches, {time.time() - t0:.0f} s", flush=True)
-print(f"soak: {done} random blocks x 4 variants in {time.time() - t0:.0f} s; K range {min(stats['K'])}..{max(stats['K'])}; "
+print(f"soak: {done} random blocks x {2 if os.environ.get('SOAK_LARGE') else 4} variants in {time.time() - t0:.0f} s; K range {min(stats['K'])}..{max(stats['K'])}; "
       f"{stats['evals'] / 1e9:.2f} G proposal evals checked; mismatches: {len(bad)}")
 for b in bad[:20]:
     print("MISMATCH case=%d variant=%s D=%d B=%d S=%d omega=%.3f K=%d style=%d seed=%d" % b)
