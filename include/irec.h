@@ -71,7 +71,7 @@ typedef struct {
                                   /* (cheaper per-call set-up) below; same outputs, bit for bit                        */
 #define IREC_FLAG_NO_SPLIT 16     /* never the split encoder (several workgroups per block for calls of few blocks)   */
 #define IREC_FLAG_TEST_SPLIT_ORPHAN 32 /* test hook: the partner workgroups of the split encoder leave at once, so workgroup 0  */
-                                  /* of every block must take the 2-second give-up exit (out_K = -2) instead of hanging   */
+                                  /* of every block must take the give-up exit (100 ms) (out_K = -2) instead of hanging   */
 #define IREC_FLAG_TABLES_PRESENT 65536 /* stronger than REUSE_TABLES: the caller vouches that the PREVIOUS irec_beam_encode call on this  */
                                   /* workspace and stream was this call's twin (same seed, S, table_dims, table window, table kind --  */
                                   /* e.g. the next residual block of the same image) and that nothing has run on the workspace since:   */

@@ -120,6 +120,11 @@ hipError_t launch_zero_counters(void *p, const TableStamps &stamps, int split_bl
 constexpr size_t WS_COUNTER_BYTES = 512 + 8 * 256;        // [0,256): counters, keep words, table stamps; [256,512): 64 arrival counters; [512,2560): XCD counters
 constexpr int COOP_MAX_BLOCKS = 384, COOP_KEYS = 1024;     // key exchange: blocks per call that are shared (split encoder: <= 64 blocks of a small call; team encoder:
                                                            // the rows beyond one per CU of a mid-size call), sort keys per step (S * NB)
+// How long a workgroup / team waits for the sort keys of its partners before it raises the sticky error flag and leaves (out_K = -2;
+// s_memrealtime ticks of 10 ns): 100 ms.  A step's hand-off takes microseconds when the partners are resident; when they are not (a
+// co-tenant holds CUs, two cooperating calls are in flight) no wait helps until that work is over -- 2 s until round 3, which turned a
+// 0.2 ms call into 2 s in that case; now into 0.1 s before the call is coded again without sharing.
+constexpr unsigned long long COOP_GIVE_UP_TICKS = 10000000ull;
 constexpr int COOP_SPLIT_MAX_BLOCKS = 64;                  // the split encoder takes calls of at most this many blocks
 #ifndef IREC_COOP_GRANULES
 #define IREC_COOP_GRANULES 1   // split encoder: sort keys travel as 8-byte {key, step tag} granules that the partners sweep directly

@@ -827,7 +827,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
         // and every partner sweeps the step's granules with `sc1` loads until each carries this step's tag -- no drain, no
         // arrival counter, no second round trip for the payload (r03l: ≈ 3 µs of a 12 µs step were the three serial round trips
         // of the counter form).  Tags: t + 1 >= 1; the head kernel zeroed this block's granules, buffer t & 1 last held tag
-        // t - 1.  A thread gives up like the counter form did: sticky error flag, 2 s.
+        // t - 1.  A thread gives up like the counter form did: sticky error flag, COOP_GIVE_UP_TICKS (100 ms).
         unsigned long long *xg = reinterpret_cast<unsigned long long *>(A.coop_xch) + ((size_t)(t & 1) * COOP_MAX_BLOCKS + (size_t)blk) * COOP_KEYS;
         const uint32_t tag = (uint32_t)(t + 1);
         unsigned long long sub_prev = A.dbg ? stamp_now() : 0ull;   // diagnostics: [12] publish, [13] sweep (wait + read back)
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
               if (((pending >> q) & 1u) && (uint32_t)(gq[q] >> 32) == tag) { kk[q] = (uint32_t)gq[q]; pending &= ~(1u << q); }
             if (pending == 0u || (turn & 63u) != 0u) continue;
             if (__hip_atomic_load(A.coop_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bad = 1; break; }
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { // 2 s: the partners are not resident -- give up, loudly
+            if (__builtin_amdgcn_s_memrealtime() - t0 > COOP_GIVE_UP_TICKS) { // the partners are not resident -- give up, loudly
               __hip_atomic_store(A.coop_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               bad = 1; break;
             }
@@ -900,7 +900,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
           for (uint32_t turn = 1; __hip_atomic_load(&A.coop_arrive[blk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want; ++turn) {
             if ((turn & 31u) != 0u) continue;
             if (__hip_atomic_load(A.coop_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bad = 1; break; }
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { // 2 s: the partners are not resident -- give up, loudly
+            if (__builtin_amdgcn_s_memrealtime() - t0 > COOP_GIVE_UP_TICKS) { // the partners are not resident -- give up, loudly
               __hip_atomic_store(A.coop_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               bad = 1; break;
             }

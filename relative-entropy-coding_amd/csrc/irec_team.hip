@@ -788,7 +788,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           }
           if (CAN_SHARE && Wrow > 1) {
             // sweep the partners' granules until each carries this step's tag (tags start at 1; the head kernel zeroed the row's
-            // granules; buffer t & 1 last held tag t - 1).  Give-up as in the split encoder: sticky error flag, 2 s.
+            // granules; buffer t & 1 last held tag t - 1).  Give-up as in the split encoder: sticky error flag, COOP_GIVE_UP_TICKS (100 ms).
             const uint32_t tag = (uint32_t)(t + 1);
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
             int32_t bad = 0;
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
                 if (((foreign >> q) & 1u) && (uint32_t)(gq[q] >> 32) == tag) { key_s[f_base + q * NT + tid] = (uint32_t)gq[q]; foreign &= ~(1u << q); }
               if (foreign == 0u || (turn & 63u) != 0u) continue;
               if (__hip_atomic_load(A.coop_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bad = 1; break; }
-              if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { // 2 s: the partners are not resident -- give up, loudly
+              if (__builtin_amdgcn_s_memrealtime() - t0 > COOP_GIVE_UP_TICKS) { // the partners are not resident -- give up, loudly
                 __hip_atomic_store(A.coop_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 bad = 1; break;
               }

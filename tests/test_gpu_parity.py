@@ -1216,7 +1216,7 @@ def test_calls_of_one_to_two_blocks_per_cu_share_rows_between_teams(engine, orac
 
 def test_shared_rows_give_up_instead_of_hanging(engine, oracle):
     """Test hook (IREC_FLAG_TEST_SPLIT_ORPHAN): the partner teams of every shared row leave at once, so team 0 of each must take the
-    2-second give-up exit: out_K = -2 on the shared rows, every whole row coded as ever; the Python coder codes the call again
+    give-up exit (100 ms): out_K = -2 on the shared rows, every whole row coded as ever; the Python coder codes the call again
     without sharing (SplitNotResident -> no_split) and returns the oracle's outputs."""
     import irec
     n_latents, S, B = 29, 36, 20                       # 261 blocks: five shared rows
@@ -1292,7 +1292,7 @@ def test_split_encoder_small_calls(engine, oracle, n_tensors, n, bs, omega, eps1
 
 def test_split_encoder_gives_up_instead_of_hanging(engine, oracle):
     """The cooperating workgroups of the split encoder wait for each other every step.  If the partners never arrive (test
-    hook: they leave at once) the waiting workgroup must reach its exit: after 2 s it raises the sticky error flag, the
+    hook: they leave at once) the waiting workgroup must reach its exit: after 100 ms it raises the sticky error flag, the
     block comes back with out_K = -2 and the Python layer turns that into a CodingError -- no hung GPU."""
     import time
     import irec
@@ -1317,7 +1317,7 @@ def test_split_encoder_give_up_is_coded_again_without_the_split(engine, oracle):
     blocks again with one workgroup per block instead of handing the caller a failed image."""
     mq, sq, mp, sp = (torch.as_tensor(a[None], device="cuda") for a in oracle.synthetic_latent(77, 1000))
     c = _coder(3.0, 20, 1.2, variant="one_table")
-    c._test_split_orphan = True                              # every split call gives up after its 2-second wait
+    c._test_split_orphan = True                              # every split call gives up after its 100 ms wait
     idx, sample = c.encode(_normal(mq, sq), _normal(mp, sp), seed=42)
     assert c.no_split                                        # the coder left the split encoder
     ridx, rs = oracle.encode_block(mq.cpu().numpy()[0], sq.cpu().numpy()[0], mp.cpu().numpy()[0], sp.cpu().numpy()[0], 42, 3.0, 36, 20)
