@@ -69,7 +69,8 @@ typedef struct {
 #define IREC_FLAG_TEAM 8          /* with table_dims: always the teams-per-CU encoder over three table copies.         */
                                   /* Neither flag: the team encoder for calls of >= 64 blocks, the one-table encoder   */
                                   /* (cheaper per-call set-up) below; same outputs, bit for bit                        */
-#define IREC_FLAG_NO_SPLIT 16     /* never the split encoder (several workgroups per block for calls of few blocks)   */
+#define IREC_FLAG_NO_SPLIT 16     /* no block is shared: neither the split encoder (several workgroups per block for calls of few     */
+                                  /* blocks) nor shared rows between teams (calls of one to 1.5 blocks per CU, B > 10)                */
 #define IREC_FLAG_TEST_SPLIT_ORPHAN 32 /* test hook: the partner workgroups of the split encoder leave at once, so workgroup 0  */
                                   /* of every block must take the give-up exit (100 ms) (out_K = -2) instead of hanging   */
 #define IREC_FLAG_TABLES_PRESENT 65536 /* stronger than REUSE_TABLES: the caller vouches that the PREVIOUS irec_beam_encode call on this  */
@@ -115,7 +116,8 @@ typedef struct {
   int32_t lds_bytes;       /* dynamic LDS of one workgroup                                                      */
   int32_t table_steps;     /* partitions the proposal tables cover (0 = no tables)                              */
   int32_t n_tables;
-  int32_t split;           /* workgroups that share one block (split encoder of small calls), 0 = one block per workgroup */
+  int32_t split;           /* workgroups that share one block (split encoder of calls of < 64 blocks), or teams that share each */
+                           /* row beyond one per CU (team encoder, calls of one to 1.5 blocks per CU); 0 = nothing is shared   */
   int32_t n_cu;            /* compute units of the context's device                                             */
   int32_t clock_mhz;       /* its maximum engine clock                                                          */
   int32_t split_beams;     /* split encoder: 1 = the workgroups of a block share its beams (each owns <= 2 beam slots,  */
@@ -213,7 +215,10 @@ irec_status irec_block_kl(irec_context *ctx, const irec_params *p, int64_t n_blo
  * GaussianCoder.encode drives it (same seed for every block, coder.py:444-449).
  *   max_block_dim                   upper bound of block_dim[] (host knows it: block_size); a block with more dims
  *                                   is not coded and gets out_K = -1
- *   out_K       [n_blocks]          K of each block.  K > max_K means "not coded: retry with a larger max_K".
+ *   out_K       [n_blocks]          K of each block.  K > max_K means "not coded: retry with a larger max_K"; -1: the block's
+ *                                   dim is not covered by max_block_dim / table_dims; -2: the block was shared between workgroups or
+ *                                   teams and its partners were not all resident within 100 ms (a co-tenant on the device, two
+ *                                   cooperating calls in flight): call again, or with IREC_FLAG_NO_SPLIT.
  *   out_indices [n_blocks, max_K]   idx[t], t < K: the sample index chosen at iteration t (rest untouched)
  *   out_sample  flat, same indexing as the inputs: beams[0] + p.loc, merged
  *   workspace   device scratch of at least irec_encode_workspace_bytes() bytes, 256-byte aligned

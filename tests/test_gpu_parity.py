@@ -1304,7 +1304,7 @@ def test_split_encoder_gives_up_instead_of_hanging(engine, oracle):
     K, idx, sample = engine.encode_blocks(params, lay, mq, sq, mp, sp, 42, 32)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    assert int(K.cpu()[0]) == -2 and 1.5 < dt < 10.0, (K.cpu(), dt)
+    assert int(K.cpu()[0]) == -2 and 0.08 < dt < 2.0, (K.cpu(), dt)            # (COOP_GIVE_UP_TICKS: 100 ms; 2 s until round 3)
     # the same call without the hook works, and the engine is usable afterwards
     c = _coder(3.0, 20, 1.2, variant="one_table")
     i2, s2 = c.encode(_normal(mq, sq), _normal(mp, sp), seed=42)
