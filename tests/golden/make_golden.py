@@ -33,6 +33,14 @@ def block_case(name, mq, sq, mp, sp, seed, omega, eps1, B):
     print(f"{name}: D={len(mq)} S={S} B={B} K={len(idx)} literal_equal={idx == idx_lit}")
 
 
+def large_blocks():
+    """Round 4: blocks of more than 1024 dims -- Coder.__init__ takes any block_size, None (the whole tensor as one block)
+    included, rec/coding/coder.py:29-36,415-419: the chunked encoder's and the generic kernel's committed vectors."""
+    for name, D, omega, eps1, B in (("block_D2500_large", 2500, 3.0, 1.2, 20), ("block_D1500_large_b10", 1500, 3.0, 1.0, 10)):
+        mq, sq, mp, sp = O.synthetic_latent(8800 + D, D)
+        block_case(name, mq, sq, mp, sp, 42, omega, eps1, B)
+
+
 def main():
     configs = [(3.0, 1.2, 20), (3.0, 1.0, 10), (5.0, 1.0, 30), (6.0, 1.0, 10)]
     for D in (1, 192, 1000):
@@ -52,6 +60,8 @@ def main():
     # S < B on the first steps (beam_search_coder.py:104-106 keeps only S beams)
     mq, sq, mp, sp = O.synthetic_latent(9001, 64)
     block_case("block_S_lt_B", mq, sq * np.float32(0.5), mp, sp, 5, 1.5, 1.0, 20)
+
+    large_blocks()
 
     # one full RVAE-shaped latent tensor [1,16,16,32], block_size 1000 -> 8 x 1000 + 192
     omega, eps1, B, seed, bs = 3.0, 1.2, 20, 42, 1000
@@ -75,4 +85,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["large"]:      # only the round-4 additions (the older fixtures are not rewritten)
+        large_blocks()
+    else:
+        main()
