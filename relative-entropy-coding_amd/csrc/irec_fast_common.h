@@ -16,6 +16,33 @@ __device__ __forceinline__ int64_t src_index(const EncArgs &A, int64_t base, int
   return base + (A.perm ? (int64_t)A.perm[pos + d] : (int64_t)(pos + d));
 }
 
+// First thing in every encode kernel: the table keys the call's preparation kernel left pending become the stamps (irec_kernels.h,
+// "The call's preparation kernel") -- by now the tables they describe have been built.  Idempotent (the deferred pass repeats it).
+__device__ __forceinline__ void commit_table_stamps(const EncArgs &A) {
+  if (A.ws_head != nullptr && blockIdx.x == 0 && threadIdx.x < 4 * WS_STAMP_WORDS)
+    A.ws_head[WS_STAMP_WORD + threadIdx.x] = A.ws_head[WS_PENDING_WORD + threadIdx.x];
+}
+
+// Rows of a plain proposal table tab[t][s][d] = 4 * dlog_g(r[s, d]) (uint16, row stride = D rounded up to 4), four entries per
+// thread; workgroup `wg` of `n_wg` (256 threads each).  The int32 draw of get_pseudo_random_sample (beam_search_coder.py:38-43)
+// depends only on (seed + t, S, D): it is evaluated once per call.
+__device__ __forceinline__ void plain_table_rows(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *__restrict__ dlog4r,
+                                                 uint16_t *__restrict__ tab, int64_t wg, int64_t n_wg) {
+  const int Dp = (D + 3) & ~3;
+  const int64_t per_step = (int64_t)S * Dp;
+  const int64_t total = per_step * K_tab;
+  for (int64_t q = (wg * 256 + threadIdx.x) * 4; q < total; q += n_wg * 256 * 4) {
+    const int t = (int)(q / per_step);
+    const int64_t rem = q - (int64_t)t * per_step;
+    const int s = (int)(rem / Dp), d0 = (int)(rem - (int64_t)s * Dp);
+    const StepSeed ss = make_step_seed(seed + t);
+    uint16_t v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = (d0 + i < D) ? dlog4r[draw_rm1(ss, (uint64_t)s * (uint64_t)D + (uint64_t)(d0 + i))] : (uint16_t)0;
+    *reinterpret_cast<uint2 *>(tab + q) = make_uint2((uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16));
+  }
+}
+
 // Diagnostic phase stamps (only when EncArgs.dbg != nullptr; the values never reach an output of the coder).
 __device__ __forceinline__ unsigned long long stamp_now() { return __builtin_amdgcn_s_memtime(); }
 

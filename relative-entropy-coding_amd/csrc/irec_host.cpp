@@ -886,24 +886,46 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   int share_grid = 0;
   const int share_W = (pl.table && pl.team) ? team_share_width(ctx, pl, p, n_blocks, pl.shape, &share_first, &share_grid) : 0;
   if (share_W >= 2) split_blocks = (int)(n_blocks - share_first);
-  HIP_TRY(irec::launch_zero_counters(workspace, stamps, split_blocks, st));
+  // Cost-ordered hand-out (team encoder, calls of more rows than workgroups whose slots the static round deals completely --
+  // one to TEAMS rows per CU): the head kernel also writes K * dims of every row, and the teams take their rows by cost rank
+  // (irec_team.hip, "Cost-ordered hand-out").  IREC_FLAG_LISTED_ORDER: rows as listed (A/B runs).
+  if (pl.table && pl.team && !pl.lone && !pl.chunk && !(p->flags & IREC_FLAG_LISTED_ORDER) && n_blocks <= irec::COST_MAX_ROWS) {
+    const int n_teams = irec::team_count_for(p->n_beams, p->n_samples, pl.shape);
+    const int64_t tg = share_W >= 2 ? share_grid : batch_grid(n_blocks, std::min(pl.grid_cap / n_teams, ctx->n_cu > 0 ? ctx->n_cu : 256));
+    const int64_t slots = share_W >= 2 ? share_first + (n_blocks - share_first) * share_W : n_blocks;
+    // (measured, profiles/r04w: the pre-pass -- a random gather of the call's statistics, +8 us on the head kernel -- and the ranking
+    //  pay for themselves on the two-team build with 20-beam steps: 342 blocks 0.467 -> 0.449 ms, 405 blocks 0.538 -> 0.507; not with
+    //  10-beam steps of half the length, nor on the three-team build)
+    if (n_blocks > tg && slots <= tg * n_teams && n_teams == 2 && p->n_beams > 10) A.row_cost = (const uint32_t *)((char *)workspace + irec::WS_COUNTER_BYTES + irec::WS_XCH_BYTES);
+  }
   int grid = (int)std::min<int64_t>(n_blocks, pl.one_grid_cap);
   A.dbg = nullptr;
 #ifdef IREC_HOST_STAMPS
   A.dbg = ctx->d_dbg;
   if (ctx->d_dbg) HIP_TRY(hipMemsetAsync(ctx->d_dbg, 0, 4096 * 16 * sizeof(unsigned long long), st));
 #endif
+  // ONE preparation kernel per call: books, exchange granules, row costs and the proposal tables (irec_kernels.h)
+  irec::PrepArgs P{};
+  P.head = (uint32_t *)workspace; P.ts = stamps;
+  P.n_granule = irec::IREC_COOP_GRANULES_ON && split_blocks > 0 ? std::min(split_blocks, irec::COOP_MAX_BLOCKS) : 0;
+  P.n_cost = A.row_cost ? (int32_t)n_blocks : 0;
+  P.cost = const_cast<uint32_t *>(A.row_cost);
+  P.seed = seed; P.S = p->n_samples; P.K_tab = pl.K_tab; P.dlog4r = ctx->d_dlog4r;
+  A.ws_head = (uint32_t *)workspace;
+  for (int q = 0; q < 4; ++q) { A.tab[q] = nullptr; A.tab_dim[q] = -1; }
   if (pl.table) {
-    for (int q = 0; q < 4; ++q) { A.tab[q] = nullptr; A.tab_dim[q] = -1; }
     for (int q = 0; q < pl.n_tab; ++q) {
       uint16_t *tab = (uint16_t *)((char *)workspace + irec::WS_HEAD_BYTES + pl.tab_off[q]);
-      const uint32_t *keep = (const uint32_t *)workspace + irec::WS_KEEP_WORD + q;
       A.tab[q] = tab; A.tab_dim[q] = pl.tab_dim[q];
-      if (p->flags & IREC_FLAG_TABLES_PRESENT) continue;   // the caller's previous call on this workspace built exactly these
-      if (pl.team || pl.chunk) HIP_TRY(irec::launch_alpha_choice(seed, p->n_samples, pl.tab_dim[q], pl.K_tab, ctx->d_dlog4r, tab, keep, st));
-      else HIP_TRY(irec::launch_alpha_table(seed, p->n_samples, pl.tab_dim[q], pl.K_tab, ctx->d_dlog4r, tab, keep, st));
-      A.tab[q] = tab; A.tab_dim[q] = pl.tab_dim[q];
+      P.jobs.tab[q] = tab; P.jobs.keep[q] = nullptr;
     }
+    if (pl.n_tab > 0 && !(p->flags & IREC_FLAG_TABLES_PRESENT)) {   // (TABLES_PRESENT: the caller's previous call on this workspace built exactly these)
+      P.table_kind = (pl.team || pl.chunk) ? 1 : 2;                  // rows with copy bits / plain rows
+      P.n_table_wgs = (int32_t)irec::prep_table_wgs(P.table_kind, p->n_samples, pl.K_tab, pl.n_tab, pl.tab_dim, &P.jobs);
+    }
+  }
+  HIP_TRY(irec::launch_prep(P, A, st));
+  if (pl.table) {
     // second pass (only when the window is shorter than max_K): the fused-Philox encoder codes the blocks whose K lies
     // beyond the table window; it returns at once when the first pass deferred nothing
     auto deferred_pass = [&]() -> irec_status {

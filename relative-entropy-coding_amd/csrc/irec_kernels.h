@@ -44,6 +44,15 @@ struct EncArgs {
   // Shared rows of the team encoder (irec_team.hip, round 4): rows [tsplit_first, n_blocks) are coded by coop_W teams each, which
   // split the row's samples and exchange their sort keys through coop_xch (row r uses exchange slot r - tsplit_first).
   int64_t tsplit_first;
+  // Cost-ordered hand-out (round 4): the key (K * dims) << 10 | row of every row, written by the call's head kernel (nullptr: rows
+  // are dealt as listed).
+  // Set only for calls whose hand-out slots all fall into the static round (every team takes at most one): workgroup w's first team
+  // then takes the row of ascending cost rank w and its other teams the costliest rows (shared rows: the costliest), so that no CU
+  // pairs two long rows while another pairs two short ones.
+  const uint32_t *row_cost;
+  // head of the workspace (nullptr: no table books, e.g. irec_block_kl): every encode kernel's first workgroup commits the table
+  // stamps the call's preparation kernel left pending (commit_table_stamps, irec_fast_common.h)
+  uint32_t *ws_head;
   int32_t coop_beams;         // 1: the workgroups of a block share its beams (slots w, w + coop_W) instead of its samples
   int32_t coop_test_orphan;   // IREC_FLAG_TEST_SPLIT_ORPHAN: partners leave at once (exercises the give-up exit)
   // diagnostics (IREC_STAMPS=1): per-workgroup cycle sums [grid][8]; nullptr in normal runs
@@ -93,6 +102,9 @@ const char *team_kernel_name(int B, int S, int shape_override);   // e.g. "encod
 const char *fast_kernel_name(int B, int S, bool table);
 hipError_t launch_alpha_choice(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *dlog4r, uint16_t *tab,
                                const uint32_t *keep, hipStream_t st);
+// every proposal table of a call (one per distinct block dim, at most four) in ONE launch
+hipError_t launch_alpha_choice_all(int64_t seed, int32_t S, int32_t K_tab, const uint16_t *dlog4r, int n, const int32_t *dims,
+                                   uint16_t *const *tabs, const uint32_t *const *keeps, hipStream_t st);
 // blocks of more than 1024 dims: a team walks the block in chunks of 1024 over the team encoder's tables (irec_team.hip, encode_chunk_kernel)
 bool chunk_applies(int B, int S, int max_dim);          // B <= 20, 1024 < max_dim <= 16384, one scoring pass fits the LDS next to the tables
 int chunk_teams();                                       // teams (= scratch slabs) per workgroup
@@ -115,8 +127,27 @@ hipError_t launch_encode_lone(const EncArgs &A, int grid, hipStream_t st);
 // compares each slot's stamp with the call's key (IREC_FLAG_REUSE_TABLES; keep = 1 on a match, else 0) and stamps the key:
 // the table kernels that follow on the stream read `keep`, nobody writes it again before the next call's head kernel.
 constexpr int WS_KEEP_WORD = 8, WS_STAMP_WORD = 16, WS_STAMP_WORDS = 8, WS_XCD_WORD = 128, WS_XCD_STRIDE = 64;
+constexpr int WS_PENDING_WORD = 132;   // [132, 164): the call's table keys until the encode kernel commits them (inside XCD 0's counter line: only its first word counts)
 struct TableStamps { uint32_t w[4][WS_STAMP_WORDS]; int32_t reuse; };   // all-zero key = slot unused (never matches)
-hipError_t launch_zero_counters(void *p, const TableStamps &stamps, int split_blocks, hipStream_t st);   // split_blocks > 0: also zeroes the exchange granules of that many blocks
+// The call's preparation kernel (round 4; until then a head kernel and one table kernel per table: three to four launches of
+// >= 4.5 us each before the block kernel): ONE launch whose workgroups
+//   [0]                 keep the books: zero the counters, compare each table slot's stamp with the call's key (keep word = 1 on a
+//                       match under IREC_FLAG_REUSE_TABLES), leave the key PENDING; a slot whose stamp differs is overwritten with the
+//                       key's complement -- never equal to the key, whatever mixture of old and new words a table workgroup reads,
+//   [1, 1 + n_granule)  zero the exchange granules of the call's shared blocks,
+//   [.., + n_cost)      write the cost key (K * dims) << 10 | row of one row each (EncArgs::row_cost),
+//   the rest            build the proposal tables of the slots whose stamp does not match (every table workgroup makes that
+//                       comparison itself: read-only, and a mismatch stays a mismatch while workgroup 0 overwrites the stamp).
+// The first workgroup of the encode kernel that follows copies the pending key over the stamp (commit_table_stamps): a table is
+// stamped only once it has been built.
+struct ChoiceJobs { int32_t D[4]; uint16_t *tab[4]; const uint32_t *keep[4]; int64_t hw_end[4]; int32_t n; };
+struct PrepArgs {
+  uint32_t *head; TableStamps ts;
+  int32_t n_granule, n_cost, n_table_wgs, table_kind;   // table_kind: 0 none, 1 rows with copy bits (team / chunk encoders), 2 plain rows
+  int64_t seed; int32_t S, K_tab; const uint16_t *dlog4r; ChoiceJobs jobs; uint32_t *cost;
+};
+hipError_t launch_prep(const PrepArgs &P, const EncArgs &A, hipStream_t st);
+int64_t prep_table_wgs(int kind, int32_t S, int32_t K_tab, int n, const int32_t *dims, ChoiceJobs *jobs);   // fills jobs.hw_end / D / n
 constexpr size_t WS_COUNTER_BYTES = 512 + 8 * 256;        // [0,256): counters, keep words, table stamps; [256,512): 64 arrival counters; [512,2560): XCD counters
 constexpr int COOP_MAX_BLOCKS = 384, COOP_KEYS = 1024;     // key exchange: blocks per call that are shared (split encoder: <= 64 blocks of a small call; team encoder:
                                                            // the rows beyond one per CU of a mid-size call), sort keys per step (S * NB)
@@ -130,8 +161,11 @@ constexpr int COOP_SPLIT_MAX_BLOCKS = 64;                  // the split encoder 
 #define IREC_COOP_GRANULES 1   // split encoder: sort keys travel as 8-byte {key, step tag} granules that the partners sweep directly
                                // (0: 4-byte keys behind an arrival counter, r02-r03l)
 #endif
+constexpr bool IREC_COOP_GRANULES_ON = IREC_COOP_GRANULES != 0;
 constexpr size_t WS_XCH_BYTES = (size_t)2 * COOP_MAX_BLOCKS * COOP_KEYS * 8;   // key exchange of the split encoder, double buffered: {key, tag} granules
-constexpr size_t WS_HEAD_BYTES = WS_COUNTER_BYTES + WS_XCH_BYTES;
+constexpr int COST_MAX_ROWS = 1024;                              // rows of a call whose hand-out is cost-ordered (EncArgs::row_cost)
+constexpr size_t WS_COST_BYTES = (size_t)COST_MAX_ROWS * 4;
+constexpr size_t WS_HEAD_BYTES = WS_COUNTER_BYTES + WS_XCH_BYTES + WS_COST_BYTES;   // (the row costs lie behind the exchange granules)
 hipError_t launch_decode(const DecArgs &A, int n_cu, hipStream_t st);   // irec_decode.hip
 int decode_tensor_waves(int n, int bs, bool table, size_t *lds_out);     // waves per workgroup of the tensor-staged decoder, 0 = does not apply
 // elementwise hand-offs of the RVAE host shim (irec_shim.hip)

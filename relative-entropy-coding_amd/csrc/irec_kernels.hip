@@ -125,6 +125,8 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform by construction: keep it in an SGPR
   const int S = A.S, B = A.B;
+  commit_table_stamps(A);
+  if (A.deferred_pass && *A.defer_count == 0u) return;   // (uniform over the grid: the first pass deferred nothing -- leave before the table is staged)
   for (int k = tid; k < (int)IREC_P; k += GEN_NT) lut_s[k] = A.lut[k];
 
   const int Dpad = A.max_dim_pad;
@@ -398,6 +400,10 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform by construction: keep it in an SGPR
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap(); // see lds_abs_f32
+  commit_table_stamps(A);
+  // second pass of a windowed-table call that deferred nothing (the usual case): leave before the tables are staged -- the launch
+  // used to cost 11 us of LDS fill per call (r04w kernel trace), now the 3 us of an empty kernel
+  if (!TABLE && A.deferred_pass && *A.defer_count == 0u) return;   // (uniform over the grid)
   {
     float *l2 = reinterpret_cast<float *>(lut2_b);
     for (int k = tid; k < (int)IREC_PM1; k += NT) {
@@ -1135,20 +1141,8 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
 __global__ __launch_bounds__(256) void alpha_table_kernel(int64_t seed, int32_t S, int32_t D, int32_t K_tab,
                                                           const uint16_t *__restrict__ dlog4r, uint16_t *__restrict__ tab,
                                                           const uint32_t *__restrict__ keep) {
-  if (keep && *keep) return;   // the table in place was built for exactly this key (head kernel of this call)
-  const int Dp = (D + 3) & ~3;
-  const int64_t per_step = (int64_t)S * Dp;
-  const int64_t total = per_step * K_tab;
-  for (int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; q < total; q += (int64_t)gridDim.x * 256 * 4) {
-    const int t = (int)(q / per_step);
-    const int64_t rem = q - (int64_t)t * per_step;
-    const int s = (int)(rem / Dp), d0 = (int)(rem - (int64_t)s * Dp);
-    const StepSeed ss = make_step_seed(seed + t);
-    uint16_t v[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = (d0 + i < D) ? dlog4r[draw_rm1(ss, (uint64_t)s * (uint64_t)D + (uint64_t)(d0 + i))] : (uint16_t)0;
-    *reinterpret_cast<uint2 *>(tab + q) = make_uint2((uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16));
-  }
+  if (keep && *keep) return;   // the table in place was built for exactly this key
+  plain_table_rows(seed, S, D, K_tab, dlog4r, tab, (int64_t)blockIdx.x, (int64_t)gridDim.x);
 }
 
 // ======================================================================================================
@@ -1276,43 +1270,6 @@ hipError_t launch_alpha_table(int64_t seed, int32_t S, int32_t D, int32_t K_tab,
   const int64_t quads = ((int64_t)S * ((D + 3) & ~3) * K_tab + 3) / 4;
   const int grid = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
   hipLaunchKernelGGL(alpha_table_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, st, seed, S, D, K_tab, dlog4r, tab, keep);
-  return hipGetLastError();
-}
-
-// zeroes the 256-byte counter block at the head of the workspace.  A kernel, not hipMemsetAsync: the call sequence of
-// irec_beam_encode is then kernels only, which is also what a HIP-graph capture of it records (r02: replaying a capture
-// that held the memset node faulted on the second replay).
-// Since r02i it also keeps the books of the proposal tables (irec_kernels.h, "Head of the workspace"): thread q < 4 compares
-// the stamp of table slot q with this call's key, publishes keep[q] and stamps the key -- one thread owns a slot's words.
-// Workgroups 1 .. n of a split call zero the exchange granules of block blockIdx.x - 1 (both parities, 16 KB): the step tags
-// of the split encoder start at 1, so no granule of an earlier call on this workspace -- or whatever the memory held before --
-// can pass for one of this call's.
-__global__ void zero_counters_kernel(uint32_t *p, TableStamps ts) {
-  const int t = (int)threadIdx.x;
-  if (blockIdx.x != 0) {
-    uint4 *x = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(p) + WS_COUNTER_BYTES);
-#pragma unroll
-    for (int par = 0; par < 2; ++par) {
-      uint4 *xb = x + ((size_t)par * COOP_MAX_BLOCKS + (size_t)(blockIdx.x - 1)) * (COOP_KEYS * 8 / 16);
-      for (int k = t; k < COOP_KEYS * 8 / 16; k += (int)blockDim.x) xb[k] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    return;
-  }
-  const bool book = (t >= WS_KEEP_WORD && t < WS_KEEP_WORD + 4) || (t >= WS_STAMP_WORD && t < WS_STAMP_WORD + 4 * WS_STAMP_WORDS);
-  if (!book) p[t] = 0u;
-  if (t < 4) {
-    uint32_t *stamp = p + WS_STAMP_WORD + t * WS_STAMP_WORDS;
-    bool same = ts.reuse != 0 && ts.w[t][0] != 0u;
-#pragma unroll
-    for (int k = 0; k < WS_STAMP_WORDS; ++k) same = same && stamp[k] == ts.w[t][k];
-    p[WS_KEEP_WORD + t] = same ? 1u : 0u;
-#pragma unroll
-    for (int k = 0; k < WS_STAMP_WORDS; ++k) stamp[k] = ts.w[t][k];
-  }
-}
-hipError_t launch_zero_counters(void *p, const TableStamps &stamps, int split_blocks, hipStream_t st) {
-  const int extra = IREC_COOP_GRANULES && split_blocks > 0 ? (split_blocks < COOP_MAX_BLOCKS ? split_blocks : COOP_MAX_BLOCKS) : 0;
-  hipLaunchKernelGGL(zero_counters_kernel, dim3(1 + extra), dim3(WS_COUNTER_BYTES / 4), 0, st, reinterpret_cast<uint32_t *>(p), stamps);
   return hipGetLastError();
 }
 

@@ -266,6 +266,7 @@ __global__ __launch_bounds__(LONE_NWV * 64, 1) void encode_lone_kernel(EncArgs A
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap(); // see lds_abs_f32
+  commit_table_stamps(A);
   {
     float *l3 = reinterpret_cast<float *>(smem);
     for (int k = (int)threadIdx.x; k < (int)IREC_PM1; k += LONE_NWV * 64) {

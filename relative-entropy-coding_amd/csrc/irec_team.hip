@@ -25,6 +25,7 @@
 // B <= 20 with more samples than one scoring pass holds: ONE team whose waves split the beams into stripes (12 waves x 10
 // beams, 8 x 16, 8 x 10) and that scores the samples in passes.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -202,6 +203,45 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   const int rs_c = rsn_owner<NBW>(lane);                                        // same for the NBW C_b partials of the update
 
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap(); // see lds_abs_f32
+  commit_table_stamps(A);
+  constexpr bool CAN_SHARE = SHARE && TEAMS >= 2 && BS == 1 && !PASSES && !ONE;
+  const int Wsh = (CAN_SHARE && A.coop_W > 1) ? A.coop_W : 1;
+  const int64_t n_whole = Wsh > 1 ? (A.tsplit_first < A.n_blocks ? A.tsplit_first : A.n_blocks) : A.n_blocks;
+  const int64_t n_slots = n_whole + (A.n_blocks - n_whole) * Wsh;
+  const int64_t n_static = (int64_t)TEAMS * (int64_t)gridDim.x < n_slots ? (int64_t)TEAMS * (int64_t)gridDim.x : n_slots;
+  // Cost-ordered hand-out (round 4; A.row_cost: distinct keys (K * dims) << 10 | row from the call's head kernel, set by the host only
+  // when the static round deals every slot): slot u < lo = min(grid, n_whole) is the row of ascending cost rank u, slot lo + k the row
+  // of rank n_blocks - 1 - k / W -- a workgroup's first team gets a cheap row, its other teams (or the teams that share a row) the
+  // costliest ones, longest first.  Every workgroup ranks the rows itself, once, in the LDS the table copies are about to fill
+  // (one row per thread, n compares each: ~2 us): no second kernel, no grid-wide wait.
+  const bool placed = A.row_cost != nullptr;
+  const int64_t lo_rank = (int64_t)gridDim.x < n_whole ? (int64_t)gridDim.x : n_whole;
+  int32_t placed_row = -1;
+  if (placed) {
+    uint32_t *cs = reinterpret_cast<uint32_t *>(smem);
+    const int n = (int)A.n_blocks;
+    for (int k = (int)threadIdx.x; k < n; k += TEAMS * NT) cs[k] = A.row_cost[k];
+    if ((int)threadIdx.x < TEAMS) cs[n + (int)threadIdx.x] = 0xFFFFFFFFu;
+    int want[TEAMS];
+#pragma unroll
+    for (int tm = 0; tm < TEAMS; ++tm) {
+      const int64_t u = (int64_t)tm * (int64_t)gridDim.x + (int64_t)blockIdx.x;
+      want[tm] = u >= n_static ? -1 : u < lo_rank ? (int)u : n - 1 - (int)((u - lo_rank) / (u < n_whole ? 1 : Wsh));
+    }
+    __syncthreads();
+    for (int i = (int)threadIdx.x; i < n; i += TEAMS * NT) {
+      const uint32_t ci = cs[i];
+      int rk = 0;
+#pragma unroll 8
+      for (int j = 0; j < n; ++j) rk += cs[j] < ci ? 1 : 0;
+#pragma unroll
+      for (int tm = 0; tm < TEAMS; ++tm)
+        if (rk == want[tm]) cs[n + tm] = (uint32_t)i;
+    }
+    __syncthreads();
+    placed_row = (int32_t)cs[n + team];
+    __syncthreads();   // (the table copies overwrite the keys)
+  }
   {
     float *l3 = reinterpret_cast<float *>(smem);
     for (int k = (int)threadIdx.x; k < (int)IREC_PM1; k += TEAMS * NT) {
@@ -243,11 +283,6 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   // selection and the same update as they do, on its own slab: nothing but keys is shared.  A 342-block call then loads a CU
   // with one whole block and a fraction of another instead of two whole ones.  Hand-out slots: one per whole row, coop_W per
   // shared row; the host sizes coop_W so that the static round deals every slot (all partners resident at once).
-  constexpr bool CAN_SHARE = SHARE && TEAMS >= 2 && BS == 1 && !PASSES && !ONE;
-  const int Wsh = (CAN_SHARE && A.coop_W > 1) ? A.coop_W : 1;
-  const int64_t n_whole = Wsh > 1 ? (A.tsplit_first < A.n_blocks ? A.tsplit_first : A.n_blocks) : A.n_blocks;
-  const int64_t n_slots = n_whole + (A.n_blocks - n_whole) * Wsh;
-  const int64_t n_static = (int64_t)TEAMS * (int64_t)gridDim.x < n_slots ? (int64_t)TEAMS * (int64_t)gridDim.x : n_slots;
   bool first_block = true;
   int steal = 0;
   for (;;) {
@@ -256,8 +291,8 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
       int64_t r;
       if (first_block) {
         r = (int64_t)team * (int64_t)gridDim.x + (int64_t)blockIdx.x;
-        r = r < n_static ? xcd_static_row(r, n_static, (int)gridDim.x) : n_slots;
-      } else r = xcd_pull_row(A, n_static, n_slots, steal);
+        r = r < n_static ? (placed ? r : xcd_static_row(r, n_static, (int)gridDim.x)) : n_slots;
+      } else r = placed ? n_slots : xcd_pull_row(A, n_static, n_slots, steal);
       misc[0] = (int32_t)r;
       misc[6] = 0;                          // (shared rows: a partner gave up)
     }
@@ -266,9 +301,14 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
     const int64_t slot = misc[0];
     TSTAMP(0);
     if (slot >= n_slots) break; // every wave of the team reaches this; the other team drains on its own
-    const int64_t blk = slot < n_whole ? slot : n_whole + (slot - n_whole) / Wsh;
+    int64_t blk = slot < n_whole ? slot : n_whole + (slot - n_whole) / Wsh;
+    const int64_t xrow = slot < n_whole ? 0 : (slot - n_whole) / Wsh;        // exchange slot of a shared row
     const int qsh = slot < n_whole ? 0 : (int)((slot - n_whole) % Wsh);      // my sample stripe of a shared row
     const int Wrow = slot < n_whole ? 1 : Wsh;                               // teams that code this row
+    if (placed) {
+      blk = placed_row;
+      if (blk < 0 || blk >= A.n_blocks) __builtin_trap();   // (the cost keys are distinct: their ranks are a permutation of the rows)
+    }
     if (Wrow > 1 && A.coop_test_orphan && qsh != 0) continue;                // test hook: team 0 of a shared row is left waiting
     const int D = A.block_dim[blk];
     const int64_t base = A.block_base[blk];
@@ -759,7 +799,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           // shared rows: a candidate is MINE when its sample lies in my stripe; the others' keys come out of the exchange
           unsigned long long *xg = nullptr;
           if (CAN_SHARE && Wrow > 1)
-            xg = reinterpret_cast<unsigned long long *>(A.coop_xch) + ((size_t)(t & 1) * COOP_MAX_BLOCKS + (size_t)(blk - n_whole)) * COOP_KEYS;
+            xg = reinterpret_cast<unsigned long long *>(A.coop_xch) + ((size_t)(t & 1) * COOP_MAX_BLOCKS + (size_t)xrow) * COOP_KEYS;
           const unsigned long long tag64 = (unsigned long long)(uint32_t)(t + 1) << 32;
           uint32_t foreign = 0u;                        // bit q: candidate q * NT + tid is a partner's
 #pragma unroll
@@ -1068,6 +1108,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
   double *kl_tot = reinterpret_cast<double *>(sm->wb);                          // running KL total of the prologue (wb is idle then)
 
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap(); // see lds_abs_f32
+  commit_table_stamps(A);
   {
     float *l3 = reinterpret_cast<float *>(smem);
     for (int k = (int)threadIdx.x; k < (int)IREC_PM1; k += TEAMS * NT) {
@@ -1404,84 +1445,191 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
 //  node p still takes (x_p = min(n_p, L - n_{p-1} + x_{p-1})) and test the closing node.
 //  One half-wave per (t, s, m); choice bits never change any emitted value (all three table copies are identical).
 // ======================================================================================================
+// Round 4 (second half): ONE launch builds every table of the call (a latent's 1000-dim and residual-dim tables used to be
+// two launches of 56 + 21 us at the default 32-step window); the rank of a look-up among those of its bank is the value an
+// LDS atomic returns (any order serves: the x lowest ranks stay) instead of 32 ballots per slot; the four draws of a quad come
+// from one Philox block (two where S * D is not a multiple of 4); the ring search starts at the average load and keeps one
+// running value instead of three 16-entry arrays -- 82 VGPRs instead of 256 + 65 AGPRs, so several workgroups share a CU.
 #ifndef IREC_CHOICE_WPE
-#define IREC_CHOICE_WPE 1   // waves per SIMD alpha_choice_kernel is compiled for (1: 256 VGPRs, one workgroup per CU at a time)
+#define IREC_CHOICE_WPE 2   // waves per SIMD the table-building kernels are compiled for
 #endif
-__global__ __launch_bounds__(256, IREC_CHOICE_WPE) void alpha_choice_kernel(int64_t seed, int32_t S, int32_t D, int32_t K_tab,
-                                                           const uint16_t *__restrict__ dlog4r, uint16_t *__restrict__ tab,
-                                                           const uint32_t *__restrict__ keep) {
-  if (keep && *keep) return;   // the table in place was built for exactly this key (head kernel of this call): uniform exit
-  __shared__ uint8_t n_s[8][4][32]; // [half-wave][slot][bank] look-ups whose c = 0 bank this is
-  __shared__ uint8_t x_s[8][4][32]; // how many of them stay (c = 0)
-  const int Dp = (D + 3) & ~3;
-  const int NQ = Dp >> 2;             // quads per row
-  const int NM = (NQ + 31) >> 5;      // 32-lane groups per row
-  const int64_t n_hw = (int64_t)K_tab * S * NM;
+// rows with copy bits: workgroup `wg` of `n_wg` (256 threads: 8 half-waves); skip bit q set: table q is in place already
+__device__ __forceinline__ void choice_table_rows(int64_t seed, int32_t S, int32_t K_tab, const uint16_t *__restrict__ dlog4r,
+                                                  const ChoiceJobs &jobs, uint32_t skip, int64_t wg, int64_t n_wg) {
+  __shared__ uint32_t n_s[8][4][32]; // [half-wave][slot][bank] look-ups whose c = 0 bank this is
+  __shared__ uint8_t x_s[8][4][32];  // how many of them stay (c = 0)
   const int hwl = threadIdx.x >> 5, j = threadIdx.x & 31;
-  for (int64_t hw0 = (int64_t)blockIdx.x * 8; hw0 < n_hw; hw0 += (int64_t)gridDim.x * 8) {
-    const int64_t hw = hw0 + hwl;
-    const bool hw_ok = hw < n_hw;
+  const int64_t n_hw = jobs.hw_end[jobs.n - 1];
+  for (int64_t hw0 = wg * 8; hw0 < n_hw; hw0 += n_wg * 8) {
+    const int64_t hwg = hw0 + hwl;
+    int q = 0;
+    while (q + 1 < jobs.n && hwg >= jobs.hw_end[q]) ++q;
+    const int64_t hw = hwg - (q ? jobs.hw_end[q - 1] : 0);
+    // (a table in place that was built for exactly this key is left alone)
+    const bool hw_ok = hwg < n_hw && !((skip >> q) & 1u) && !(jobs.keep[q] && *jobs.keep[q]);
+    const int D = jobs.D[q];
+    const int Dp = (D + 3) & ~3;
+    const int NQ = Dp >> 2;             // quads per row
+    const int NM = (NQ + 31) >> 5;      // 32-lane groups per row
     const int64_t row = hw_ok ? hw / NM : 0;           // t * S + s
     const int m = hw_ok ? (int)(hw - row * NM) : 0;
     const int t = (int)(row / S), s = (int)(row - (int64_t)t * S);
     const int quad = 32 * m + j;
     const bool q_ok = hw_ok && quad < NQ;
     uint32_t al[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) n_s[hwl][i][j] = 0u;
     if (q_ok) {
       const StepSeed ss = make_step_seed(seed + t);
+      uint32_t rm1[4];
+      draw_rm1_x4(ss, (uint64_t)s * (uint64_t)D + (uint64_t)(4 * quad), rm1);   // (draws past the row's end are not used)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (4 * quad + i < D) al[i] = (uint32_t)dlog4r[draw_rm1(ss, (uint64_t)s * (uint64_t)D + (uint64_t)(4 * quad + i))] >> 2;
+        if (4 * quad + i < D) al[i] = (uint32_t)dlog4r[rm1[i]] >> 2;
     }
+    __syncthreads();
     // rank of every look-up among those of its group with the same c = 0 bank, and the per-bank counts
     uint32_t rank[4] = {0u, 0u, 0u, 0u};
+    if (q_ok) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t a = al[i] & 31u;
-      uint32_t cnt_mine = 0u;
-      for (uint32_t v = 0; v < 32u; ++v) {
-        const unsigned long long mask = __ballot(q_ok && a == v);
-        const uint32_t half = (threadIdx.x & 32) ? (uint32_t)(mask >> 32) : (uint32_t)mask;
-        if (a == v) rank[i] = (uint32_t)__popc(half & ((1u << j) - 1u));
-        if ((uint32_t)j == v) cnt_mine = (uint32_t)__popc(half);
-      }
-      n_s[hwl][i][j] = (uint8_t)cnt_mine;
+      for (int i = 0; i < 4; ++i) rank[i] = atomicAdd(&n_s[hwl][i][al[i] & 31u], 1u);
     }
     __syncthreads();
     if (j < 8 && hw_ok) { // 4 slots x 2 rings per half-wave
       const int slot = j >> 1, ring = j & 1;
-      int n[16], x[16];
+      int n[16];
+      int tot = 0;
 #pragma unroll
-      for (int p = 0; p < 16; ++p) { n[p] = n_s[hwl][slot][(ring + 22 * p) & 31]; x[p] = n[p]; }
+      for (int p = 0; p < 16; ++p) { n[p] = (int)n_s[hwl][slot][(ring + 22 * p) & 31]; tot += n[p]; }
+      int Lf = 32, x0f = n[0];           // (L = 32 with every look-up at c = 0 is always feasible)
       bool done = false;
-      for (int L = 1; L <= 32 && !done; ++L)
+      for (int L = tot > 16 ? (tot + 15) >> 4 : 1; L < 32 && !done; ++L)
         for (int x0 = 0; x0 <= n[0] && !done; ++x0) {
-          int xx[16];
-          xx[0] = x0;
+          int xp = x0;
           bool ok = true;
 #pragma unroll
           for (int p = 1; p < 16; ++p) {
-            const int ub = L - n[p - 1] + xx[p - 1];
-            if (ub < 0) ok = false;
-            xx[p] = n[p] < ub ? n[p] : (ub < 0 ? 0 : ub);
+            const int ub = L - n[p - 1] + xp;
+            ok = ok && ub >= 0;
+            xp = n[p] < ub ? n[p] : (ub < 0 ? 0 : ub);
           }
-          if (ok && xx[0] + n[15] - xx[15] <= L) {
-            done = true;
-#pragma unroll
-            for (int p = 0; p < 16; ++p) x[p] = xx[p];
-          }
+          if (ok && x0 + n[15] - xp <= L) { done = true; Lf = L; x0f = x0; }
         }
+      int xp = x0f;
+      x_s[hwl][slot][ring] = (uint8_t)xp;
 #pragma unroll
-      for (int p = 0; p < 16; ++p) x_s[hwl][slot][(ring + 22 * p) & 31] = (uint8_t)x[p];
+      for (int p = 1; p < 16; ++p) {
+        const int ub = Lf - n[p - 1] + xp;
+        xp = n[p] < ub ? n[p] : (ub < 0 ? 0 : ub);
+        x_s[hwl][slot][(ring + 22 * p) & 31] = (uint8_t)xp;
+      }
     }
     __syncthreads();
     if (q_ok) {
       uint32_t v[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = al[i] + (rank[i] < (uint32_t)x_s[hwl][i][al[i] & 31u] ? 0u : IREC_PM1);
-      *reinterpret_cast<uint2 *>(tab + (row * Dp + 4 * quad)) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+      *reinterpret_cast<uint2 *>(jobs.tab[q] + (row * Dp + 4 * quad)) = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
     }
     __syncthreads(); // n_s / x_s are reused by the next round
+  }
+}
+__global__ __launch_bounds__(256, IREC_CHOICE_WPE) void alpha_choice_kernel(int64_t seed, int32_t S, int32_t K_tab,
+                                                           const uint16_t *__restrict__ dlog4r, ChoiceJobs jobs) {
+  choice_table_rows(seed, S, K_tab, dlog4r, jobs, 0u, (int64_t)blockIdx.x, (int64_t)gridDim.x);
+}
+
+// ======================================================================================================
+//  the call's preparation kernel (irec_kernels.h, "The call's preparation kernel"): books, exchange granules, row costs, tables
+// ======================================================================================================
+__global__ __launch_bounds__(256, IREC_CHOICE_WPE) void prep_kernel(PrepArgs P, EncArgs A) {
+  const int t = (int)threadIdx.x;
+  uint32_t *p = P.head;
+  int wg = (int)blockIdx.x;
+  if (wg == 0) { // ---- books
+    for (int w = t; w < (int)(WS_COUNTER_BYTES / 4); w += 256) {
+      const bool book = (w >= WS_KEEP_WORD && w < WS_KEEP_WORD + 4) || (w >= WS_STAMP_WORD && w < WS_STAMP_WORD + 4 * WS_STAMP_WORDS) ||
+                        (w >= WS_PENDING_WORD && w < WS_PENDING_WORD + 4 * WS_STAMP_WORDS);
+      if (!book) p[w] = 0u;
+    }
+    if (t < 4) {   // one thread owns a slot's words
+      uint32_t *stamp = p + WS_STAMP_WORD + t * WS_STAMP_WORDS, *pend = p + WS_PENDING_WORD + t * WS_STAMP_WORDS;
+      bool same = P.ts.reuse != 0 && P.ts.w[t][0] != 0u;
+#pragma unroll
+      for (int k = 0; k < WS_STAMP_WORDS; ++k) same = same && stamp[k] == P.ts.w[t][k];
+      p[WS_KEEP_WORD + t] = same ? 1u : 0u;
+#pragma unroll
+      for (int k = 0; k < WS_STAMP_WORDS; ++k) pend[k] = P.ts.w[t][k];
+      if (!same) {   // not this call's table: no word of the slot may pass for the key's until the encode kernel commits it
+#pragma unroll
+        for (int k = 0; k < WS_STAMP_WORDS; ++k) stamp[k] = ~P.ts.w[t][k];
+      }
+    }
+    return;
+  }
+  wg -= 1;
+  if (wg < P.n_granule) { // ---- exchange granules of shared block `wg`, both parities (16 KB): the step tags of the split encoder
+                          // start at 1, so no granule of an earlier call on this workspace -- or whatever the memory held -- passes for one of this call's
+    uint4 *x = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(p) + WS_COUNTER_BYTES);
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      uint4 *xb = x + ((size_t)par * COOP_MAX_BLOCKS + (size_t)wg) * (COOP_KEYS * 8 / 16);
+      for (int k = t; k < COOP_KEYS * 8 / 16; k += 256) xb[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    return;
+  }
+  wg -= P.n_granule;
+  if (wg < P.n_cost) { // ---- cost key of row `wg`: its KL summed in any order -- it places the row, it does not code it
+    __shared__ double part[4];
+    const int64_t blk = wg;
+    const int D = A.block_dim[blk];
+    const int64_t base = A.block_base[blk];
+    const int32_t pos = A.block_pos[blk];
+    const bool okD = D >= 1 && D <= FAST_MAX_DIM;
+    double acc = 0.0;
+    if (okD) {   // (four dims per thread, all loads of a level in flight together)
+      int64_t ix[4];
+      bool ok[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int d = t + 256 * i; ok[i] = d < D; ix[i] = ok[i] ? src_index(A, base, pos, d) : 0; }
+      float v[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (ok[i]) { v[i][0] = A.q_loc[ix[i]]; v[i][1] = A.q_scale[ix[i]]; v[i][2] = A.p_loc[ix[i]]; v[i][3] = A.p_scale[ix[i]]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (ok[i]) acc = acc + kl_dim(v[i][0], v[i][1], v[i][2], v[i][3]);
+    }
+    const double ws = wave_tree_sum(acc);
+    if ((t & 63) == 0) part[t >> 6] = ws;
+    __syncthreads();
+    if (t == 0) {
+      const double tot = ((part[0] + part[1]) + part[2]) + part[3];
+      int32_t K = okD ? num_aux((float)tot, A.omega) : 0;
+      K = K < 0 ? 0 : (K > (1 << 20) ? (1 << 20) : K);
+      const uint32_t c = (uint32_t)K * (uint32_t)(okD ? D : 0);
+      P.cost[blk] = ((c < (1u << 22) ? c : (1u << 22) - 1u) << 10) | (uint32_t)blk;   // distinct keys: ties go to the lower row
+    }
+    return;
+  }
+  wg -= P.n_cost;
+  // ---- proposal tables: which slots are in place?  (read-only; see irec_kernels.h for why the race with workgroup 0 is benign)
+  uint32_t skip = 0u;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    bool same = P.ts.reuse != 0 && P.ts.w[q][0] != 0u;
+#pragma unroll
+    for (int k = 0; k < WS_STAMP_WORDS; ++k) same = same && __builtin_nontemporal_load(p + WS_STAMP_WORD + q * WS_STAMP_WORDS + k) == P.ts.w[q][k];
+    skip |= same ? (1u << q) : 0u;
+  }
+  if (P.table_kind == 1) choice_table_rows(P.seed, P.S, P.K_tab, P.dlog4r, P.jobs, skip, (int64_t)wg, (int64_t)P.n_table_wgs);
+  else if (P.table_kind == 2) {
+    // plain rows: the workgroups are dealt to the tables in proportion to their rows (jobs.hw_end counts 1024-entry units)
+    int q = 0;
+    while (q + 1 < P.jobs.n && (int64_t)wg >= P.jobs.hw_end[q]) ++q;
+    if ((skip >> q) & 1u) return;
+    const int64_t first = q ? P.jobs.hw_end[q - 1] : 0;
+    plain_table_rows(P.seed, P.S, P.jobs.D[q], P.K_tab, P.dlog4r, P.jobs.tab[q], (int64_t)wg - first, P.jobs.hw_end[q] - first);
   }
 }
 
@@ -1647,13 +1795,39 @@ hipError_t launch_encode_chunk(const EncArgs &A, int grid, hipStream_t st) {
   return chunk_nb_for(A.B) == 10 ? launch_chunk_t<10>(A, grid, st) : launch_chunk_t<20>(A, grid, st);
 }
 
+// workgroups that build the call's tables (kind 1: 8 half-waves per workgroup, at most 4096 workgroups, grid-stride; kind 2: per table
+// one workgroup per 1024 entries, at most 1024 per table, grid-stride inside the table); fills jobs->D / hw_end / n
+int64_t prep_table_wgs(int kind, int32_t S, int32_t K_tab, int n, const int32_t *dims, ChoiceJobs *jobs) {
+  int64_t end = 0;
+  for (int q = 0; q < n; ++q) {
+    if (kind == 1) end += (int64_t)K_tab * S * ((((dims[q] + 3) >> 2) + 31) >> 5);   // half-waves: one per (step, sample, 32-quad group)
+    else {
+      const int64_t total = (int64_t)K_tab * S * ((dims[q] + 3) & ~3);
+      end += std::min<int64_t>((total + 1023) / 1024, 1024);
+    }
+    jobs->D[q] = dims[q]; jobs->hw_end[q] = end;
+  }
+  jobs->n = n;
+  if (kind == 1) { const int64_t want = (end + 7) / 8; return want < 4096 ? want : 4096; }
+  return end;
+}
+hipError_t launch_prep(const PrepArgs &P, const EncArgs &A, hipStream_t st) {
+  const int64_t grid = 1 + (int64_t)P.n_granule + P.n_cost + P.n_table_wgs;
+  hipLaunchKernelGGL(prep_kernel, dim3((unsigned)grid), dim3(256), 0, st, P, A);
+  return hipGetLastError();
+}
+hipError_t launch_alpha_choice_all(int64_t seed, int32_t S, int32_t K_tab, const uint16_t *dlog4r, int n, const int32_t *dims,
+                                   uint16_t *const *tabs, const uint32_t *const *keeps, hipStream_t st) {
+  if (n < 1 || n > 4) return hipErrorInvalidValue;
+  ChoiceJobs jobs{};
+  const int64_t grid = prep_table_wgs(1, S, K_tab, n, dims, &jobs);
+  for (int q = 0; q < n; ++q) { jobs.tab[q] = tabs[q]; jobs.keep[q] = keeps ? keeps[q] : nullptr; }
+  hipLaunchKernelGGL(alpha_choice_kernel, dim3(grid > 0 ? (unsigned)grid : 1u), dim3(256), 0, st, seed, S, K_tab, dlog4r, jobs);
+  return hipGetLastError();
+}
 hipError_t launch_alpha_choice(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *dlog4r, uint16_t *tab,
                                const uint32_t *keep, hipStream_t st) {
-  const int64_t n_hw = (int64_t)K_tab * S * ((((D + 3) >> 2) + 31) >> 5);
-  const int64_t want = (n_hw + 7) / 8;
-  const int grid = (int)(want < 4096 ? want : 4096);
-  hipLaunchKernelGGL(alpha_choice_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, st, seed, S, D, K_tab, dlog4r, tab, keep);
-  return hipGetLastError();
+  return launch_alpha_choice_all(seed, S, K_tab, dlog4r, 1, &D, &tab, &keep, st);
 }
 
 } // namespace irec

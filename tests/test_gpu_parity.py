@@ -1214,6 +1214,44 @@ def test_calls_of_one_to_two_blocks_per_cu_share_rows_between_teams(engine, orac
         assert np.array_equal(sample[i].cpu().numpy(), rs), i
 
 
+@pytest.mark.parametrize("B,n_latents,shape", [(20, 38, "default"), (20, 45, "default"), (10, 38, "default"), (20, 60, "3"), (20, 29, "default")])
+def test_cost_ordered_hand_out_of_mid_size_calls(engine, oracle, B, n_latents, shape):
+    """Round 4: a call of more rows than CUs whose rows all find a team at once (one to TEAMS rows per CU) is dealt BY COST: the head
+    kernel writes K * dims of every row, a CU's first team takes the row of ascending rank w, the other teams (and the teams sharing a
+    row) the costliest rows (irec_team.hip, "Cost-ordered hand-out").  Which CU codes a row never changes what it emits: same K, index
+    rows and samples as with IREC_FLAG_LISTED_ORDER, bit for bit, with K from 0 to several dozen inside one call; the oracle's on the
+    tensors with the shortest and the longest rows; decode(encode) exact."""
+    import irec
+    S = oracle.n_samples(3.0, 1.2 if B > 10 else 1.0)
+    rng = np.random.default_rng(77)
+    stats = []
+    for i in range(n_latents):
+        mq, sq, mp, sp = oracle.synthetic_latent(2100 + i, 8192)
+        f = np.float32(np.exp(np.clip(rng.normal(0.0, 0.6), -1.5, 0.9)))  # per-tensor scale on delta: K differs between tensors
+        stats.append(((mp + (mq - mp) * f).astype(np.float32), sq, mp, sp))
+    stats[3] = (stats[3][2].copy(), stats[3][3].copy(), stats[3][2], stats[3][3])   # one tensor with KL = 0
+    ql, qs, pl, ps = (torch.from_numpy(np.stack([s[k] for s in stats])).cuda().contiguous() for k in range(4))
+    lay = engine.layout(n_latents, 8192, 1000, 42)
+    fl = irec._lib.IREC_FLAG_SHAPE[shape]
+    by_cost = engine.params(3.0, S, B, fl)
+    listed = engine.params(3.0, S, B, fl | irec._lib.IREC_FLAG_LISTED_ORDER)
+    K, idx, sample = engine.encode_blocks(by_cost, lay, ql, qs, pl, ps, 42, 64)
+    K2, idx2, sample2 = engine.encode_blocks(listed, lay, ql, qs, pl, ps, 42, 64)
+    Kh = K.cpu().numpy()
+    assert Kh.min() == 0 and Kh.max() <= 64 and Kh.max() >= 12, (Kh.min(), Kh.max())
+    assert torch.equal(K, K2) and torch.equal(sample, sample2)
+    ih, ih2 = idx.cpu().numpy(), idx2.cpu().numpy()
+    for r in range(lay.n_blocks):
+        assert np.array_equal(ih[r, :Kh[r]], ih2[r, :Kh[r]]), r
+    assert torch.equal(engine.decode_blocks(by_cost, lay, pl, ps, 42, K, idx), sample)
+    bpt = lay.blocks_per_tensor
+    per_tensor = np.array([sum(int(Kh[lay.natural[i * bpt + j]]) for j in range(bpt)) for i in range(n_latents)])
+    for i in (int(np.argmax(per_tensor)), int(np.argsort(per_tensor)[1]), 3):
+        ridx, rs = oracle.encode_tensor(*stats[i], 42, 3.0, S, B, block_size=1000)
+        assert [ih[lay.natural[i * bpt + j], :Kh[lay.natural[i * bpt + j]]].tolist() for j in range(bpt)] == ridx, i
+        assert np.array_equal(sample[i].cpu().numpy(), rs), i
+
+
 def test_shared_rows_give_up_instead_of_hanging(engine, oracle):
     """Test hook (IREC_FLAG_TEST_SPLIT_ORPHAN): the partner teams of every shared row leave at once, so team 0 of each must take the
     give-up exit (100 ms): out_K = -2 on the shared rows, every whole row coded as ever; the Python coder codes the call again
