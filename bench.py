@@ -251,14 +251,16 @@ def cpu_baselines(q, n_ref, n_opt_budget_s):
             "opt_lps": done / max(t_opt, 1e-9), "opt_threads": used, "opt_latents": done, "opt_first": first}
 
 
-def secondary_config(eng, device, name, omega, eps1, beams, n_tensors, n_dims, reps, check, ref_line, block_size=BLOCK_SIZE, max_K=48):
+def secondary_config(eng, device, name, omega, eps1, beams, n_tensors, n_dims, reps, check, ref_line, block_size=BLOCK_SIZE, max_K=32):
     """One further BASELINE configuration, outside the timed headline: `reps` calls of irec_beam_encode on `n_tensors`
     synthetic tensors of `n_dims` dims (blocks of 1000) by HIP events; kernel from irec_encode_plan; look-ups per clock per
-    CU; the first `check` tensors compared with the oracle (indices and sample, bit for bit)."""
+    CU; the first `check` tensors compared with the oracle (indices and sample, bit for bit).
+    max_K = 32 as in the headline and as irec.BeamSearchCoder issues its calls (its first hint; until r04x 48, which made every
+    call launch the -- empty -- second pass behind the 32-step table window)."""
     import torch
     from oracle import oracle as O
     S = int(np.exp(omega * eps1))
-    params = eng.params(omega, S, beams, table_steps=max_K if max_K > 48 else 0)
+    params = eng.params(omega, S, beams, table_steps=max_K if max_K > 32 else 0)
     q = synthetic_batch(n_tensors, device, 77, n_dims)
     lay = eng.layout(n_tensors, n_dims, block_size, SEED)
     out = (torch.empty(lay.n_blocks, dtype=torch.int32, device=device),

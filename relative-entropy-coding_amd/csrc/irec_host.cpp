@@ -658,6 +658,22 @@ int split_beam_width(const irec_params *p, int W) {
 // IREC_FLAG_SHARE_ALL (diagnostics): every row of a call of 64 .. 384 blocks is shared, W = slots / blocks -- slower than the
 // default at every size (r04j: 252 blocks 0.49 against 0.44 ms on the 8-wave team; the partners of a row wait for the slowest).
 // Returns W (0: no sharing) for the shape the call runs; *first = first shared row, *grid = workgroups the static round needs.
+// Calls of 64 blocks up to ~ a block per CU, no shape pinned: EVERY row is shared between the teams of the two-team build (shape 2)
+// instead of sitting alone on a CU's one team -- r04x/share_all_probe.log, max_K = 32, as issued: B = 20: 72 blocks 0.296 -> 0.245 ms,
+// 126 blocks 0.331 -> 0.287, 162 blocks 0.332 -> 0.312 (three partners or more; with two the per-step wait for the slower partner
+// costs more than half a step's scoring saves: 180 blocks 0.332 -> 0.368); B = 10 (whose default build has three 4-wave teams of which
+// such a call uses one): 72 blocks 0.159 -> 0.134, 252 blocks 0.183 -> 0.168 -- also with two partners.
+bool share_all_auto(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks) {
+  if (!pl.team || pl.lone || pl.team_only || pl.chunk || !pl.table || (p->flags & (IREC_FLAG_NO_SPLIT | IREC_FLAG_SHARE_ALL))) return false;
+  if ((p->flags & IREC_FLAG_SHAPE_MASK) != 0 || n_blocks < 64 || n_blocks > irec::COOP_MAX_BLOCKS) return false;
+  const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+  const int B = p->n_beams, S = p->n_samples;
+  if (B > 20 || irec::team_shareable(B, S, 2) != 2 || irec::team_lds_for(B, S, 2) == (size_t)-1 ||
+      irec::team_ws_extra_for(B, S, 2) > irec::team_ws_extra_for(B, S, 0) || irec::team_count_for(B, S, 0) < 2)
+    return false;
+  const int64_t W = std::min<int64_t>(std::min<int64_t>(8, S), 2LL * n_cu / n_blocks);
+  return B > 10 ? W >= 3 : (W >= 2 && n_blocks <= n_cu);
+}
 int team_share_width(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks, int shape, int64_t *first, int *grid) {
   if (!pl.team || pl.lone || pl.team_only || (p->flags & IREC_FLAG_NO_SPLIT)) return 0;
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
@@ -667,7 +683,7 @@ int team_share_width(const irec_context *ctx, const Plan &pl, const irec_params 
   const int64_t cap = std::min<int64_t>(8, p->n_samples);
   const int64_t slots = (int64_t)teams * n_cu;
   int64_t W = 0, f = 0;
-  if (p->flags & IREC_FLAG_SHARE_ALL) {
+  if ((p->flags & IREC_FLAG_SHARE_ALL) || (shape == 2 && share_all_auto(ctx, pl, p, n_blocks))) {
     if (n_blocks < 64 || n_blocks > irec::COOP_MAX_BLOCKS || 2 * n_blocks > slots) return 0;
     W = slots / n_blocks;
   } else {
@@ -702,6 +718,7 @@ int shape_for_call(const irec_context *ctx, const Plan &pl, const irec_params *p
   const int B = p->n_beams, S = p->n_samples;
   if ((p->flags & IREC_FLAG_SHARE_ALL) && !(p->flags & IREC_FLAG_NO_SPLIT) && pl.shape == 0 &&
       team_share_width(ctx, pl, p, n_blocks, 0, nullptr, nullptr) >= 2) return pl.shape;   // (diagnostics) every row shared between teams: the three-team shape
+  if (share_all_auto(ctx, pl, p, n_blocks)) return 2;                             // every row shared between the teams of the two-team build
   if (pl.shape != 0 || !pl.team || pl.lone || n_blocks < 64 || n_blocks > 2 * (int64_t)n_cu || B > 20) return pl.shape;   // (< 64 blocks: only calls
                                                                          // that pin IREC_FLAG_TEAM get here, tests of the default shape among them)
   if (irec::team_count_for(B, S, 0) < 2) return pl.shape;                       // already one striped team

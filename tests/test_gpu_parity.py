@@ -1137,22 +1137,38 @@ def test_diagnostic_team_shapes_are_bit_exact(engine, oracle, shape):
     assert idx[3] == ridx and np.array_equal(sample[3].cpu().numpy(), rs)
 
 
-@pytest.mark.parametrize("B,n_latents", [(20, 12), (11, 28), (16, 8)])
-def test_mid_size_calls_take_the_eight_wave_team(engine, oracle, B, n_latents):
-    """64 .. n_CU blocks with 10 < B <= 20: one block per CU at most, so the call runs ONE 8-wave beam-striped team per CU
-    (irec_encode_plan says so) -- and a larger call of the same coder the three-team shape; the oracle's outputs both ways."""
+@pytest.mark.parametrize("B,n_latents,want_W", [(20, 12, 4), (11, 28, 0), (16, 8, 7), (20, 18, 3), (20, 20, 0), (10, 20, 2), (10, 28, 2), (7, 8, 7)])
+def test_mid_size_calls_take_the_eight_wave_team(engine, oracle, B, n_latents, want_W):
+    """64 .. n_CU blocks: one block per CU at most.  Round 4 (r04x/share_all_probe.log): where the two-team build's 2 n_CU team slots
+    hold three partners or more per row (two or more for B <= 10), EVERY row of the call is shared between that many teams
+    (irec_encode_plan: the two-team kernel, split = W); otherwise, 10 < B <= 20, the call runs ONE 8-wave beam-striped team per CU.
+    A larger call of the same coder takes a multi-team shape without sharing; the oracle's outputs every way."""
     q = [np.stack([oracle.synthetic_latent(300 + i, 8192)[j] for i in range(n_latents)]) for j in range(4)]
-    c = _coder(3.0, B, 1.2, block_size=1000)
+    eps1 = 1.2 if B > 10 else 1.0
+    S = oracle.n_samples(3.0, eps1)
+    c = _coder(3.0, B, eps1, block_size=1000)
     lay = engine.layout(n_latents, 8192, 1000, 42)
     plan = engine.plan(c._params(), lay, 32)
-    assert 64 <= lay.n_blocks <= plan["n_cu"] and plan["kernel"] == "encode_team_kernel<20,1,2>" and plan["teams_per_wg"] == 1, plan
-    assert plan["grid"] == -(-lay.n_blocks // 8) * 8 and plan["waves_per_wg"] == 8   # (a multiple of 8: slot u on XCD u mod 8)
+    assert 64 <= lay.n_blocks <= plan["n_cu"], plan
+    if want_W:
+        nb = 10 if B <= 10 else 20
+        assert plan["kernel"] == f"encode_team_kernel<{nb},2,1>" and plan["teams_per_wg"] == 2 and plan["split"] == want_W, plan
+        assert plan["grid"] * 2 >= lay.n_blocks * want_W and plan["grid"] <= plan["n_cu"], plan
+    else:
+        assert plan["kernel"] == "encode_team_kernel<20,1,2>" and plan["teams_per_wg"] == 1 and plan["split"] == 0, plan
+        assert plan["grid"] == -(-lay.n_blocks // 8) * 8 and plan["waves_per_wg"] == 8   # (a multiple of 8: slot u on XCD u mod 8)
     big = engine.plan(c._params(), engine.layout(64, 8192, 1000, 42), 32)
-    assert big["kernel"] != plan["kernel"] and big["teams_per_wg"] >= 2, big
+    assert big["kernel"] != plan["kernel"] and big["teams_per_wg"] >= 2 and big["split"] == 0, big
     idx, sample = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)
+    assert not c.no_split                                       # (no partner gave up: the call was not coded again without sharing)
     for i in (0, n_latents // 2, n_latents - 1):
-        ridx, rs = oracle.encode_tensor(q[0][i], q[1][i], q[2][i], q[3][i], 42, 3.0, 36, B, block_size=1000)
+        ridx, rs = oracle.encode_tensor(q[0][i], q[1][i], q[2][i], q[3][i], 42, 3.0, S, B, block_size=1000)
         assert idx[i] == ridx and np.array_equal(sample[i].cpu().numpy(), rs), i
+    if want_W:   # the same call with every row on one team: the same bits
+        c2 = _coder(3.0, B, eps1, block_size=1000)
+        c2.no_split = True
+        idx2, sample2 = c2.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)
+        assert idx2 == idx and torch.equal(sample2, sample)
 
 
 @pytest.mark.parametrize("B,eps1", [(20, 1.2), (10, 1.0)])
