@@ -913,7 +913,7 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
     // (measured, profiles/r04w: the pre-pass -- a random gather of the call's statistics, +8 us on the head kernel -- and the ranking
     //  pay for themselves on the two-team build with 20-beam steps: 342 blocks 0.467 -> 0.449 ms, 405 blocks 0.538 -> 0.507; not with
     //  10-beam steps of half the length, nor on the three-team build)
-    if (n_blocks > tg && slots <= tg * n_teams && n_teams == 2 && p->n_beams > 10) A.row_cost = (const uint32_t *)((char *)workspace + irec::WS_COUNTER_BYTES + irec::WS_XCH_BYTES);
+    if (n_blocks > tg && slots <= tg * n_teams && n_teams == 2 && p->n_beams > 10 && irec::team_placeable(p->n_beams, p->n_samples, pl.shape)) A.row_cost = (const uint32_t *)((char *)workspace + irec::WS_COUNTER_BYTES + irec::WS_XCH_BYTES);
   }
   int grid = (int)std::min<int64_t>(n_blocks, pl.one_grid_cap);
   A.dbg = nullptr;

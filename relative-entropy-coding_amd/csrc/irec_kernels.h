@@ -93,6 +93,7 @@ hipError_t launch_alpha_table(int64_t seed, int32_t S, int32_t D, int32_t K_tab,
 // (shape_override: 0 = default shape, 1..4 = the diagnostic shapes of IREC_FLAG_SHAPE_*, see team_cfg() in irec_team.hip)
 int team_count_for(int B, int S, int shape_override);   // teams per workgroup (= scratch slabs per workgroup) of the build that serves B beams
 int team_shareable(int B, int S, int shape_override);   // teams per workgroup when that build can share rows between teams (several 4-wave teams, one pass, keys within the exchange), else 0
+bool team_placeable(int B, int S, int shape_override);  // that build can deal the rows of a mid-size call by cost (EncArgs::row_cost)
 int team_waves_for(int B, int S, int shape_override);   // waves per workgroup of that build
 size_t team_ws_extra_for(int B, int S, int shape_override); // extra scratch-slab bytes of that build
 size_t team_ws_bytes_for(int B, int S, int shape_override, int max_K);   // whole scratch slab of one team of that build

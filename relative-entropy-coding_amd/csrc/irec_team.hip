@@ -214,7 +214,8 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   // of rank n_blocks - 1 - k / W -- a workgroup's first team gets a cheap row, its other teams (or the teams that share a row) the
   // costliest ones, longest first.  Every workgroup ranks the rows itself, once, in the LDS the table copies are about to fill
   // (one row per thread, n compares each: ~2 us): no second kernel, no grid-wide wait.
-  const bool placed = A.row_cost != nullptr;
+  constexpr bool CAN_PLACE = NB == 20 && TEAMS == 2 && BS == 1 && !PASSES && !ONE;   // (team_placeable(): the builds the host asks it of)
+  const bool placed = CAN_PLACE && A.row_cost != nullptr;
   const int64_t lo_rank = (int64_t)gridDim.x < n_whole ? (int64_t)gridDim.x : n_whole;
   int32_t placed_row = -1;
   if (placed) {
@@ -1696,6 +1697,10 @@ int team_count_for(int B, int S, int ovr) { return team_shape(B, S, ovr).teams; 
 int team_shareable(int B, int S, int ovr) {
   const TeamShape sh = team_shape(B, S, ovr);
   return (sh.nb && sh.teams >= 2 && sh.bs == 1 && !sh.passes && !sh.one && (int64_t)S * sh.nb <= COOP_KEYS) ? sh.teams : 0;
+}
+bool team_placeable(int B, int S, int ovr) {   // the builds that can deal their rows by cost (CAN_PLACE in encode_team_kernel)
+  const TeamShape sh = team_shape(B, S, ovr);
+  return sh.nb == 20 && sh.teams == 2 && sh.bs == 1 && !sh.passes && !sh.one;
 }
 int team_waves_for(int B, int S, int ovr) { const TeamShape sh = team_shape(B, S, ovr); return sh.teams * sh.bs * TEAM_NW; }
 size_t team_ws_extra_for(int B, int S, int ovr) { // scratch-slab bytes on top of fast_ws_for(): the sort keys when they do not fit the LDS
