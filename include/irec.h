@@ -113,7 +113,8 @@ typedef struct {
 /* What irec_beam_encode does for a given call: filled by irec_encode_plan (same decision code as the launch). */
 typedef struct {
   char kernel[64];         /* block kernel, e.g. "encode_team_kernel<20,2,1>"                                   */
-  char table_kernel[32];   /* "alpha_choice_kernel", "alpha_table_kernel" or "" (Philox fused in the block kernel) */
+  char table_kernel[32];   /* who builds the proposal tables: "prep_kernel (copy bits)" / "prep_kernel (plain rows)" -- the call's one */
+                           /* preparation launch (books, exchange granules, row costs, tables) -- or "" (Philox fused in the block kernel) */
   int32_t grid;            /* workgroups of the block kernel                                                    */
   int32_t waves_per_wg;
   int32_t teams_per_wg;    /* independent teams inside a workgroup (1 for the one-workgroup-per-block encoders) */

@@ -761,7 +761,7 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
   if (pl.chunk) {
     const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
     std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::chunk_kernel_name(B));
-    std::snprintf(out->table_kernel, sizeof out->table_kernel, "alpha_choice_kernel");
+    std::snprintf(out->table_kernel, sizeof out->table_kernel, "prep_kernel (copy bits)");
     out->grid = batch_grid(n_blocks, n_cu);
     out->waves_per_wg = irec::chunk_teams() * 4;
     out->teams_per_wg = irec::chunk_teams();
@@ -769,7 +769,7 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
   } else if (team && pl.lone) {
     const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
     std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::lone_kernel_name());
-    std::snprintf(out->table_kernel, sizeof out->table_kernel, "alpha_choice_kernel");
+    std::snprintf(out->table_kernel, sizeof out->table_kernel, "prep_kernel (copy bits)");
     out->grid = batch_grid(n_blocks, n_cu);
     out->waves_per_wg = irec::lone_waves();
     out->teams_per_wg = irec::lone_waves();       // every wave codes its own block
@@ -779,7 +779,7 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
     const int n_teams = irec::team_count_for(B, S, shape);
     const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
     std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::team_kernel_name(B, S, shape));
-    std::snprintf(out->table_kernel, sizeof out->table_kernel, "alpha_choice_kernel");
+    std::snprintf(out->table_kernel, sizeof out->table_kernel, "prep_kernel (copy bits)");
     out->grid = batch_grid(n_blocks, std::min(pl.grid_cap / n_teams, n_cu));
     {
       int sgrid = 0;
@@ -791,7 +791,7 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
     out->lds_bytes = (int32_t)irec::team_lds_for(B, S, shape);
   } else if (pl.fast) {
     std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::fast_kernel_name(B, S, pl.table));
-    if (pl.table) std::snprintf(out->table_kernel, sizeof out->table_kernel, "alpha_table_kernel");
+    if (pl.table) std::snprintf(out->table_kernel, sizeof out->table_kernel, "prep_kernel (plain rows)");
     out->grid = (int32_t)std::min<int64_t>(n_blocks, pl.one_grid_cap);
     out->split = split_width(ctx, pl, p, n_blocks);
     if (const int wb = split_beam_width(p, out->split)) { out->split = wb; out->split_beams = 1; }

@@ -605,20 +605,28 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
         constexpr int HB = SPB < 8 ? SPB : 8;                     // rows fetched together
         if (active && own_b[0] < Bcur) {
           const int n_mine = S > sw ? (S - sw + NSW - 1) / NSW : 0;   // my samples: sw, sw + NSW, ...
+          // Rows are fetched ONE SUB-BATCH AHEAD (round 4): with two beams per workgroup a sub-batch of eight rows is 64 look-ups per
+          // lane, far less than the L2 latency of its row loads, which every sub-batch used to wait out (five per step at S = 36).
+          uint2 ap_nxt[HB];
+          auto load_rows = [&](const int first) {
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+              const int m = first + k;
+              ap_nxt[k] = make_uint2(0u, 0u);
+              if (m < n_mine) ap_nxt[k] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)(m * NSW + sw) * Dp);
+            }
+          };
+          load_rows(0);
           for (int m0 = 0; m0 < n_mine; m0 += SPB) {
             float acc[RW];
 #pragma unroll
             for (int p = 0; p < RW; ++p) acc[p] = 0.f;
             // one sub-batch of NH rows: rows m0 + h .. + NH - 1 (past my last sample: entry 0, the total is dropped)
-            auto sub_batch = [&](auto nh_tag, const int h) {
+            auto sub_batch = [&](auto nh_tag, const int h, const uint2 (&apb)[HB]) {
               constexpr int NH = decltype(nh_tag)::value;
               uint2 ap[NH];
 #pragma unroll
-              for (int k = 0; k < NH; ++k) {
-                const int m = m0 + h + k;
-                ap[k] = make_uint2(0u, 0u);
-                if (m < n_mine) ap[k] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)(m * NSW + sw) * Dp);
-              }
+              for (int k = 0; k < NH; ++k) ap[k] = apb[k];
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
                 float z[NH][NOWN];
@@ -647,10 +655,14 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
             for (int h = 0; h < SPB; h += HB) {
               const int left = n_mine - (m0 + h);                  // wave-uniform
               if (left <= 0) continue;
+              uint2 ap_cur[HB];
+#pragma unroll
+              for (int k = 0; k < HB; ++k) ap_cur[k] = ap_nxt[k];
+              if (left > HB) load_rows(m0 + h + HB);               // the next sub-batch's rows, under this one's look-ups
               if constexpr (HB >= 8) {
-                if (left <= HB / 2) { sub_batch(std::integral_constant<int, HB / 2>{}, h); continue; }
+                if (left <= HB / 2) { sub_batch(std::integral_constant<int, HB / 2>{}, h, ap_cur); continue; }
               }
-              sub_batch(std::integral_constant<int, HB>{}, h);
+              sub_batch(std::integral_constant<int, HB>{}, h, ap_cur);
             }
             const float tot = reduce_scatter<RW>(acc, lane);
             const int p = RW == 64 ? lane : (lane >> 1);

@@ -298,7 +298,7 @@ def test_blocks_beyond_1024_dims_take_the_chunked_encoder(engine, oracle, n, bs,
     params = engine.params(omega, S, B, table_steps=max_K)      # (tables over every partition: nothing is left to the second pass)
     plan = engine.plan(params, lay, max_K)
     assert plan["kernel"] == ("encode_chunk_kernel<10,2>" if B <= 10 else "encode_chunk_kernel<20,2>"), plan["kernel"]
-    assert plan["table_kernel"] == "alpha_choice_kernel" and plan["lds_bytes"] <= 160 * 1024
+    assert plan["table_kernel"] == "prep_kernel (copy bits)" and plan["lds_bytes"] <= 160 * 1024
     K, idx, sample = engine.encode_blocks(params, lay, ql, qs, pl, ps, 42, max_K)
     Kh, ih = K.cpu().numpy(), idx.cpu().numpy()
     assert Kh.min() >= 0 and Kh.max() <= max_K, (int(Kh.min()), int(Kh.max()))
@@ -1077,7 +1077,7 @@ def test_plan_names_the_kernels_that_run(engine, oracle):
     small = engine.layout(1, 8192, 1000, 42)
     p = engine.params(3.0, S, 20)
     assert engine.plan(p, big, 32)["kernel"] == "encode_team_kernel<20,3,1>"
-    assert engine.plan(p, big, 32)["table_kernel"] == "alpha_choice_kernel"
+    assert engine.plan(p, big, 32)["table_kernel"] == "prep_kernel (copy bits)"
     assert engine.plan(p, small, 32)["kernel"].startswith("encode_fast_kernel<20,")       # < 64 blocks: one-table set-up
     assert engine.plan(engine.params(3.0, S, 20, irec._lib.IREC_FLAG_FUSED_PHILOX), big, 32)["table_kernel"] == ""
     assert engine.plan(engine.params(3.0, 20, 10), big, 32)["kernel"] == "encode_team_kernel<10,3,1>"
@@ -1091,7 +1091,7 @@ def test_plan_names_the_kernels_that_run(engine, oracle):
     assert engine.plan(engine.params(6.0, 8103, 10), big, 32)["kernel"] == "encode_team_kernel<10,3,1,passes>"
     # one beam: one wave per block (irec_lone.hip), 12 blocks in flight per CU; the team encoder's one-beam builds on request
     lone = engine.plan(engine.params(6.0, 8103, 1), big, 32)
-    assert lone["kernel"] == "encode_lone_kernel" and lone["waves_per_wg"] == 12 and lone["table_kernel"] == "alpha_choice_kernel"
+    assert lone["kernel"] == "encode_lone_kernel" and lone["waves_per_wg"] == 12 and lone["table_kernel"] == "prep_kernel (copy bits)"
     pin = irec._lib.IREC_FLAG_SHAPE["team"]
     assert engine.plan(engine.params(6.0, 8103, 1, pin), big, 32)["kernel"] == "encode_team_kernel<10,3,1,passes,one>"
     assert engine.plan(engine.params(5.0, 403, 1, pin), big, 32)["kernel"] == "encode_team_kernel<10,3,1,one>"   # 403 samples in one pass
