@@ -89,7 +89,7 @@ typedef struct {
 #define IREC_FLAG_SHARE_ALL 131072 /* team encoder, calls that leave team slots idle: share EVERY row of the call between teams instead of only */
                                   /* the rows beyond one per CU (diagnostics, r04j: slower than the default at every size; same outputs)     */
 #define IREC_FLAG_LISTED_ORDER 262144 /* team encoder, calls of one to a few rows per CU: deal the rows to the CUs in the order listed.    */
-                                  /* Default: by cost -- the call's head kernel also computes K * dims of every row and a CU's first   */
+                                  /* Default: by cost -- the call's preparation kernel also computes K * dims of every row and a CU's first   */
                                   /* team takes a cheap row, its other teams (and the teams that share a row) the costliest ones, so   */
                                   /* that the longest rows do not meet on one CU.  Results do not depend on it (diagnostics, A/B).     */
 #define IREC_FLAG_SPLIT_SHIFT 12  /* bits 12-15: workgroups per block of the split encoder, 0 = chosen by the library (diagnostics) */

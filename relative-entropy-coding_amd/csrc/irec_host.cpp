@@ -884,7 +884,7 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   A.max_dim_pad = pl.dpad;
   // table bookkeeping (IREC_FLAG_REUSE_TABLES): the key of every proposal table this call needs -- what it is a function
   // of (seed, S, D, window), which kernel writes it (the team encoder's rows carry copy bits) and where it lies -- is
-  // compared with the slot's stamp ON THE DEVICE by the head kernel; a slot the call does not use is stamped with zeros,
+  // compared with the slot's stamp ON THE DEVICE by the preparation kernel; a slot the call does not use is stamped with zeros,
   // so a call without tables (whose slabs may lie over the table area) invalidates what was there
   irec::TableStamps stamps{};
   if (pl.table)
@@ -897,20 +897,20 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
       w[7] = ~(w[1] ^ w[2] ^ w[3] ^ w[4] ^ w[5] ^ w[6]);
     }
   stamps.reuse = (p->flags & IREC_FLAG_REUSE_TABLES) ? 1 : 0;
-  int split_blocks = 0;   // a split call: the head kernel also zeroes the exchange granules of its blocks
+  int split_blocks = 0;   // a split call: the preparation kernel also zeroes the exchange granules of its blocks
   if (pl.table && !pl.team && split_width(ctx, pl, p, n_blocks) >= 2) split_blocks = (int)n_blocks;   // (pl.team: of THIS call, above)
   int64_t share_first = 0;
   int share_grid = 0;
   const int share_W = (pl.table && pl.team) ? team_share_width(ctx, pl, p, n_blocks, pl.shape, &share_first, &share_grid) : 0;
   if (share_W >= 2) split_blocks = (int)(n_blocks - share_first);
   // Cost-ordered hand-out (team encoder, calls of more rows than workgroups whose slots the static round deals completely --
-  // one to TEAMS rows per CU): the head kernel also writes K * dims of every row, and the teams take their rows by cost rank
+  // one to TEAMS rows per CU): the preparation kernel also writes K * dims of every row, and the teams take their rows by cost rank
   // (irec_team.hip, "Cost-ordered hand-out").  IREC_FLAG_LISTED_ORDER: rows as listed (A/B runs).
   if (pl.table && pl.team && !pl.lone && !pl.chunk && !(p->flags & IREC_FLAG_LISTED_ORDER) && n_blocks <= irec::COST_MAX_ROWS) {
     const int n_teams = irec::team_count_for(p->n_beams, p->n_samples, pl.shape);
     const int64_t tg = share_W >= 2 ? share_grid : batch_grid(n_blocks, std::min(pl.grid_cap / n_teams, ctx->n_cu > 0 ? ctx->n_cu : 256));
     const int64_t slots = share_W >= 2 ? share_first + (n_blocks - share_first) * share_W : n_blocks;
-    // (measured, profiles/r04w: the pre-pass -- a random gather of the call's statistics, +8 us on the head kernel -- and the ranking
+    // (measured, profiles/r04w: the pre-pass -- a random gather of the call's statistics, +8 us on the preparation kernel -- and the ranking
     //  pay for themselves on the two-team build with 20-beam steps: 342 blocks 0.467 -> 0.449 ms, 405 blocks 0.538 -> 0.507; not with
     //  10-beam steps of half the length, nor on the three-team build)
     if (n_blocks > tg && slots <= tg * n_teams && n_teams == 2 && p->n_beams > 10 && irec::team_placeable(p->n_beams, p->n_samples, pl.shape)) A.row_cost = (const uint32_t *)((char *)workspace + irec::WS_COUNTER_BYTES + irec::WS_XCH_BYTES);

@@ -44,7 +44,7 @@ struct EncArgs {
   // Shared rows of the team encoder (irec_team.hip, round 4): rows [tsplit_first, n_blocks) are coded by coop_W teams each, which
   // split the row's samples and exchange their sort keys through coop_xch (row r uses exchange slot r - tsplit_first).
   int64_t tsplit_first;
-  // Cost-ordered hand-out (round 4): the key (K * dims) << 10 | row of every row, written by the call's head kernel (nullptr: rows
+  // Cost-ordered hand-out (round 4): the key (K * dims) << 10 | row of every row, written by the call's preparation kernel (nullptr: rows
   // are dealt as listed).
   // Set only for calls whose hand-out slots all fall into the static round (every team takes at most one): workgroup w's first team
   // then takes the row of ascending cost rank w and its other teams the costliest rows (shared rows: the costliest), so that no CU
@@ -85,7 +85,7 @@ size_t fast_ws_for(int B, int max_K);
 size_t fast_ws_bytes_nb(int NB, int max_K);
 hipError_t launch_encode_fast(const EncArgs &A, bool table, int grid, hipStream_t st);
 int fast_waves_for(int B, int S, bool table);
-// (`keep`: device word the per-call head kernel has set to 1 when the table in place already is this one -- the kernel
+// (`keep`: device word that is 1 when the table in place already is this one -- the kernel
 //  then returns at once; nullptr = always build)
 hipError_t launch_alpha_table(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *dlog4r, uint16_t *tab,
                               const uint32_t *keep, hipStream_t st);
@@ -124,9 +124,9 @@ hipError_t launch_encode_lone(const EncArgs &A, int grid, hipStream_t st);
 // and behind them the eight per-XCD block counters of the batch encoders' first pass, [128 + 64 x]: 256 bytes apart, so that the
 // adds of different XCDs do not queue on one line.
 // words of the call's proposal tables, [16..47] the stamps of the four table slots (8 words each: what the table in place
-// was built for), [64..127] arrival counters of the split encoder.  The head kernel of every call zeroes the counters,
+// was built for), [64..127] arrival counters of the split encoder.  The preparation kernel of every call zeroes the counters,
 // compares each slot's stamp with the call's key (IREC_FLAG_REUSE_TABLES; keep = 1 on a match, else 0) and stamps the key:
-// the table kernels that follow on the stream read `keep`, nobody writes it again before the next call's head kernel.
+// its table workgroups make the same comparison themselves (`keep` is kept for diagnostics and the tests).
 constexpr int WS_KEEP_WORD = 8, WS_STAMP_WORD = 16, WS_STAMP_WORDS = 8, WS_XCD_WORD = 128, WS_XCD_STRIDE = 64;
 constexpr int WS_PENDING_WORD = 132;   // [132, 164): the call's table keys until the encode kernel commits them (inside XCD 0's counter line: only its first word counts)
 struct TableStamps { uint32_t w[4][WS_STAMP_WORDS]; int32_t reuse; };   // all-zero key = slot unused (never matches)

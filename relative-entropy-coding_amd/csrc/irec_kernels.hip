@@ -844,7 +844,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
         // Granules (MI355X_MICROARCH.md, handoff-1to1): a key travels as ONE naturally aligned 8-byte {key, step tag} `sc1` store
         // and every partner sweeps the step's granules with `sc1` loads until each carries this step's tag -- no drain, no
         // arrival counter, no second round trip for the payload (r03l: ≈ 3 µs of a 12 µs step were the three serial round trips
-        // of the counter form).  Tags: t + 1 >= 1; the head kernel zeroed this block's granules, buffer t & 1 last held tag
+        // of the counter form).  Tags: t + 1 >= 1; the preparation kernel zeroed this block's granules, buffer t & 1 last held tag
         // t - 1.  A thread gives up like the counter form did: sticky error flag, COOP_GIVE_UP_TICKS (100 ms).
         unsigned long long *xg = reinterpret_cast<unsigned long long *>(A.coop_xch) + ((size_t)(t & 1) * COOP_MAX_BLOCKS + (size_t)blk) * COOP_KEYS;
         const uint32_t tag = (uint32_t)(t + 1);

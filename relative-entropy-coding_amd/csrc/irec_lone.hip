@@ -10,7 +10,7 @@
 // Here the whole beam lives in ONE wave's registers -- lane l owns dims 256 g + 4 l .. + 3 of all four dim groups g, exactly
 // the lanes the canonical reduction tree gives them -- so a step needs no exchange with any other wave:
 //   * 12 waves per CU, each coding its own block (block counter pulls per wave), three quantile-table copies shared in LDS
-//     and the team encoder's proposal tables with their bank-spreading copy bits (alpha_choice_kernel): a ds_read_b32 still
+//     and the team encoder's proposal tables with their bank-spreading copy bits (choice_table_rows, irec_team.hip): a ds_read_b32 still
 //     gathers dims 256 g + 4 l + i of one (g, i) over the lanes, the grouping the copy bits were chosen for;
 //   * scores of four samples x four dim groups leave one 16-value reduce-scatter (lane distances 32 .. 1, the canonical
 //     tree); the four group totals of a sample then sit 4 lanes apart in one row and are added in group order by DPP;

@@ -12,7 +12,7 @@
 //     e = alpha' + beta with alpha' = dlog r + 10006 c, c in {0, 1}, beta = dlog hash never leaves the three copies, so
 //     the address is ONE add (no "mod 10006"), and bank(e) = (dlog r + 22 c + beta) mod 32: the copy bit c moves a
 //     lane by 22 banks whatever the beam.  c is chosen once per call for every (step, sample, 32-lane group, dim
-//     slot) by alpha_choice_kernel -- an exact min-max assignment on two 16-rings of banks -- and travels inside the
+//     slot) by the call's preparation kernel (choice_table_rows) -- an exact min-max assignment on two 16-rings of banks -- and travels inside the
 //     proposal table the block kernel streams anyway.  Busiest bank: 2.15 addresses instead of 3.5.
 //   * one workgroup owns the CU; its teams code blocks independently (own block counter pulls, own LDS scratch, own
 //     scratch slab) and synchronise with team barriers (an LDS counter), never with s_barrier, so one team's serial
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   const int64_t n_whole = Wsh > 1 ? (A.tsplit_first < A.n_blocks ? A.tsplit_first : A.n_blocks) : A.n_blocks;
   const int64_t n_slots = n_whole + (A.n_blocks - n_whole) * Wsh;
   const int64_t n_static = (int64_t)TEAMS * (int64_t)gridDim.x < n_slots ? (int64_t)TEAMS * (int64_t)gridDim.x : n_slots;
-  // Cost-ordered hand-out (round 4; A.row_cost: distinct keys (K * dims) << 10 | row from the call's head kernel, set by the host only
+  // Cost-ordered hand-out (round 4; A.row_cost: distinct keys (K * dims) << 10 | row from the call's preparation kernel, set by the host only
   // when the static round deals every slot): slot u < lo = min(grid, n_whole) is the row of ascending cost rank u, slot lo + k the row
   // of rank n_blocks - 1 - k / W -- a workgroup's first team gets a cheap row, its other teams (or the teams that share a row) the
   // costliest ones, longest first.  Every workgroup ranks the rows itself, once, in the LDS the table copies are about to fill
@@ -828,7 +828,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
             }
           }
           if (CAN_SHARE && Wrow > 1) {
-            // sweep the partners' granules until each carries this step's tag (tags start at 1; the head kernel zeroed the row's
+            // sweep the partners' granules until each carries this step's tag (tags start at 1; the preparation kernel zeroed the row's
             // granules; buffer t & 1 last held tag t - 1).  Give-up as in the split encoder: sticky error flag, COOP_GIVE_UP_TICKS (100 ms).
             const uint32_t tag = (uint32_t)(t + 1);
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();          // 100 MHz
@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 //  groups, one per wave, exactly the lane ownership of the canonical tree) twice per step:
 //    scoring   per chunk: the step's constants from the slab's statistics and cumulative variance (the IEEE chain of
 //              coder.py:141-154), G and the C_b terms of the live beams from the beams in the slab, then every sample x beam
-//              over the chunk -- three table copies, copy bits of alpha_choice_kernel, as in encode_team_kernel -- into the
+//              over the chunk -- three table copies, copy bits of choice_table_rows, as in encode_team_kernel -- into the
 //              per-group partials; a combine adds the chunk's group sums to the RUNNING score of every candidate in
 //              increasing group order, which is the specification's order ("group sums are added in increasing
 //              group order"), so the bits are encode_generic_kernel's;
