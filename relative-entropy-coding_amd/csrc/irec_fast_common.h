@@ -88,6 +88,22 @@ constexpr size_t SMALL_LDS_BYTES = (sizeof(SmallLds) + 15) & ~(size_t)15;
 // `post(j, s, b, key)` is called by the thread that has just recorded new beam j = candidate (sample s, parent beam b)
 // with sort key `key`, before the barrier that publishes the selection.
 struct NoPost { __device__ __forceinline__ void operator()(int, int32_t, int32_t, uint32_t) const {} };
+// The Bnew-th largest of the 64 lane maxima M (every lane calls; wave-uniform result): at least Bnew keys are >= it.  Lane l counts the
+// lanes with a strictly larger maximum; the value whose count is the largest one below Bnew is the Bnew-th largest (values below it
+// see at least Bnew larger ones) -- found by probing the counts downwards from Bnew - 1: without ties the counts are a permutation of
+// 0..63 and the first probe hits.  (Round 4: this replaced a 64-bit wave reduction of six cross-lane steps, r04ah/select_rates.log.)
+__device__ __forceinline__ uint32_t kth_largest_lane_max(uint32_t M, int Bnew) {
+  uint32_t cnt_gt = 0u;
+#pragma unroll
+  for (int l = 0; l < 64; ++l) cnt_gt += (uint32_t)__builtin_amdgcn_readlane((int)M, l) > M ? 1u : 0u;
+  uint32_t T = 0u;
+  for (int c = Bnew <= 64 ? Bnew - 1 : 63; c >= 0; --c) {   // (more than 64 beams, generic kernel: the smallest lane maximum)
+    const unsigned long long hit = __ballot(cnt_gt == (uint32_t)c);
+    if (hit) { T = (uint32_t)__builtin_amdgcn_readlane((int)M, (int)__builtin_ctzll(hit)); break; }   // (wave-uniform)
+  }
+  return T;
+}
+
 // Stage 3 of the threshold selection, run by ONE wave (lane = tid < 64): cand[0, C) holds the (key, flat) pairs of every
 // candidate >= T, at least Bnew of them.  Ranks them by (key descending, flat ascending) and records rank r < Bnew as new beam
 // r (sel_s / sel_b, post()).  More than 64 survivors (many beams: the B-th largest of 64 lane maxima leaves ~2 B candidates
@@ -133,11 +149,22 @@ __device__ __forceinline__ bool rank_survivors(SM *sm, uint32_t C, int Bnew, int
   // rank the C <= 64 survivors; lanes >= C hold a null candidate
   const unsigned long long mine = tid < (int)C ? sm->cand[tid] : 0ull;
   const uint32_t mk1 = (uint32_t)(mine >> 32), mf1 = (uint32_t)mine;
+  // (key, ~flat) as ONE 64-bit number: larger = better (key descending, ties to the lower flat index).  Constant-lane broadcasts in
+  // groups of eight, one 64-bit compare per candidate (round 4; a run-time lane index and three compares until then).  The lanes >= C
+  // hold key 0, which beats no survivor (T >= 1).
+  const uint32_t nf1 = ~mf1;
+  const unsigned long long mp = ((unsigned long long)mk1 << 32) | nf1;
   uint32_t rank = 0u;
-  for (uint32_t l = 0; l < C; ++l) {
-    const uint32_t ok_ = (uint32_t)__builtin_amdgcn_readlane((int)mk1, (int)l);
-    const uint32_t of_ = (uint32_t)__builtin_amdgcn_readlane((int)mf1, (int)l);
-    rank += (ok_ > mk1 || (ok_ == mk1 && of_ < mf1)) ? 1u : 0u;
+#pragma unroll
+  for (int l0 = 0; l0 < 64; l0 += 8) {
+    if ((uint32_t)l0 < C) { // wave-uniform
+#pragma unroll
+      for (int l = l0; l < l0 + 8; ++l) {
+        const uint32_t ok_ = (uint32_t)__builtin_amdgcn_readlane((int)mk1, l);
+        const uint32_t on_ = (uint32_t)__builtin_amdgcn_readlane((int)nf1, l);
+        rank += (((unsigned long long)ok_ << 32) | on_) > mp ? 1u : 0u;
+      }
+    }
   }
   if (tid < (int)C && rank < (uint32_t)Bnew) {
     const int32_t s_ = (int32_t)(mf1 / (uint32_t)Bcur); // best_ind_aux  (beam_search_coder.py:89)
@@ -225,11 +252,7 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
         M = k[q] > M ? k[q] : M;
       }
       // 1. threshold: #lanes with a strictly larger maximum
-      uint32_t cnt_gt = 0u;
-#pragma unroll
-      for (int l = 0; l < 64; ++l) cnt_gt += (uint32_t)__builtin_amdgcn_readlane((int)M, l) > M ? 1u : 0u;
-      uint32_t T = cnt_gt < (uint32_t)Bnew ? M : 0xFFFFFFFFu;
-      T = 0xFFFFFFFFu - (uint32_t)wave_max_u64((unsigned long long)(0xFFFFFFFFu - T)); // wave min
+      uint32_t T = kth_largest_lane_max(M, Bnew);
       // 2. compact candidates >= T (T >= 1 because at least Bnew <= N lanes hold a real key)
       uint32_t base = 0u;
 #pragma unroll
@@ -277,11 +300,7 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
     uint32_t T;
     {
       const uint32_t M = lane_max[lane];
-      uint32_t cnt_gt = 0u;
-#pragma unroll
-      for (int l = 0; l < 64; ++l) cnt_gt += (uint32_t)__builtin_amdgcn_readlane((int)M, l) > M ? 1u : 0u;
-      T = cnt_gt < (uint32_t)Bnew ? M : 0xFFFFFFFFu;
-      T = 0xFFFFFFFFu - (uint32_t)wave_max_u64((unsigned long long)(0xFFFFFFFFu - T)); // wave min
+      T = kth_largest_lane_max(M, Bnew);
       T = T ? T : 1u;                                        // (0 marks a taken / empty key)
     }
     sync(); // every wave has read the maxima: cand[] may be written
@@ -338,11 +357,7 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
         M = M > b ? M : b;
       }
       for (int f = (n4 << 2) + tid; f < N; f += 64) M = key[f] > M ? key[f] : M;
-      uint32_t cnt_gt = 0u;
-#pragma unroll
-      for (int l = 0; l < 64; ++l) cnt_gt += (uint32_t)__builtin_amdgcn_readlane((int)M, l) > M ? 1u : 0u;
-      uint32_t T = cnt_gt < (uint32_t)Bnew ? M : 0xFFFFFFFFu;
-      T = 0xFFFFFFFFu - (uint32_t)wave_max_u64((unsigned long long)(0xFFFFFFFFu - T)); // wave min
+      uint32_t T = kth_largest_lane_max(M, Bnew);
       T = T ? T : 1u;                                        // (0 marks a taken / empty key)
       uint32_t base = 0u;
       auto put = [&](bool in, uint32_t k, uint32_t flat) {
