@@ -25,6 +25,12 @@ using namespace irec;
 #ifndef V_SKIP_COUNT
 #define V_SKIP_COUNT 0
 #endif
+#ifndef V_RANK32
+#define V_RANK32 0
+#endif
+#ifndef SM_CANDS
+#define SM_CANDS 64
+#endif
 #ifndef SELECT_IMPL
 #define SELECT_IMPL select_topB_sync
 #endif
@@ -32,7 +38,7 @@ using namespace irec;
 __global__ __launch_bounds__(256) void time_select(const uint32_t *keys_g, int N, int Bnew, int Bcur, int reps, int32_t *sel_out,
                                                    unsigned long long *cycles) {
   __shared__ uint32_t key_s[4096];
-  __shared__ SmallLdsT<64, 64, 512> sm;
+  __shared__ SmallLdsT<64, 64, SM_CANDS> sm;
   const int tid = threadIdx.x;
   unsigned long long tot = 0ull;
   for (int r = 0; r < reps; ++r) {
@@ -126,7 +132,7 @@ __device__ __forceinline__ void select_staged(uint32_t *key, int N, int Bnew, in
 }
 __global__ __launch_bounds__(256) void time_staged(const uint32_t *keys_g, int N, int Bnew, int Bcur, int reps, int32_t *sel_out, unsigned long long *st_out) {
   __shared__ uint32_t key_s[4096];
-  __shared__ SmallLdsT<64, 64, 512> sm;
+  __shared__ SmallLdsT<64, 64, SM_CANDS> sm;
   const int tid = threadIdx.x;
   unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int r = 0; r < reps; ++r) {
@@ -190,7 +196,7 @@ __device__ __forceinline__ void select_v3(uint32_t *key, int N, int Bnew, int Bc
 #else
     uint32_t cnt_gt = 0u;
 #pragma unroll
-    for (int l = 0; l < (V_SKIP_COUNT ? 8 : 64); ++l) cnt_gt += (uint32_t)__builtin_amdgcn_readlane((int)M, l) > M ? 1u : 0u;
+    for (int l = 0; l < (V_SKIP_COUNT ? 0 : 64); ++l) cnt_gt += (uint32_t)__builtin_amdgcn_readlane((int)M, l) > M ? 1u : 0u;
     stamp(2);
     // the Bnew-th largest lane maximum: the lane(s) with the largest count below Bnew (without ties the counts are a permutation of
     // 0..63 and the first probe hits)
@@ -199,6 +205,7 @@ __device__ __forceinline__ void select_v3(uint32_t *key, int N, int Bnew, int Bc
       const unsigned long long hit = __ballot(cnt_gt == (uint32_t)c);
       if (hit) { T = (uint32_t)__builtin_amdgcn_readlane((int)M, (int)__builtin_ctzll(hit)); break; }
     }
+    if (V_SKIP_COUNT) T = 1u;
 #endif
     stamp(3);
     uint32_t base = 0u;
@@ -220,6 +227,20 @@ __device__ __forceinline__ void select_v3(uint32_t *key, int N, int Bnew, int Bc
       const uint32_t nf1 = ~mf1;
       const unsigned long long mp = ((unsigned long long)mk1 << 32) | nf1;     // larger = better: key descending, flat ascending
       uint32_t rank = 0u;
+#if V_RANK32
+      // by key alone (one broadcast, one 32-bit compare per candidate); equal keys -- rare -- show up as two survivors with one rank
+#pragma unroll
+      for (int l0 = 0; l0 < 64; l0 += 8) {
+        if ((uint32_t)l0 < C) {   // wave-uniform
+#pragma unroll
+          for (int l = l0; l < l0 + 8; ++l) rank += (uint32_t)__builtin_amdgcn_readlane((int)mk1, l) > mk1 ? 1u : 0u;
+        }
+      }
+      if (tid < (int)C) sm->cand[rank] = (unsigned long long)tid;
+      const bool lost = tid < (int)C && sm->cand[rank] != (unsigned long long)tid;
+      if (__ballot(lost)) {   // (wave-uniform) a tie: the exact order, key descending then flat ascending
+        rank = 0u;
+#endif
 #pragma unroll
       for (int l0 = 0; l0 < (V_SKIP_RANK ? 0 : 64); l0 += 8) {
         if ((uint32_t)l0 < C) {   // wave-uniform
@@ -232,6 +253,9 @@ __device__ __forceinline__ void select_v3(uint32_t *key, int N, int Bnew, int Bc
           }
         }
       }
+#if V_RANK32
+      }
+#endif
       if (tid < (int)C && rank < (uint32_t)Bnew) { sm->sel_s[rank] = (int32_t)(mf1 / (uint32_t)Bcur); sm->sel_b[rank] = (int32_t)(mf1 % (uint32_t)Bcur); }
       sm->misc[7] = 1;
     } else sm->misc[7] = rank_survivors(sm, C, Bnew, Bcur, tid, NoPost()) ? 1 : 0;
@@ -243,7 +267,7 @@ __device__ __forceinline__ void select_v3(uint32_t *key, int N, int Bnew, int Bc
 }
 __global__ __launch_bounds__(256) void time_v3(const uint32_t *keys_g, int N, int Bnew, int Bcur, int reps, int32_t *sel_out, unsigned long long *st_out) {
   __shared__ uint32_t key_s[4096];
-  __shared__ SmallLdsT<64, 64, 512> sm;
+  __shared__ SmallLdsT<64, 64, SM_CANDS> sm;
   const int tid = threadIdx.x;
   unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int r = 0; r < reps; ++r) {
