@@ -354,6 +354,10 @@ irec_status irec_test_reduce_scatter(irec_context *ctx, const float *in, float *
  * beam_search_coder.py:85-89 in isolation.  scores: float [n]; scratch_keys: uint32 [n]; out_sel: int32 [n_select][2]. */
 irec_status irec_test_select(irec_context *ctx, const float *scores, int32_t n, int32_t n_select, int32_t n_beams_cur,
                              uint32_t *scratch_keys, int32_t *out_sel, void *hip_stream);
+/* The same step in the form the one-table / split encoders and the two-team builds of the team encoder run since round 4 (threshold by
+ * probing the lane counts, ranks by the key alone with a collision check for ties): same outputs. */
+irec_status irec_test_select_quick(irec_context *ctx, const float *scores, int32_t n, int32_t n_select, int32_t n_beams_cur,
+                                   uint32_t *scratch_keys, int32_t *out_sel, void *hip_stream);
 /* The per-call proposal table of the default encoder for blocks of `dim` dims: out_tab uint16 [n_steps][n_samples][dim
  * rounded up to 4] = dlog_g(r) + 10006 * c, r the int32 draw of beam_search_coder.py:38-43 at seed + t, c the copy bit
  * that spreads each 32-lane look-up group over the LDS banks. */

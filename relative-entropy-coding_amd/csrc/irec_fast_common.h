@@ -7,6 +7,15 @@
 #include "irec_device.h"
 #include "irec_kernels.h"
 
+#ifndef IREC_QUICK_SELECT
+#define IREC_QUICK_SELECT 1   // the round-4 form of the top-B selection where it pays (0: the form of rounds 1-3 everywhere; A/B builds)
+#endif
+#ifndef IREC_RANK_KEY32
+#define IREC_RANK_KEY32 1   // rank the survivors by the key alone first (0: always by (key, ~flat); A/B builds)
+#endif
+#ifndef IREC_SELECT_ASSUME
+#define IREC_SELECT_ASSUME 1   // tell the compiler N <= 1024 where the host guarantees it (0: A/B builds)
+#endif
 namespace irec {
 
 // ======================================================================================================
@@ -92,10 +101,16 @@ struct NoPost { __device__ __forceinline__ void operator()(int, int32_t, int32_t
 // lanes with a strictly larger maximum; the value whose count is the largest one below Bnew is the Bnew-th largest (values below it
 // see at least Bnew larger ones) -- found by probing the counts downwards from Bnew - 1: without ties the counts are a permutation of
 // 0..63 and the first probe hits.  (Round 4: this replaced a 64-bit wave reduction of six cross-lane steps, r04ah/select_rates.log.)
+template <bool QUICK>
 __device__ __forceinline__ uint32_t kth_largest_lane_max(uint32_t M, int Bnew) {
   uint32_t cnt_gt = 0u;
 #pragma unroll
   for (int l = 0; l < 64; ++l) cnt_gt += (uint32_t)__builtin_amdgcn_readlane((int)M, l) > M ? 1u : 0u;
+  if constexpr (!QUICK) {   // the form of rounds 1-3: the minimum over the lanes whose count is below Bnew, by a 64-bit wave reduction
+    uint32_t T = cnt_gt < (uint32_t)Bnew ? M : 0xFFFFFFFFu;
+    T = 0xFFFFFFFFu - (uint32_t)wave_max_u64((unsigned long long)(0xFFFFFFFFu - T)); // wave min
+    return T;
+  }
   uint32_t T = 0u;
   for (int c = Bnew <= 64 ? Bnew - 1 : 63; c >= 0; --c) {   // (more than 64 beams, generic kernel: the smallest lane maximum)
     const unsigned long long hit = __ballot(cnt_gt == (uint32_t)c);
@@ -110,7 +125,7 @@ __device__ __forceinline__ uint32_t kth_largest_lane_max(uint32_t M, int Bnew) {
 // above it) are first cut down: the exact Bnew-th largest key T' is found bit by bit -- 32 rounds of "how many survivors
 // are >= T' | bit" over the <= NC / 64 survivors a lane holds in registers -- and the survivors >= T' are compacted again.
 // Returns false when more than 64 candidates remain at the threshold (ties) or C exceeded the buffer: caller falls back.
-template <class SM, class Post>
+template <bool QUICK, class SM, class Post>
 __device__ __forceinline__ bool rank_survivors(SM *sm, uint32_t C, int Bnew, int Bcur, int tid, Post &&post) {
   constexpr int NQ = SM::CANDS / 64;
   if (C > (uint32_t)SM::CANDS) return false;
@@ -149,22 +164,47 @@ __device__ __forceinline__ bool rank_survivors(SM *sm, uint32_t C, int Bnew, int
   // rank the C <= 64 survivors; lanes >= C hold a null candidate
   const unsigned long long mine = tid < (int)C ? sm->cand[tid] : 0ull;
   const uint32_t mk1 = (uint32_t)(mine >> 32), mf1 = (uint32_t)mine;
+  uint32_t rank = 0u;
+  if constexpr (!QUICK) {   // the form of rounds 1-3
+    for (uint32_t l = 0; l < C; ++l) {
+      const uint32_t ok_ = (uint32_t)__builtin_amdgcn_readlane((int)mk1, (int)l);
+      const uint32_t of_ = (uint32_t)__builtin_amdgcn_readlane((int)mf1, (int)l);
+      rank += (ok_ > mk1 || (ok_ == mk1 && of_ < mf1)) ? 1u : 0u;
+    }
+  } else {
   // (key, ~flat) as ONE 64-bit number: larger = better (key descending, ties to the lower flat index).  Constant-lane broadcasts in
   // groups of eight, one 64-bit compare per candidate (round 4; a run-time lane index and three compares until then).  The lanes >= C
   // hold key 0, which beats no survivor (T >= 1).
   const uint32_t nf1 = ~mf1;
   const unsigned long long mp = ((unsigned long long)mk1 << 32) | nf1;
-  uint32_t rank = 0u;
+  // First by the key alone -- one broadcast and one 32-bit compare per candidate.  Equal keys among the survivors (exactly equal
+  // float32 scores: rare) then share a rank: every survivor writes its lane into slot `rank` of cand[] (all lanes have read their
+  // candidate: one wave, program order) and reads it back; a lane that finds another's there lost a collision, and the wave ranks
+  // again by (key, ~flat).
 #pragma unroll
   for (int l0 = 0; l0 < 64; l0 += 8) {
     if ((uint32_t)l0 < C) { // wave-uniform
 #pragma unroll
-      for (int l = l0; l < l0 + 8; ++l) {
-        const uint32_t ok_ = (uint32_t)__builtin_amdgcn_readlane((int)mk1, l);
-        const uint32_t on_ = (uint32_t)__builtin_amdgcn_readlane((int)nf1, l);
-        rank += (((unsigned long long)ok_ << 32) | on_) > mp ? 1u : 0u;
+      for (int l = l0; l < l0 + 8; ++l) rank += (uint32_t)__builtin_amdgcn_readlane((int)mk1, l) > mk1 ? 1u : 0u;
+    }
+  }
+  volatile unsigned long long *slot = sm->cand;   // (another lane may own the slot: no store-to-load forwarding)
+  if (tid < (int)C) slot[rank] = (unsigned long long)tid;
+  const bool lost = tid < (int)C && slot[rank] != (unsigned long long)tid;
+  if (!IREC_RANK_KEY32 || __ballot(lost)) { // wave-uniform
+    rank = 0u;
+#pragma unroll
+    for (int l0 = 0; l0 < 64; l0 += 8) {
+      if ((uint32_t)l0 < C) { // wave-uniform
+#pragma unroll
+        for (int l = l0; l < l0 + 8; ++l) {
+          const uint32_t ok_ = (uint32_t)__builtin_amdgcn_readlane((int)mk1, l);
+          const uint32_t on_ = (uint32_t)__builtin_amdgcn_readlane((int)nf1, l);
+          rank += (((unsigned long long)ok_ << 32) | on_) > mp ? 1u : 0u;
+        }
       }
     }
+  }
   }
   if (tid < (int)C && rank < (uint32_t)Bnew) {
     const int32_t s_ = (int32_t)(mf1 / (uint32_t)Bcur); // best_ind_aux  (beam_search_coder.py:89)
@@ -226,7 +266,11 @@ __device__ __forceinline__ int64_t xcd_pull_row(const EncArgs &A, int64_t first,
 #ifndef IREC_SELECT_PAR_MIN
 #define IREC_SELECT_PAR_MIN 4096   // candidates per step from which every wave takes part in the streamed selection (0x7FFFFFFF: never)
 #endif
-template <int NT, class SM, class Sync, class Post = NoPost>
+// QUICK (round 4, scripts/microbench/select_rates.hip): the threshold by probing the lane counts and the ranks by constant-lane
+// broadcasts -- 6.6 k -> 5.0 k cycles per selection at 720 candidates.  The encoders whose calls are bound by a lone chain's serial
+// phases take it (one-table / split encoder, the two-team builds: 9 blocks 0.137 -> 0.131 ms); the three-team 168-VGPR builds keep the
+// form they were tuned with -- with QUICK the headline kernel is 1.1 % slower on the same box (r04al/ab.log).
+template <int NT, bool QUICK = false, class SM, class Sync, class Post = NoPost>
 __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew, int Bcur, SM *sm, const int tid, Sync &&sync,
                                                  unsigned long long *dbg = nullptr, Post &&post = Post()) {
   constexpr int NWV = NT / 64;
@@ -252,7 +296,7 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
         M = k[q] > M ? k[q] : M;
       }
       // 1. threshold: #lanes with a strictly larger maximum
-      uint32_t T = kth_largest_lane_max(M, Bnew);
+      uint32_t T = kth_largest_lane_max<QUICK>(M, Bnew);
       // 2. compact candidates >= T (T >= 1 because at least Bnew <= N lanes hold a real key)
       uint32_t base = 0u;
 #pragma unroll
@@ -266,7 +310,7 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
         }
       }
       const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      sm->misc[7] = rank_survivors(sm, C, Bnew, Bcur, tid, post) ? 1 : 0;   // 0: pathological tie storm -> the scan below
+      sm->misc[7] = rank_survivors<QUICK>(sm, C, Bnew, Bcur, tid, post) ? 1 : 0;   // 0: pathological tie storm -> the scan below
       __builtin_amdgcn_s_setprio(0);
       if (dbg && tid == 0) { const unsigned long long t1 = stamp_now(); dbg[9] += t1 - t0; t0 = t1; } // wave-0 selection
     }
@@ -300,7 +344,7 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
     uint32_t T;
     {
       const uint32_t M = lane_max[lane];
-      T = kth_largest_lane_max(M, Bnew);
+      T = kth_largest_lane_max<QUICK>(M, Bnew);
       T = T ? T : 1u;                                        // (0 marks a taken / empty key)
     }
     sync(); // every wave has read the maxima: cand[] may be written
@@ -337,7 +381,7 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
     if (tid < 64) {
       __builtin_amdgcn_s_setprio(3);
       const uint32_t C = (uint32_t)sm->misc[4];
-      sm->misc[7] = rank_survivors(sm, C, Bnew, Bcur, tid, post) ? 1 : 0;
+      sm->misc[7] = rank_survivors<QUICK>(sm, C, Bnew, Bcur, tid, post) ? 1 : 0;
       __builtin_amdgcn_s_setprio(0);
     }
     sync();
@@ -357,7 +401,7 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
         M = M > b ? M : b;
       }
       for (int f = (n4 << 2) + tid; f < N; f += 64) M = key[f] > M ? key[f] : M;
-      uint32_t T = kth_largest_lane_max(M, Bnew);
+      uint32_t T = kth_largest_lane_max<QUICK>(M, Bnew);
       T = T ? T : 1u;                                        // (0 marks a taken / empty key)
       uint32_t base = 0u;
       auto put = [&](bool in, uint32_t k, uint32_t flat) {
@@ -385,7 +429,7 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
         put(k >= T, k, (uint32_t)f);
       }
       const uint32_t C = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      sm->misc[7] = rank_survivors(sm, C, Bnew, Bcur, tid, post) ? 1 : 0;
+      sm->misc[7] = rank_survivors<QUICK>(sm, C, Bnew, Bcur, tid, post) ? 1 : 0;
       __builtin_amdgcn_s_setprio(0);
     }
     sync();
@@ -422,10 +466,10 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
 
 
 struct WorkgroupSync { __device__ __forceinline__ void operator()() const { __syncthreads(); } };
-template <int NT>
+template <int NT, bool QUICK = false>
 __device__ __forceinline__ void select_topB(uint32_t *key, int N, int Bnew, int Bcur, SmallLds *sm,
                                             unsigned long long *dbg = nullptr) {
-  select_topB_sync<NT>(key, N, Bnew, Bcur, sm, (int)threadIdx.x, WorkgroupSync(), dbg);
+  select_topB_sync<NT, QUICK>(key, N, Bnew, Bcur, sm, (int)threadIdx.x, WorkgroupSync(), dbg);
 }
 
 // ======================================================================================================

@@ -1249,7 +1249,17 @@ irec_status irec_test_select(irec_context *ctx, const float *scores, int32_t n, 
       n_beams_cur < 1)
     return fail(IREC_E_INVALID, "irec_test_select: bad arguments");
   IREC_ON_DEVICE(ctx->device);
-  HIP_TRY(irec::launch_select_test(scores, n, n_select, n_beams_cur, scratch_keys, out_sel, (hipStream_t)hip_stream));
+  HIP_TRY(irec::launch_select_test(scores, n, n_select, n_beams_cur, scratch_keys, out_sel, false, (hipStream_t)hip_stream));
+  return IREC_OK;
+}
+
+irec_status irec_test_select_quick(irec_context *ctx, const float *scores, int32_t n, int32_t n_select, int32_t n_beams_cur,
+                                   uint32_t *scratch_keys, int32_t *out_sel, void *hip_stream) {
+  if (!ctx || !scores || !scratch_keys || !out_sel || n < 1 || n_select < 1 || n_select > n || n_select > 64 ||
+      n_beams_cur < 1)
+    return fail(IREC_E_INVALID, "irec_test_select_quick: bad arguments");
+  IREC_ON_DEVICE(ctx->device);
+  HIP_TRY(irec::launch_select_test(scores, n, n_select, n_beams_cur, scratch_keys, out_sel, true, (hipStream_t)hip_stream));
   return IREC_OK;
 }
 

@@ -178,7 +178,7 @@ hipError_t launch_shim_residual_elu(const float *inp, const float *t, float alph
                                     const float *bt, int C, int HW, hipStream_t st);
 hipError_t launch_dec_sqrt_test(unsigned long long *out, hipStream_t st);
 hipError_t launch_uniform_int(int64_t seed, int64_t n, int32_t *out, hipStream_t st);
-hipError_t launch_select_test(const float *scores, int N, int Bnew, int Bcur, uint32_t *keys, int32_t *sel, hipStream_t st);
+hipError_t launch_select_test(const float *scores, int N, int Bnew, int Bcur, uint32_t *keys, int32_t *sel, bool quick, hipStream_t st);
 hipError_t launch_reduce_scatter_test(const float *in, float *out, int width, hipStream_t st);
 
 } // namespace irec

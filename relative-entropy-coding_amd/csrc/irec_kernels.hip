@@ -948,7 +948,8 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
         sub_stamp(14);
 #endif
       }
-      select_topB<NT>(key_s, Ng, Bnew, Bcur, sm, A.dbg ? A.dbg + (size_t)blockIdx.x * 16 : nullptr); // first barrier inside orders key_s writes
+      if constexpr (SPLIT != 0 && IREC_QUICK_SELECT && IREC_SELECT_ASSUME) __builtin_assume(Ng <= 1024);   // (host, split_width(): S * NB <= 1024 -- the selection's other paths fold away)
+      select_topB<NT, IREC_QUICK_SELECT != 0>(key_s, Ng, Bnew, Bcur, sm, A.dbg ? A.dbg + (size_t)blockIdx.x * 16 : nullptr); // first barrier inside orders key_s writes
       IREC_STAMP(2);
       // ---------------- new hashes / back-pointers (beam_search_coder.py:94-95) ----------------
       // (the discrete log of the new hash is a load from the global table when the proposals come from tables: it is issued
@@ -1167,11 +1168,12 @@ __global__ void uniform_int_kernel(int64_t seed, int64_t n, int32_t *out) {
 }
 
 // scores[N] float -> sel[2 * Bnew] = (sample, beam) of the Bnew best candidates in order (tie -> lower flat index)
+template <bool QUICK>
 __global__ __launch_bounds__(256) void select_test_kernel(const float *scores, int N, int Bnew, int Bcur, uint32_t *keys,
                                                           int32_t *sel) {
   __shared__ SmallLdsT<64, 64, 512> sm;   // (the 60-beam team build's: room to refine up to 512 survivors)
   for (int f = threadIdx.x; f < N; f += 256) keys[f] = score_key(scores[f]);
-  select_topB_sync<256>(keys, N, Bnew, Bcur, &sm, (int)threadIdx.x, WorkgroupSync());
+  select_topB_sync<256, QUICK>(keys, N, Bnew, Bcur, &sm, (int)threadIdx.x, WorkgroupSync());
   if (threadIdx.x < Bnew) { sel[2 * threadIdx.x] = sm.sel_s[threadIdx.x]; sel[2 * threadIdx.x + 1] = sm.sel_b[threadIdx.x]; }
 }
 
@@ -1291,8 +1293,9 @@ hipError_t launch_uniform_int(int64_t seed, int64_t n, int32_t *out, hipStream_t
   return hipGetLastError();
 }
 
-hipError_t launch_select_test(const float *scores, int N, int Bnew, int Bcur, uint32_t *keys, int32_t *sel, hipStream_t st) {
-  hipLaunchKernelGGL(select_test_kernel, dim3(1), dim3(256), 0, st, scores, N, Bnew, Bcur, keys, sel);
+hipError_t launch_select_test(const float *scores, int N, int Bnew, int Bcur, uint32_t *keys, int32_t *sel, bool quick, hipStream_t st) {
+  if (quick) hipLaunchKernelGGL(select_test_kernel<true>, dim3(1), dim3(256), 0, st, scores, N, Bnew, Bcur, keys, sel);
+  else hipLaunchKernelGGL(select_test_kernel<false>, dim3(1), dim3(256), 0, st, scores, N, Bnew, Bcur, keys, sel);
   return hipGetLastError();
 }
 

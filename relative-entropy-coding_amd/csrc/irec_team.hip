@@ -868,7 +868,10 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 #else
       // top-B (beam_search_coder.py:85-89); the thread that records new beam j also extends its hash / back-pointer
       // (:94-95) and notes its parent's table offset, so one barrier publishes everything the update needs
-      select_topB_sync<NT>(key_s, N, Bnew, Bcur, sm, tid, tsync, nullptr, [&](int j, int32_t sp_, int32_t bp_, uint32_t) {
+      constexpr bool QUICK_SEL = IREC_QUICK_SELECT && TEAMS <= 2 && !MULTI_PASS;   // (fast_common.h, select_topB_sync: not the 168-VGPR builds)
+      if constexpr (QUICK_SEL && IREC_SELECT_ASSUME) __builtin_assume(N <= 1024);   // (host: one pass holds S * NB <= CMAX = 1024 candidates -- the
+                                                                //  selection's other paths fold away: -500 cycles per step, scripts/microbench/select_rates.hip)
+      select_topB_sync<NT, QUICK_SEL>(key_s, N, Bnew, Bcur, sm, tid, tsync, nullptr, [&](int j, int32_t sp_, int32_t bp_, uint32_t) {
         const int32_t nh = (int32_t)((uint32_t)hsum[cur * TEAM_MB + bp_] + (uint32_t)sp_ * (uint32_t)(69 + t));
         hsum[(cur ^ 1) * TEAM_MB + j] = nh;                    // (its discrete log: looked up by every wave in the update, below)
         sm->sel_bo[j] = beta4[cur * TEAM_MB + bp_];

@@ -101,6 +101,7 @@ SIGNATURES = {
     "irec_test_decoder_sqrt": (ctypes.c_int, [_vp, _vp, _vp]),
     "irec_test_reduce_scatter": (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "irec_test_select": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "irec_test_select_quick": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "irec_test_proposal_table": (ctypes.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "irec_device_tables": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
                                           ctypes.POINTER(_vp)]),

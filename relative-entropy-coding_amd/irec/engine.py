@@ -376,12 +376,13 @@ class Engine:
                                                      self._stream()), "irec_test_proposal_table")
         return out
 
-    def test_select(self, scores, n_select, n_beams_cur, key_offset=0):
+    def test_select(self, scores, n_select, n_beams_cur, key_offset=0, quick=False):
         n = scores.numel()
         keys = torch.empty(n + key_offset, dtype=torch.int32, device=self.device)[key_offset:]   # (offset: a 4-byte-aligned key array)
         sel = torch.empty((n_select, 2), dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.irec_test_select(self.ctx, _ptr(scores), n, int(n_select), int(n_beams_cur), _ptr(keys),
-                                             _ptr(sel), self._stream()), "irec_test_select")
+        fn = self.lib.irec_test_select_quick if quick else self.lib.irec_test_select   # (the round-4 form of the selection)
+        _lib.check(fn(self.ctx, _ptr(scores), n, int(n_select), int(n_beams_cur), _ptr(keys), _ptr(sel), self._stream()),
+                   "irec_test_select")
         return sel
 
     def test_reduce_scatter(self, x, scoring_form=False):

@@ -8,6 +8,7 @@
 #include <string.h>
 #include <vector>
 #include <algorithm>
+#include <functional>
 #include "irec_device.h"
 #include "irec_kernels.h"
 #include "irec_fast_common.h"
@@ -45,6 +46,9 @@ __global__ __launch_bounds__(256) void time_select(const uint32_t *keys_g, int N
     for (int f = tid; f < N; f += 256) key_s[f] = keys_g[(size_t)r * N + f];
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#ifdef V_ASSUME_SMALL
+    if (N > 1024) __builtin_unreachable();
+#endif
     SELECT_IMPL<256>(key_s, N, Bnew, Bcur, &sm, tid, WorkgroupSync());
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     tot += t1 - t0;
@@ -236,8 +240,9 @@ __device__ __forceinline__ void select_v3(uint32_t *key, int N, int Bnew, int Bc
           for (int l = l0; l < l0 + 8; ++l) rank += (uint32_t)__builtin_amdgcn_readlane((int)mk1, l) > mk1 ? 1u : 0u;
         }
       }
-      if (tid < (int)C) sm->cand[rank] = (unsigned long long)tid;
-      const bool lost = tid < (int)C && sm->cand[rank] != (unsigned long long)tid;
+      volatile unsigned long long *vc = sm->cand;   // (another lane may own the slot: no store-to-load forwarding)
+      if (tid < (int)C) vc[rank] = (unsigned long long)tid;
+      const bool lost = tid < (int)C && vc[rank] != (unsigned long long)tid;
       if (__ballot(lost)) {   // (wave-uniform) a tie: the exact order, key descending then flat ascending
         rank = 0u;
 #endif
@@ -292,6 +297,12 @@ int main() {
     srand(1234 + N);
     for (auto &v : h) { float f = -20.f + 5.f * ((float)rand() / RAND_MAX + (float)rand() / RAND_MAX); uint32_t u; memcpy(&u, &f, 4); v = (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
     for (int r = 0; r < reps; r += 7) { h[(size_t)r * N + 3] = h[(size_t)r * N + 11]; }   // a few exact ties
+    for (int r = 0; r < reps; r += 3) {   // ties among the best: several copies of the row's maximum, and of a value near the B-th best
+      uint32_t *k = &h[(size_t)r * N];
+      std::vector<uint32_t> srt(k, k + N); std::sort(srt.begin(), srt.end(), std::greater<uint32_t>());
+      for (int c = 0; c < 4; ++c) k[rand() % N] = srt[0];
+      if (N > Bnew + 4) for (int c = 0; c < 3; ++c) k[rand() % N] = srt[Bnew - 1];
+    }
     uint32_t *d_k; int32_t *d_sel; unsigned long long *d_c;
     hipMalloc(&d_k, h.size() * 4); hipMalloc(&d_sel, (size_t)reps * 64 * 2 * 4); hipMalloc(&d_c, 8);
     hipMemcpy(d_k, h.data(), h.size() * 4, hipMemcpyHostToDevice);

@@ -127,6 +127,8 @@ def test_top_b_selection(engine, case):
         sc, B, bcur = rng.standard_normal(4440).astype(np.float32), 30, 30
     got = engine.test_select(torch.from_numpy(sc).cuda(), B, bcur).cpu().numpy().tolist()
     assert [tuple(g) for g in got] == _ref_select(sc.tolist(), B, bcur)
+    got = engine.test_select(torch.from_numpy(sc).cuda(), B, bcur, quick=True).cpu().numpy().tolist()   # (round 4: the quick form)
+    assert [tuple(g) for g in got] == _ref_select(sc.tolist(), B, bcur)
     if len(sc) > 1024:   # the streamed selection reads 16 bytes at a time only from a 16-byte-aligned key array
         got = engine.test_select(torch.from_numpy(sc).cuda(), B, bcur, key_offset=1).cpu().numpy().tolist()
         assert [tuple(g) for g in got] == _ref_select(sc.tolist(), B, bcur)
@@ -677,6 +679,7 @@ def test_many_beams_selection_refinement(engine):
         order = torch.sort(sc.cpu().double() * 1.0, descending=True, stable=True).indices[:nsel].numpy()
         want = np.stack([order // bcur, order % bcur], axis=1)
         assert np.array_equal(sel, want), (n, nsel, bcur, ties)
+        assert np.array_equal(engine.test_select(sc, nsel, bcur, quick=True).cpu().numpy(), want), (n, nsel, bcur, ties, "quick")
 
 
 def test_new_entry_points_reject_what_they_cannot_serve(engine):
