@@ -797,10 +797,11 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
     if (const int wb = split_beam_width(p, out->split)) { out->split = wb; out->split_beams = 1; }
     if (out->split >= 2) {
       out->grid = (int32_t)(n_blocks * out->split);
-      // (the split forms are builds of their own: <NB,4,true,1> shares a block's samples, <NB,4,true,2> its beams)
-      std::snprintf(out->kernel, sizeof out->kernel, "encode_fast_kernel<%d,4,true,%d>", irec::fast_nb_for(B), out->split_beams ? 2 : 1);
+      // (the split forms are builds of their own: <NB,4,true,1> shares a block's samples, <NB,4|8,true,2> its beams -- 8 waves for 20 beams)
+      std::snprintf(out->kernel, sizeof out->kernel, "encode_fast_kernel<%d,%d,true,%d>", irec::fast_nb_for(B),
+                    out->split_beams ? irec::fast_split_beam_waves(B) : 4, out->split_beams ? 2 : 1);
     }
-    out->waves_per_wg = irec::fast_waves_for(B, S, pl.table);
+    out->waves_per_wg = (out->split >= 2 && out->split_beams) ? irec::fast_split_beam_waves(B) : irec::fast_waves_for(B, S, pl.table);
     out->teams_per_wg = 1;
     out->lds_bytes = (int32_t)irec::fast_lds_for(B, S, pl.table) + (out->split >= 2 && out->split_beams ? 40024 : 0);   // (beam split: two table copies of 10 006 floats)
   } else {

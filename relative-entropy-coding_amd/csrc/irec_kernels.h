@@ -85,6 +85,7 @@ size_t fast_ws_for(int B, int max_K);
 size_t fast_ws_bytes_nb(int NB, int max_K);
 hipError_t launch_encode_fast(const EncArgs &A, bool table, int grid, hipStream_t st);
 int fast_waves_for(int B, int S, bool table);
+int fast_split_beam_waves(int B);                        // waves per workgroup of the split encoder's beam mode
 // (`keep`: device word that is 1 when the table in place already is this one -- the kernel
 //  then returns at once; nullptr = always build)
 hipError_t launch_alpha_table(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *dlog4r, uint16_t *tab,

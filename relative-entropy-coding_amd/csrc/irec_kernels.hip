@@ -38,8 +38,10 @@ namespace irec {
                                     // (r04 A/B, profiles/r04d: neutral -- the wait is skew between the partners, not hand-off latency); 0: in the update
 #endif
 #ifndef IREC_SPLIT_NW
-#define IREC_SPLIT_NW 4             // waves per workgroup of the beam-split build (8: two sample stripes per dim group, A/B)
+#define IREC_SPLIT_NW 0             // waves per workgroup of the beam-split build; 0 = 8 for the 20-beam build (two sample stripes per dim group:
+                                    // 9 blocks 0.132 -> 0.127 ms on the same box, r04ao), 4 for the others (13 ten-beam blocks: 0.105 against 0.108 with 8)
 #endif
+constexpr int split_beam_nw(int NB) { return IREC_SPLIT_NW ? IREC_SPLIT_NW : (NB == 20 ? 8 : 4); }
 #define IREC_STAMP(slot)                                                    \
   do {                                                                      \
     if (A.dbg && tid == 0) {                                                \
@@ -1249,6 +1251,7 @@ size_t fast_lds_for(int B, int S, bool table) {
   const FastPlan p = fast_plan(nb, S, table);
   return p.s_pass >= 1 ? p.bytes : (size_t)-1;
 }
+int fast_split_beam_waves(int B) { const int nb = fast_nb_for(B); return nb ? split_beam_nw(nb) : 0; }   // waves per workgroup of the beam-split build
 int fast_waves_for(int B, int S, bool table) { const int nb = fast_nb_for(B); return nb ? fast_plan(nb, S, table).nw : 0; }
 const char *fast_kernel_name(int B, int S, bool table) {
   static thread_local char buf[64];
@@ -1265,7 +1268,7 @@ static hipError_t launch_fast_nw(const EncArgs &A, int grid, hipStream_t st) {
   if constexpr (TABLE)
     if (A.coop_W > 1) {   // split call (host: split_width / split_beam_width; aliased-key plans only, four waves)
       if (fast_plan(NB, A.S, TABLE).nw != 4) return hipErrorInvalidValue;
-      return A.coop_beams != 0 ? launch_fast_t<NB, IREC_SPLIT_NW, true, 2>(A, grid, st) : launch_fast_t<NB, 4, true, 1>(A, grid, st);
+      return A.coop_beams != 0 ? launch_fast_t<NB, split_beam_nw(NB), true, 2>(A, grid, st) : launch_fast_t<NB, 4, true, 1>(A, grid, st);
     }
   return fast_plan(NB, A.S, TABLE).nw == 8 ? launch_fast_t<NB, 8, TABLE>(A, grid, st) : launch_fast_t<NB, 4, TABLE>(A, grid, st);
 }
