@@ -533,6 +533,7 @@ def run_rank(args):
         rvae = "BASELINE.json configs[1]/[2] settings (B = 20, Omega = 3, S = 36)"
         result["secondary"]["midsize"] = [
             secondary_config(eng, device, "one GPU's share of config 3: 38 latents = 342 blocks per call", OMEGA, EPS1, BEAMS, 38, N_DIMS, 30, 2, rvae),
+            secondary_config(eng, device, "14 latents = 126 blocks per call (about half a block per CU: every row shared between teams)", OMEGA, EPS1, BEAMS, 14, N_DIMS, 30, 2, rvae),
             secondary_config(eng, device, "one image's residual block: 1 latent = 9 blocks per call", OMEGA, EPS1, BEAMS, 1, N_DIMS, 30, 1, rvae)]
         # blocks of more than 1024 dims (coder.py:29-36,415-419: block_size is the caller's, None = the whole tensor as one block)
         big = "Coder.__init__(block_size=...) beyond 1024 dims (rec/coding/coder.py:29-36,415-419), headline settings"
