@@ -112,7 +112,8 @@ __device__ __forceinline__ uint32_t kth_largest_lane_max(uint32_t M, int Bnew) {
     return T;
   }
   uint32_t T = 0u;
-  for (int c = Bnew <= 64 ? Bnew - 1 : 63; c >= 0; --c) {   // (more than 64 beams, generic kernel: the smallest lane maximum)
+  for (int c = Bnew <= 64 ? Bnew - 1 : 63; c >= 0; --c) {   // (more than 64 beams, generic kernel: the smallest lane maximum -- at least 64
+                                                            //  survivors, not Bnew: rank_survivors sends the shortfall to the scan)
     const unsigned long long hit = __ballot(cnt_gt == (uint32_t)c);
     if (hit) { T = (uint32_t)__builtin_amdgcn_readlane((int)M, (int)__builtin_ctzll(hit)); break; }   // (wave-uniform)
   }
@@ -124,11 +125,14 @@ __device__ __forceinline__ uint32_t kth_largest_lane_max(uint32_t M, int Bnew) {
 // r (sel_s / sel_b, post()).  More than 64 survivors (many beams: the B-th largest of 64 lane maxima leaves ~2 B candidates
 // above it) are first cut down: the exact Bnew-th largest key T' is found bit by bit -- 32 rounds of "how many survivors
 // are >= T' | bit" over the <= NC / 64 survivors a lane holds in registers -- and the survivors >= T' are compacted again.
-// Returns false when more than 64 candidates remain at the threshold (ties) or C exceeded the buffer: caller falls back.
+// Returns false when more than 64 candidates remain at the threshold (ties), C exceeded the buffer or FEWER than Bnew survived:
+// caller falls back.  (Fewer than Bnew: only with more than 64 beams -- the generic kernel -- where kth_largest_lane_max returns the
+// smallest lane maximum and guarantees 64 survivors, not Bnew: S = 65, B >= 65 at step 0 when the 64 largest keys sit in 64
+// distinct lanes.  Round 4 recorded ranks 0..63 there and left sel_s / sel_b[64..Bnew) stale.)
 template <bool QUICK, class SM, class Post>
 __device__ __forceinline__ bool rank_survivors(SM *sm, uint32_t C, int Bnew, int Bcur, int tid, Post &&post) {
   constexpr int NQ = SM::CANDS / 64;
-  if (C > (uint32_t)SM::CANDS) return false;
+  if (C > (uint32_t)SM::CANDS || C < (uint32_t)Bnew) return false;
   if (C > 64u) {
     if constexpr (NQ > 1) {
       uint32_t mk[NQ], mf[NQ];

@@ -215,7 +215,9 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
   // costliest ones, longest first.  Every workgroup ranks the rows itself, once, in the LDS the table copies are about to fill
   // (one row per thread, n compares each: ~2 us): no second kernel, no grid-wide wait.
   constexpr bool CAN_PLACE = NB == 20 && TEAMS == 2 && BS == 1 && !PASSES && !ONE;   // (team_placeable(): the builds the host asks it of)
-  const bool placed = CAN_PLACE && A.row_cost != nullptr;
+  // (n_static == n_slots: the static round deals every slot, which the ranking below assumes -- the host only sets row_cost then
+  //  (irec_host.cpp); should a later change break that, the rows are dealt as listed instead of the slots beyond the static round being lost)
+  const bool placed = CAN_PLACE && A.row_cost != nullptr && n_static == n_slots;
   const int64_t lo_rank = (int64_t)gridDim.x < n_whole ? (int64_t)gridDim.x : n_whole;
   int32_t placed_row = -1;
   if (placed) {

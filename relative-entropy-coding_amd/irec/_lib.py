@@ -5,8 +5,7 @@ import os
 from .errors import IrecLibraryError  # noqa: F401  (re-exported: irec._lib.IrecLibraryError)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# IREC_LIB_PATH: load a diagnostic build (csrc/variants/*.so) by path instead of copying it over the product library
-LIB_PATH = os.environ.get("IREC_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "csrc", "libirec_hip.so")
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libirec_hip.so")   # the product library; no environment variable is read
 
 IREC_OK = 0
 IREC_E_INVALID = -1
@@ -110,22 +109,34 @@ SIGNATURES = {
 _lib = None
 
 
-def load():
-    """Load libirec_hip.so.  No fallback of any kind: a missing library is an error."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise IrecLibraryError(
-                f"{LIB_PATH} not found: build it with `make -C relative-entropy-coding_amd/csrc` "
-                "(or `python -c 'import __graft_entry__ as g; g.build()'`).  irec has no CPU fallback.")
-        lib = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            if os.environ.get("IREC_LIB_PATH") and not hasattr(lib, name):
-                continue             # a diagnostic build of older sources (same-box A/B against an earlier round) may lack newer entries
-            fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
-            fn.restype = res
-            fn.argtypes = args
-        _lib = lib
+_lib_path = None
+
+
+def load(path=None):
+    """Load libirec_hip.so.  No fallback of any kind: a missing library is an error.
+
+    `path`: a diagnostic build (csrc/variants/*.so) to load INSTEAD of the product library -- an explicit argument of the
+    A/B tooling (scripts/with_lib.py), which must make this call before anything else loads the library; the product
+    itself never passes it and no environment variable can redirect the loader."""
+    global _lib, _lib_path
+    if _lib is not None:
+        if path is not None and os.path.abspath(path) != _lib_path:
+            raise IrecLibraryError(f"irec._lib.load({path!r}): {_lib_path} is loaded already")
+        return _lib
+    variant = path is not None
+    path = os.path.abspath(path) if variant else LIB_PATH
+    if not os.path.exists(path):
+        raise IrecLibraryError(
+            f"{path} not found: build it with `make -C relative-entropy-coding_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`).  irec has no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        if variant and not hasattr(lib, name):
+            continue             # a diagnostic build of older sources (same-box A/B against an earlier round) may lack newer entries
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib, _lib_path = lib, path
     return _lib
 
 

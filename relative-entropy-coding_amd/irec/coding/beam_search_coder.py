@@ -24,22 +24,30 @@ class MorePartitionsNeeded(CodingError):
 
 
 class SplitNotResident(CodingError):
-    """The split encoder (several workgroups per block, calls of few blocks) gave up waiting for partner workgroups that were
-    not resident -- other work held the CUs.  The blocks were NOT coded; code again with coder.no_split = True."""
+    """A cooperative encoder (the split encoder: several workgroups per block of a small call; shared rows: several teams per
+    row of a mid-size call) gave up waiting for partners that were not resident -- other work held the CUs.  The blocks were NOT
+    coded.  The coder that issued the call has been told (`BeamSearchCoder._split_gave_up`): its next call -- the one that
+    codes these blocks again -- goes out without sharing; see there for when sharing comes back."""
 
 
 class PendingCode:
     """Result of one asynchronous encode call: everything stays on the device until the host asks.
     K [n_blocks] int32, idx [n_blocks, max_K] int32 (rows in layout order), sample (input shape)."""
 
-    def __init__(self, coder, lay, K, idx, sample, max_K):
+    def __init__(self, coder, lay, K, idx, sample, max_K, shared=False, params=None):
         self.coder, self.lay, self.K, self.idx, self.sample, self.max_K = coder, lay, K, idx, sample, max_K
+        self.shared, self.params = shared, params   # the call was allowed to share blocks between workgroups / teams; its irec_params
 
     def _check(self, K_host):
         """Errors and hints from the partition counts read back (shared by the list and the packed read-backs)."""
         if (K_host == -2).any():
-            raise SplitNotResident("the split encoder's cooperating workgroups were not all resident (too many small calls in "
-                                   "flight on this device): encode again with coder.no_split = True")
+            raise SplitNotResident("the cooperating workgroups of a shared block were not all resident (other work on this device, "
+                                   "or two cooperating calls in flight on different streams): the call is coded again without sharing")
+        if self.shared and self.coder._split_strikes and self.params is not None and K_host.size:
+            # a call that did share blocks came back whole: the device is ours again, the back-off starts over
+            eng = self.coder._engine_for(self.K)
+            if eng.plan(self.params, self.lay, self.max_K)["split"] >= 2:
+                self.coder._split_strikes = 0
         if (K_host < 0).any():
             raise CodingError("a block exceeded the engine's dimension bound")
         need = int(K_host.max()) if K_host.size else 0
@@ -110,11 +118,19 @@ class PendingCode:
                 split_failed = True
                 retry = retry if isinstance(retry, MorePartitionsNeeded) else e
         if split_failed:
-            for p in pendings:
-                p.coder.no_split = True
+            PendingCode._all_gave_up(pendings)
         if retry is not None:
             raise retry
         return np.ascontiguousarray(K), np.ascontiguousarray(idx)
+
+    @staticmethod
+    def _all_gave_up(pendings):
+        """One call of a pass (the residual blocks of an image) gave up: every coder of the pass steps back, once."""
+        seen = set()
+        for p in pendings:
+            if id(p.coder) not in seen:
+                seen.add(id(p.coder))
+                p.coder._split_gave_up()
 
     @staticmethod
     def gather(pendings):
@@ -136,14 +152,12 @@ class PendingCode:
                 out.append(p._lists(both[at:at + n, 0], both[at:at + n, 1:1 + p.idx.shape[1]]))
             except MorePartitionsNeeded as e:     # keep going: every coder's hint is raised before the caller codes again
                 retry = e if retry is None or e.need > retry.need else retry
-            except SplitNotResident as e:         # likewise: every coder of the pass leaves the split encoder before it is coded again
-                p.coder.no_split = True
+            except SplitNotResident as e:         # likewise: every coder of the pass steps back before it is coded again
                 retry = retry if isinstance(retry, MorePartitionsNeeded) else e
                 split_failed = True
             at += n
         if split_failed:
-            for p in pendings:
-                p.coder.no_split = True
+            PendingCode._all_gave_up(pendings)
         if retry is not None:
             raise retry
         return out
@@ -164,7 +178,9 @@ class BeamSearchCoder(GaussianCoder):
         self.fused_philox = False    # debugging / testing knob: IREC_FLAG_FUSED_PHILOX
         self.one_table = False       # debugging / testing knob: IREC_FLAG_ONE_TABLE
         self.team = False            # debugging / testing knob: IREC_FLAG_TEAM (the team encoder also for small calls)
-        self.no_split = False        # debugging / testing knob: IREC_FLAG_NO_SPLIT (one workgroup per block also for small calls)
+        self.no_split = False        # the caller's knob: IREC_FLAG_NO_SPLIT on every call (no block is ever shared between workgroups / teams)
+        self._split_strikes = 0      # consecutive give-ups of the cooperative encoders (SplitNotResident), see _split_gave_up
+        self._split_pause = 0        # calls still to be issued without sharing
         self.split_samples = False   # IREC_FLAG_SPLIT_SAMPLES: the split encoder shares a block's samples (r02b form), not its beams
         self._test_split_orphan = False  # test hook (IREC_FLAG_TEST_SPLIT_ORPHAN): the split encoder's partners leave at once
         self.team_shape = "default"  # diagnostics: IREC_FLAG_SHAPE_* workgroup shape of the team encoder
@@ -197,7 +213,30 @@ class BeamSearchCoder(GaussianCoder):
             return int(self.table_steps)
         return min(_lib.IREC_TABLE_STEPS_MAX, max(8, (self._K_seen + 4 + 3) // 4 * 4))
 
-    def _params(self, table_steps=None):
+    # ---- recovery from a give-up (round 5; until then one give-up set no_split for the life of the coder) -----------
+    SPLIT_PAUSE_MAX = 64
+
+    def _split_gave_up(self):
+        """A cooperative call of this coder read back K = -2 (partners not resident within 100 ms).  Bounded back-off: the
+        n-th consecutive give-up keeps the next 2^(n-1) calls -- the first of which codes the failed blocks again -- free of
+        shared blocks (1, 2, 4, ... at most SPLIT_PAUSE_MAX calls); then the cooperative form is tried again, and the first
+        shared call that comes back whole resets the count.  One transient co-tenant therefore costs ONE call its 100 ms and
+        a recode, not every later small call a factor of two."""
+        self._split_strikes = min(self._split_strikes + 1, 1 + self.SPLIT_PAUSE_MAX.bit_length())
+        self._split_pause = min(1 << (self._split_strikes - 1), self.SPLIT_PAUSE_MAX)
+
+    def _take_sharing_turn(self):
+        """May the call about to be issued share blocks?  Consumes one call of a running pause."""
+        if self.no_split:
+            return False
+        if self._split_pause > 0:
+            self._split_pause -= 1
+            return False
+        return True
+
+    def _params(self, table_steps=None, shared=None):
+        if shared is None:
+            shared = not self.no_split and self._split_pause == 0
         if not self.extrapolate_auxiliary_ratios:
             raise CodingError("only extrapolate_auxiliary_ratios=True is supported on the beam-search path")
         if not (1 <= self.n_beams <= _lib.MAX_BEAMS):
@@ -207,10 +246,10 @@ class BeamSearchCoder(GaussianCoder):
         flags = (_lib.IREC_FLAG_FORCE_GENERIC if self.force_generic else 0) | \
                 (_lib.IREC_FLAG_FUSED_PHILOX if self.fused_philox else 0) | \
                 (_lib.IREC_FLAG_ONE_TABLE if self.one_table else 0) | \
-                (_lib.IREC_FLAG_TEAM if self.team else 0) | (_lib.IREC_FLAG_NO_SPLIT if self.no_split else 0) | \
+                (_lib.IREC_FLAG_TEAM if self.team else 0) | (0 if shared else _lib.IREC_FLAG_NO_SPLIT) | \
                 (_lib.IREC_FLAG_REUSE_TABLES if self.reuse_tables else 0) | \
                 (_lib.IREC_FLAG_SPLIT_SAMPLES if self.split_samples else 0) | _lib.IREC_FLAG_SHAPE[self.team_shape] | \
-                (32 if self._test_split_orphan and not self.no_split else 0)
+                (_lib.IREC_FLAG_TEST_SPLIT_ORPHAN if self._test_split_orphan and shared else 0)
         steps = int(table_steps) if table_steps else self.table_window()
         return Engine.params(self.kl_per_partition, self.n_samples, self.n_beams, flags, table_steps=steps)
 
@@ -233,7 +272,8 @@ class BeamSearchCoder(GaussianCoder):
         if src.ndim < 2 or src.shape[0] < 1 or src[0].numel() < 1:
             raise CodingError(f"nothing to encode: distributions of shape {tuple(src.shape)} (need [batch >= 1, dims >= 1 ...])")
         eng = self._engine_for(src)
-        params = self._params(table_steps)   # (a model passes ONE window to all its coders: equal keys, tables built once)
+        shared = self._take_sharing_turn()
+        params = self._params(table_steps, shared)   # (a model passes ONE window to all its coders: equal keys, tables built once)
         n_tensors = src.shape[0]
         n = src[0].numel()
         shapes = {tuple(torch.as_tensor(t).shape) for t in (q_loc, q_scale, p_loc, p_scale)}
@@ -243,7 +283,7 @@ class BeamSearchCoder(GaussianCoder):
         lay = eng.layout(n_tensors, n, block_size, seed)
         max_K = self._max_K_hint if max_K is None else int(max_K)
         K, idx, sample = eng.encode_blocks(params, lay, ql, qs, pl, ps, seed, max_K)
-        return PendingCode(self, lay, K, idx, sample.reshape(src.shape).to(src.device), max_K)
+        return PendingCode(self, lay, K, idx, sample.reshape(src.shape).to(src.device), max_K, shared, params)
 
     def encode_tensors(self, q_loc, q_scale, p_loc, p_scale, seed, block_size):
         """Batched core of encode / encode_block: leading dim = independent latent tensors.
@@ -255,10 +295,10 @@ class BeamSearchCoder(GaussianCoder):
                 return pending.to_lists(), pending.sample
             except MorePartitionsNeeded as e:     # a block's KL asks for more partitions than the index buffer holds
                 max_K = e.need
-            except SplitNotResident:              # partner workgroups not resident (the device is shared): one workgroup per
-                if self.no_split:                 # block from now on -- slower for calls this small, but it cannot wait in vain
+            except SplitNotResident:              # partners not resident (the device is shared): the next call -- this loop's --
+                if not pending.shared:            # codes the blocks again without sharing, which cannot wait in vain
                     raise
-                self.no_split = True
+                self._split_gave_up()
     def decode_tensors(self, p_loc, p_scale, indices, seed, block_size):
         src = torch.as_tensor(p_loc)
         if src.ndim < 2 or src.shape[0] < 1 or src[0].numel() < 1:

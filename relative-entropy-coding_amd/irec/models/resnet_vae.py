@@ -337,7 +337,7 @@ class BidirectionalResNetVAE(nn.Module):
                 break
             except (MorePartitionsNeeded, SplitNotResident):
                 continue   # some block's KL needs more index slots than the coders' hint (the hints are raised), or the split
-                           # encoder's partner workgroups were not resident (every coder now has no_split set): code again
+                           # encoder's partner workgroups were not resident (every coder's next call goes out unshared): code again
         else:
             raise MorePartitionsNeeded(max(b.coder._max_K_hint for b in self.residual_blocks) + 1)
         return self._indices_structure(per_block, image.shape[0]), reconstruction
@@ -463,6 +463,10 @@ class GraphedCompress:
         for lane, sl in enumerate(self.slices):
             self.static_images[lane].copy_(image[sl])
         if self.graphs is None:
+            if any(getattr(b.coder, "_split_pause", 0) for b in self.model.residual_blocks):
+                # a coder is stepping back from a give-up of its cooperative encoder: eager until its pause is over -- a graph
+                # captured now would keep the pause's IREC_FLAG_NO_SPLIT for good
+                return self.model.compress(image, seed=self.seed, update_sampler=self.update_sampler)
             self._capture()
         cur = torch.cuda.current_stream(self.device)
         for lane, st in enumerate(self.streams):                       # the lanes' graphs side by side, each on its own stream
@@ -474,7 +478,7 @@ class GraphedCompress:
         try:
             flat = PendingCode.gather([p for lane in self.pendings for p in lane])   # ONE device-to-host copy for all lanes
         except (MorePartitionsNeeded, SplitNotResident):
-            self.graphs = None                                         # hints were raised / the split left: eager now, re-capture next time
+            self.graphs = None                                         # hints were raised / the coders step back from sharing: eager now, re-capture later
             return self.model.compress(image, seed=self.seed, update_sampler=self.update_sampler)
         n_res = len(self.pendings[0])
         per_block = [[img for lane in range(self.lanes) for img in flat[lane * n_res + r]] for r in range(n_res)]

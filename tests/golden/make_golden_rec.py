@@ -1,8 +1,9 @@
 """Golden vectors of the `.rec` wire format and of the arithmetic coder, produced by the REAL reference code:
-/root/reference/rec/io/utils.py + data_structures.py running on the reference's own Cython coder compiled by
-oracle/build_ref.sh into oracle/_ref/.  Only inputs and expected outputs are stored (no reference source).
+/root/reference/rec/io/utils.py + data_structures.py running on the reference's own Cython coder, which oracle/ref_io.py
+compiles (oracle/build_ref.sh) into a temporary directory outside the tree and removes when this script ends.  Only inputs and
+expected outputs are stored (no reference source, no compiled reference).
 
-Run (build container only):  bash oracle/build_ref.sh && python tests/golden/make_golden_rec.py
+Run (build container only):  python tests/golden/make_golden_rec.py
 """
 import contextlib
 import io

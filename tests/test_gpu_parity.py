@@ -2,6 +2,7 @@
 golden fixtures.  Bar: bit-exact indices, K and codelength; bit-exact samples (tolerance stated by BASELINE.json's
 north_star is 1e-5 on reconstructions -- we require equality and also assert the 1e-5 bound explicitly)."""
 import os
+import time
 
 import ctypes
 
@@ -380,6 +381,30 @@ def test_more_than_64_beams_take_the_generic_kernel(engine, oracle, B, omega, ep
     assert [int(i) for i in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
     assert torch.equal(c.decode(_normal(mp[None], sp[None]), idx, seed=11), sample)
     lay = engine.layout(1, n, None, 11)
+    assert engine.plan(engine.params(omega, S, B), lay, 32)["kernel"] == "encode_generic_kernel"
+
+
+@pytest.mark.parametrize("omega,B", [(4.18, 65), (4.18, 100), (4.2, 70)])
+def test_first_step_of_more_beams_than_lane_maxima_guarantee(engine, oracle, omega, B):
+    """Round 4's advice: with more than 64 beams the threshold of the selection is the SMALLEST lane maximum, which guarantees 64
+    survivors, not Bnew.  At step 0 with S = 65 (66) candidates and B >= S, Bnew = S: when the 64 largest keys sit in 64 distinct lanes
+    (2 in 65 blocks at S = 65) only 64 survive and rank_survivors used to record ranks 0..63 and return -- beams 64.. kept stale
+    parents.  Now it sends the shortfall to the scan.  Many blocks, K >= 2 so that step 0's selection feeds a second step."""
+    S = oracle.n_samples(omega, 1.0)
+    assert S in (65, 66)
+    n_t, n = 96, 420
+    stats = [oracle.synthetic_latent(7000 + i, n) for i in range(n_t)]
+    ql, qs, pl, ps = (np.stack([s[k] for s in stats]) for k in range(4))
+    c = _coder(omega, B, 1.0)
+    idx, sample = c.encode(_normal(ql, qs), _normal(pl, ps), seed=5, batched=True)
+    deep = 0
+    for t in range(n_t):
+        ridx, rs = oracle.encode_block(ql[t], qs[t], pl[t], ps[t], 5, omega, S, B)
+        assert [int(i) for i in idx[t][0]] == ridx, t
+        assert np.array_equal(sample[t].cpu().numpy(), rs), t
+        deep += len(ridx) >= 2
+    assert deep >= n_t // 2
+    lay = engine.layout(n_t, n, None, 5)
     assert engine.plan(engine.params(omega, S, B), lay, 32)["kernel"] == "encode_generic_kernel"
 
 
@@ -1274,7 +1299,7 @@ def test_cost_ordered_hand_out_of_mid_size_calls(engine, oracle, B, n_latents, s
 def test_shared_rows_give_up_instead_of_hanging(engine, oracle):
     """Test hook (IREC_FLAG_TEST_SPLIT_ORPHAN): the partner teams of every shared row leave at once, so team 0 of each must take the
     give-up exit (100 ms): out_K = -2 on the shared rows, every whole row coded as ever; the Python coder codes the call again
-    without sharing (SplitNotResident -> no_split) and returns the oracle's outputs."""
+    without sharing (SplitNotResident -> BeamSearchCoder._split_gave_up) and returns the oracle's outputs."""
     import irec
     n_latents, S, B = 29, 36, 20                       # 261 blocks: five shared rows
     stats = [oracle.synthetic_latent(950 + i, 8192) for i in range(n_latents)]
@@ -1289,7 +1314,7 @@ def test_shared_rows_give_up_instead_of_hanging(engine, oracle):
     c = _coder(3.0, B, 1.2, block_size=1000, variant="auto")
     c._test_split_orphan = True
     idx_l, smp = c.encode(_normal(ql, qs), _normal(pl, ps), seed=42, batched=True)
-    assert c.no_split
+    assert not c.no_split and c._split_strikes == 1 and c._split_pause == 0   # one give-up, one recode without sharing: sharing is back
     for i in (0, n_latents - 1):
         ridx, rs = oracle.encode_tensor(*stats[i], 42, 3.0, S, B, block_size=1000)
         assert idx_l[i] == ridx and np.array_equal(smp[i].cpu().numpy(), rs), i
@@ -1377,9 +1402,45 @@ def test_split_encoder_give_up_is_coded_again_without_the_split(engine, oracle):
     c = _coder(3.0, 20, 1.2, variant="one_table")
     c._test_split_orphan = True                              # every split call gives up after its 100 ms wait
     idx, sample = c.encode(_normal(mq, sq), _normal(mp, sp), seed=42)
-    assert c.no_split                                        # the coder left the split encoder
+    assert not c.no_split and c._split_strikes == 1          # the coder stepped back for the recode only (test below: recovery)
     ridx, rs = oracle.encode_block(mq.cpu().numpy()[0], sq.cpu().numpy()[0], mp.cpu().numpy()[0], sp.cpu().numpy()[0], 42, 3.0, 36, 20)
     assert [int(v) for v in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
+
+
+def test_recovery_from_a_give_up(engine, oracle):
+    """Round 4's review (#7): one give-up used to set no_split for the life of the coder object -- a transient co-tenant cost every
+    later small call a factor of two.  Now a bounded back-off (BeamSearchCoder._split_gave_up): the n-th consecutive give-up keeps the
+    next 2^(n-1) calls unshared, the first of them being the recode; the call after takes the split encoder AGAIN
+    (irec_encode_plan.split > 0), and a shared call that comes back whole resets the count."""
+    import irec
+    stats = oracle.synthetic_latent(78, 1000)
+    mq, sq, mp, sp = (torch.as_tensor(a[None], device="cuda") for a in stats)
+    ridx, rs = oracle.encode_block(*stats, 42, 3.0, 36, 20)
+    c = _coder(3.0, 20, 1.2, variant="one_table")
+    lay = engine.layout(1, 1000, None, 42)
+
+    def plan_split():                                        # what the coder's NEXT call would launch
+        return engine.plan(c._params(), lay, 32)["split"]
+    assert plan_split() >= 2
+    c._test_split_orphan = True                              # a co-tenant: every shared call gives up after its 100 ms
+    idx, sample = c.encode(_normal(mq, sq), _normal(mp, sp), seed=42)
+    assert [int(v) for v in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
+    assert (c._split_strikes, c._split_pause) == (1, 0) and plan_split() >= 2      # the next call takes the split encoder again
+    idx, sample = c.encode(_normal(mq, sq), _normal(mp, sp), seed=42)              # ... and gives up again: two calls unshared,
+    assert [int(v) for v in idx] == ridx and (c._split_strikes, c._split_pause) == (2, 1)   # the recode and one more
+    assert plan_split() == 0
+    c._test_split_orphan = False                             # the co-tenant has left
+    idx, sample = c.encode(_normal(mq, sq), _normal(mp, sp), seed=42)              # the pause's last call: unshared
+    assert [int(v) for v in idx] == ridx and (c._split_strikes, c._split_pause) == (2, 0) and plan_split() >= 2
+    t0 = time.perf_counter()
+    idx, sample = c.encode(_normal(mq, sq), _normal(mp, sp), seed=42)              # shared again, comes back whole: count reset
+    assert time.perf_counter() - t0 < 0.08                                         # (no 100 ms wait in it)
+    assert [int(v) for v in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
+    assert (c._split_strikes, c._split_pause) == (0, 0) and plan_split() >= 2
+    # the bound: the pause never exceeds SPLIT_PAUSE_MAX calls, and the caller's own knob is never touched
+    for _ in range(12):
+        c._split_gave_up()
+    assert c._split_pause == c.SPLIT_PAUSE_MAX == 64 and not c.no_split
 
 
 def test_infinite_kl_block_does_not_poison_the_partition_hint(engine, oracle):

@@ -81,6 +81,39 @@ def test_product_never_imports_the_oracle():
                 assert "oracle" not in text.replace("test oracle's restatement", ""), os.path.join(dirpath, f)
 
 
+def test_loader_honours_no_path_override():
+    """The product loader reads no environment variable: a variant build is loaded only by an explicit
+    irec._lib.load(path) of the A/B tooling (scripts/with_lib.py), never by ambient state."""
+    import subprocess
+    import sys
+    pkg = os.path.join(ROOT, "relative-entropy-coding_amd")
+    for dirpath, _, files in os.walk(os.path.join(pkg, "irec")):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "os.environ" not in text and "getenv" not in text, os.path.join(dirpath, f)
+    code = ("import sys; sys.path[:0] = [%r, %r]; import irec; irec._lib.load(); print(irec._lib._lib_path)" % (ROOT, pkg))
+    env = dict(os.environ, IREC_LIB_PATH="/nonexistent/libirec_hip.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-400:]
+    assert out.stdout.strip().splitlines()[-1] == os.path.join(pkg, "csrc", "libirec_hip.so")
+    import irec
+    irec._lib.load()
+    with pytest.raises(irec._lib.IrecLibraryError, match="is loaded already"):   # no switching libraries under a running process
+        irec._lib.load("/nonexistent/other.so")
+
+
+def test_no_compiled_reference_in_the_tree():
+    """Round 5: the reference's Cython coder (the checker of the .rec row) is compiled on demand into a temporary directory outside
+    the repository (oracle/ref_io.py) -- no form of the reference sits in the tree or travels to the GPU box."""
+    for dirpath, dirs, files in os.walk(ROOT):
+        dirs[:] = [d for d in dirs if d not in (".git", "gpurun_out", "__pycache__")]
+        for f in files:
+            assert not (f.startswith("entropy_coding") and f.endswith((".so", ".c", ".o"))), os.path.join(dirpath, f)
+    assert not os.path.isdir(os.path.join(ROOT, "oracle", "_ref")) or not os.listdir(os.path.join(ROOT, "oracle", "_ref"))
+    assert "build_ref" not in open(os.path.join(ROOT, "__graft_entry__.py")).read().replace("oracle/build_ref.sh)", "")
+
+
 def test_coder_api_mirrors_reference():
     import irec
     from irec.coding import BeamSearchCoder, Coder, GaussianCoder, CodingError

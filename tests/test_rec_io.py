@@ -93,7 +93,7 @@ def test_empty_message_round_trip():
 def test_against_live_reference_when_available(tmp_path):
     from oracle import ref_io
     if not ref_io.available():
-        pytest.skip("reference rec.io not built here (GPU box)")
+        pytest.skip("no reference sources here (GPU box)")
     from irec.io import ArithmeticCoder, write_compressed_code
     with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
         U = ref_io.load()
