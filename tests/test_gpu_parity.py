@@ -400,7 +400,7 @@ def test_first_step_of_more_beams_than_lane_maxima_guarantee(engine, oracle, ome
     deep = 0
     for t in range(n_t):
         ridx, rs = oracle.encode_block(ql[t], qs[t], pl[t], ps[t], 5, omega, S, B)
-        assert [int(i) for i in idx[t][0]] == ridx, t
+        assert [int(i) for i in idx[t]] == ridx, t
         assert np.array_equal(sample[t].cpu().numpy(), rs), t
         deep += len(ridx) >= 2
     assert deep >= n_t // 2
