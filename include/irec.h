@@ -92,6 +92,10 @@ typedef struct {
                                   /* Default: by cost -- the call's preparation kernel also computes K * dims of every row and a CU's first   */
                                   /* team takes a cheap row, its other teams (and the teams that share a row) the costliest ones, so   */
                                   /* that the longest rows do not meet on one CU.  Results do not depend on it (diagnostics, A/B).     */
+#define IREC_FLAG_MARGINS 524288   /* the call reports its top-B margins: irec_beam_encode_ex with out_margin (and only that entry point) takes it.  The    */
+                                  /* flag is part of the params because it sizes the workspace (irec_encode_workspace_bytes) and picks the kernels     */
+                                  /* (irec_encode_plan): a margin build of the team encoder where one exists, the generic kernel otherwise; no block   */
+                                  /* is shared between workgroups or teams.  Indices, K and samples are the plain call's, bit for bit.                 */
 #define IREC_FLAG_SPLIT_SHIFT 12  /* bits 12-15: workgroups per block of the split encoder, 0 = chosen by the library (diagnostics) */
 #define IREC_FLAG_SPLIT_MASK (0xF << IREC_FLAG_SPLIT_SHIFT)
 /* Diagnostic workgroup shapes of the team encoder for B <= 20 (bits 8-11 of flags; 0 = the default shape).  Same outputs. */
@@ -233,6 +237,25 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
                              const int32_t *perm, const float *q_loc, const float *q_scale, const float *p_loc,
                              const float *p_scale, int64_t seed, int32_t max_K, int32_t *out_K, int32_t *out_indices,
                              float *out_sample, void *workspace, size_t workspace_bytes, void *hip_stream);
+
+/* irec_beam_encode that also says HOW CLOSE every block's selections were (round 5) -- the top-B step of beam_search_coder.py:85-89
+ * (`tf.argsort(..., direction='DESCENDING')[:n_beams]`) decides the emitted indices through two comparisons only: which candidates
+ * make the top-B SET of every step but the last, and which candidate WINS the last step (beams[0], :118-122).  Another float32
+ * summation order of the same terms -- TensorFlow's reduce_sum (:84) -- can move an index only where those
+ * comparisons are closer than the two orders disagree, so the margins measure the encoder-side exposure of index parity.
+ *   out_margin [n_blocks][4] float32, device pointer; needs IREC_FLAG_MARGINS in p->flags (NULL without it: plain irec_beam_encode):
+ *     [0] min over the steps t < K - 1 that reject a candidate of  score(rank Bnew - 1) - score(rank Bnew), Bnew = min(B, S * Bcur):
+ *         the gap between the last candidate kept and the best one rejected; +inf when there is no such step (K <= 1)
+ *     [1] |score(rank Bnew - 1)| at that step (scale of the sum the gap is a difference of)
+ *     [2] score(rank 0) - score(rank 1) at the last step (+inf: a single candidate)        [3] |score(rank 0)| at the last step
+ *   Scores are the float32 values the selection ranks, differences are float32 subtractions: the oracle's traced
+ *   scores give the same four numbers bit for bit.  A block that is not coded (K = 0, K > max_K, K < 0) reports {+inf, 0, +inf, 0}.
+ *   Decoding needs none of this: decode_block never compares scores (beam_search_coder.py:124-148). */
+irec_status irec_beam_encode_ex(irec_context *ctx, const irec_params *p, int64_t n_blocks, const int64_t *block_base,
+                                const int32_t *block_pos, const int32_t *block_dim, int32_t max_block_dim,
+                                const int32_t *perm, const float *q_loc, const float *q_scale, const float *p_loc,
+                                const float *p_scale, int64_t seed, int32_t max_K, int32_t *out_K, int32_t *out_indices,
+                                float *out_sample, float *out_margin, void *workspace, size_t workspace_bytes, void *hip_stream);
 
 /* BeamSearchCoder.decode_block on n_blocks blocks -- beam_search_coder.py:124-148 (GaussianCoder.decode, coder.py:459-491).
  *   K [n_blocks], indices [n_blocks, max_K] in ENCODER order (idx[t] = choice at iteration t).  A row with K < 0 or

@@ -438,11 +438,24 @@ static int cand_before(float va, int32_t fa, float vb, int32_t fb) {
  *   trace_sel   : optional [K][B][2] selected (s', b') per step, -1 padded
  *   trace_score : optional [K][S*B] scores in flat order f = s*B_cur + b (unused tail = 0)
  * returns K.
- * ---------------------------------------------------------------------------------------------- */
+ *   out_margin  : optional [4] -- how close the selections were, the numbers irec_beam_encode_ex reports (include/irec.h):
+ *                 [0] min over the steps t < K - 1 that reject a candidate of score(rank Bnew - 1) - score(rank Bnew), +inf if none;
+ *                 [1] |score(rank Bnew - 1)| at that step; [2] score(rank 0) - score(rank 1) at the last step, +inf if one candidate;
+ *                 [3] |score(rank 0)| at the last step.  float32 subtractions of the scores the selection ranked (-0 counts as +0). */
+int32_t irec_oracle_encode_block_ex(int mode, float omega, int S, int B, int D, const float *mq, const float *sq,
+                                    const float *mp, const float *sp, int64_t seed, int32_t max_K,
+                                    int32_t *out_indices, float *out_sample, int32_t *trace_sel, float *trace_score, float *out_margin);
 int32_t irec_oracle_encode_block(int mode, float omega, int S, int B, int D, const float *mq, const float *sq,
                                  const float *mp, const float *sp, int64_t seed, int32_t max_K,
                                  int32_t *out_indices, float *out_sample, int32_t *trace_sel, float *trace_score) {
+  return irec_oracle_encode_block_ex(mode, omega, S, B, D, mq, sq, mp, sp, seed, max_K, out_indices, out_sample, trace_sel, trace_score, 0);
+}
+int32_t irec_oracle_encode_block_ex(int mode, float omega, int S, int B, int D, const float *mq, const float *sq,
+                                    const float *mp, const float *sp, int64_t seed, int32_t max_K,
+                                    int32_t *out_indices, float *out_sample, int32_t *trace_sel, float *trace_score, float *out_margin) {
   const float *lut = oracle_lut();
+  float m_gap = INFINITY, m_at = 0.0f, m_top = INFINITY, m_top_at = 0.0f;
+  if (out_margin) { out_margin[0] = m_gap; out_margin[1] = m_at; out_margin[2] = m_top; out_margin[3] = m_top_at; }
 
   float kl = irec_oracle_block_kl(mode, D, mq, sq, mp, sp);
   int32_t K = irec_oracle_num_aux(kl, omega);
@@ -550,6 +563,7 @@ int32_t irec_oracle_encode_block(int mode, float omega, int S, int B, int D, con
     /* top-B, descending, ties to the lower flat index */
     int Bnew = B < N ? B : N;
     memset(taken, 0, (size_t)N);
+    float s_rank0 = 0.0f, s_rank1 = 0.0f, s_rankB = 0.0f;
     for (int j = 0; j < Bnew; ++j) {
       int best = -1;
       for (int f = 0; f < N; ++f) {
@@ -557,6 +571,9 @@ int32_t irec_oracle_encode_block(int mode, float omega, int S, int B, int D, con
         if (best < 0 || cand_before(score[f], f, score[best], best)) best = f;
       }
       taken[best] = 1;
+      if (j == 0) s_rank0 = score[best];
+      if (j == 1) s_rank1 = score[best];
+      if (j == Bnew - 1) s_rankB = score[best];
       int bsrc = best % Bcur, ssrc = best / Bcur; /* :88-89 */
       const float *beam = beams + (size_t)bsrc * D;
       const int32_t *rs = r + (size_t)ssrc * D;
@@ -577,6 +594,23 @@ int32_t irec_oracle_encode_block(int mode, float omega, int S, int B, int D, con
     }
     if (trace_sel)
       for (int j = Bnew; j < B; ++j) { trace_sel[((size_t)t * B + j) * 2] = -1; trace_sel[((size_t)t * B + j) * 2 + 1] = -1; }
+    if (out_margin) { /* the best rejected candidate = rank Bnew */
+      int rej = -1;
+      for (int f = 0; f < N; ++f) {
+        if (taken[f]) continue;
+        if (rej < 0 || cand_before(score[f], f, score[rej], rej)) rej = f;
+      }
+      if (t < K - 1) {
+        if (rej >= 0) {
+          float g = (s_rankB + 0.0f) - (score[rej] + 0.0f);
+          if (g < m_gap) { m_gap = g; m_at = fabsf(s_rankB); }
+        }
+      } else {
+        if (Bnew >= 2) m_top = (s_rank0 + 0.0f) - (s_rank1 + 0.0f);
+        else if (rej >= 0) m_top = (s_rank0 + 0.0f) - (score[rej] + 0.0f);
+        m_top_at = fabsf(s_rank0);
+      }
+    }
     { float *tmp = beams; beams = nbeams; nbeams = tmp; }
     { int32_t *tmp = path; path = npath; npath = tmp; }
     memcpy(hsum, nhsum, (size_t)Bnew * sizeof(int32_t));
@@ -586,6 +620,7 @@ int32_t irec_oracle_encode_block(int mode, float omega, int S, int B, int D, con
 
   for (int t = 0; t < K; ++t) out_indices[t] = path[t];
   for (int d = 0; d < D; ++d) out_sample[d] = beams[d] + mp[d]; /* :122 */
+  if (out_margin) { out_margin[0] = m_gap; out_margin[1] = m_at; out_margin[2] = m_top; out_margin[3] = m_top_at; }
 
   free(Gtab); free(beams); free(nbeams); free(c); free(a); free(sd); free(r); free(score); free(path); free(npath); free(taken);
   return K;
@@ -601,10 +636,21 @@ int32_t irec_oracle_encode_block(int mode, float omega, int S, int B, int D, con
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+int irec_oracle_encode_blocks_omp_ex(int mode, float omega, int S, int B, int64_t n_blocks, const int32_t *dim,
+                                     const int64_t *offset, const float *mq, const float *sq, const float *mp,
+                                     const float *sp, int64_t seed, int32_t max_K, int32_t *out_K, int32_t *out_indices,
+                                     float *out_sample, float *out_margin /* [n_blocks][4] or NULL */, int n_threads);
 int irec_oracle_encode_blocks_omp(int mode, float omega, int S, int B, int64_t n_blocks, const int32_t *dim,
                                   const int64_t *offset, const float *mq, const float *sq, const float *mp,
                                   const float *sp, int64_t seed, int32_t max_K, int32_t *out_K, int32_t *out_indices,
                                   float *out_sample, int n_threads) {
+  return irec_oracle_encode_blocks_omp_ex(mode, omega, S, B, n_blocks, dim, offset, mq, sq, mp, sp, seed, max_K, out_K, out_indices,
+                                          out_sample, 0, n_threads);
+}
+int irec_oracle_encode_blocks_omp_ex(int mode, float omega, int S, int B, int64_t n_blocks, const int32_t *dim,
+                                     const int64_t *offset, const float *mq, const float *sq, const float *mp,
+                                     const float *sp, int64_t seed, int32_t max_K, int32_t *out_K, int32_t *out_indices,
+                                     float *out_sample, float *out_margin, int n_threads) {
   int used = 1;
   if (n_blocks > 0) { /* builds the function-static LUT before any thread races for it */
     float s1[1], q1 = 0.0f, one = 1.0f; int32_t i1[1];
@@ -618,16 +664,16 @@ int irec_oracle_encode_blocks_omp(int mode, float omega, int S, int B, int64_t n
     used = omp_get_num_threads();
 #pragma omp for schedule(dynamic, 1)
     for (int64_t k = 0; k < n_blocks; ++k)
-      out_K[k] = irec_oracle_encode_block(mode, omega, S, B, dim[k], mq + offset[k], sq + offset[k], mp + offset[k],
-                                          sp + offset[k], seed, max_K, out_indices + k * (int64_t)max_K,
-                                          out_sample + offset[k], 0, 0);
+      out_K[k] = irec_oracle_encode_block_ex(mode, omega, S, B, dim[k], mq + offset[k], sq + offset[k], mp + offset[k],
+                                             sp + offset[k], seed, max_K, out_indices + k * (int64_t)max_K,
+                                             out_sample + offset[k], 0, 0, out_margin ? out_margin + 4 * k : 0);
   }
 #else
   (void)n_threads;
   for (int64_t k = 0; k < n_blocks; ++k)
-    out_K[k] = irec_oracle_encode_block(mode, omega, S, B, dim[k], mq + offset[k], sq + offset[k], mp + offset[k],
-                                        sp + offset[k], seed, max_K, out_indices + k * (int64_t)max_K,
-                                        out_sample + offset[k], 0, 0);
+    out_K[k] = irec_oracle_encode_block_ex(mode, omega, S, B, dim[k], mq + offset[k], sq + offset[k], mp + offset[k],
+                                           sp + offset[k], seed, max_K, out_indices + k * (int64_t)max_K,
+                                           out_sample + offset[k], 0, 0, out_margin ? out_margin + 4 * k : 0);
 #endif
   return used;
 }

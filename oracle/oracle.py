@@ -81,6 +81,12 @@ def lib():
                                                f32p, f32p, f32p, f32p, ctypes.c_int64, ctypes.c_int32, i32p, f32p,
                                                i32p, f32p]
         L.irec_oracle_encode_block.restype = ctypes.c_int32
+        L.irec_oracle_encode_block_ex.argtypes = L.irec_oracle_encode_block.argtypes + [f32p]
+        L.irec_oracle_encode_block_ex.restype = ctypes.c_int32
+        L.irec_oracle_encode_blocks_omp_ex.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                                       i32p, i64p, f32p, f32p, f32p, f32p, ctypes.c_int64, ctypes.c_int32,
+                                                       i32p, i32p, f32p, f32p, ctypes.c_int]
+        L.irec_oracle_encode_blocks_omp_ex.restype = ctypes.c_int
         L.irec_oracle_encode_blocks_omp.argtypes = [ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
                                                     i32p, i64p, f32p, f32p, f32p, f32p, ctypes.c_int64, ctypes.c_int32,
                                                     i32p, i32p, f32p, ctypes.c_int]
@@ -231,8 +237,32 @@ def num_aux(kl, omega):
     return lib().irec_oracle_num_aux(float(kl), float(np.float32(omega)))
 
 
-def encode_block(mq, sq, mp, sp, seed, omega, S, B, mode=CANONICAL, max_K=4096, trace=False):
-    """BeamSearchCoder.encode_block on one already-permuted block.  Returns (indices list, sample[, trace])."""
+def margins_from_trace(trace, S, B):
+    """The four floats of irec_beam_encode_ex's out_margin (include/irec.h) from the scores encode_block(trace=True) recorded --
+    an independent (numpy) statement of what irec_oracle_encode_block_ex computes in C."""
+    K = trace["K"]
+    out = np.array([np.inf, 0.0, np.inf, 0.0], dtype=np.float32)
+    Bcur = 1
+    for t in range(K):
+        N = S * Bcur
+        Bnew = min(B, N)
+        sc = trace["score"][t][:N].astype(np.float32) + np.float32(0.0)        # (-0 counts as +0)
+        srt = sc[np.argsort(-sc, kind="stable")]                                  # value descending, ties to the lower flat index
+        if t < K - 1:
+            if N > Bnew:
+                g = np.float32(srt[Bnew - 1] - srt[Bnew])
+                if g < out[0]:
+                    out[0], out[1] = g, np.abs(srt[Bnew - 1])
+        else:
+            if N >= 2:
+                out[2] = np.float32(srt[0] - srt[1])
+            out[3] = np.abs(srt[0])
+        Bcur = Bnew
+    return out
+
+
+def encode_block(mq, sq, mp, sp, seed, omega, S, B, mode=CANONICAL, max_K=4096, trace=False, margins=False):
+    """BeamSearchCoder.encode_block on one already-permuted block.  Returns (indices list, sample[, trace][, margins [4]])."""
     mq, sq, mp, sp = map(lambda a: _f32(a).reshape(-1), (mq, sq, mp, sp))
     D = mq.size
     idx = np.zeros(max_K, dtype=np.int32)
@@ -240,16 +270,20 @@ def encode_block(mq, sq, mp, sp, seed, omega, S, B, mode=CANONICAL, max_K=4096, 
     K0 = num_aux(block_kl(mq, sq, mp, sp, mode), omega)
     sel = np.full((max(K0, 1), B, 2), -1, dtype=np.int32) if trace else None
     sc = np.zeros((max(K0, 1), S * B), dtype=np.float32) if trace else None
-    K = lib().irec_oracle_encode_block(mode, float(np.float32(omega)), S, B, D, _p(mq, ctypes.c_float),
-                                       _p(sq, ctypes.c_float), _p(mp, ctypes.c_float), _p(sp, ctypes.c_float),
-                                       int(seed), max_K, _p(idx, ctypes.c_int32), _p(sample, ctypes.c_float),
-                                       _p(sel, ctypes.c_int32) if trace else None,
-                                       _p(sc, ctypes.c_float) if trace else None)
+    mg = np.zeros(4, dtype=np.float32) if margins else None
+    K = lib().irec_oracle_encode_block_ex(mode, float(np.float32(omega)), S, B, D, _p(mq, ctypes.c_float),
+                                          _p(sq, ctypes.c_float), _p(mp, ctypes.c_float), _p(sp, ctypes.c_float),
+                                          int(seed), max_K, _p(idx, ctypes.c_int32), _p(sample, ctypes.c_float),
+                                          _p(sel, ctypes.c_int32) if trace else None,
+                                          _p(sc, ctypes.c_float) if trace else None,
+                                          _p(mg, ctypes.c_float) if margins else None)
     if K > max_K:
         raise ValueError(f"K={K} exceeds max_K={max_K}")
     out = ([int(v) for v in idx[:K]], sample)
     if trace:
         out = out + ({"sel": sel[:K], "score": sc[:K], "K": K},)
+    if margins:
+        out = out + (mg,)
     return out
 
 
@@ -289,9 +323,9 @@ def encode_tensor(q_loc, q_scale, p_loc, p_scale, seed, omega, S, B, block_size=
 
 
 def encode_tensors_omp(q_loc, q_scale, p_loc, p_scale, seed, omega, S, B, block_size, mode=CANONICAL, max_K=64,
-                       n_threads=0):
+                       n_threads=0, margins=False):
     """CPU-opt baseline: GaussianCoder.encode over a batch [N, n] of latent tensors, OpenMP over the
-    N * blocks independent blocks.  Returns (indices[N][blocks][K], sample [N, n], threads used)."""
+    N * blocks independent blocks.  Returns (indices[N][blocks][K], sample [N, n], threads used[, margins [N, blocks, 4]])."""
     mq, sq, mp, sp = (np.ascontiguousarray(a, dtype=np.float32).reshape(len(a), -1) for a in (q_loc, q_scale, p_loc, p_scale))
     N, n = mq.shape
     perm = tf_shuffle_perm(seed, n)
@@ -302,16 +336,20 @@ def encode_tensors_omp(q_loc, q_scale, p_loc, p_scale, seed, omega, S, B, block_
     out_K = np.zeros(len(dims), dtype=np.int32)
     out_idx = np.zeros((len(dims), max_K), dtype=np.int32)
     out_s = np.zeros(N * n, dtype=np.float32)
-    used = lib().irec_oracle_encode_blocks_omp(mode, float(np.float32(omega)), S, B, len(dims), _p(dims, ctypes.c_int32),
-                                               _p(offs, ctypes.c_int64), *(_p(a, ctypes.c_float) for a in pm), int(seed),
-                                               max_K, _p(out_K, ctypes.c_int32), _p(out_idx, ctypes.c_int32),
-                                               _p(out_s, ctypes.c_float), int(n_threads))
+    mg = np.zeros((len(dims), 4), dtype=np.float32) if margins else None
+    used = lib().irec_oracle_encode_blocks_omp_ex(mode, float(np.float32(omega)), S, B, len(dims), _p(dims, ctypes.c_int32),
+                                                  _p(offs, ctypes.c_int64), *(_p(a, ctypes.c_float) for a in pm), int(seed),
+                                                  max_K, _p(out_K, ctypes.c_int32), _p(out_idx, ctypes.c_int32),
+                                                  _p(out_s, ctypes.c_float), _p(mg, ctypes.c_float) if margins else None,
+                                                  int(n_threads))
     if (out_K > max_K).any():
         raise ValueError(f"K={int(out_K.max())} exceeds max_K={max_K}")
     sample = np.zeros((N, n), dtype=np.float32)
     sample[:, perm] = out_s.reshape(N, n)                                             # merge: inverse permutation
     nb = len(blocks)
     indices = [[[int(v) for v in out_idx[i * nb + j, :out_K[i * nb + j]]] for j in range(nb)] for i in range(N)]
+    if margins:
+        return indices, sample, used, mg.reshape(N, nb, 4)
     return indices, sample, used
 
 

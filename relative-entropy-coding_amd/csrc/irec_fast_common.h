@@ -469,6 +469,60 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
 }
 
 
+// ======================================================================================================
+//  top-B margins (round 5; irec_beam_encode_ex, IREC_FLAG_MARGINS): how close was the selection?
+//
+//  The emitted indices depend on the scores only through the top-B SET of every step but the last and through the WINNER of the
+//  last step (beams[0], beam_search_coder.py:85-89,118-122).  Another summation order of the same float32 terms (TensorFlow's
+//  reduce_sum) can change an index only where those comparisons are closer than the orders disagree.  A margin
+//  build reports, per block (EncArgs::out_margin, four floats):
+//    [0] min over the steps t < K - 1 that reject a candidate of  score(rank Bnew - 1) - score(rank Bnew)   (+inf: no such step)
+//    [1] |score(rank Bnew - 1)| at that step
+//    [2] score(rank 0) - score(rank 1) at the last step   (+inf: one candidate)
+//    [3] |score(rank 0)| at the last step
+//  Scores are the float32 values the selection ranked (the inverse of score_key); the differences are float32 subtractions.
+//
+//  Mechanics: the selection's post() callback stashes the key of new beam j (margin_stash: the upper half of the first 512 bytes of
+//  cand[], idle once the ranks are final and never touched by the scan's wb[]); after the selection's closing barrier ONE wave
+//  zeroes the selected keys in key[] (the scan path has done so already), takes the maximum of what is left -- the best rejected
+//  candidate -- and the minimum of the stash.  The caller puts a barrier behind it before anything overwrites key[].
+// ======================================================================================================
+struct MarginAcc { float gap = __builtin_inff(), at = 0.f, top_gap = __builtin_inff(), top_at = 0.f; };
+__device__ __forceinline__ float key_score(uint32_t key) {   // inverse of score_key (-0 comes back as +0, NaN as a NaN)
+  return __uint_as_float((key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key);
+}
+template <class SM>
+__device__ __forceinline__ void margin_stash(SM *sm, int j, uint32_t key) { reinterpret_cast<uint32_t *>(sm->cand)[64 + j] = key; }
+template <class SM>
+__device__ __forceinline__ void margin_step(uint32_t *key, int N, int Bnew, int Bcur, SM *sm, int lane, bool last, MarginAcc &acc) {
+  static_assert(sizeof(sm->cand) >= (64 + (sizeof(sm->sel_s) / sizeof(int32_t))) * 4, "the key stash must fit behind the scan's wb[]");
+  const uint32_t *stash = reinterpret_cast<const uint32_t *>(sm->cand) + 64;
+  uint32_t kmin = 0xFFFFFFFFu;
+  for (int j = lane; j < Bnew; j += 64) {
+    const uint32_t k = stash[j];
+    kmin = k < kmin ? k : kmin;
+    key[sm->sel_s[j] * Bcur + sm->sel_b[j]] = 0u;          // taken
+  }
+  kmin = 0xFFFFFFFFu - (uint32_t)wave_max_u64((unsigned long long)(0xFFFFFFFFu - kmin));   // key of rank Bnew - 1
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // (keys in the slab: the zeroes are in place before other lanes read them)
+  uint32_t M = 0u;
+  for (int f = lane; f < N; f += 64) { const uint32_t k = key[f]; M = k > M ? k : M; }
+  M = (uint32_t)wave_max_u64((unsigned long long)M);        // key of rank Bnew: the best rejected candidate (0: none)
+  if (!last) {
+    if (M != 0u) {
+      const float g = key_score(kmin) - key_score(M);
+      if (g < acc.gap) { acc.gap = g; acc.at = __builtin_fabsf(key_score(kmin)); }
+    }
+  } else {
+    const uint32_t k0 = stash[0], k1 = Bnew >= 2 ? stash[1] : M;
+    if (k1 != 0u) acc.top_gap = key_score(k0) - key_score(k1);
+    acc.top_at = __builtin_fabsf(key_score(k0));
+  }
+}
+__device__ __forceinline__ void margin_write(float *out_margin, int64_t blk, const MarginAcc &acc) {
+  *reinterpret_cast<float4 *>(out_margin + 4 * blk) = make_float4(acc.gap, acc.at, acc.top_gap, acc.top_at);
+}
+
 struct WorkgroupSync { __device__ __forceinline__ void operator()() const { __syncthreads(); } };
 template <int NT, bool QUICK = false>
 __device__ __forceinline__ void select_topB(uint32_t *key, int N, int Bnew, int Bcur, SmallLds *sm,

@@ -608,6 +608,14 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
       pl.ws_per_wg = generic_ws;
     }
   }
+  if (p->flags & IREC_FLAG_MARGINS) {
+    // top-B margins (irec_beam_encode_ex): a margin build of the team encoder where one exists, the generic kernel for everything else and
+    // for the blocks beyond the table window -- the slabs serve both
+    const size_t generic_ws = round_up_sz((size_t)10 * pl.dpad * 4 + (size_t)3 * B * pl.dpad * 4 +
+                                          (size_t)(max_K > 0 ? max_K : 1) * B * 4 + (size_t)S * B * 4, 256);
+    pl.ws_per_wg = std::max(pl.ws_per_wg, generic_ws);
+    pl.grid_cap = std::max(pl.grid_cap, 2 * n_cu);
+  }
   if (!pl.table) pl.K_tab = 0;
   return pl;
 }
@@ -739,6 +747,16 @@ int shape_for_call(const irec_context *ctx, const Plan &pl, const irec_params *p
   return 5;
 }
 
+// A call with IREC_FLAG_MARGINS: the team-encoder shape whose MARGIN build (irec_team_margin.hip) serves it, or -1 = the generic kernel.
+// No block is shared under the flag (the cooperative forms have no margin builds), so the call's shape is the plain one of its size.
+int margin_team_shape(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks) {
+  if (!pl.table || !pl.team || pl.lone || pl.chunk || (p->flags & (IREC_FLAG_FORCE_GENERIC | IREC_FLAG_FUSED_PHILOX | IREC_FLAG_ONE_TABLE))) return -1;
+  const int shape = shape_for_call(ctx, pl, p, n_blocks);
+  if (irec::team_margin_build(p->n_beams, p->n_samples, shape)) return shape;
+  if (irec::team_margin_build(p->n_beams, p->n_samples, pl.shape)) return pl.shape;
+  return -1;
+}
+
 } // namespace
 
 extern "C" {
@@ -754,10 +772,36 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
   if (!ctx || !out) return fail(IREC_E_INVALID, "irec_encode_plan: null argument");
   if (irec_status s = check_params(p)) return s;
   if (n_blocks < 0 || max_block_dim < 1 || max_K < 0) return fail(IREC_E_INVALID, "irec_encode_plan: bad sizes");
+  irec_params pm = *p;
+  if (pm.flags & IREC_FLAG_MARGINS) { pm.flags |= IREC_FLAG_NO_SPLIT; p = &pm; }
   const Plan pl = make_plan(ctx, p, max_block_dim, max_K);
   const bool team = team_for_call(pl, p, n_blocks);
   std::memset(out, 0, sizeof(*out));
   const int B = p->n_beams, S = p->n_samples;
+  if (p->flags & IREC_FLAG_MARGINS) {   // irec_beam_encode_ex: a margin build of the team encoder, or the generic kernel
+    const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+    const int mshape = margin_team_shape(ctx, pl, p, n_blocks);
+    if (mshape >= 0) {
+      const int n_teams = irec::team_count_for(B, S, mshape);
+      std::string nm = irec::team_kernel_name(B, S, mshape);
+      nm.insert(nm.size() - 1, ",margins");
+      std::snprintf(out->kernel, sizeof out->kernel, "%s", nm.c_str());
+      std::snprintf(out->table_kernel, sizeof out->table_kernel, "prep_kernel (copy bits)");
+      out->grid = batch_grid(n_blocks, std::min(pl.grid_cap / n_teams, n_cu));
+      out->waves_per_wg = irec::team_waves_for(B, S, mshape);
+      out->teams_per_wg = n_teams;
+      out->lds_bytes = (int32_t)irec::team_lds_for(B, S, mshape);
+      out->table_steps = pl.K_tab; out->n_tables = pl.n_tab; out->table_bytes = (int64_t)pl.tab_bytes;
+    } else {
+      std::snprintf(out->kernel, sizeof out->kernel, "encode_generic_kernel (margins)");
+      out->grid = (int32_t)std::min<int64_t>(n_blocks, 2 * n_cu);
+      out->waves_per_wg = 4; out->teams_per_wg = 1;
+      out->lds_bytes = (int32_t)irec::generic_lds_bytes();
+    }
+    out->n_cu = ctx->n_cu; out->clock_mhz = ctx->clock_mhz;
+    out->workspace_bytes = (int64_t)(irec::WS_HEAD_BYTES + pl.tab_bytes + (size_t)pl.grid_cap * pl.ws_per_wg);
+    return IREC_OK;
+  }
   if (pl.chunk) {
     const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
     std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::chunk_kernel_name(B));
@@ -845,8 +889,22 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
                              const int32_t *perm, const float *q_loc, const float *q_scale, const float *p_loc,
                              const float *p_scale, int64_t seed, int32_t max_K, int32_t *out_K, int32_t *out_indices,
                              float *out_sample, void *workspace, size_t workspace_bytes, void *hip_stream) {
+  if (p && (p->flags & IREC_FLAG_MARGINS)) return fail(IREC_E_INVALID, "irec_beam_encode: IREC_FLAG_MARGINS needs irec_beam_encode_ex (out_margin)");
+  return irec_beam_encode_ex(ctx, p, n_blocks, block_base, block_pos, block_dim, max_block_dim, perm, q_loc, q_scale, p_loc, p_scale, seed,
+                             max_K, out_K, out_indices, out_sample, nullptr, workspace, workspace_bytes, hip_stream);
+}
+
+irec_status irec_beam_encode_ex(irec_context *ctx, const irec_params *p, int64_t n_blocks, const int64_t *block_base,
+                                const int32_t *block_pos, const int32_t *block_dim, int32_t max_block_dim,
+                                const int32_t *perm, const float *q_loc, const float *q_scale, const float *p_loc,
+                                const float *p_scale, int64_t seed, int32_t max_K, int32_t *out_K, int32_t *out_indices,
+                                float *out_sample, float *out_margin, void *workspace, size_t workspace_bytes, void *hip_stream) {
   if (!ctx) return fail(IREC_E_INVALID, "irec_beam_encode: null context");
   if (irec_status s = check_params(p)) return s;
+  if (((p->flags & IREC_FLAG_MARGINS) != 0) != (out_margin != nullptr))
+    return fail(IREC_E_INVALID, "irec_beam_encode_ex: out_margin and IREC_FLAG_MARGINS go together (the flag sizes the workspace)");
+  irec_params pm = *p;
+  if (out_margin) { pm.flags |= IREC_FLAG_NO_SPLIT; p = &pm; }   // (no block is shared under the flag: the cooperative forms have no margin builds)
   if (n_blocks < 0) return fail(IREC_E_INVALID, "irec_beam_encode: n_blocks < 0");
   if (n_blocks > 0x7FFF0000ll) return fail(IREC_E_INVALID, "irec_beam_encode: more than 2^31 - 65536 blocks in one call");   // (block rows are int32 in the kernels)
   if (n_blocks == 0) return IREC_OK;
@@ -859,7 +917,11 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   const size_t need = irec::WS_HEAD_BYTES + pl.tab_bytes + (size_t)pl.grid_cap * pl.ws_per_wg;
   if (!workspace || workspace_bytes < need)
     return fail(IREC_E_WORKSPACE, "irec_beam_encode: workspace %zu bytes < required %zu", workspace_bytes, need);
-  pl.team = team_for_call(pl, p, n_blocks);
+  // top-B margins: a margin build of the team encoder where one serves the call's shape (whatever the call's size), else the generic
+  // kernel, which draws in the kernel: no tables
+  const int mshape = out_margin ? margin_team_shape(ctx, pl, p, n_blocks) : -1;
+  if (out_margin && mshape < 0) { pl.table = false; pl.team = false; pl.lone = false; pl.chunk = false; pl.fast = false; pl.team_only = false; pl.n_tab = 0; pl.K_tab = 0; }
+  pl.team = mshape >= 0 ? true : team_for_call(pl, p, n_blocks);
   if (((uintptr_t)workspace & 255) != 0) return fail(IREC_E_WORKSPACE, "irec_beam_encode: workspace must be 256-byte aligned");
   IREC_ON_DEVICE(ctx->device);
   hipStream_t st = (hipStream_t)hip_stream;
@@ -876,13 +938,15 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   A.counter = (unsigned int *)workspace;
   A.xcd_counter = (unsigned int *)workspace + irec::WS_XCD_WORD;
   A.defer_count = (unsigned int *)workspace + 1;
-  if (pl.team) pl.shape = shape_for_call(ctx, pl, p, n_blocks);
+  if (mshape >= 0) pl.shape = mshape;
+  else if (pl.team) pl.shape = shape_for_call(ctx, pl, p, n_blocks);
   A.K_tab = pl.K_tab; A.deferred_pass = 0; A.shape_override = pl.shape;
   A.coop_W = 1; A.coop_err = (unsigned int *)workspace + 3; A.coop_arrive = (unsigned int *)workspace + 64;
   A.coop_xch = (uint32_t *)((char *)workspace + irec::WS_COUNTER_BYTES);
   A.ws = (char *)workspace + irec::WS_HEAD_BYTES + pl.tab_bytes;
   A.ws_per_wg = pl.ws_per_wg;
   A.max_dim_pad = pl.dpad;
+  A.out_margin = out_margin;
   // table bookkeeping (IREC_FLAG_REUSE_TABLES): the key of every proposal table this call needs -- what it is a function
   // of (seed, S, D, window), which kernel writes it (the team encoder's rows carry copy bits) and where it lies -- is
   // compared with the slot's stamp ON THE DEVICE by the preparation kernel; a slot the call does not use is stamped with zeros,
@@ -952,7 +1016,8 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
       A2.deferred_pass = 1; A2.coop_W = 1;
       A2.counter = (unsigned int *)workspace + 2;
       for (int q = 0; q < 4; ++q) { A2.tab[q] = nullptr; A2.tab_dim[q] = -1; }
-      if (pl.team_only || pl.chunk) HIP_TRY(irec::launch_encode_generic(A2, (int)std::min<int64_t>(n_blocks, pl.fast_grid_cap), st));
+      if (out_margin) HIP_TRY(irec::launch_encode_generic(A2, (int)std::min<int64_t>(n_blocks, 2 * (ctx->n_cu > 0 ? ctx->n_cu : 256)), st));
+      else if (pl.team_only || pl.chunk) HIP_TRY(irec::launch_encode_generic(A2, (int)std::min<int64_t>(n_blocks, pl.fast_grid_cap), st));
       else HIP_TRY(irec::launch_encode_fast(A2, false, (int)std::min<int64_t>(n_blocks, pl.fast_grid_cap), st));
       return IREC_OK;
     };
@@ -985,7 +1050,8 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
         A.coop_W = share_W; A.tsplit_first = share_first; tgrid = share_grid;
         A.coop_test_orphan = (p->flags & IREC_FLAG_TEST_SPLIT_ORPHAN) ? 1 : 0;
       }
-      HIP_TRY(irec::launch_encode_team(A, tgrid, st));
+      if (out_margin) HIP_TRY(irec::launch_encode_team_margin(A, tgrid, st));
+      else HIP_TRY(irec::launch_encode_team(A, tgrid, st));
 #ifndef IREC_HOST_STAMPS
       if (irec_status s2 = deferred_pass()) return s2;
 #else
@@ -1043,6 +1109,7 @@ irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_
   } else if (pl.fast) {
     HIP_TRY(irec::launch_encode_fast(A, false, grid, st));
   } else {
+    if (out_margin) grid = (int)std::min<int64_t>(n_blocks, 2 * (ctx->n_cu > 0 ? ctx->n_cu : 256));
     HIP_TRY(irec::launch_encode_generic(A, grid, st));
   }
 #ifdef IREC_HOST_STAMPS

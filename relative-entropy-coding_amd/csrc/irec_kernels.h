@@ -55,6 +55,9 @@ struct EncArgs {
   uint32_t *ws_head;
   int32_t coop_beams;         // 1: the workgroups of a block share its beams (slots w, w + coop_W) instead of its samples
   int32_t coop_test_orphan;   // IREC_FLAG_TEST_SPLIT_ORPHAN: partners leave at once (exercises the give-up exit)
+  // top-B margins (irec_beam_encode_ex, IREC_FLAG_MARGINS): [n_blocks][4] floats, see "top-B margins" in irec_fast_common.h; nullptr in
+  // every other call.  Read by the margin builds of the team encoder (irec_team_margin.hip) and by the generic kernel only.
+  float *out_margin;
   // diagnostics (IREC_STAMPS=1): per-workgroup cycle sums [grid][8]; nullptr in normal runs
   unsigned long long *dbg;
 };
@@ -100,6 +103,8 @@ size_t team_ws_extra_for(int B, int S, int shape_override); // extra scratch-sla
 size_t team_ws_bytes_for(int B, int S, int shape_override, int max_K);   // whole scratch slab of one team of that build
 size_t team_lds_for(int B, int S, int shape_override);  // LDS bytes of one workgroup, or (size_t)-1 when the configuration is not served
 hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st);
+bool team_margin_build(int B, int S, int shape_override);   // a MARGIN build of the team encoder serves this shape (irec_team_margin.hip)
+hipError_t launch_encode_team_margin(const EncArgs &A, int grid, hipStream_t st);
 const char *team_kernel_name(int B, int S, int shape_override);   // e.g. "encode_team_kernel<20,2,1>"
 const char *fast_kernel_name(int B, int S, bool table);
 hipError_t launch_alpha_choice(int64_t seed, int32_t S, int32_t D, int32_t K_tab, const uint16_t *dlog4r, uint16_t *tab,

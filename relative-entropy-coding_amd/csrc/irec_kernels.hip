@@ -199,6 +199,9 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
     }
     __syncthreads();
     const int K = misc[1];
+    const bool margins = A.out_margin != nullptr;
+    MarginAcc macc;
+    if (margins && tid == 0) margin_write(A.out_margin, blk, macc);   // (a block that is not coded keeps "no comparison")
     if (K > A.max_K || K > IREC_MAX_PARTITIONS_DEV) continue;
 
     int cur = 0, Bcur = 1;
@@ -289,7 +292,12 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
       // phase 3: top-B (beam_search_coder.py:85-89 / :104)
       const int Bnew = B < N ? B : N;
       for (int f = tid; f < N; f += GEN_NT) key[f] = score_key(__uint_as_float(key[f]));
-      select_topB_sync<GEN_NT>(key, N, Bnew, Bcur, sm, tid, WorkgroupSync());
+      select_topB_sync<GEN_NT>(key, N, Bnew, Bcur, sm, tid, WorkgroupSync(), nullptr,
+                               [&](int j, int32_t, int32_t, uint32_t key_) { if (margins) margin_stash(sm, j, key_); });
+      if (margins) {   // (uniform) how close was it?  irec_fast_common.h, "top-B margins"
+        if (tid < 64) margin_step(key, N, Bnew, Bcur, sm, lane, t == K - 1, macc);
+        __syncthreads();
+      }
       // phase 4: gather the surviving beams, extend their index paths (:92-95 / :105-106)
       if (tid < Bnew) {
         const int32_t sp_ = sel_s[tid], bp_ = sel_b[tid];
@@ -335,6 +343,7 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
         A.out_indices[blk * (int64_t)A.max_K + t] = (int32_t)(v >> 8);
         j = (int)(v & 255u);
       }
+      if (margins && K > 0) margin_write(A.out_margin, blk, macc);
     }
   }
 }

@@ -153,7 +153,11 @@ struct TeamBarrier {
 // the extra row buffers cost registers everywhere else (r03e A/B: B = 32 -14 %, B = 30 -2 %, B = 10 -3 % with it).
 // SHARE: the build of calls whose rows beyond one per CU are shared between teams (A.coop_W > 1, below) -- its own instantiation:
 // the exchange code costs the two-team builds their spill-free register allocation (r04: <20,2,1> 80 -> 400 B of scratch with it).
-template <int NB, int TEAMS, int BS, bool PASSES = false, bool ONE = false, bool SHARE = false>
+// MARGIN (round 5): the build behind irec_beam_encode_ex / IREC_FLAG_MARGINS -- after every selection wave 0 also takes the gap between
+// the last candidate kept and the best one rejected (margin_step, irec_fast_common.h) and the block leaves four floats in
+// A.out_margin; one team barrier more per step.  Instantiated in its own translation unit (irec_team_margin.hip) for the shapes the
+// BASELINE configurations run; every other call with margins takes the generic kernel.  Same indices and samples, bit for bit.
+template <int NB, int TEAMS, int BS, bool PASSES = false, bool ONE = false, bool SHARE = false, bool MARGIN = false>
 __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(EncArgs A) {
   using TeamLds = TeamLdsT<NB>;
   constexpr int TEAM_MB = team_mb(NB);
@@ -371,10 +375,12 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         if (qsh == 0) A.out_K[blk] = K;
         hsum[0] = 0;
         beta4[0] = 0u; // hash of the empty path is 1 = g^0
+        if constexpr (MARGIN) { if (qsh == 0) margin_write(A.out_margin, blk, MarginAcc()); }   // (a block that is not coded here keeps "no comparison")
       }
       tsync();
     }
     const int K = misc[1];
+    MarginAcc macc;
     if (K > A.max_K || K > IREC_MAX_PARTITIONS_DEV) continue;
     if (K > A.K_tab) { // beyond the table window: the fused-Philox pass codes it
       if (tid == 0 && qsh == 0) atomicAdd(A.defer_count, 1u);
@@ -873,12 +879,17 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
       constexpr bool QUICK_SEL = IREC_QUICK_SELECT && TEAMS <= 2 && !MULTI_PASS;   // (fast_common.h, select_topB_sync: not the 168-VGPR builds)
       if constexpr (QUICK_SEL && IREC_SELECT_ASSUME) __builtin_assume(N <= 1024);   // (host: one pass holds S * NB <= CMAX = 1024 candidates -- the
                                                                 //  selection's other paths fold away: -500 cycles per step, scripts/microbench/select_rates.hip)
-      select_topB_sync<NT, QUICK_SEL>(key_s, N, Bnew, Bcur, sm, tid, tsync, nullptr, [&](int j, int32_t sp_, int32_t bp_, uint32_t) {
+      select_topB_sync<NT, QUICK_SEL>(key_s, N, Bnew, Bcur, sm, tid, tsync, nullptr, [&](int j, int32_t sp_, int32_t bp_, uint32_t key_) {
         const int32_t nh = (int32_t)((uint32_t)hsum[cur * TEAM_MB + bp_] + (uint32_t)sp_ * (uint32_t)(69 + t));
         hsum[(cur ^ 1) * TEAM_MB + j] = nh;                    // (its discrete log: looked up by every wave in the update, below)
         sm->sel_bo[j] = beta4[cur * TEAM_MB + bp_];
         bp[(size_t)t * NB + j] = (sp_ << 6) | bp_;
+        if constexpr (MARGIN) margin_stash(sm, j, key_);
       });
+      if constexpr (MARGIN) {   // how close was it?  (wave 0; the barrier keeps the next step's partials off the keys meanwhile)
+        if (tid < 64) margin_step(key_s, N, Bnew, Bcur, sm, lane, t == K - 1, macc);
+        tsync();
+      }
 #endif
       TSTAMP(5);
       // ---------------- gather the surviving beams (beam_search_coder.py:92-93), prepare the next step ----------------
@@ -1040,6 +1051,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         A.out_indices[blk * (int64_t)A.max_K + t] = v >> 6;
         j = v & 63;
       }
+      if constexpr (MARGIN) margin_write(A.out_margin, blk, macc);
     }
     TSTAMP(8);
   }
@@ -1053,6 +1065,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 #endif
 }
 
+#ifndef IREC_TEAM_MARGIN_TU   // (irec_team_margin.hip compiles the team kernel's margin builds only)
 // ======================================================================================================
 //  encode_chunk_kernel: blocks of MORE than 1024 dims on the team encoder's tables (round 4).
 //
@@ -1639,6 +1652,7 @@ __global__ __launch_bounds__(256, IREC_CHOICE_WPE) void prep_kernel(PrepArgs P, 
   }
 }
 
+#endif   // IREC_TEAM_MARGIN_TU
 // ======================================================================================================
 //  launchers
 // ======================================================================================================
@@ -1698,6 +1712,7 @@ static TeamShape team_shape(int B, int S, int ovr) {
   if (B <= 60) return TeamShape{60, 1, 3, false};
   return TeamShape{0, 0, 0, false};
 }
+#ifndef IREC_TEAM_MARGIN_TU
 int team_count_for(int B, int S, int ovr) { return team_shape(B, S, ovr).teams; }
 int team_shareable(int B, int S, int ovr) {
   const TeamShape sh = team_shape(B, S, ovr);
@@ -1736,17 +1751,41 @@ size_t team_lds_for(int B, int S, int ovr) {
   return b <= FAST_LDS_LIMIT ? b : (size_t)-1;
 }
 
-template <int NB, int TEAMS, int BS, bool PASSES = false, bool ONE = false, bool SHARE = false>
+#endif   // IREC_TEAM_MARGIN_TU
+
+template <int NB, int TEAMS, int BS, bool PASSES = false, bool ONE = false, bool SHARE = false, bool MARGIN = false>
 static hipError_t launch_team_t(const EncArgs &A, int grid, hipStream_t st) {
   const int ps = team_row(NB, A.B);
   const int sp = (TEAMS == 1 || PASSES) ? team_s_pass(NB, A.S, TEAMS, TEAMS == 1 ? 2048 : 1024, PASSES, ps) : A.S;
   const size_t lds = team_lds_total(NB, A.S, sp, TEAMS, PASSES, ps);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_team_kernel<NB, TEAMS, BS, PASSES, ONE, SHARE>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_team_kernel<NB, TEAMS, BS, PASSES, ONE, SHARE, MARGIN>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((encode_team_kernel<NB, TEAMS, BS, PASSES, ONE, SHARE>), dim3(grid), dim3(TEAMS * BS * TEAM_NT), lds, st, A);
+  hipLaunchKernelGGL((encode_team_kernel<NB, TEAMS, BS, PASSES, ONE, SHARE, MARGIN>), dim3(grid), dim3(TEAMS * BS * TEAM_NT), lds, st, A);
   return hipGetLastError();
 }
+
+#ifdef IREC_TEAM_MARGIN_TU
+// ---- margin builds (irec_beam_encode_ex, IREC_FLAG_MARGINS): the shapes the BASELINE configurations run ----
+static int team_margin_key(int B, int S, int ovr) {
+  const TeamShape sh = team_shape(B, S, ovr);
+  if (!sh.nb || sh.passes || sh.one) return 0;
+  const int key = sh.nb * 100 + sh.teams * 10 + sh.bs;
+  return (key == 2031 || key == 2021 || key == 1031 || key == 1021 || key == 3013) ? key : 0;
+}
+bool team_margin_build(int B, int S, int shape_override) { return team_margin_key(B, S, shape_override) != 0; }
+hipError_t launch_encode_team_margin(const EncArgs &A, int grid, hipStream_t st) {
+  if (A.out_margin == nullptr || A.coop_W > 1) return hipErrorInvalidValue;   // (no rows are shared under IREC_FLAG_MARGINS)
+  switch (team_margin_key(A.B, A.S, A.shape_override)) {
+    case 2031: return launch_team_t<20, 3, 1, false, false, false, true>(A, grid, st);
+    case 2021: return launch_team_t<20, 2, 1, false, false, false, true>(A, grid, st);
+    case 1031: return launch_team_t<10, 3, 1, false, false, false, true>(A, grid, st);
+    case 1021: return launch_team_t<10, 2, 1, false, false, false, true>(A, grid, st);
+    case 3013: return launch_team_t<30, 1, 3, false, false, false, true>(A, grid, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+#else
 
 hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
   const TeamShape sh = team_shape(A.B, A.S, A.shape_override);
@@ -1839,5 +1878,7 @@ hipError_t launch_alpha_choice(int64_t seed, int32_t S, int32_t D, int32_t K_tab
                                const uint32_t *keep, hipStream_t st) {
   return launch_alpha_choice_all(seed, S, K_tab, dlog4r, 1, &D, &tab, &keep, st);
 }
+
+#endif   // IREC_TEAM_MARGIN_TU
 
 } // namespace irec

@@ -208,9 +208,12 @@ class Engine:
                 return False
         return _Session()
 
-    def plan(self, params, lay, max_K):
+    def plan(self, params, lay, max_K, margins=False):
         """What irec_beam_encode launches for this call (kernel names, grid, LDS, table window): irec_encode_plan."""
         params = self.with_table_dims(params, lay)
+        if margins:
+            params = self.params(params.kl_per_partition, params.n_samples, params.n_beams, params.flags | _lib.IREC_FLAG_MARGINS,
+                                 list(params.table_dims), params.table_steps)
         info = _lib.IrecPlanInfo()
         _lib.check(self.lib.irec_encode_plan(self.ctx, ctypes.byref(params), lay.n_blocks, lay.max_dim, int(max_K),
                                              ctypes.byref(info)), "irec_encode_plan")
@@ -241,6 +244,30 @@ class Engine:
                                           _ptr(q_scale), _ptr(p_loc), _ptr(p_scale), _ptr(out_kl), _ptr(out_K),
                                           self._stream()), "irec_block_kl")
         return out_kl, out_K
+
+    def encode_blocks_margins(self, params, lay, q_loc, q_scale, p_loc, p_scale, seed, max_K):
+        """encode_blocks that also reports how close every block's top-B selections were (irec_beam_encode_ex, include/irec.h):
+        returns (K, indices, sample, margin [n_blocks, 4] float32) -- the same K, indices and sample as encode_blocks, bit for bit."""
+        for t in (q_loc, q_scale, p_loc, p_scale):
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.device == self.device
+            assert t.numel() == lay.n_tensors * lay.n
+        params = self.with_table_dims(params, lay)
+        params = self.params(params.kl_per_partition, params.n_samples, params.n_beams, params.flags | _lib.IREC_FLAG_MARGINS,
+                             list(params.table_dims), params.table_steps)
+        out_K = torch.empty(lay.n_blocks, dtype=torch.int32, device=self.device)
+        out_idx = torch.empty((lay.n_blocks, max(max_K, 1)), dtype=torch.int32, device=self.device)
+        sample = torch.empty_like(q_loc)
+        margin = torch.empty((lay.n_blocks, 4), dtype=torch.float32, device=self.device)
+        ws, need = self.workspace(params, lay.max_dim, max_K)
+        session = getattr(self._tls, "session", None)
+        if session is not None:
+            session["key"] = None
+        _lib.check(self.lib.irec_beam_encode_ex(self.ctx, ctypes.byref(params), lay.n_blocks, _ptr(lay.block_base),
+                                                _ptr(lay.block_pos), _ptr(lay.block_dim), lay.max_dim, _ptr(lay.perm),
+                                                _ptr(q_loc), _ptr(q_scale), _ptr(p_loc), _ptr(p_scale), int(seed),
+                                                int(max_K), _ptr(out_K), _ptr(out_idx), _ptr(sample), _ptr(margin), _ptr(ws),
+                                                ws.numel(), self._stream()), "irec_beam_encode_ex")
+        return out_K, out_idx, sample, margin
 
     def encode_blocks(self, params, lay, q_loc, q_scale, p_loc, p_scale, seed, max_K, out=None, order_by_K=False):
         """Asynchronous.  Returns device tensors (K [n_blocks], indices [n_blocks, max_K], sample [like q_loc]),
