@@ -186,6 +186,63 @@ def skewed_K_leg(eng, device, n_tensors, reps, check):
     return out_
 
 
+def margins_leg(eng, device, params, lay, q, out, S, max_K):
+    """Encoder-side exposure of index parity, from the device, over EVERY block of a step (round 4's review, "Next" #1): the call of
+    the timed region once more through irec_beam_encode_ex (outside the timed region) -- same K / indices / sample, asserted -- plus
+    four floats per block: the smallest gap between the last candidate kept and the best one rejected over the block's steps, and
+    the winner's lead at the last step (beam_search_coder.py:85-89,118-122).  An index can differ under another float32 summation
+    order (TensorFlow's reduce_sum) only where such a comparison is closer than the orders disagree; the noise figures
+    are the literal-vs-canonical score differences scripts/margins.py measured for these statistics (profiles/margins.json), the
+    measured flip rate next to them is scripts/margins_flips.py's (profiles/margins_flips.json, >= 10^5 blocks on the CPU).
+    K = ceil(KL / Omega) (:57-59): exposed where KL / Omega lies within the float32-sum noise of an integer (scripts/k_margins.py)."""
+    import torch
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    eng.encode_blocks_margins(params, lay, *q, SEED, max_K)           # (scratch of the flag's plan allocated, tables built)
+    ev[0].record()
+    K2, idx2, samp2, mg = eng.encode_blocks_margins(params, lay, *q, SEED, max_K)
+    ev[1].record()
+    torch.cuda.synchronize(device)
+    plan = eng.plan(params, lay, max_K, margins=True)
+    assert torch.equal(K2, out[0]) and torch.equal(samp2, out[2]), "margins call: K / sample differ from the timed call's"
+    live = torch.arange(max_K, device=device)[None, :] < out[0][:, None]
+    assert bool(((idx2 == out[1]) | ~live).all()), "margins call: indices differ from the timed call's"
+    m = mg.cpu().numpy().astype(np.float64)
+    gap, at, top, top_at = m[:, 0], m[:, 1], m[:, 2], m[:, 3]
+    small = np.minimum(gap, top)                                       # the closest comparison that decides an index of the block
+    fin = np.isfinite(small)
+    edges = [0.0, 1e-6, 3e-6, 1e-5, 3e-5, 1e-4, 3e-4, 1e-3, 1e-2, 1e-1, 1.0, np.inf]
+    noise_p99, noise_max = 4.6e-5, 6.5e-5                              # profiles/margins.json, by_regime "SURVEY 8d statistics"
+    rel = gap[np.isfinite(gap)] / np.maximum(at[np.isfinite(gap)], 1e-30)
+    kl, Kk = eng.block_kl(params, lay, *q)
+    x = kl.cpu().numpy().astype(np.float64) / float(np.float32(OMEGA))
+    dK = np.abs(x - np.rint(x))
+    k_noise = 2.0e-5                                                   # float32-sum noise of KL / Omega, profiles/margins.json k_margin (max 1.7e-5)
+    res = {"what": "per block: min over its steps of score(last kept) - score(best rejected), and the winner's lead at the last step "
+                   "(irec_beam_encode_ex; include/irec.h)", "blocks": int(m.shape[0]), "kernel": plan["kernel"],
+           "ms_per_call": float(ev[0].elapsed_time(ev[1])), "same_outputs_as_the_timed_call": True,
+           "set_gap_quantiles": {str(qq): float(np.quantile(gap[np.isfinite(gap)], qq)) for qq in (0.0, 1e-5, 1e-4, 1e-3, 1e-2, 0.1, 0.5)},
+           "winner_lead_quantiles": {str(qq): float(np.quantile(top[np.isfinite(top)], qq)) for qq in (0.0, 1e-5, 1e-4, 1e-3, 1e-2, 0.1, 0.5)},
+           "set_gap_over_score_quantiles": {str(qq): float(np.quantile(rel, qq)) for qq in (0.0, 1e-4, 1e-2, 0.5)},
+           "closest_comparison_histogram": {"edges": [str(e) for e in edges], "blocks": np.histogram(small[fin], bins=edges)[0].tolist()},
+           "exact_ties_at_a_deciding_comparison": int((small == 0).sum()),
+           "noise": {"score_noise_p99": noise_p99, "score_noise_max": noise_max, "source": "profiles/margins.json (literal vs canonical, these statistics)"},
+           "blocks_closer_than_noise_p99": float((small < noise_p99).mean()), "blocks_closer_than_noise_max": float((small < noise_max).mean()),
+           "K_exposure": {"what": "|KL / Omega - nearest integer| per block (irec_block_kl)", "blocks_within_float32_sum_noise": float((dK < k_noise).mean()),
+                          "noise": k_noise, "margin_quantiles": {str(qq): float(np.quantile(dK, qq)) for qq in (0.0, 1e-4, 1e-2, 0.5)}}}
+    fj = os.path.join(ROOT, "profiles", "margins_flips.json")
+    if os.path.exists(fj):
+        fl = json.load(open(fj))
+        res["measured_on_cpu"] = {"source": "profiles/margins_flips.json (scripts/margins_flips.py: canonical vs literal restatement, same statistics)",
+                                  "blocks": fl.get("blocks"), "index_flips": fl.get("index_flips_literal_vs_canonical"),
+                                  "flip_rate_per_block": fl.get("measured_flip_rate_per_block"), "K_differs": fl.get("K_differs_literal_vs_canonical"),
+                                  "predicted_exposure_below_noise_max": (fl.get("predicted_exposure") or {}).get("blocks_below_noise_max")}
+    log(f"secondary margins: {plan['kernel']} {res['ms_per_call']:.1f} ms; closest comparison below noise p99 / max: "
+        f"{100 * res['blocks_closer_than_noise_p99']:.3f} % / {100 * res['blocks_closer_than_noise_max']:.3f} % of {res['blocks']} blocks, "
+        f"{res['exact_ties_at_a_deciding_comparison']} exact ties; K exposed: {100 * res['K_exposure']['blocks_within_float32_sum_noise']:.4f} %")
+    del K2, idx2, samp2, mg
+    return res
+
+
 def host_cores():
     """Cores this process may run on (cgroup / affinity aware)."""
     try:
@@ -541,6 +598,7 @@ def run_rank(args):
             secondary_config(eng, device, "block_size = 2048, 512 latents of 8192 dims", OMEGA, EPS1, BEAMS, 512, N_DIMS, 5, 2, big, block_size=2048, max_K=128),
             secondary_config(eng, device, "block_size = None (one 8192-dim block per latent), 512 latents", OMEGA, EPS1, BEAMS, 512, N_DIMS, 3, 2, big, block_size=None, max_K=128)]
         result["secondary"]["skewed_K"] = skewed_K_leg(eng, device, 8192, 5, 16)
+        result["secondary"]["margins"] = margins_leg(eng, device, params, lay, q, out, S, max_K)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
         cb = cpu_baselines(q, args.cpu_ref_latents, args.cpu_opt_seconds)

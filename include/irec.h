@@ -201,6 +201,23 @@ irec_status irec_create(int device, irec_context **out);
  * permutation of Coder.split, is a caller argument already: `perm` of irec_beam_encode / irec_beam_decode.)
  * All entries 1..10006 must be finite (IREC_E_INVALID otherwise). */
 irec_status irec_create_ex(int device, const float *lut10007, irec_context **out);
+/* The context's caller-supplied tables in one (extensible) struct; zero-initialise it, every member is optional.
+ *   lut10007       as irec_create_ex.
+ *   aux_ratios     host float [n_aux_ratios]: the FITTED auxiliary-variance ratios of a coder constructed with
+ *                  extrapolate_auxiliary_ratios=False -- the values of its `aux_variable_variance_ratios` variable, which
+ *                  GaussianCoder.get_auxiliary_ratio(index) returns in place of the power law (coder.py:203-231; the SGD fitter that
+ *                  produces them, coder.py:233-410, stays on the caller's side: SURVEY.md §2).  Every entry must lie in (0, 1].
+ *                  A block whose K = ceil(KL / Omega) exceeds n_aux_ratios is NOT coded (out_K = K is still written, as for K > max_K):
+ *                  the reference raises "KL divergence higher than auxiliary variables can account for" there (coder.py:222-229), and so
+ *                  does the Python mirror.  The decoder treats such a row as not decodable.  irec_max_partitions(ctx) tells the bound. */
+typedef struct {
+  const float *lut10007;
+  const float *aux_ratios;
+  int32_t n_aux_ratios;
+} irec_tables;
+irec_status irec_create_with(int device, const irec_tables *tables, irec_context **out);
+/* Partitions the context's auxiliary ratios cover: IREC_MAX_PARTITIONS (power law) or n_aux_ratios. */
+int32_t irec_max_partitions(const irec_context *ctx);
 void irec_destroy(irec_context *ctx);
 
 /* Bytes of device scratch irec_beam_encode needs for blocks of at most max_dim dims and max_K partitions. */

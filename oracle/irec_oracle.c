@@ -326,7 +326,16 @@ int32_t irec_oracle_simple_hash(const int32_t *idx, int n) {
 
 /* get_auxiliary_ratio, coder.py:16,218-220: np.power(i + 1., -0.7864636765648174), then cast to float32 when it
  * multiplies a float32 tensor (beam_search_coder.py:68). */
-float irec_oracle_aux_ratio(int i) { return (float)pow((double)i + 1.0, -0.7864636765648174); }
+/* get_auxiliary_ratio (coder.py:218-231): the power law, or -- extrapolate_auxiliary_ratios=False -- entry i of the fitted table the caller set
+ * (irec_oracle_set_aux_ratios; test infrastructure: one process-wide table, as irec_oracle_set_lut's). */
+static const float *g_aux_ratios = 0;
+static int g_n_aux_ratios = 0;
+void irec_oracle_set_aux_ratios(const float *ratios, int n) { g_aux_ratios = n > 0 ? ratios : 0; g_n_aux_ratios = n > 0 ? n : 0; }
+int irec_oracle_max_partitions(void) { return g_aux_ratios ? g_n_aux_ratios : 65536; }
+float irec_oracle_aux_ratio(int i) {
+  if (g_aux_ratios) return i < g_n_aux_ratios ? g_aux_ratios[i] : 1.0f;
+  return (float)pow((double)i + 1.0, -0.7864636765648174);
+}
 
 /* Canonical reduction tree: dims in groups of 256; inside a group "lane" l (0..63) owns dims
  * 4l..4l+3 and has already produced part[l]; pair lanes at distance 32,16,8,4,2,1; groups added in order. */

@@ -71,6 +71,7 @@ def lib():
         L.irec_oracle_tf_shuffle_perm.argtypes = [ctypes.c_int64, ctypes.c_int64, i64p]
         L.irec_oracle_simple_hash.argtypes = [i32p, ctypes.c_int]
         L.irec_oracle_simple_hash.restype = ctypes.c_int32
+        L.irec_oracle_set_aux_ratios.argtypes = [f32p, ctypes.c_int]
         L.irec_oracle_aux_ratio.argtypes = [ctypes.c_int]
         L.irec_oracle_aux_ratio.restype = ctypes.c_float
         L.irec_oracle_block_kl.argtypes = [ctypes.c_int, ctypes.c_int, f32p, f32p, f32p, f32p]
@@ -221,6 +222,20 @@ def tf_shuffle_perm(seed, n):
 def simple_hash(idx):
     a = np.ascontiguousarray(idx, dtype=np.int32)
     return lib().irec_oracle_simple_hash(_p(a, ctypes.c_int32), len(a))
+
+
+_aux_keep = None
+
+
+def set_aux_ratios(ratios=None):
+    """Fitted auxiliary-variance ratios (extrapolate_auxiliary_ratios=False, coder.py:203-231) for every later call; None: the power law."""
+    global _aux_keep
+    if ratios is None:
+        _aux_keep = None
+        lib().irec_oracle_set_aux_ratios(None, 0)
+    else:
+        _aux_keep = np.ascontiguousarray(ratios, dtype=np.float32)      # (the C side keeps the pointer)
+        lib().irec_oracle_set_aux_ratios(_p(_aux_keep, ctypes.c_float), int(_aux_keep.size))
 
 
 def aux_ratio(i):

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(DEC_NT) __attribute__((amdgpu_waves_per_eu(6, 8))) 
     const int32_t *idx = A.indices + blk * (int64_t)A.max_K;
     const int d0 = chunk * 256 + lane * 4;
     const bool live = d0 < D;
-    if (K > A.max_K || K < 0) {                               // not decodable: its elements come out as mu_p (as the staged decoder's)
+    if (K > A.max_K || K > A.K_limit || K < 0) {                               // not decodable: its elements come out as mu_p (as the staged decoder's)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         if (d0 + i < D) {
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(IREC_DEC_W
         const float sp = d0 + i < D ? region[at[i]] : 0.f;
         var_p[i] = sp * sp;
       }
-      if (K >= 0 && K <= A.max_K) {                         // (else not decodable: its elements come out as mu_p)
+      if (K >= 0 && K <= A.max_K && K <= A.K_limit) {                         // (else not decodable: its elements come out as mu_p)
         const uint16_t *tab = nullptr;
         const int Dp = (D + 3) & ~3;
         if (TABLE && K <= A.K_tab) {
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(IREC_DEC_W
       if (chunk * 256 >= D) continue;
       const int64_t row = A.block_row ? (int64_t)A.block_row[tensor * bpt + j] : tensor * bpt + j;
       const int K = A.K[row];
-      if (K < 0 || K > A.max_K) continue;                   // not decodable: its elements come out as mu_p
+      if (K < 0 || K > A.max_K || K > A.K_limit) continue;                   // not decodable: its elements come out as mu_p
       const int32_t *idx = A.indices + row * (int64_t)A.max_K;
       const int d0 = chunk * 256 + lane * 4;
       float var_p[4], smp[4];
@@ -504,9 +504,9 @@ __global__ __launch_bounds__(256) void decode_kernel(DecArgs A) {
     const int K = A.K[blk];
     const int32_t *idx = A.indices + blk * (int64_t)A.max_K;
     bool bad_idx = false;                                     // (every thread reads the same row: uniform over the workgroup)
-    if (K >= 0 && K <= A.max_K)
+    if (K >= 0 && K <= A.max_K && K <= A.K_limit)
       for (int t = 0; t < K; ++t) bad_idx |= (uint32_t)idx[t] >= (uint32_t)A.S;
-    if (K > A.max_K || K < 0 || bad_idx) {                    // not decodable: its elements come out as mu_p
+    if (K > A.max_K || K > A.K_limit || K < 0 || bad_idx) {                    // not decodable: its elements come out as mu_p
       for (int d = tid; d < D; d += 256) {
         const int64_t ixo = base + (A.perm ? (int64_t)A.perm[pos + d] : (int64_t)(pos + d));
         A.out_sample[ixo] = 0.f + A.p_loc[ixo];

@@ -282,6 +282,7 @@ struct irec_context {
   float *d_lut2 = nullptr;
   uint16_t *d_dlog4r = nullptr;
   float *d_rho = nullptr;
+  int32_t n_rho = IREC_MAX_PARTITIONS;  // partitions the ratios cover: the power law's IREC_MAX_PARTITIONS, or the caller's table (irec_create_with)
   unsigned long long *d_dbg = nullptr; // IREC_STAMPS=1 diagnostics only
 };
 
@@ -405,9 +406,25 @@ irec_status irec_importance_decode(const float *p_loc, const float *p_scale, int
 
 irec_status irec_create(int device, irec_context **out) { return irec_create_ex(device, nullptr, out); }
 
-irec_status irec_create_ex(int device, const float *lut10007, irec_context **out) try {
+irec_status irec_create_ex(int device, const float *lut10007, irec_context **out) {
+  irec_tables t{};
+  t.lut10007 = lut10007;
+  return irec_create_with(device, &t, out);
+}
+
+int32_t irec_max_partitions(const irec_context *ctx) { return ctx ? ctx->n_rho : 0; }
+
+irec_status irec_create_with(int device, const irec_tables *tables, irec_context **out) try {
   if (!out) return fail(IREC_E_INVALID, "irec_create: null output");
   *out = nullptr;
+  const float *lut10007 = tables ? tables->lut10007 : nullptr;
+  const float *aux_ratios = tables ? tables->aux_ratios : nullptr;
+  const int32_t n_aux = tables ? tables->n_aux_ratios : 0;
+  if (aux_ratios) {   // fitted ratios (coder.py:203-231): positive numbers at most 1, as many as the caller has -- at most IREC_MAX_PARTITIONS
+    if (n_aux < 1 || n_aux > IREC_MAX_PARTITIONS) return fail(IREC_E_INVALID, "irec_create_with: n_aux_ratios %d out of range [1, %d]", n_aux, IREC_MAX_PARTITIONS);
+    for (int i = 0; i < n_aux; ++i)
+      if (!(aux_ratios[i] > 0.0f) || !(aux_ratios[i] <= 1.0f)) return fail(IREC_E_INVALID, "irec_create_with: aux_ratios[%d] is not in (0, 1]", i);
+  } else if (n_aux != 0) return fail(IREC_E_INVALID, "irec_create_with: n_aux_ratios without aux_ratios");
   if (lut10007)   // an injected quantile table must hold numbers: one NaN / inf entry would poison every score it touches
     for (int k = 1; k < IREC_BIG_PRIME; ++k)
       if (!std::isfinite(lut10007[k])) return fail(IREC_E_INVALID, "irec_create_ex: lut10007[%d] is not finite", k);
@@ -449,11 +466,14 @@ irec_status irec_create_ex(int device, const float *lut10007, irec_context **out
   std::vector<float> rho(IREC_MAX_PARTITIONS);
   for (int i = 0; i < IREC_MAX_PARTITIONS; ++i) // get_auxiliary_ratio, coder.py:16,218-220 (float64 -> float32)
     rho[i] = (float)std::pow((double)i + 1.0, -0.7864636765648174);
+  if (aux_ratios)   // ... or self.aux_variable_variance_ratios[index] (coder.py:231); entries past the table are never read (K_limit)
+    for (int i = 0; i < IREC_MAX_PARTITIONS; ++i) rho[i] = i < n_aux ? aux_ratios[i] : 1.0f;
 
   irec_context *ctx = new irec_context();
   ctx->device = device;
   ctx->n_cu = prop.multiProcessorCount;
   ctx->clock_mhz = prop.clockRate / 1000;
+  ctx->n_rho = aux_ratios ? n_aux : IREC_MAX_PARTITIONS;
   const irec_status st = [&]() -> irec_status { // any failure below frees what was allocated so far
     HIP_TRY(hipMalloc(&ctx->d_lut, P * sizeof(float)));
     HIP_TRY(hipMalloc(&ctx->d_lut2, (P - 1) * sizeof(float)));
@@ -879,6 +899,7 @@ irec_status irec_block_kl(irec_context *ctx, const irec_params *p, int64_t n_blo
   A.block_base = block_base; A.block_pos = block_pos; A.block_dim = block_dim; A.perm = perm;
   A.q_loc = q_loc; A.q_scale = q_scale; A.p_loc = p_loc; A.p_scale = p_scale;
   A.n_blocks = n_blocks; A.omega = p->kl_per_partition; A.S = p->n_samples; A.B = p->n_beams; A.out_K = out_K;
+  A.K_limit = ctx->n_rho;
   const int grid = (int)std::min<int64_t>(n_blocks, 8LL * ctx->n_cu);
   HIP_TRY(irec::launch_block_kl(A, out_kl, grid, (hipStream_t)hip_stream));
   return IREC_OK;
@@ -930,6 +951,7 @@ irec_status irec_beam_encode_ex(irec_context *ctx, const irec_params *p, int64_t
   A.q_loc = q_loc; A.q_scale = q_scale; A.p_loc = p_loc; A.p_scale = p_scale;
   A.n_blocks = n_blocks; A.seed = seed;
   A.omega = p->kl_per_partition; A.S = p->n_samples; A.B = p->n_beams; A.max_K = max_K;
+  A.K_limit = ctx->n_rho;
   A.out_K = out_K; A.out_indices = out_indices; A.out_sample = out_sample;
   A.lut = ctx->d_lut; A.lut2 = ctx->d_lut2; A.dlog4r = ctx->d_dlog4r; A.rho = ctx->d_rho;
   // workspace head: counter block (WS_COUNTER_BYTES, zeroed per call: [0] block counter of the first pass, [1] deferred-block
@@ -1197,6 +1219,7 @@ static irec_status beam_decode_impl(irec_context *ctx, const irec_params *p, int
   A.block_base = block_base; A.block_pos = block_pos; A.block_dim = block_dim; A.perm = perm;
   A.p_loc = p_loc; A.p_scale = p_scale; A.n_blocks = n_blocks; A.seed = seed; A.max_K = max_K; A.K = K;
   A.indices = indices; A.out_sample = out_sample; A.lut = ctx->d_lut; A.rho = ctx->d_rho;
+  A.K_limit = ctx->n_rho;
   A.upb = dp.upb; A.S = p->n_samples; A.K_tab = dp.K_tab; A.lut2 = ctx->d_lut2; A.dlog4r = ctx->d_dlog4r;
   for (int q = 0; q < 4; ++q) { A.tab[q] = nullptr; A.tab_dim[q] = -1; }
   for (int q = 0; q < dp.n_tab && dp.K_tab > 0; ++q) {

@@ -18,6 +18,8 @@ struct EncArgs {
   const float *q_loc, *q_scale, *p_loc, *p_scale;
   int64_t n_blocks; int64_t seed;
   float omega; int32_t S, B, max_K;
+  int32_t K_limit;   // partitions the context's auxiliary ratios cover: IREC_MAX_PARTITIONS_DEV (the power law of coder.py:16), or the length of the
+                     // caller's fitted table (irec_create_with) -- a block that needs more is not coded (coder.py:222-229 raises for it)
   // outputs
   int32_t *out_K; int32_t *out_indices; float *out_sample;
   // constant tables of the context
@@ -67,6 +69,7 @@ struct DecArgs {
   const float *p_loc, *p_scale;
   int64_t n_blocks; int64_t seed;
   int32_t max_K; const int32_t *K; const int32_t *indices; float *out_sample;
+  int32_t K_limit;   // as EncArgs::K_limit: a row with more partitions than the context's ratios cover is not decodable
   const float *lut; const float *rho;
   // wave-granular decoder (irec_decode.hip): upb = 256-dim units per block (0: the call gave no dim hints -> round-2 kernel),
   // quantile table in discrete-log order, and the per-call proposal tables tab[q][t][s][d] = 4 * dlog_g(r) of the first

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
     if (A.deferred_pass) { // second pass of a windowed-table call of the team encoder (B > 32): only the blocks it left
       if (*A.defer_count == 0u) break;   // (uniform over the grid: nothing was deferred)
       const int32_t k1 = A.out_K[blk];
-      if (k1 <= A.K_tab || k1 > A.max_K) continue;
+      if (k1 <= A.K_tab || k1 > A.max_K || k1 > A.K_limit) continue;
     }
     const int D = A.block_dim[blk];
     const int64_t base = A.block_base[blk];
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(GEN_NT) void encode_generic_kernel(EncArgs A) {
     const bool margins = A.out_margin != nullptr;
     MarginAcc macc;
     if (margins && tid == 0) margin_write(A.out_margin, blk, macc);   // (a block that is not coded keeps "no comparison")
-    if (K > A.max_K || K > IREC_MAX_PARTITIONS_DEV) continue;
+    if (K > A.max_K || K > A.K_limit) continue;
 
     int cur = 0, Bcur = 1;
     for (int t = 0; t < K; ++t) {
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
     if (!TABLE && A.deferred_pass) { // second pass of a windowed-table call: only the blocks the table kernels left
       if (*A.defer_count == 0u) break;   // (uniform over the grid: nothing was deferred)
       const int32_t k1 = A.out_K[blk];
-      if (k1 <= A.K_tab || k1 > A.max_K) continue;
+      if (k1 <= A.K_tab || k1 > A.max_K || k1 > A.K_limit) continue;
     }
     const int D = A.block_dim[blk];
     const int64_t base = A.block_base[blk];
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
       __syncthreads();
     }
     const int K = misc[1];
-    if (K > A.max_K || K > IREC_MAX_PARTITIONS_DEV) continue;
+    if (K > A.max_K || K > A.K_limit) continue;
     if (TABLE && K > A.K_tab) { // beyond the table window: the fused-Philox pass codes it
       if (tid == 0 && coop_w == 0) atomicAdd(A.defer_count, 1u);
       continue;

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(LONE_NWV * 64, 1) void encode_lone_kernel(EncArgs A
     }
     const int32_t K = __builtin_amdgcn_readfirstlane(num_aux((float)tot, A.omega));
     if (lane == 0) A.out_K[blk] = K;
-    if (K > A.max_K || K > IREC_MAX_PARTITIONS_DEV) continue;
+    if (K > A.max_K || K > A.K_limit) continue;
     if (K > A.K_tab) { // beyond the table window: the fused-Philox pass codes it
       if (lane == 0) atomicAdd(A.defer_count, 1u);
       continue;

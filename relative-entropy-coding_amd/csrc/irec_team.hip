@@ -381,7 +381,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
     }
     const int K = misc[1];
     MarginAcc macc;
-    if (K > A.max_K || K > IREC_MAX_PARTITIONS_DEV) continue;
+    if (K > A.max_K || K > A.K_limit) continue;
     if (K > A.K_tab) { // beyond the table window: the fused-Philox pass codes it
       if (tid == 0 && qsh == 0) atomicAdd(A.defer_count, 1u);
       continue;
@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
     }
     tsync();
     const int K = misc[1];
-    if (K > A.max_K || K > IREC_MAX_PARTITIONS_DEV) continue;
+    if (K > A.max_K || K > A.K_limit) continue;
     if (K > A.K_tab) { // beyond the table window: the second pass (generic kernel) codes it
       if (tid == 0) atomicAdd(A.defer_count, 1u);
       continue;

@@ -38,6 +38,11 @@ class IrecParams(ctypes.Structure):
                 ("flags", ctypes.c_int32), ("table_dims", ctypes.c_int32 * 4), ("table_steps", ctypes.c_int32)]
 
 
+class IrecTables(ctypes.Structure):
+    """irec_tables of include/irec.h: the caller-supplied tables of a context (irec_create_with)."""
+    _fields_ = [("lut10007", ctypes.c_void_p), ("aux_ratios", ctypes.c_void_p), ("n_aux_ratios", ctypes.c_int32)]
+
+
 class IrecPlanInfo(ctypes.Structure):
     """irec_plan_info of include/irec.h."""
     _fields_ = [("kernel", ctypes.c_char * 64), ("table_kernel", ctypes.c_char * 32), ("grid", ctypes.c_int32),
@@ -72,6 +77,8 @@ SIGNATURES = {
     "irec_tf_random_normal": (ctypes.c_int, [_i64, _i64, _vp]),
     "irec_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
     "irec_create_ex": (ctypes.c_int, [ctypes.c_int, _vp, ctypes.POINTER(_vp)]),
+    "irec_create_with": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(IrecTables), ctypes.POINTER(_vp)]),
+    "irec_max_partitions": (_i32, [_vp]),
     "irec_destroy": (None, [_vp]),
     "irec_encode_workspace_bytes": (ctypes.c_size_t, [_vp, _PP, _i32, _i32]),
     "irec_encode_plan": (ctypes.c_int, [_vp, _PP, _i64, _i32, _i32, ctypes.POINTER(IrecPlanInfo)]),

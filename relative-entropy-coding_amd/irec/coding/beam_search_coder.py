@@ -51,6 +51,9 @@ class PendingCode:
         if (K_host < 0).any():
             raise CodingError("a block exceeded the engine's dimension bound")
         need = int(K_host.max()) if K_host.size else 0
+        limit = getattr(self.coder._engine_for(self.K), "max_partitions", _lib.MAX_PARTITIONS) if not self.coder.extrapolate_auxiliary_ratios else _lib.MAX_PARTITIONS
+        if need > limit:                 # fitted ratios: GaussianCoder.get_auxiliary_ratio raises for the first index past the table
+            self.coder.get_auxiliary_ratio(need - 1)
         if need > _lib.MAX_PARTITIONS:   # (before any hint is touched: one degenerate block -- an infinite KL reads back as
             # 10^9 partitions -- must not leave the coder, or the model that shares its hints, asking for more than the library takes)
             raise CodingError(f"KL divergence needs {need} partitions; this build supports {_lib.MAX_PARTITIONS}")
@@ -238,7 +241,7 @@ class BeamSearchCoder(GaussianCoder):
         if shared is None:
             shared = not self.no_split and self._split_pause == 0
         if not self.extrapolate_auxiliary_ratios:
-            raise CodingError("only extrapolate_auxiliary_ratios=True is supported on the beam-search path")
+            self.get_auxiliary_ratio(0)          # (raises the reference's "has not been initialized yet", coder.py:222-225)
         if not (1 <= self.n_beams <= _lib.MAX_BEAMS):
             raise CodingError(f"n_beams must be in [1, {_lib.MAX_BEAMS}], got {self.n_beams}")
         if self.n_samples < 1:
@@ -259,10 +262,20 @@ class BeamSearchCoder(GaussianCoder):
         return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
     def _engine_for(self, tensor):
-        if self.engine is not None:
+        if self.engine is not None and self.extrapolate_auxiliary_ratios:
             return self.engine
         t = torch.as_tensor(tensor)
-        return get_engine(t.device if t.device.type == "cuda" else None)
+        if self.extrapolate_auxiliary_ratios:
+            return get_engine(t.device if t.device.type == "cuda" else None)
+        # fitted ratios (extrapolate_auxiliary_ratios=False, coder.py:203-231): a context of this coder's own carries them
+        if getattr(self, "_ratio_engine", None) is None:
+            self.get_auxiliary_ratio(0)
+            dev = t.device if t.device.type == "cuda" else (self.engine.device if self.engine is not None else
+                                                            torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None)
+            if dev is None:
+                raise _lib.IrecLibraryError("irec needs a HIP device (MI355X / gfx950); there is no CPU fallback")
+            self._ratio_engine = Engine(dev, lut=getattr(self.engine, "lut", None), aux_ratios=self.aux_variable_variance_ratios)
+        return self._ratio_engine
 
     def encode_tensors_device(self, q_loc, q_scale, p_loc, p_scale, seed, block_size, max_K=None, table_steps=None):
         """Asynchronous core of encode: launches the encoder on the current stream and returns a `PendingCode` -- K,

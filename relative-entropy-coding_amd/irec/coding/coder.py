@@ -1,8 +1,9 @@
 """Host mirror of rec/coding/coder.py for the beam-search path (reference file:line in each docstring).
 
-Only what `sampler='beam_search'` needs is implemented: the block split/merge bookkeeping and the extrapolated
-auxiliary-variance ratios.  The sampler-driven GaussianCoder.encode_block (coder.py:493-584) and the SGD ratio fitter
-(coder.py:233-410) are out of scope.
+Only what `sampler='beam_search'` needs is implemented: the block split/merge bookkeeping and the auxiliary-variance
+ratios -- extrapolated (the power law), or FITTED ones handed over as data (round 5).  The sampler-driven
+GaussianCoder.encode_block (coder.py:493-584) and the SGD ratio fitter that produces fitted ratios (coder.py:233-410) are
+out of scope.
 """
 import abc
 
@@ -82,18 +83,44 @@ class GaussianCoder(Coder):
         self.sampler = sampler
         self.kl_per_partition = np.float32(kl_per_partition)  # tf.cast(kl_per_partition, tf.float32), coder.py:192
         self.extrapolate_auxiliary_ratios = extrapolate_auxiliary_ratios
+        if not self.extrapolate_auxiliary_ratios:          # coder.py:203-216: the variables a checkpoint restores
+            self.aux_variable_variance_ratios = np.array([1.], dtype=np.float32)
+            self._initialized = False
+
+    def set_auxiliary_variance_ratios(self, ratios):
+        """The FITTED ratios of an extrapolate_auxiliary_ratios=False coder, as data: what the reference restores into
+        `aux_variable_variance_ratios` / `_initialized` from a checkpoint (coder.py:203-216).  The fitter itself
+        (update_auxiliary_variance_ratios, coder.py:233-410) stays on the caller's side."""
+        if self.extrapolate_auxiliary_ratios:
+            raise CodingError("this coder extrapolates its auxiliary ratios (extrapolate_auxiliary_ratios=True)")
+        r = np.ascontiguousarray(np.asarray(ratios, dtype=np.float32).reshape(-1))
+        if r.size < 1 or not np.all((r > 0) & (r <= 1)):
+            raise CodingError("auxiliary variance ratios must be a non-empty sequence of numbers in (0, 1]")
+        self.aux_variable_variance_ratios = r
+        self._initialized = True
+        self._ratio_engine = None
 
     def get_auxiliary_ratio(self, index):
-        """coder.py:218-220 (extrapolated power law only)."""
+        """coder.py:218-231."""
         if self.extrapolate_auxiliary_ratios:
             return np.power(index + 1., AUX_RATIO_POWER_LAW)
-        raise CodingError("Coder has not been initialized yet, please use extrapolation: fitted auxiliary "
-                          "variance ratios (update_auxiliary_variance_ratios) are outside the beam-search path")
+        if not self._initialized:
+            raise CodingError("Coder has not been initialized yet, please call"
+                              "update_auxiliary_variance_ratios() first"
+                              " or use extrapolation")
+        if index >= self.aux_variable_variance_ratios.shape[0]:
+            raise CodingError("KL divergence higher than auxiliary variables can account for. "
+                              "Update auxiliary variable ratios with high-enough KL divergence."
+                              "Maximum possible number of partitions is {}."
+                              "Requested {}".format(self.aux_variable_variance_ratios.shape[0], index + 1))
+        return self.aux_variable_variance_ratios[index]
 
     def update_auxiliary_variance_ratios(self, target_dist, coding_dist, seed=42, **kwargs):
-        """coder.py:233-264.  A no-op with extrapolated ratios (the coder is stateless)."""
+        """coder.py:233-264.  A no-op with extrapolated ratios (the coder is stateless); the SGD fit of
+        coder.py:265-410 is out of scope -- hand fitted ratios over with set_auxiliary_variance_ratios."""
         if not self.extrapolate_auxiliary_ratios:
-            raise CodingError("fitting auxiliary variance ratios is outside the beam-search path")
+            raise CodingError("fitting auxiliary variance ratios is outside the beam-search path: "
+                              "set_auxiliary_variance_ratios(ratios) takes fitted ones as data")
 
     def encode(self, target_dist, coding_dist, seed, **kwargs):
         raise CodingError("GaussianCoder with a rejection/importance sampler is outside the beam-search path; "

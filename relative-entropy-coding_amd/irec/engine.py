@@ -127,9 +127,10 @@ class Engine:
     """`lut` (optional, float32 [10007]): the caller's own table of Normal(0,1).quantile(float32(k)/10007) -- the values
     `dist.quantile` takes at beam_search_coder.py:48-49 -- instead of the library's restatement of TFP's float32 ndtri
     (irec_create_ex, include/irec.h).  An engine built this way is private to its creator: pass it to a coder as
-    `BeamSearchCoder(..., engine=...)`; `get_engine()` keeps handing out the default-table engine of the device."""
+    `BeamSearchCoder(..., engine=...)`; `get_engine()` keeps handing out the default-table engine of the device.
+    `aux_ratios` (optional, float32 [n]): fitted auxiliary-variance ratios in place of the power law (irec_create_with)."""
 
-    def __init__(self, device, lut=None):
+    def __init__(self, device, lut=None, aux_ratios=None):
         if not torch.cuda.is_available():
             raise _lib.IrecLibraryError("irec needs a HIP device (MI355X / gfx950); there is no CPU fallback")
         self.device = torch.device(device)
@@ -139,14 +140,22 @@ class Engine:
         self.device = torch.device("cuda", self.index)
         self.lib = _lib.load()
         ctx = ctypes.c_void_p()
-        if lut is None:
+        self.lut = None if lut is None else np.ascontiguousarray(np.asarray(lut), dtype=np.float32)   # (kept: a coder with fitted ratios builds a twin context)
+        if lut is None and aux_ratios is None:
             _lib.check(self.lib.irec_create(self.index, ctypes.byref(ctx)), "irec_create")
         else:
-            table = np.ascontiguousarray(np.asarray(lut), dtype=np.float32)
-            if table.shape != (_lib.BIG_PRIME,):
-                raise ValueError(f"lut must hold {_lib.BIG_PRIME} float32 values (entry k = quantile(k / 10007)), got shape {table.shape}")
-            _lib.check(self.lib.irec_create_ex(self.index, table.ctypes.data_as(ctypes.c_void_p), ctypes.byref(ctx)), "irec_create_ex")
+            tables = _lib.IrecTables(None, None, 0)
+            if lut is not None:
+                table = np.ascontiguousarray(np.asarray(lut), dtype=np.float32)
+                if table.shape != (_lib.BIG_PRIME,):
+                    raise ValueError(f"lut must hold {_lib.BIG_PRIME} float32 values (entry k = quantile(k / 10007)), got shape {table.shape}")
+                tables.lut10007 = table.ctypes.data
+            if aux_ratios is not None:   # fitted auxiliary-variance ratios (extrapolate_auxiliary_ratios=False, coder.py:203-231)
+                ratios = np.ascontiguousarray(np.asarray(aux_ratios), dtype=np.float32).reshape(-1)
+                tables.aux_ratios, tables.n_aux_ratios = ratios.ctypes.data, int(ratios.size)
+            _lib.check(self.lib.irec_create_with(self.index, ctypes.byref(tables), ctypes.byref(ctx)), "irec_create_with")
         self.ctx = ctx
+        self.max_partitions = int(self.lib.irec_max_partitions(ctx))
         self._layouts = {}
         self._ws = {}      # one scratch buffer per HIP stream: calls on different streams never share counters / slabs
         self._tls = threading.local()   # table_session(): key of the calling THREAD's previous call of a back-to-back run of twins

@@ -1608,3 +1608,43 @@ def test_table_session_skips_only_twin_calls(engine, oracle):
             for i in range(n_t):
                 assert idx[i] == refs[seed][i][0] and np.array_equal(sample[i].cpu().numpy(), refs[seed][i][1]), (seed, n_t, i)
     assert getattr(engine._tls, "session", None) is None
+
+
+def test_fitted_auxiliary_ratios_as_data(engine, oracle):
+    """Round 4's review (missing #4): a coder built with extrapolate_auxiliary_ratios=False reads its ratios from a variable a checkpoint
+    restores (coder.py:203-231).  The fitter stays out of scope; the fitted ratios are data: BeamSearchCoder.set_auxiliary_variance_ratios
+    -> irec_create_with(aux_ratios).  Same error behaviour as the reference: not initialised, and KL beyond the table."""
+    import irec
+    from irec.coding import CodingError
+    c = irec.BeamSearchCoder(kl_per_partition=3., n_beams=20, extra_samples=1.2, extrapolate_auxiliary_ratios=False, block_size=1000)
+    stats = oracle.synthetic_latent(5150, 8192)
+    q, p = _normal(stats[0][None], stats[1][None]), _normal(stats[2][None], stats[3][None])
+    with pytest.raises(CodingError, match="has not been initialized yet"):
+        c.encode(q, p, seed=42)
+    ratios = (0.9 * (np.arange(12) + 1.0) ** -0.7).astype(np.float32)      # some fitted table of 12 entries: not the power law
+    ratios[0] = 1.0
+    c.set_auxiliary_variance_ratios(ratios)
+    assert c.get_auxiliary_ratio(3) == ratios[3]
+    with pytest.raises(CodingError, match="higher than auxiliary variables can account for"):
+        c.get_auxiliary_ratio(12)
+    idx, sample = c.encode(q, p, seed=42)
+    oracle.set_aux_ratios(ratios)
+    try:
+        ridx, rs = oracle.encode_tensor(*stats, 42, 3.0, 36, 20, block_size=1000)
+        assert idx == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
+        oracle.set_aux_ratios(None)
+        pidx, _ = oracle.encode_tensor(*stats, 42, 3.0, 36, 20, block_size=1000)
+        assert pidx != ridx                                                   # (the table matters)
+    finally:
+        oracle.set_aux_ratios(None)
+    assert torch.equal(c.decode(p, idx, seed=42), sample)
+    assert c._engine_for(q.loc).max_partitions == 12
+    # a block whose KL asks for more partitions than the table has: the reference's error, nothing coded
+    sharp = oracle.synthetic_latent(5151, 8192)
+    sq = (sharp[1] * 0.25).astype(np.float32)                                # KL ~ 1.4 nats per dim more: K far beyond 12
+    with pytest.raises(CodingError, match="Maximum possible number of partitions is 12"):
+        c.encode(_normal(sharp[0][None], sq[None]), _normal(sharp[2][None], sharp[3][None]), seed=42)
+    # the default engine of the device is untouched
+    d = _coder(3.0, 20, 1.2, block_size=1000, variant="auto")
+    didx, _ = d.encode(q, p, seed=42)
+    assert didx == pidx
