@@ -113,6 +113,8 @@ typedef struct {
 #define IREC_TABLE_BYTES_MAX (64u << 20)
 #define IREC_TABLE_STEPS_FLOOR 8            /* ... but the byte bound never cuts the window below 8 steps (one step of S = 8103, */
 #define IREC_TABLE_BYTES_HARD (1u << 30)    /* the reference's largest, is 19 MB for 1000 + 192 dims) unless those exceed 1 GB   */
+#define IREC_TABLE_BYTES_BIG (4ull << 30)   /* the bound of calls whose blocks exceed 1024 dims (block_size = None on a whole tensor:  */
+                                            /* K grows with the dims -- an 8192-dim block has ~60 partitions of 590 KB of rows each)   */
 
 /* What irec_beam_encode does for a given call: filled by irec_encode_plan (same decision code as the launch). */
 typedef struct {

@@ -530,8 +530,11 @@ struct Plan {
 
 // steps of proposal tables the byte bounds allow at `per_step` bytes per step: what IREC_TABLE_BYTES_MAX holds, but not fewer
 // than IREC_TABLE_STEPS_FLOOR while those stay within IREC_TABLE_BYTES_HARD
-size_t table_steps_that_fit(size_t per_step) {
-  const size_t soft = (size_t)IREC_TABLE_BYTES_MAX / per_step, hard = (size_t)IREC_TABLE_BYTES_HARD / per_step;
+// (big: a call whose blocks exceed 1024 dims -- block_size = None on a whole tensor: K grows with the dims, and so must the window, or
+//  every block falls to the generic kernel's second pass: IREC_TABLE_BYTES_BIG)
+size_t table_steps_that_fit(size_t per_step, bool big = false) {
+  const size_t soft = (big ? (size_t)IREC_TABLE_BYTES_BIG : (size_t)IREC_TABLE_BYTES_MAX) / per_step;
+  const size_t hard = (big ? (size_t)IREC_TABLE_BYTES_BIG : (size_t)IREC_TABLE_BYTES_HARD) / per_step;
   return std::max(soft, std::min<size_t>((size_t)IREC_TABLE_STEPS_FLOOR, hard));
 }
 
@@ -561,7 +564,7 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
   {
     size_t per_step = 0;   // bytes of one partition step over all tables of the call
     for (int q = 0; q < 4 && p->table_dims[q] > 0; ++q) per_step += (size_t)S * round_up(p->table_dims[q], 4) * 2;
-    if (per_step > 0) pl.K_tab = std::max(1, (int)std::min<size_t>((size_t)pl.K_tab, table_steps_that_fit(per_step)));
+    if (per_step > 0) pl.K_tab = std::max(1, (int)std::min<size_t>((size_t)pl.K_tab, table_steps_that_fit(per_step, max_dim > irec::FAST_MAX_DIM)));
   }
   // B > 32 has no one-workgroup-per-block encoder; where the team encoder serves it (32 < B <= 60) it is the only table
   // consumer and its deferred pass is the generic kernel
@@ -621,7 +624,7 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
     } else if (pl.chunk) {   // one slab per team of the chunked encoder; the generic kernel's second pass lies over the same slabs
       pl.one_grid_cap = 0;
       pl.fast_grid_cap = 2 * n_cu;
-      pl.grid_cap = std::max(irec::chunk_teams() * n_cu, pl.fast_grid_cap);
+      pl.grid_cap = std::max(irec::chunk_teams(B, S) * n_cu, pl.fast_grid_cap);
       pl.ws_per_wg = std::max(generic_ws, round_up_sz(irec::chunk_ws_for(B, pl.dpad, max_K), 256));
     } else {
       pl.one_grid_cap = pl.grid_cap; pl.fast_grid_cap = 0;
@@ -824,11 +827,11 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
   }
   if (pl.chunk) {
     const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
-    std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::chunk_kernel_name(B));
+    std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::chunk_kernel_name(B, S));
     std::snprintf(out->table_kernel, sizeof out->table_kernel, "prep_kernel (copy bits)");
     out->grid = batch_grid(n_blocks, n_cu);
-    out->waves_per_wg = irec::chunk_teams() * 4;
-    out->teams_per_wg = irec::chunk_teams();
+    out->waves_per_wg = irec::chunk_teams(B, S) * 4;
+    out->teams_per_wg = irec::chunk_teams(B, S);
     out->lds_bytes = (int32_t)irec::chunk_lds_for(B, S);
   } else if (team && pl.lone) {
     const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;

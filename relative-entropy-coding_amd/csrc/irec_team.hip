@@ -1081,11 +1081,11 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 //              group order"), so the bits are encode_generic_kernel's;
 //    update    per chunk: the selected parents and proposal rows -> new beams into the slab's other buffer.
 //  A (chunk, dim group) is read and written by ONE wave in both phases: no cross-wave traffic through global memory, the
-//  only shared state is the team's LDS (partials, running scores / keys, selection).  Scoring is the plain form (a dim
-//  slot's look-ups issued together, then consumed); two teams per CU at 256 VGPRs.
+//  only shared state is the team's LDS (partials, running scores / keys, selection).  Two teams per CU at 256 VGPRs for up to 20
+//  beams; one team (beam passes of 10 / 16) for 30 / 32 beam slots, whose partials take the LDS of two.
 //  Slab of a team: stats [3][Dpad] | cvar [2][Dpad] (by step parity) | sa [Dpad] | beams [2][NB][Dpad] | bp [max_K][NB].
 // ======================================================================================================
-constexpr int CHUNK_MAX_DIM = 16384;
+constexpr int CHUNK_MAX_DIM = 65536;
 __host__ __device__ inline size_t chunk_ws_bytes(int NB, int dpad, int max_K) {
   return (size_t)(6 + 2 * NB) * dpad * 4 + ((((size_t)(max_K > 0 ? max_K : 1) * NB * 4) + 255) & ~(size_t)255);
 }
@@ -1094,15 +1094,19 @@ __host__ __device__ inline size_t chunk_lds_one(int NB, int S) {   // part [4][S
 }
 __host__ __device__ inline size_t chunk_lds_total(int NB, int S, int teams) { return T3_BYTES + (size_t)teams * chunk_lds_one(NB, S); }
 
-template <int NB, int TEAMS>
+// NB beam slots; NBP beams per scoring PASS (the G of NBP beams is what a wave holds in registers: NB = 30 scores a chunk in three passes
+// of 10 beams, NB = 32 in two of 16 -- the chunk's step constants are formed once, its rows are re-read per pass); TEAMS per workgroup.
+// Round 5: the steady-state scoring is the team encoder's software pipeline (the look-ups of the next dim slot in flight under the
+// current slot's fma, accumulators in register pairs, reduce_scatter_20 where 20 values are reduced together); B <= 32; D <= 65536.
+template <int NB, int NBP, int TEAMS>
 __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArgs A) {
   using TeamLds = TeamLdsT<NB>;
   constexpr int TEAM_MB = team_mb(NB);
   constexpr size_t TEAM_SMALL_BYTES = (sizeof(TeamLds) + 15) & ~(size_t)15;
   constexpr int NT = TEAM_NT;
-  constexpr int SPC = 20 / NB;                     // samples per reduce-scatter (20 accumulators)
-  constexpr int RW = NB * SPC;
-  static_assert(NB == 10 || NB == 20, "chunked encoder: 10 or 20 beams");
+  constexpr int SPC = NBP <= 10 ? 20 / NBP : 1;    // samples per reduce-scatter
+  constexpr int RW = NBP * SPC;                    // accumulators reduced together
+  static_assert(NB % NBP == 0 && (NBP == 10 || NBP == 16 || NBP == 20) && NB <= 32, "chunked encoder: passes of 10, 16 or 20 beams, at most 32 beam slots");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int S = A.S, B = A.B;
   const int lane = threadIdx.x & 63;
@@ -1123,7 +1127,8 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
   float *cpart_s = &sm->cpart[0][0];
   float *Cb_s = sm->Cb;
   const uint16_t *dlog_s = A.dlog4r;
-  const int rs_p = rsn_owner<RW>(lane), rs_c = rsn_owner<NB>(lane);
+  const int rs_p = rsn_owner<RW>(lane), rs_c = rsn_owner<NBP>(lane);
+  const int rs_p20 = RW == 20 ? rs20_owner(lane) : -1;
   double *kl_tot = reinterpret_cast<double *>(sm->wb);                          // running KL total of the prologue (wb is idle then)
 
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap(); // see lds_abs_f32
@@ -1240,9 +1245,6 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
     for (int t = 0; t < K; ++t) {
       const uint16_t *tab_tu = tab + (size_t)t * S * Dp;             // this step's rows
       const float rho = A.rho[K - 1 - t];
-      uint32_t bet[NB];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) bet[b] = (uint32_t)__builtin_amdgcn_readlane((int)bv_cur, b < Bcur ? b : 0);
       const int N = S * Bcur;
       // ---------------- scoring, chunk by chunk (beam_search_coder.py:67-84) ----------------
       for (int c = 0; c < NC; ++c) {
@@ -1270,84 +1272,166 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
             *reinterpret_cast<float4 *>(cvar_g + (size_t)((t + 1) & 1) * Dpad + d0) = make_float4(cn[0], cn[1], cn[2], cn[3]);
             *reinterpret_cast<float4 *>(sa_g + d0) = make_float4(sa[0], sa[1], sa[2], sa[3]);
           }
-          // G and the C_b terms of the live beams (dead slots: G = 0, never read)
-          float G[NB][4];
-          float cacc[rsn_room(NB)];
-#pragma unroll
-          for (int b = 0; b < rsn_room(NB); ++b) cacc[b] = 0.f;
-          {
-            const float *bold = beams_g + (size_t)cur * NB * Dpad + d0;
-            float4 bq[NB];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-              bq[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (t && b < Bcur) bq[b] = *reinterpret_cast<const float4 *>(bold + (size_t)b * Dpad);   // (wave-uniform)
-            }
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-              const float bv4[4] = {bq[b].x, bq[b].y, bq[b].z, bq[b].w};
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                G[b][i] = b < Bcur ? beam_G(bv4[i], m[i], cA[i], cBv[i], sa[i]) : 0.f;
-                if (b < Bcur) cacc[b] = beam_C_term(cacc[b], bv4[i], m[i], cA[i], cBv[i]);
-              }
-            }
-          }
-          {
-            const float ctot = reduce_scatter_n<NB>(cacc, lane);
-            if ((lane & 1) == 0 && rs_c >= 0 && rs_c < Bcur) cpart_s[g * TEAM_MB + rs_c] = ctot;
-          }
-          // every sample x beam over my four dims; rows one chunk of samples ahead
           const uint32_t tab_lo = (uint32_t)(d0 < Dp ? d0 : Dp - 4);   // lanes past the row's end: its last quad (zero coefficients)
           const uint16_t *tab_t = tab_tu + tab_lo;
-          const int nchunks = (S + SPC - 1) / SPC;
-          uint2 alp_next[SPC];
+#pragma unroll 1
+          for (int bp0 = 0; bp0 < NB; bp0 += NBP) {                    // beam passes (one for NB = NBP)
+            const int nlive = Bcur - bp0 < NBP ? Bcur - bp0 : NBP;     // live beams of this pass
+            if (nlive <= 0) break;                                     // (wave-uniform)
+            // G and the C_b terms of the pass's live beams (dead slots: G = 0, never read)
+            float G[NBP][4];
+            {
+              float cacc[rsn_room(NBP)];
 #pragma unroll
-          for (int cc = 0; cc < SPC; ++cc) {
-            alp_next[cc] = make_uint2(0u, 0u);
-            if (cc < S) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)cc * Dp);
-          }
-          for (int ch = 0; ch < nchunks; ++ch) {
-            float acc[rsn_room(RW)];
+              for (int b = 0; b < rsn_room(NBP); ++b) cacc[b] = 0.f;
+              const float *bold = beams_g + ((size_t)cur * NB + bp0) * Dpad + d0;
+              float4 bq[NBP];
 #pragma unroll
-            for (int p = 0; p < rsn_room(RW); ++p) acc[p] = 0.f;
-            uint2 alp[SPC];
+              for (int b = 0; b < NBP; ++b) {
+                bq[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t && b < nlive) bq[b] = *reinterpret_cast<const float4 *>(bold + (size_t)b * Dpad);   // (wave-uniform)
+              }
 #pragma unroll
-            for (int cc = 0; cc < SPC; ++cc) {
-              alp[cc] = alp_next[cc];
-              const int sn = (ch + 1) * SPC + cc;
-              if (sn < S) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sn * Dp);
-            }
-#pragma unroll
-            for (int cc = 0; cc < SPC; ++cc) {
-              const int s = ch * SPC + cc;
-              if (s < S) { // wave-uniform
-                const uint2 ap = alp[cc];
-                const uint32_t al[4] = {(ap.x & 0xFFFFu) << 2, (ap.x >> 16) << 2, (ap.y & 0xFFFFu) << 2, (ap.y >> 16) << 2};
+              for (int b = 0; b < NBP; ++b) {
+                const float bv4[4] = {bq[b].x, bq[b].y, bq[b].z, bq[b].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                  float z[NB];
-#pragma unroll
-                  for (int b = 0; b < NB; ++b) z[b] = lds_abs_f32(al[i] + bet[b]);   // 4 * (dlog r + 10006 c + dlog h): no wrap
-#pragma unroll
-                  for (int b = 0; b < NB; ++b) acc[cc * NB + b] = proposal_term(acc[cc * NB + b], z[b], cH[i], G[b][i]);
-                  __builtin_amdgcn_sched_barrier(0);
+                  G[b][i] = b < nlive ? beam_G(bv4[i], m[i], cA[i], cBv[i], sa[i]) : 0.f;
+                  if (b < nlive) cacc[b] = beam_C_term(cacc[b], bv4[i], m[i], cA[i], cBv[i]);
                 }
               }
+              const float ctot = reduce_scatter_n<NBP>(cacc, lane);
+              if ((lane & 1) == 0 && rs_c >= 0 && rs_c < nlive) cpart_s[g * TEAM_MB + bp0 + rs_c] = ctot;
             }
-            const float tot = reduce_scatter_n<RW>(acc, lane);
-            const int cc = rs_p / NB, b = rs_p - cc * NB;               // rs_p < 0: unused slot
-            const int s = ch * SPC + cc;
-            if (rs_p >= 0 && (lane & 1) == 0 && s < S && b < Bcur) part_s[((size_t)g * S + s) * NB + b] = tot;
+            uint32_t bet[NBP];
+#pragma unroll
+            for (int b = 0; b < NBP; ++b) bet[b] = (uint32_t)__builtin_amdgcn_readlane((int)bv_cur, bp0 + b < Bcur ? bp0 + b : 0);
+            if (nlive == NBP && Bcur > 1) {
+              // ---- steady state, software pipelined by dim slot (as encode_team_kernel's scoring loop): the NBP look-ups of the NEXT slot are
+              // issued before the current slot's values are consumed; values in register pairs (v_pk_fma_f32); rows two sample-chunks ahead
+              typedef float f2 __attribute__((ext_vector_type(2)));
+              constexpr int NP = NBP / 2, NQ = 4 * SPC;
+              const int n_sch = (S + SPC - 1) / SPC;
+              auto row = [&](int s_) {
+                uint2 r = make_uint2(0u, 0u);
+                if (s_ < S) r = *reinterpret_cast<const uint2 *>(tab_tu + ((uint32_t)s_ * (uint32_t)Dp + tab_lo));
+                return r;
+              };
+              uint2 ap_cur[SPC], ap_nxt[SPC];
+#pragma unroll
+              for (int cc = 0; cc < SPC; ++cc) { ap_cur[cc] = row(cc); ap_nxt[cc] = row(SPC + cc); }
+#define CHUNK_AL(CC, I) ((((I) & 2) ? (((I) & 1) ? (ap_cur[CC].y >> 16) : (ap_cur[CC].y & 0xFFFFu)) : (((I) & 1) ? (ap_cur[CC].x >> 16) : (ap_cur[CC].x & 0xFFFFu))) << 2)
+#define CHUNK_ISSUE(Z, AD) do { _Pragma("unroll") for (int k = 0; k < NP; ++k) { Z[k].x = lds_abs_f32((AD) + bet[2 * k]); Z[k].y = lds_abs_f32((AD) + bet[2 * k + 1]); } \
+                                __builtin_amdgcn_sched_barrier(0); } while (0)
+#define CHUNK_CONSUME(Z, I, ACC) do { _Pragma("unroll") for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(Z[k])); \
+                                f2 t2_[NP]; \
+                                _Pragma("unroll") for (int k = 0; k < NP; ++k) { \
+                                  const f2 h2 = {cH[I], cH[I]}, g2 = {G[2 * k][I], G[2 * k + 1][I]}; \
+                                  t2_[k] = __builtin_elementwise_fma(h2, Z[k], g2); } \
+                                _Pragma("unroll") for (int k = 0; k < NP; ++k) ACC[k] = __builtin_elementwise_fma(t2_[k], Z[k], ACC[k]); \
+                                _Pragma("unroll") for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(ACC[k])); \
+                                __builtin_amdgcn_sched_barrier(0); } while (0)
+              f2 zz[2][NP];
+              CHUNK_ISSUE(zz[0], CHUNK_AL(0, 0));
+              for (int ch = 0; ch < n_sch; ++ch) {
+                f2 acc2[SPC][NP];
+#pragma unroll
+                for (int cc = 0; cc < SPC; ++cc)
+#pragma unroll
+                  for (int k = 0; k < NP; ++k) acc2[cc][k] = (f2){0.f, 0.f};
+                uint2 ap_new[SPC];
+#pragma unroll
+                for (int cc = 0; cc < SPC; ++cc) ap_new[cc] = row((ch + 2) * SPC + cc);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                  if (q + 1 < NQ) CHUNK_ISSUE(zz[(q + 1) & 1], CHUNK_AL((q + 1) >> 2, (q + 1) & 3));
+                  else {
+#pragma unroll
+                    for (int cc = 0; cc < SPC; ++cc) { ap_cur[cc] = ap_nxt[cc]; ap_nxt[cc] = ap_new[cc]; }
+                    CHUNK_ISSUE(zz[0], CHUNK_AL(0, 0));
+                  }
+                  CHUNK_CONSUME(zz[q & 1], q & 3, acc2[q >> 2]);
+                }
+                float tot;
+                int own;
+                if constexpr (RW == 20 && IREC_RS20 != 0) {
+                  rs_f2 a20[10];
+#pragma unroll
+                  for (int cc = 0; cc < SPC; ++cc)
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) a20[cc * NP + k] = acc2[cc][k];
+                  tot = reduce_scatter_20(a20, lane);
+                  own = rs_p20;
+                } else {
+                  float acc[rsn_room(RW)];
+#pragma unroll
+                  for (int cc = 0; cc < SPC; ++cc)
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) { acc[cc * NBP + 2 * k] = acc2[cc][k].x; acc[cc * NBP + 2 * k + 1] = acc2[cc][k].y; }
+                  tot = reduce_scatter_n<RW>(acc, lane);
+                  own = rs_p;
+                }
+                const int cc = own / NBP, b = own - cc * NBP;          // own < 0: unused slot
+                const int s_ = ch * SPC + cc;
+                if (own >= 0 && (lane & 1) == 0 && s_ < S) part_s[((size_t)g * S + s_) * NB + bp0 + b] = tot;
+              }
+#pragma unroll
+              for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(zz[0][k])); // drain the look-ups issued past the last sample
+#undef CHUNK_AL
+#undef CHUNK_ISSUE
+#undef CHUNK_CONSUME
+            } else {
+              // ---- the first step (one beam) and passes that are not full: a dim slot's look-ups issued together, then consumed
+              const int nchunks = (S + SPC - 1) / SPC;
+              uint2 alp_next[SPC];
+#pragma unroll
+              for (int cc = 0; cc < SPC; ++cc) {
+                alp_next[cc] = make_uint2(0u, 0u);
+                if (cc < S) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)cc * Dp);
+              }
+              for (int ch = 0; ch < nchunks; ++ch) {
+                float acc[rsn_room(RW)];
+#pragma unroll
+                for (int p_ = 0; p_ < rsn_room(RW); ++p_) acc[p_] = 0.f;
+                uint2 alp[SPC];
+#pragma unroll
+                for (int cc = 0; cc < SPC; ++cc) {
+                  alp[cc] = alp_next[cc];
+                  const int sn = (ch + 1) * SPC + cc;
+                  if (sn < S) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sn * Dp);
+                }
+#pragma unroll
+                for (int cc = 0; cc < SPC; ++cc) {
+                  const int s_ = ch * SPC + cc;
+                  if (s_ < S) { // wave-uniform
+                    const uint2 ap = alp[cc];
+                    const uint32_t al[4] = {(ap.x & 0xFFFFu) << 2, (ap.x >> 16) << 2, (ap.y & 0xFFFFu) << 2, (ap.y >> 16) << 2};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                      float z[NBP];
+#pragma unroll
+                      for (int b = 0; b < NBP; ++b) z[b] = lds_abs_f32(al[i] + bet[b]);   // 4 * (dlog r + 10006 c + dlog h): no wrap
+#pragma unroll
+                      for (int b = 0; b < NBP; ++b) acc[cc * NBP + b] = proposal_term(acc[cc * NBP + b], z[b], cH[i], G[b][i]);
+                      __builtin_amdgcn_sched_barrier(0);
+                    }
+                  }
+                }
+                const float tot = reduce_scatter_n<RW>(acc, lane);
+                const int cc = rs_p / NBP, b = rs_p - cc * NBP;         // rs_p < 0: unused slot
+                const int s_ = ch * SPC + cc;
+                if (rs_p >= 0 && (lane & 1) == 0 && s_ < S && b < nlive) part_s[((size_t)g * S + s_) * NB + bp0 + b] = tot;
+              }
+            }
           }
         }
         tsync();
         // the chunk's group sums onto the running scores / C_b, increasing group order
         for (int f = tid; f < N; f += NT) {
-          const int s = f / Bcur, b = f - s * Bcur;
-          float v = part_s[((size_t)0 * S + s) * NB + b];
+          const int s_ = f / Bcur, b = f - s_ * Bcur;
+          float v = part_s[((size_t)0 * S + s_) * NB + b];
           if (c > 0) v = run_s[f] + v;
-          for (int gg = 1; gg < ngc; ++gg) v = v + part_s[((size_t)gg * S + s) * NB + b];
+          for (int gg = 1; gg < ngc; ++gg) v = v + part_s[((size_t)gg * S + s_) * NB + b];
           run_s[f] = v;
         }
         if (tid < Bcur) {
@@ -1359,7 +1443,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
         tsync();   // partials free for the next chunk; running sums and C_b published
       }
       for (int f = tid; f < N; f += NT) {
-        const int s = f / Bcur, b = f - s * Bcur;
+        const int s_ = f / Bcur, b = f - s_ * Bcur;
         key_s[f] = score_key(run_s[f] + Cb_s[b]);
       }
       const int Bnew = B < N ? B : N;
@@ -1819,29 +1903,45 @@ hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
 }
 
 // ---- chunked encoder (blocks of more than 1024 dims) ----
-constexpr int CHUNK_TEAMS = 2;
-static int chunk_nb_for(int B) { return B <= 10 ? 10 : B <= 20 ? 20 : 0; }
-bool chunk_applies(int B, int S, int max_dim) {
+// beam slots of the build that serves B beams, and its teams per workgroup: two where their LDS fits next to the table copies, else one
+static int chunk_nb_for(int B) { return B <= 10 ? 10 : B <= 20 ? 20 : B <= 30 ? 30 : B <= 32 ? 32 : 0; }
+int chunk_teams(int B, int S) {
   const int nb = chunk_nb_for(B);
-  return nb != 0 && max_dim > FAST_MAX_DIM && max_dim <= CHUNK_MAX_DIM && (int64_t)S * nb <= 2048 &&
-         chunk_lds_total(nb, S, CHUNK_TEAMS) <= FAST_LDS_LIMIT;
+  if (!nb || (int64_t)S * nb > 2048) return 0;
+  if (nb <= 20 && chunk_lds_total(nb, S, 2) <= FAST_LDS_LIMIT) return 2;     // (the 30- / 32-slot builds are instantiated with one team only)
+  return chunk_lds_total(nb, S, 1) <= FAST_LDS_LIMIT ? 1 : 0;
 }
-int chunk_teams() { return CHUNK_TEAMS; }
-size_t chunk_lds_for(int B, int S) { return chunk_lds_total(chunk_nb_for(B), S, CHUNK_TEAMS); }
+bool chunk_applies(int B, int S, int max_dim) {
+  return max_dim > FAST_MAX_DIM && max_dim <= CHUNK_MAX_DIM && chunk_teams(B, S) != 0;
+}
+size_t chunk_lds_for(int B, int S) { return chunk_lds_total(chunk_nb_for(B), S, chunk_teams(B, S)); }
 size_t chunk_ws_for(int B, int dpad, int max_K) { return chunk_ws_bytes(chunk_nb_for(B), dpad, max_K); }
-const char *chunk_kernel_name(int B) { return chunk_nb_for(B) == 10 ? "encode_chunk_kernel<10,2>" : "encode_chunk_kernel<20,2>"; }
-template <int NB>
+const char *chunk_kernel_name(int B, int S) {
+  static thread_local char buf[48];
+  const int nb = chunk_nb_for(B);
+  snprintf(buf, sizeof buf, "encode_chunk_kernel<%d,%d,%d>", nb, nb == 30 ? 10 : nb == 32 ? 16 : nb, chunk_teams(B, S));
+  return buf;
+}
+template <int NB, int NBP, int TEAMS>
 static hipError_t launch_chunk_t(const EncArgs &A, int grid, hipStream_t st) {
-  const size_t lds = chunk_lds_total(NB, A.S, CHUNK_TEAMS);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_chunk_kernel<NB, CHUNK_TEAMS>),
+  const size_t lds = chunk_lds_total(NB, A.S, TEAMS);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_chunk_kernel<NB, NBP, TEAMS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((encode_chunk_kernel<NB, CHUNK_TEAMS>), dim3(grid), dim3(CHUNK_TEAMS * TEAM_NT), lds, st, A);
+  hipLaunchKernelGGL((encode_chunk_kernel<NB, NBP, TEAMS>), dim3(grid), dim3(TEAMS * TEAM_NT), lds, st, A);
   return hipGetLastError();
 }
 hipError_t launch_encode_chunk(const EncArgs &A, int grid, hipStream_t st) {
   if (!chunk_applies(A.B, A.S, A.max_dim_pad)) return hipErrorInvalidValue;
-  return chunk_nb_for(A.B) == 10 ? launch_chunk_t<10>(A, grid, st) : launch_chunk_t<20>(A, grid, st);
+  switch (chunk_nb_for(A.B) * 10 + chunk_teams(A.B, A.S)) {
+    case 102: return launch_chunk_t<10, 10, 2>(A, grid, st);
+    case 101: return launch_chunk_t<10, 10, 1>(A, grid, st);
+    case 202: return launch_chunk_t<20, 20, 2>(A, grid, st);
+    case 201: return launch_chunk_t<20, 20, 1>(A, grid, st);
+    case 301: return launch_chunk_t<30, 10, 1>(A, grid, st);
+    case 321: return launch_chunk_t<32, 16, 1>(A, grid, st);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 // workgroups that build the call's tables (kind 1: 8 half-waves per workgroup, at most 4096 workgroups, grid-stride; kind 2: per table

@@ -39,6 +39,10 @@ def large_blocks():
     for name, D, omega, eps1, B in (("block_D2500_large", 2500, 3.0, 1.2, 20), ("block_D1500_large_b10", 1500, 3.0, 1.0, 10)):
         mq, sq, mp, sp = O.synthetic_latent(8800 + D, D)
         block_case(name, mq, sq, mp, sp, 42, omega, eps1, B)
+    # Round 5: the chunked encoder's beam passes (20 < B <= 32: 30 slots in three passes of 10, 32 in two of 16)
+    for name, D, omega, eps1, B in (("block_D3200_large_b30", 3200, 3.0, 1.2, 30), ("block_D2100_large_b32", 2100, 3.0, 1.0, 32)):
+        mq, sq, mp, sp = O.synthetic_latent(8800 + D, D)
+        block_case(name, mq, sq, mp, sp, 42, omega, eps1, B)
 
 
 def main():

@@ -285,14 +285,19 @@ def test_large_block_uses_generic_path(engine, oracle):
 @pytest.mark.parametrize("n,bs,omega,eps1,B,n_t", [(8192, 2048, 3.0, 1.2, 20, 6), (8192, 4096, 3.0, 1.2, 20, 4), (8192, None, 3.0, 1.2, 20, 5),
                                                    (8192, None, 3.0, 1.0, 10, 3), (5000, 2048, 3.0, 1.0, 7, 3), (3001, None, 2.0, 1.5, 1, 4),
                                                    (1025, None, 3.0, 1.2, 20, 3), (2500, 2048, 3.0, 1.2, 13, 3), (12288, None, 3.0, 1.0, 10, 2),
-                                                   (4099, 1100, 3.5, 1.0, 20, 2)])
+                                                   (4099, 1100, 3.5, 1.0, 20, 2),
+                                                   # round 5: up to 32 beams (beam passes of 10 / 16 on one team), blocks beyond 16 384 dims
+                                                   (8192, None, 3.0, 1.2, 30, 2), (8192, 2048, 3.0, 1.2, 32, 3), (3000, None, 3.0, 1.0, 25, 2),
+                                                   (2600, 1300, 3.0, 1.2, 21, 5), (17000, None, 3.0, 1.0, 10, 1)])
 def test_blocks_beyond_1024_dims_take_the_chunked_encoder(engine, oracle, n, bs, omega, eps1, B, n_t):
     """Coder.__init__ takes any block_size, None included (coder.py:29-36,415-419: the whole tensor as ONE block -- the
     reference's default).  Round 4: such blocks are walked in chunks of 1024 dims by encode_chunk_kernel over the team
     encoder's tables instead of falling to the generic kernel.  Indices, K and samples against the oracle, bit for bit:
     block_size 2048 / 4096 / None on 8192-dim tensors, ragged chunks and dim groups (5000, 3001, 1025, 4099 dims), a call that
     mixes blocks above and below 1024 dims (2500 = 2048 + 452), one beam, beam counts that are not a build's, a 12 288-dim
-    block; decode(encode) exact; the generic kernel pinned gives the same bits; irec_encode_plan names the kernel."""
+    block; decode(encode) exact; the generic kernel pinned gives the same bits; irec_encode_plan names the kernel.
+    Round 5: the steady-state scoring is the team encoder's software pipeline; 20 < B <= 32 (30 slots in three passes of 10 beams,
+    32 in two of 16, one team per CU); blocks of up to 65 536 dims (a 17 000-dim block: K = 123)."""
     S = oracle.n_samples(omega, eps1)
     stats = [oracle.synthetic_latent(8100 + i, n) for i in range(n_t)]
     ql, qs, pl, ps = (torch.from_numpy(np.stack([s[k] for s in stats])).cuda().contiguous() for k in range(4))
@@ -300,7 +305,9 @@ def test_blocks_beyond_1024_dims_take_the_chunked_encoder(engine, oracle, n, bs,
     max_K = 160
     params = engine.params(omega, S, B, table_steps=max_K)      # (tables over every partition: nothing is left to the second pass)
     plan = engine.plan(params, lay, max_K)
-    assert plan["kernel"] == ("encode_chunk_kernel<10,2>" if B <= 10 else "encode_chunk_kernel<20,2>"), plan["kernel"]
+    want = ("encode_chunk_kernel<10,10,2>" if B <= 10 else "encode_chunk_kernel<20,20,2>" if B <= 20 else
+            "encode_chunk_kernel<30,10,1>" if B <= 30 else "encode_chunk_kernel<32,16,1>")
+    assert plan["kernel"] == want, plan["kernel"]
     assert plan["table_kernel"] == "prep_kernel (copy bits)" and plan["lds_bytes"] <= 160 * 1024
     K, idx, sample = engine.encode_blocks(params, lay, ql, qs, pl, ps, 42, max_K)
     Kh, ih = K.cpu().numpy(), idx.cpu().numpy()
