@@ -1089,15 +1089,17 @@ constexpr int CHUNK_MAX_DIM = 65536;
 __host__ __device__ inline size_t chunk_ws_bytes(int NB, int dpad, int max_K) {
   return (size_t)(6 + 2 * NB) * dpad * 4 + ((((size_t)(max_K > 0 ? max_K : 1) * NB * 4) + 255) & ~(size_t)255);
 }
-__host__ __device__ inline size_t chunk_lds_one(int NB, int S) {   // part [4][S][NB] | run / keys [S][NB] | TeamLds | barrier
-  return team_part_bytes(NB, S) + team_key_bytes(NB, S) + team_small_bytes(NB) + 16;
+__host__ __device__ inline size_t chunk_lds_one(int NB, int NBP, int S) {   // part [4][S][NBP] (of ONE beam pass) | run / keys [S][NB] | TeamLds | barrier
+  return team_part_bytes(NBP, S) + team_key_bytes(NB, S) + team_small_bytes(NB) + 16;
 }
-__host__ __device__ inline size_t chunk_lds_total(int NB, int S, int teams) { return T3_BYTES + (size_t)teams * chunk_lds_one(NB, S); }
+__host__ __device__ inline size_t chunk_lds_total(int NB, int NBP, int S, int teams) { return T3_BYTES + (size_t)teams * chunk_lds_one(NB, NBP, S); }
 
 // NB beam slots; NBP beams per scoring PASS (the G of NBP beams is what a wave holds in registers: NB = 30 scores a chunk in three passes
 // of 10 beams, NB = 32 in two of 16 -- the chunk's step constants are formed once, its rows are re-read per pass); TEAMS per workgroup.
 // Round 5: the steady-state scoring is the team encoder's software pipeline (the look-ups of the next dim slot in flight under the
-// current slot's fma, accumulators in register pairs, reduce_scatter_20 where 20 values are reduced together); B <= 32; D <= 65536.
+// current slot's fma, accumulators in register pairs, reduce_scatter_20 where 20 values are reduced together); B <= 32; D <= 65536;
+// the partials are those of ONE pass (combined into the running scores pass by pass), so three teams of 10-beam passes -- 12 waves
+// per CU at 168 VGPRs, the register budget G of 10 beams fits without a spill -- find room next to the table copies.
 template <int NB, int NBP, int TEAMS>
 __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArgs A) {
   using TeamLds = TeamLdsT<NB>;
@@ -1113,12 +1115,12 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
   const int wave_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int team = wave_wg / TEAM_NW, g = wave_wg % TEAM_NW;                    // wave g of a team owns dim group g of every chunk
   const int tid = (int)threadIdx.x - team * NT;
-  char *tbase = smem + T3_BYTES + (size_t)team * chunk_lds_one(NB, S);
-  float *part_s = reinterpret_cast<float *>(tbase);                             // [4][S][NB]
-  float *run_s = reinterpret_cast<float *>(tbase + team_part_bytes(NB, S));     // [S * Bcur] running scores, then the sort keys
+  char *tbase = smem + T3_BYTES + (size_t)team * chunk_lds_one(NB, NBP, S);
+  float *part_s = reinterpret_cast<float *>(tbase);                             // [4][S][NBP] of the beam pass being scored
+  float *run_s = reinterpret_cast<float *>(tbase + team_part_bytes(NBP, S));    // [S * Bcur] running scores, then the sort keys
   uint32_t *key_s = reinterpret_cast<uint32_t *>(run_s);
-  TeamLds *sm = reinterpret_cast<TeamLds *>(tbase + team_part_bytes(NB, S) + team_key_bytes(NB, S));
-  uint32_t *bar_word = reinterpret_cast<uint32_t *>(tbase + team_part_bytes(NB, S) + team_key_bytes(NB, S) + TEAM_SMALL_BYTES);
+  TeamLds *sm = reinterpret_cast<TeamLds *>(tbase + team_part_bytes(NBP, S) + team_key_bytes(NB, S));
+  uint32_t *bar_word = reinterpret_cast<uint32_t *>(tbase + team_part_bytes(NBP, S) + team_key_bytes(NB, S) + TEAM_SMALL_BYTES);
   double *gpart = sm->gpart;
   int32_t *sel_s = sm->sel_s, *sel_b = sm->sel_b;
   int32_t *hsum = &sm->hsum[0][0];
@@ -1250,9 +1252,11 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
       for (int c = 0; c < NC; ++c) {
         const int ngc = groups_of(c);
         const int d0 = (c << 10) + g * 256 + lane * 4;
-        if (g < ngc) {
-          // the step's constants of my four dims (coder.py:141-154), from the statistics and the cumulative variance in the slab
-          float sa[4], cH[4], m[4], cA[4], cBv[4], cn[4];
+        const bool mine = g < ngc;                                    // (wave-uniform) this dim group exists in the chunk
+        // the step's constants of my four dims (coder.py:141-154), from the statistics and the cumulative variance in the slab
+        float sa[4] = {0.f, 0.f, 0.f, 0.f}, cH[4] = {0.f, 0.f, 0.f, 0.f}, m[4] = {0.f, 0.f, 0.f, 0.f}, cA[4] = {0.f, 0.f, 0.f, 0.f}, cBv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (mine) {
+          float cn[4];
           {
             const float4 q0 = *reinterpret_cast<const float4 *>(stats_g + d0);
             const float4 q1 = *reinterpret_cast<const float4 *>(stats_g + (size_t)Dpad + d0);
@@ -1272,12 +1276,14 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
             *reinterpret_cast<float4 *>(cvar_g + (size_t)((t + 1) & 1) * Dpad + d0) = make_float4(cn[0], cn[1], cn[2], cn[3]);
             *reinterpret_cast<float4 *>(sa_g + d0) = make_float4(sa[0], sa[1], sa[2], sa[3]);
           }
-          const uint32_t tab_lo = (uint32_t)(d0 < Dp ? d0 : Dp - 4);   // lanes past the row's end: its last quad (zero coefficients)
-          const uint16_t *tab_t = tab_tu + tab_lo;
+        }
+        const uint32_t tab_lo = (uint32_t)(d0 < Dp ? d0 : Dp - 4);   // lanes past the row's end: its last quad (zero coefficients)
+        const uint16_t *tab_t = tab_tu + tab_lo;
 #pragma unroll 1
-          for (int bp0 = 0; bp0 < NB; bp0 += NBP) {                    // beam passes (one for NB = NBP)
-            const int nlive = Bcur - bp0 < NBP ? Bcur - bp0 : NBP;     // live beams of this pass
-            if (nlive <= 0) break;                                     // (wave-uniform)
+        for (int bp0 = 0; bp0 < NB; bp0 += NBP) {                    // beam passes (one for NB = NBP)
+          const int nlive = Bcur - bp0 < NBP ? Bcur - bp0 : NBP;     // live beams of this pass
+          if (nlive <= 0) break;                                     // (uniform over the team)
+          if (mine) {
             // G and the C_b terms of the pass's live beams (dead slots: G = 0, never read)
             float G[NBP][4];
             {
@@ -1373,7 +1379,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
                 }
                 const int cc = own / NBP, b = own - cc * NBP;          // own < 0: unused slot
                 const int s_ = ch * SPC + cc;
-                if (own >= 0 && (lane & 1) == 0 && s_ < S) part_s[((size_t)g * S + s_) * NB + bp0 + b] = tot;
+                if (own >= 0 && (lane & 1) == 0 && s_ < S) part_s[((size_t)g * S + s_) * NBP + b] = tot;
               }
 #pragma unroll
               for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(zz[0][k])); // drain the look-ups issued past the last sample
@@ -1420,27 +1426,29 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
                 const float tot = reduce_scatter_n<RW>(acc, lane);
                 const int cc = rs_p / NBP, b = rs_p - cc * NBP;         // rs_p < 0: unused slot
                 const int s_ = ch * SPC + cc;
-                if (rs_p >= 0 && (lane & 1) == 0 && s_ < S && b < nlive) part_s[((size_t)g * S + s_) * NB + bp0 + b] = tot;
+                if (rs_p >= 0 && (lane & 1) == 0 && s_ < S && b < nlive) part_s[((size_t)g * S + s_) * NBP + b] = tot;
               }
             }
           }
+          tsync();
+          // the pass's group sums of this chunk onto the running scores / C_b of its beams, increasing group order
+          for (int f = tid; f < S * nlive; f += NT) {
+            const int s_ = f / nlive, bl = f - s_ * nlive;
+            const int fr = s_ * Bcur + bp0 + bl;                       // flat candidate index of (sample, beam)
+            float v = part_s[((size_t)0 * S + s_) * NBP + bl];
+            if (c > 0) v = run_s[fr] + v;
+            for (int gg = 1; gg < ngc; ++gg) v = v + part_s[((size_t)gg * S + s_) * NBP + bl];
+            run_s[fr] = v;
+          }
+          if (tid < nlive) {
+            const int b = bp0 + tid;
+            float cb = cpart_s[b];
+            if (c > 0) cb = Cb_s[b] + cb;
+            for (int gg = 1; gg < ngc; ++gg) cb = cb + cpart_s[gg * TEAM_MB + b];
+            Cb_s[b] = cb;
+          }
+          tsync();   // partials free for the next pass / chunk; running sums and C_b published
         }
-        tsync();
-        // the chunk's group sums onto the running scores / C_b, increasing group order
-        for (int f = tid; f < N; f += NT) {
-          const int s_ = f / Bcur, b = f - s_ * Bcur;
-          float v = part_s[((size_t)0 * S + s_) * NB + b];
-          if (c > 0) v = run_s[f] + v;
-          for (int gg = 1; gg < ngc; ++gg) v = v + part_s[((size_t)gg * S + s_) * NB + b];
-          run_s[f] = v;
-        }
-        if (tid < Bcur) {
-          float cb = cpart_s[tid];
-          if (c > 0) cb = Cb_s[tid] + cb;
-          for (int gg = 1; gg < ngc; ++gg) cb = cb + cpart_s[gg * TEAM_MB + tid];
-          Cb_s[tid] = cb;
-        }
-        tsync();   // partials free for the next chunk; running sums and C_b published
       }
       for (int f = tid; f < N; f += NT) {
         const int s_ = f / Bcur, b = f - s_ * Bcur;
@@ -1903,28 +1911,33 @@ hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
 }
 
 // ---- chunked encoder (blocks of more than 1024 dims) ----
-// beam slots of the build that serves B beams, and its teams per workgroup: two where their LDS fits next to the table copies, else one
-static int chunk_nb_for(int B) { return B <= 10 ? 10 : B <= 20 ? 20 : B <= 30 ? 30 : B <= 32 ? 32 : 0; }
-int chunk_teams(int B, int S) {
-  const int nb = chunk_nb_for(B);
-  if (!nb || (int64_t)S * nb > 2048) return 0;
-  if (nb <= 20 && chunk_lds_total(nb, S, 2) <= FAST_LDS_LIMIT) return 2;     // (the 30- / 32-slot builds are instantiated with one team only)
-  return chunk_lds_total(nb, S, 1) <= FAST_LDS_LIMIT ? 1 : 0;
+// The build that serves B beams and S samples: beam slots, beams per scoring pass, teams per workgroup -- the first of the candidates
+// whose LDS fits next to the table copies (three teams only with passes of 10 beams: 168 VGPRs hold the G of ten, not of twenty).
+struct ChunkShape { int nb, nbp, teams; };
+static ChunkShape chunk_shape(int B, int S) {
+  static const ChunkShape cand[] = {{10, 10, 3}, {10, 10, 2}, {10, 10, 1}, {20, 10, 3}, {20, 20, 2}, {20, 10, 1},
+                                    {30, 10, 3}, {30, 10, 2}, {30, 10, 1}, {32, 16, 2}, {32, 16, 1}};
+  const int nb = B <= 10 ? 10 : B <= 20 ? 20 : B <= 30 ? 30 : B <= 32 ? 32 : 0;
+  if (!nb || (int64_t)S * nb > 2048) return ChunkShape{0, 0, 0};
+  for (const ChunkShape &c : cand)
+    if (c.nb == nb && chunk_lds_total(c.nb, c.nbp, S, c.teams) <= FAST_LDS_LIMIT) return c;
+  return ChunkShape{0, 0, 0};
 }
+int chunk_teams(int B, int S) { return chunk_shape(B, S).teams; }
 bool chunk_applies(int B, int S, int max_dim) {
-  return max_dim > FAST_MAX_DIM && max_dim <= CHUNK_MAX_DIM && chunk_teams(B, S) != 0;
+  return max_dim > FAST_MAX_DIM && max_dim <= CHUNK_MAX_DIM && chunk_shape(B, S).teams != 0;
 }
-size_t chunk_lds_for(int B, int S) { return chunk_lds_total(chunk_nb_for(B), S, chunk_teams(B, S)); }
-size_t chunk_ws_for(int B, int dpad, int max_K) { return chunk_ws_bytes(chunk_nb_for(B), dpad, max_K); }
+size_t chunk_lds_for(int B, int S) { const ChunkShape c = chunk_shape(B, S); return chunk_lds_total(c.nb, c.nbp, S, c.teams); }
+size_t chunk_ws_for(int B, int dpad, int max_K) { return chunk_ws_bytes(B <= 10 ? 10 : B <= 20 ? 20 : B <= 30 ? 30 : 32, dpad, max_K); }
 const char *chunk_kernel_name(int B, int S) {
   static thread_local char buf[48];
-  const int nb = chunk_nb_for(B);
-  snprintf(buf, sizeof buf, "encode_chunk_kernel<%d,%d,%d>", nb, nb == 30 ? 10 : nb == 32 ? 16 : nb, chunk_teams(B, S));
+  const ChunkShape c = chunk_shape(B, S);
+  snprintf(buf, sizeof buf, "encode_chunk_kernel<%d,%d,%d>", c.nb, c.nbp, c.teams);
   return buf;
 }
 template <int NB, int NBP, int TEAMS>
 static hipError_t launch_chunk_t(const EncArgs &A, int grid, hipStream_t st) {
-  const size_t lds = chunk_lds_total(NB, A.S, TEAMS);
+  const size_t lds = chunk_lds_total(NB, NBP, A.S, TEAMS);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_chunk_kernel<NB, NBP, TEAMS>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
@@ -1933,13 +1946,19 @@ static hipError_t launch_chunk_t(const EncArgs &A, int grid, hipStream_t st) {
 }
 hipError_t launch_encode_chunk(const EncArgs &A, int grid, hipStream_t st) {
   if (!chunk_applies(A.B, A.S, A.max_dim_pad)) return hipErrorInvalidValue;
-  switch (chunk_nb_for(A.B) * 10 + chunk_teams(A.B, A.S)) {
-    case 102: return launch_chunk_t<10, 10, 2>(A, grid, st);
-    case 101: return launch_chunk_t<10, 10, 1>(A, grid, st);
-    case 202: return launch_chunk_t<20, 20, 2>(A, grid, st);
-    case 201: return launch_chunk_t<20, 20, 1>(A, grid, st);
-    case 301: return launch_chunk_t<30, 10, 1>(A, grid, st);
-    case 321: return launch_chunk_t<32, 16, 1>(A, grid, st);
+  const ChunkShape c = chunk_shape(A.B, A.S);
+  switch (c.nb * 1000 + c.nbp * 10 + c.teams) {
+    case 10103: return launch_chunk_t<10, 10, 3>(A, grid, st);
+    case 10102: return launch_chunk_t<10, 10, 2>(A, grid, st);
+    case 10101: return launch_chunk_t<10, 10, 1>(A, grid, st);
+    case 20103: return launch_chunk_t<20, 10, 3>(A, grid, st);
+    case 20202: return launch_chunk_t<20, 20, 2>(A, grid, st);
+    case 20101: return launch_chunk_t<20, 10, 1>(A, grid, st);
+    case 30103: return launch_chunk_t<30, 10, 3>(A, grid, st);
+    case 30102: return launch_chunk_t<30, 10, 2>(A, grid, st);
+    case 30101: return launch_chunk_t<30, 10, 1>(A, grid, st);
+    case 32162: return launch_chunk_t<32, 16, 2>(A, grid, st);
+    case 32161: return launch_chunk_t<32, 16, 1>(A, grid, st);
     default: return hipErrorInvalidValue;
   }
 }

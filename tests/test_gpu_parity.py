@@ -296,8 +296,9 @@ def test_blocks_beyond_1024_dims_take_the_chunked_encoder(engine, oracle, n, bs,
     block_size 2048 / 4096 / None on 8192-dim tensors, ragged chunks and dim groups (5000, 3001, 1025, 4099 dims), a call that
     mixes blocks above and below 1024 dims (2500 = 2048 + 452), one beam, beam counts that are not a build's, a 12 288-dim
     block; decode(encode) exact; the generic kernel pinned gives the same bits; irec_encode_plan names the kernel.
-    Round 5: the steady-state scoring is the team encoder's software pipeline; 20 < B <= 32 (30 slots in three passes of 10 beams,
-    32 in two of 16, one team per CU); blocks of up to 65 536 dims (a 17 000-dim block: K = 123)."""
+    Round 5: the steady-state scoring is the team encoder's software pipeline; beams are scored in passes of 10 (16 for 32 slots) whose
+    partials are combined pass by pass, so THREE teams per CU fit next to the table copies (12 waves at 168 VGPRs); 20 < B <= 32;
+    blocks of up to 65 536 dims (a 17 000-dim block: K = 123)."""
     S = oracle.n_samples(omega, eps1)
     stats = [oracle.synthetic_latent(8100 + i, n) for i in range(n_t)]
     ql, qs, pl, ps = (torch.from_numpy(np.stack([s[k] for s in stats])).cuda().contiguous() for k in range(4))
@@ -305,8 +306,8 @@ def test_blocks_beyond_1024_dims_take_the_chunked_encoder(engine, oracle, n, bs,
     max_K = 160
     params = engine.params(omega, S, B, table_steps=max_K)      # (tables over every partition: nothing is left to the second pass)
     plan = engine.plan(params, lay, max_K)
-    want = ("encode_chunk_kernel<10,10,2>" if B <= 10 else "encode_chunk_kernel<20,20,2>" if B <= 20 else
-            "encode_chunk_kernel<30,10,1>" if B <= 30 else "encode_chunk_kernel<32,16,1>")
+    want = ("encode_chunk_kernel<10,10,3>" if B <= 10 else "encode_chunk_kernel<20,10,3>" if B <= 20 else
+            "encode_chunk_kernel<30,10,3>" if B <= 30 else "encode_chunk_kernel<32,16,2>")
     assert plan["kernel"] == want, plan["kernel"]
     assert plan["table_kernel"] == "prep_kernel (copy bits)" and plan["lds_bytes"] <= 160 * 1024
     K, idx, sample = engine.encode_blocks(params, lay, ql, qs, pl, ps, 42, max_K)
