@@ -177,11 +177,17 @@ class BidirectionalResidualBlock(nn.Module):
         return v if self._infer_bias is None else v + self._infer_bias[k * s:(k + 1) * s].reshape(1, -1, 1, 1)
 
     def _handoff(self, *tensors):
-        """Whether this block's passes take the hand-off kernels: the explicit flag, else float32-on-CUDA of the block itself."""
-        if self.use_handoff_kernels is not None:
-            return bool(self.use_handoff_kernels)
+        """Whether this block's passes take the hand-off kernels: the explicit flag, else float32-on-CUDA of the block ITSELF -- decided
+        by the block's own parameters, identically in compress and decompress, never by the activations of one call (round 5: a
+        decompress whose activations arrived in another dtype or on another device used to take the torch path silently, and
+        torch.exp / F.elu differ from the kernels' expf / expm1f in the last ulp: the prior scales, and with them the reconstruction,
+        diverged).  Activations that disagree with the block are an error."""
         w = self.gen_conv1.weight
-        return w.is_cuda and w.dtype == torch.float32 and all(t is None or (t.is_cuda and t.dtype == torch.float32) for t in tensors)
+        use = bool(self.use_handoff_kernels) if self.use_handoff_kernels is not None else (w.is_cuda and w.dtype == torch.float32)
+        if use and not all(t is None or (t.is_cuda and t.dtype == torch.float32 and t.device == w.device) for t in tensors):
+            raise ModelError("this residual block runs its hand-off kernels (float32 parameters on a HIP device): its activations must be "
+                             "float32 on that device too, in compress and decompress alike")
+        return use
 
     @property
     def posterior_loc(self):
