@@ -4,7 +4,7 @@
 # written under gpurun_out/$TAG/ as it goes (no output held back behind a pipe).
 set -u
 export TMPDIR=/tmp
-TAG=${TAG:-r04h}
+TAG=${TAG:-r05d}
 STAGES=${STAGES:-ab}    # a: GPU suite, smoke;  b: PMC passes -> traffic.json, bench line, kernel trace of the same command;  g: sweep grid, decoder bench;  c: end-to-end shim
 O=gpurun_out/$TAG
 mkdir -p $O
@@ -42,7 +42,7 @@ fi
 if [[ $STAGES == *g* ]]; then   # g: the reference's 60-cell sweep grid (one oracle-checked latent per cell), decoder bench, large-block rates
 echo "== sweep grid"; timeout -k 10 1000 python scripts/grid_bench.py > $O/grid.full.log 2>&1; grep -v amdgpu.ids $O/grid.full.log > $O/grid.log; tail -3 $O/grid.log
 echo "== decode bench"; timeout -k 10 300 python scripts/decode_bench.py 2>&1 | grep -v amdgpu.ids > $O/decode_bench.log; cat $O/decode_bench.log
-echo "== blocks of more than 1024 dims"; timeout -k 10 300 python scripts/generic_rate.py 2>&1 | grep -v amdgpu.ids > $O/chunk_rate.log; cat $O/chunk_rate.log
+echo "== blocks of more than 1024 dims"; LATENTS=3072 SKIP_GENERIC=1 timeout -k 10 300 python scripts/generic_rate.py 2>&1 | grep -v amdgpu.ids > $O/chunk_rate.log; cat $O/chunk_rate.log
 fi
 if [[ $STAGES == *c* ]]; then   # c: the end-to-end shim: 38-image share and single image (eager / one HIP graph), kernel trace of the single-image pass
 echo "== config 3 harness (38 images, 12 singles)"; timeout -k 10 300 python scripts/config3_harness.py --images 38 --singles 12 2>&1 | grep -v amdgpu.ids > $O/config3.log; tail -1 $O/config3.log | cut -c1-300

@@ -22,7 +22,7 @@ for case in range(n_cases):
         D = int(rng.choice([192, 777, 1000, 1024]))
     if os.environ.get("SOAK_LARGE"):   # round 4: blocks of more than 1024 dims (chunked encoder for B <= 20, generic beyond) and up to 256 beams
         D = int(rng.choice([1025, 1279, 1500, 2048, 2049, 2500, 3000, 4096, int(rng.integers(1025, 4200))]))
-        B = int(rng.choice([1, 2, 7, 10, 11, 20, 20, 10, 33, 100, 256])); omega = float(rng.choice([2.0, 3.0, 3.5, float(rng.uniform(1.0, 3.6))]))
+        B = int(rng.choice([1, 2, 7, 10, 11, 20, 20, 10, 21, 25, 30, 31, 32, 33, 100, 256])); omega = float(rng.choice([2.0, 3.0, 3.5, float(rng.uniform(1.0, 3.6))]))
         eps1 = float(rng.choice([1.0, 1.2]))
     S = int(np.exp(omega * eps1))
     if S * B * D > (1.3e7 if (os.environ.get("SOAK_BIG") or os.environ.get("SOAK_LARGE")) else 6e6):          # keep the oracle fast
@@ -55,7 +55,7 @@ for case in range(n_cases):
     if not tens:
         continue
     seed = int(rng.integers(0, 2 ** 31))
-    refs = [O.encode_block(*t4, seed, omega, S, B, max_K=512) for t4 in tens]
+    refs = [O.encode_block(*t4, seed, omega, S, B, max_K=512, margins=True) for t4 in tens]
     mq, sq, mp, sp = (np.stack([t4[k] for t4 in tens]) for k in range(4))
     q = torch.distributions.Normal(torch.from_numpy(mq).cuda(), torch.from_numpy(sq).cuda(), validate_args=False)
     p = torch.distributions.Normal(torch.from_numpy(mp).cuda(), torch.from_numpy(sp).cuda(), validate_args=False)
@@ -70,6 +70,17 @@ for case in range(n_cases):
             ok = torch.equal(c.decode(p, idx, seed=seed, batched=True), sample)
         if not ok:
             bad.append((case, variant, D, B, S, omega, max(Ks), style, seed))
+    if os.environ.get("SOAK_MARGINS"):   # round 5: irec_beam_encode_ex -- same outputs, and the four margin floats of every block against the oracle's
+        lay = eng.layout(len(tens), D, None, seed)
+        qd = tuple(torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (mq, sq, mp, sp))
+        mk = max(max(Ks), 1)
+        Kd, idd, smp, mg = eng.encode_blocks_margins(eng.params(omega, S, B), lay, *qd, seed, mk)
+        Kh, ih, mh, sh2 = Kd.cpu().numpy(), idd.cpu().numpy(), mg.cpu().numpy(), smp.cpu().numpy()
+        for n in range(len(tens)):
+            r = lay.natural[n]
+            if not (ih[r, :Kh[r]].tolist() == refs[n][0] and np.array_equal(sh2[n], refs[n][1]) and np.array_equal(mh[r], refs[n][2])):
+                bad.append((case, "margins", D, B, S, omega, max(Ks), style, seed))
+                break
     K = max(Ks)
     for Kn in Ks:
         stats["evals"] += S * D * (1 + max(Kn - 1, 0) * B)
