@@ -513,7 +513,9 @@ def run_rank(args):
     if os.path.exists(tj):
         tr = json.load(open(tj))
         # (the profiler prints a template's bool arguments, irec_encode_plan names only those that are set)
-        if tr.get("source_sha16") == src_hash and tr.get("kernel", "").replace(" ", "").replace(",false", "").endswith(plan["kernel"]):
+        def norm(name):   # "irec::encode_team_kernel<20, 3, 1, false, ...": no namespace, spaces, unset bool arguments or (truncated) tail
+            return name.split("::")[-1].replace(" ", "").replace(",false", "").rstrip(",>")
+        if tr.get("source_sha16") == src_hash and norm(tr.get("kernel", "")) == norm(plan["kernel"]):
             traffic = tr["hbm_bytes_per_latent"] * L
             traffic_note = tr.get("source", "")
         else:
@@ -596,8 +598,8 @@ def run_rank(args):
         big = "Coder.__init__(block_size=...) beyond 1024 dims (rec/coding/coder.py:29-36,415-419), headline settings"
         result["secondary"]["large_blocks"] = [
             secondary_config(eng, device, "block_size = 2048, 512 latents of 8192 dims", OMEGA, EPS1, BEAMS, 512, N_DIMS, 5, 2, big, block_size=2048, max_K=128),
-            # (one 8192-dim block holds a team for ~33 ms: two blocks per team slot of the three-team build, 768 slots)
-            secondary_config(eng, device, "block_size = None (one 8192-dim block per latent), 1536 latents", OMEGA, EPS1, BEAMS, 1536, N_DIMS, 3, 2, big, block_size=None, max_K=128)]
+            # (one 8192-dim block holds a team for ~40 ms: four blocks per team slot of the three-team build, 768 slots)
+            secondary_config(eng, device, "block_size = None (one 8192-dim block per latent), 3072 latents", OMEGA, EPS1, BEAMS, 3072, N_DIMS, 3, 2, big, block_size=None, max_K=128)]
         result["secondary"]["skewed_K"] = skewed_K_leg(eng, device, 8192, 5, 16)
         result["secondary"]["margins"] = margins_leg(eng, device, params, lay, q, out, S, max_K)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -10,8 +10,8 @@ for row in csv.DictReader(open(path)):
     k = row.get("Kernel_Name", "")
     if pat and pat not in k:
         continue
-    key = (k.split("(")[0][:60], row["Counter_Name"])
+    key = (k.split("(")[0][:90], row["Counter_Name"])
     acc[key][0] += float(row["Counter_Value"])
     acc[key][1] += 1
 for (k, c), (v, n) in sorted(acc.items()):
-    print(f"{k:60s} {c:28s} mean/dispatch {v / n:18.1f}  dispatches {n}")
+    print(f"{k:90s} {c:28s} mean/dispatch {v / n:18.1f}  dispatches {n}")
