@@ -36,7 +36,8 @@ for p in (ROOT, PKG):
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 LDS_HW_LOOKUPS = 32.0     # ds_read_b32: 128 B/clk/CU = 32 four-byte look-ups per clock per CU (MI355X_MICROARCH.md §LDS)
 LDS_2CHOICE_LOOKUPS = 13.70  # measured ceiling of random look-ups with the 2-choice bank assignment at the 12 waves per CU
-                             # the default kernel runs (profiles/r01j/gather_rates.log; 13.4 at 8 waves, 14.0 at 16)
+                             # the default kernel runs (profiles/r01j/gather_rates.log; 13.4 at 8 waves, 14.0 at 16; round 5, with the
+                             # kernel's own instruction stream: 13.68, profiles/r05b/bank_limits.log -- DESIGN.md §4 "The gather ceiling")
 TENSOR_SHAPE = (16, 16, 32)
 N_DIMS = 8192
 BLOCK_SIZE = 1000
