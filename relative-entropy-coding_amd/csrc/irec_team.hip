@@ -1099,7 +1099,8 @@ __host__ __device__ inline size_t chunk_lds_total(int NB, int NBP, int S, int te
 // Round 5: the steady-state scoring is the team encoder's software pipeline (the look-ups of the next dim slot in flight under the
 // current slot's fma, accumulators in register pairs, reduce_scatter_20 where 20 values are reduced together); B <= 32; D <= 65536;
 // the partials are those of ONE pass (combined into the running scores pass by pass), so three teams of 10-beam passes -- 12 waves
-// per CU at 168 VGPRs, the register budget G of 10 beams fits without a spill -- find room next to the table copies.
+// per CU at 168 VGPRs, the register budget G of 10 beams fits without a spill -- find room next to the table copies; up to 60 beam slots
+// (passes of 10, two teams: 32 < B <= 60 of blocks beyond 1024 dims no longer falls to the generic kernel).
 template <int NB, int NBP, int TEAMS>
 __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArgs A) {
   using TeamLds = TeamLdsT<NB>;
@@ -1108,7 +1109,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
   constexpr int NT = TEAM_NT;
   constexpr int SPC = NBP <= 10 ? 20 / NBP : 1;    // samples per reduce-scatter
   constexpr int RW = NBP * SPC;                    // accumulators reduced together
-  static_assert(NB % NBP == 0 && (NBP == 10 || NBP == 16 || NBP == 20) && NB <= 32, "chunked encoder: passes of 10, 16 or 20 beams, at most 32 beam slots");
+  static_assert(NB % NBP == 0 && (NBP == 10 || NBP == 16 || NBP == 20) && NB <= 60, "chunked encoder: passes of 10, 16 or 20 beams, at most 60 beam slots (6-bit back-pointers)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int S = A.S, B = A.B;
   const int lane = threadIdx.x & 63;
@@ -1914,11 +1915,13 @@ hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
 // The build that serves B beams and S samples: beam slots, beams per scoring pass, teams per workgroup -- the first of the candidates
 // whose LDS fits next to the table copies (three teams only with passes of 10 beams: 168 VGPRs hold the G of ten, not of twenty).
 struct ChunkShape { int nb, nbp, teams; };
+static int chunk_nb(int B) { return B <= 10 ? 10 : B <= 20 ? 20 : B <= 30 ? 30 : B <= 32 ? 32 : B <= 40 ? 40 : B <= 50 ? 50 : B <= 60 ? 60 : 0; }
 static ChunkShape chunk_shape(int B, int S) {
   static const ChunkShape cand[] = {{10, 10, 3}, {10, 10, 2}, {10, 10, 1}, {20, 10, 3}, {20, 20, 2}, {20, 10, 1},
-                                    {30, 10, 3}, {30, 10, 2}, {30, 10, 1}, {32, 16, 2}, {32, 16, 1}};
-  const int nb = B <= 10 ? 10 : B <= 20 ? 20 : B <= 30 ? 30 : B <= 32 ? 32 : 0;
-  if (!nb || (int64_t)S * nb > 2048) return ChunkShape{0, 0, 0};
+                                    {30, 10, 3}, {30, 10, 2}, {30, 10, 1}, {32, 16, 2}, {32, 16, 1},
+                                    {40, 10, 2}, {40, 10, 1}, {50, 10, 2}, {50, 10, 1}, {60, 10, 2}, {60, 10, 1}};
+  const int nb = chunk_nb(B);
+  if (!nb || (int64_t)S * nb > 4096) return ChunkShape{0, 0, 0};
   for (const ChunkShape &c : cand)
     if (c.nb == nb && chunk_lds_total(c.nb, c.nbp, S, c.teams) <= FAST_LDS_LIMIT) return c;
   return ChunkShape{0, 0, 0};
@@ -1928,7 +1931,7 @@ bool chunk_applies(int B, int S, int max_dim) {
   return max_dim > FAST_MAX_DIM && max_dim <= CHUNK_MAX_DIM && chunk_shape(B, S).teams != 0;
 }
 size_t chunk_lds_for(int B, int S) { const ChunkShape c = chunk_shape(B, S); return chunk_lds_total(c.nb, c.nbp, S, c.teams); }
-size_t chunk_ws_for(int B, int dpad, int max_K) { return chunk_ws_bytes(B <= 10 ? 10 : B <= 20 ? 20 : B <= 30 ? 30 : 32, dpad, max_K); }
+size_t chunk_ws_for(int B, int dpad, int max_K) { return chunk_ws_bytes(chunk_nb(B) ? chunk_nb(B) : 60, dpad, max_K); }
 const char *chunk_kernel_name(int B, int S) {
   static thread_local char buf[48];
   const ChunkShape c = chunk_shape(B, S);
@@ -1959,6 +1962,12 @@ hipError_t launch_encode_chunk(const EncArgs &A, int grid, hipStream_t st) {
     case 30101: return launch_chunk_t<30, 10, 1>(A, grid, st);
     case 32162: return launch_chunk_t<32, 16, 2>(A, grid, st);
     case 32161: return launch_chunk_t<32, 16, 1>(A, grid, st);
+    case 40102: return launch_chunk_t<40, 10, 2>(A, grid, st);
+    case 40101: return launch_chunk_t<40, 10, 1>(A, grid, st);
+    case 50102: return launch_chunk_t<50, 10, 2>(A, grid, st);
+    case 50101: return launch_chunk_t<50, 10, 1>(A, grid, st);
+    case 60102: return launch_chunk_t<60, 10, 2>(A, grid, st);
+    case 60101: return launch_chunk_t<60, 10, 1>(A, grid, st);
     default: return hipErrorInvalidValue;
   }
 }

@@ -22,7 +22,7 @@ for case in range(n_cases):
         D = int(rng.choice([192, 777, 1000, 1024]))
     if os.environ.get("SOAK_LARGE"):   # round 4: blocks of more than 1024 dims (chunked encoder for B <= 20, generic beyond) and up to 256 beams
         D = int(rng.choice([1025, 1279, 1500, 2048, 2049, 2500, 3000, 4096, int(rng.integers(1025, 4200))]))
-        B = int(rng.choice([1, 2, 7, 10, 11, 20, 20, 10, 21, 25, 30, 31, 32, 33, 100, 256])); omega = float(rng.choice([2.0, 3.0, 3.5, float(rng.uniform(1.0, 3.6))]))
+        B = int(rng.choice([1, 2, 7, 10, 11, 20, 20, 10, 21, 25, 30, 31, 32, 33, 41, 50, 60, 61, 100, 256])); omega = float(rng.choice([2.0, 3.0, 3.5, float(rng.uniform(1.0, 3.6))]))
         eps1 = float(rng.choice([1.0, 1.2]))
     S = int(np.exp(omega * eps1))
     if S * B * D > (1.3e7 if (os.environ.get("SOAK_BIG") or os.environ.get("SOAK_LARGE")) else 6e6):          # keep the oracle fast

@@ -288,7 +288,9 @@ def test_large_block_uses_generic_path(engine, oracle):
                                                    (4099, 1100, 3.5, 1.0, 20, 2),
                                                    # round 5: up to 32 beams (beam passes of 10 / 16 on one team), blocks beyond 16 384 dims
                                                    (8192, None, 3.0, 1.2, 30, 2), (8192, 2048, 3.0, 1.2, 32, 3), (3000, None, 3.0, 1.0, 25, 2),
-                                                   (2600, 1300, 3.0, 1.2, 21, 5), (17000, None, 3.0, 1.0, 10, 1)])
+                                                   (2600, 1300, 3.0, 1.2, 21, 5), (17000, None, 3.0, 1.0, 10, 1),
+                                                   # ... and up to 60 beam slots (passes of 10, two teams): 32 < B <= 60 of blocks beyond 1024 dims
+                                                   (3000, None, 2.0, 1.0, 50, 2), (2500, 2048, 3.0, 1.0, 40, 3), (2500, None, 3.0, 1.2, 60, 2)])
 def test_blocks_beyond_1024_dims_take_the_chunked_encoder(engine, oracle, n, bs, omega, eps1, B, n_t):
     """Coder.__init__ takes any block_size, None included (coder.py:29-36,415-419: the whole tensor as ONE block -- the
     reference's default).  Round 4: such blocks are walked in chunks of 1024 dims by encode_chunk_kernel over the team
@@ -307,7 +309,8 @@ def test_blocks_beyond_1024_dims_take_the_chunked_encoder(engine, oracle, n, bs,
     params = engine.params(omega, S, B, table_steps=max_K)      # (tables over every partition: nothing is left to the second pass)
     plan = engine.plan(params, lay, max_K)
     want = ("encode_chunk_kernel<10,10,3>" if B <= 10 else "encode_chunk_kernel<20,10,3>" if B <= 20 else
-            "encode_chunk_kernel<30,10,3>" if B <= 30 else "encode_chunk_kernel<32,16,2>")
+            "encode_chunk_kernel<30,10,3>" if B <= 30 else "encode_chunk_kernel<32,16,2>" if B <= 32 else
+            "encode_chunk_kernel<%d,10,2>" % (-(-B // 10) * 10))
     assert plan["kernel"] == want, plan["kernel"]
     assert plan["table_kernel"] == "prep_kernel (copy bits)" and plan["lds_bytes"] <= 160 * 1024
     K, idx, sample = engine.encode_blocks(params, lay, ql, qs, pl, ps, 42, max_K)
