@@ -272,7 +272,7 @@ def cpu_baselines(q, n_ref, n_opt_budget_s):
         return R.encode_tensor(*(h[i % n_host] for h in host), SEED, OMEGA, S, BEAMS, BLOCK_SIZE)
 
     probe = {}
-    # (measured once on the 256-thread GPU box, profiles/r02a/bench_default.err: 256 threads -> 0.005 latents/s against 3.9
+    # (measured once on the 256-thread GPU box, profiles/archive/r02a/bench_default.err: 256 threads -> 0.005 latents/s against 3.9
     # at 32 -- every eager op then pays a 256-way fork/join; the probe stops at 64 so that the bench finishes in minutes)
     for nt in sorted({min(cores, 16), min(cores, 32), min(cores, 64)}):
         torch.set_num_threads(nt)
@@ -638,7 +638,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--latents", type=int, default=65536, help="latent tensors per step per GPU (65 536: 589 824 blocks, "
                     "~378 ms per step -- a timed region of 7.6 s at the driver's 20 steps, so that its 5-second device "
-                    "samples cannot miss it; the rate per latent is the same from 8192 latents up, profiles/r03g/batch_size.log)")
+                    "samples cannot miss it; the rate per latent is the same from 8192 latents up, profiles/archive/r03g/batch_size.log)")
     ap.add_argument("--cpu-ref-latents", type=int, default=20, help="latents per CPU-ref repeat (5 repeats, median)")
     ap.add_argument("--cpu-opt-seconds", type=float, default=8.0, help="time budget of the CPU-opt (OpenMP oracle) leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(IREC_DEC_W
     // writes its samples over them: split and merge address the SAME elements (coder.py:62-83,111-117), each owned by one
     // unit, so nobody else reads or writes them between the two barriers -- no second barrier, no zero fill, no samples
     // waiting in registers.  A block that cannot be decoded leaves zeros.  (Handing the blocks out longest first, K and row
-    // of a tensor's blocks fetched a tensor ahead into lanes: no further gain, profiles/r03h/ab_dec_lpt.log.)
+    // of a tensor's blocks fetched a tensor ahead into lanes: no further gain, profiles/archive/r03h/ab_dec_lpt.log.)
     for (;;) {
       uint32_t u_ = 0u;
       if (lane == 0) u_ = __hip_atomic_fetch_add(unit_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -225,7 +225,7 @@ __device__ __forceinline__ bool rank_survivors(SM *sm, uint32_t C, int Bnew, int
 // latent tensor lie next to each other (eight 1000-dim blocks of an 8192-dim tensor) and gather their statistics out of the
 // same 4 x 32 KB through the shuffle, a line of 32 floats feeding all eight blocks.  Handing consecutive rows to consecutive
 // workgroups makes every XCD fetch every line of every tensor (a one-beam call of 256 latents: 0.26 ms; XCD-aware: 0.19 ms,
-// profiles/r03l/ab_lone_xcd.log).  So rows are dealt in groups of 64 = 8 x 8: the rows 8 x .. 8 x + 7 of a group go to XCD x.
+// profiles/archive/r03l/ab_lone_xcd.log).  So rows are dealt in groups of 64 = 8 x 8: the rows 8 x .. 8 x + 7 of a group go to XCD x.
 //   * static first round (slot u = k * gridDim.x + w for the k-th block stream of workgroup w, one block per CU before any
 //     CU gets a second): each aligned group of 64 slots is transposed as an 8 x 8 when gridDim.x is a multiple of 8 (then
 //     u mod 8 == w mod 8); a bijection on every full group below n_static, the tail and other grids keep u -> u;

@@ -1000,7 +1000,7 @@ irec_status irec_beam_encode_ex(irec_context *ctx, const irec_params *p, int64_t
     const int n_teams = irec::team_count_for(p->n_beams, p->n_samples, pl.shape);
     const int64_t tg = share_W >= 2 ? share_grid : batch_grid(n_blocks, std::min(pl.grid_cap / n_teams, ctx->n_cu > 0 ? ctx->n_cu : 256));
     const int64_t slots = share_W >= 2 ? share_first + (n_blocks - share_first) * share_W : n_blocks;
-    // (measured, profiles/r04w: the pre-pass -- a random gather of the call's statistics, +8 us on the preparation kernel -- and the ranking
+    // (measured, profiles/archive/r04w: the pre-pass -- a random gather of the call's statistics, +8 us on the preparation kernel -- and the ranking
     //  pay for themselves on the two-team build with 20-beam steps: 342 blocks 0.467 -> 0.449 ms, 405 blocks 0.538 -> 0.507; not with
     //  10-beam steps of half the length, nor on the three-team build)
     if (n_blocks > tg && slots <= tg * n_teams && n_teams == 2 && p->n_beams > 10 && irec::team_placeable(p->n_beams, p->n_samples, pl.shape)) A.row_cost = (const uint32_t *)((char *)workspace + irec::WS_COUNTER_BYTES + irec::WS_XCH_BYTES);

@@ -35,7 +35,7 @@ namespace irec {
 
 #ifndef IREC_SPLIT_CONSTS_EARLY
 #define IREC_SPLIT_CONSTS_EARLY 0   // beam-split build: 1 = next step's constants between publishing the keys and sweeping the partners'
-                                    // (r04 A/B, profiles/r04d: neutral -- the wait is skew between the partners, not hand-off latency); 0: in the update
+                                    // (r04 A/B, profiles/archive/r04d: neutral -- the wait is skew between the partners, not hand-off latency); 0: in the update
 #endif
 #ifndef IREC_SPLIT_NW
 #define IREC_SPLIT_NW 0             // waves per workgroup of the beam-split build; 0 = 8 for the 20-beam build (two sample stripes per dim group:
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
       // Beam-split build (r04): this step's sample scale is copied and the NEXT step's IEEE constants (six divisions and a
       // square root per dim: ~3 k cycles of one wave per SIMD) are formed HERE, between publishing my keys and sweeping the
       // partners' -- they depend on t only, not on the selection -- instead of in the update behind it: the wait for the
-      // partners (4.3 k cycles per step, profiles/r04a/stamps.log) absorbs them.
+      // partners (4.3 k cycles per step, profiles/archive/r04a/stamps.log) absorbs them.
       float sa_now[4] = {sa[0], sa[1], sa[2], sa[3]};
       float m_nx[4] = {0.f, 0.f, 0.f, 0.f}, cA_nx[4] = {0.f, 0.f, 0.f, 0.f}, cBv_nx[4] = {0.f, 0.f, 0.f, 0.f};
       if constexpr (beam_mode && IREC_SPLIT_CONSTS_EARLY != 0) {

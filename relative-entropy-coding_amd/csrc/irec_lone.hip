@@ -312,7 +312,7 @@ __global__ __launch_bounds__(LONE_NWV * 64, 1) void encode_lone_kernel(EncArgs A
     // ---- the block's statistics (split == gather through perm) and its KL ----
     // All dim groups' loads in two batches -- the 16 positions through perm, then the 64 statistics -- instead of a dependent
     // pair per group: a wave owns the whole block here, and eight dependent random-access round trips in front of every block
-    // were 29 % of a wave's time at S = 7 (profiles/r03j/stamps_lone.log).
+    // were 29 % of a wave's time at S = 7 (profiles/archive/r03j/stamps_lone.log).
     double tot = 0.0;
     {
       int64_t ixs[4][4];

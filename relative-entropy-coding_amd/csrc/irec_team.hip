@@ -1800,7 +1800,7 @@ static TeamShape team_shape(int B, int S, int ovr) {
   // (its third stripe holds 14 live beams and 4 phantoms instead of 10 and 10): -3 % time from S = 148 on (10.06 against
   // 9.71 look-ups/clk/CU at S = 1808), but its full-slot look-up pipeline at 168 VGPRs (416 B of scratch) loses 10-26 % to the
   // 60-beam build's half-slot diet below S ~ 100; stripes of 16 for B <= 48 lose at every S (B = 40 on the 60-beam build
-  // leaves its third stripe idle anyway) and are not built (profiles/r04g/).
+  // leaves its third stripe idle anyway) and are not built (profiles/archive/r04g/).
   if (cfg != 3 && B > 48 && B <= 54 && S >= 128) return TeamShape{54, 1, 3, false};
   if (B <= 60) return TeamShape{60, 1, 3, false};
   return TeamShape{0, 0, 0, false};
