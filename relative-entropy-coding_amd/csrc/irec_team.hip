@@ -55,6 +55,9 @@
 #ifndef IREC_PRIO_ROTATE_SHIFT
 #define IREC_PRIO_ROTATE_SHIFT 2
 #endif
+#ifndef IREC_BARRIER_SLEEP
+#define IREC_BARRIER_SLEEP 1   // s_sleep argument (x 64 clocks) between two polls of a team barrier's LDS counter (A/B r05l)
+#endif
 #ifndef IREC_STEP0_WIDE
 #define IREC_STEP0_WIDE 1   // first step (one beam): RW samples per reduce-scatter instead of one (0: the beam-wise path, A/B builds)
 #endif
@@ -129,7 +132,7 @@ struct TeamBarrier {
     for (;;) {
       const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
       if ((int32_t)(v - epoch) >= 0) break; // every wave of the team has arrived
-      __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_s_sleep(IREC_BARRIER_SLEEP);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
