@@ -60,7 +60,8 @@ typedef struct {
                           /* call's tables (2 * S * sum of the table dims bytes per step; at least               */
                           /* IREC_TABLE_STEPS_FLOOR steps within IREC_TABLE_BYTES_HARD).  Table scratch is       */
                           /* O(table_steps * S * D): a block with more partitions is coded by the fused-Philox   */
-                          /* kernel in a second pass of the same call -- same outputs, bit for bit.              */
+                          /* kernel in a second pass of the same call (blocks of more than 1024 dims: inside the */
+                          /* chunked encoder, which draws the rows of those steps itself) -- same outputs.       */
 } irec_params;
 
 #define IREC_FLAG_FORCE_GENERIC 1 /* use the generic (any D, any B) kernel even where the fast kernels apply   */
@@ -113,6 +114,8 @@ typedef struct {
 #define IREC_TABLE_BYTES_MAX (64u << 20)
 #define IREC_TABLE_STEPS_FLOOR 8            /* ... but the byte bound never cuts the window below 8 steps (one step of S = 8103, */
 #define IREC_TABLE_BYTES_HARD (1u << 30)    /* the reference's largest, is 19 MB for 1000 + 192 dims) unless those exceed 1 GB   */
+#define IREC_SLAB_BYTES_MAX (16ull << 30)   /* scratch slabs of a call whose blocks exceed 1024 dims: one per resident team, but no more than this  */
+                                            /* holds (a 301 056-dim block needs 55 MB of slab: 290 teams instead of 768 code such a call)         */
 #define IREC_TABLE_BYTES_BIG (4ull << 30)   /* the bound of calls whose blocks exceed 1024 dims (block_size = None on a whole tensor:  */
                                             /* K grows with the dims -- an 8192-dim block has ~60 partitions of 590 KB of rows each)   */
 

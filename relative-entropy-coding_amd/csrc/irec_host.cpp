@@ -621,11 +621,15 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
       pl.fast_grid_cap = 2 * n_cu;
       pl.grid_cap = std::max(pl.grid_cap, pl.fast_grid_cap);
       pl.ws_per_wg = std::max(generic_ws, round_up_sz(irec::team_ws_bytes_for(B, S, pl.shape, max_K), 256));
-    } else if (pl.chunk) {   // one slab per team of the chunked encoder; the generic kernel's second pass lies over the same slabs
+    } else if (pl.chunk) {   // one slab per team of the chunked encoder (it codes every block itself: no second pass)
       pl.one_grid_cap = 0;
-      pl.fast_grid_cap = 2 * n_cu;
-      pl.grid_cap = std::max(irec::chunk_teams(B, S) * n_cu, pl.fast_grid_cap);
-      pl.ws_per_wg = std::max(generic_ws, round_up_sz(irec::chunk_ws_for(B, pl.dpad, max_K), 256));
+      pl.fast_grid_cap = 0;
+      pl.ws_per_wg = round_up_sz(irec::chunk_ws_for(B, pl.dpad, max_K), 256);
+      // blocks of hundreds of thousands of dims: 55 MB of slab each at 301 056 dims -- no more slabs than IREC_SLAB_BYTES_MAX holds (and at
+      // least one workgroup's): such a call has a handful of blocks, each of which holds its team for seconds
+      const int teams = irec::chunk_teams(B, S);
+      const size_t fit = (size_t)IREC_SLAB_BYTES_MAX / pl.ws_per_wg;
+      pl.grid_cap = (int)std::max<size_t>((size_t)teams, std::min<size_t>((size_t)teams * n_cu, fit / teams * teams));
     } else {
       pl.one_grid_cap = pl.grid_cap; pl.fast_grid_cap = 0;
       pl.ws_per_wg = generic_ws;
@@ -638,10 +642,15 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
                                           (size_t)(max_K > 0 ? max_K : 1) * B * 4 + (size_t)S * B * 4, 256);
     pl.ws_per_wg = std::max(pl.ws_per_wg, generic_ws);
     pl.grid_cap = std::max(pl.grid_cap, 2 * n_cu);
+    if (max_dim > irec::FAST_MAX_DIM)   // (huge blocks: no more slabs than IREC_SLAB_BYTES_MAX holds; the generic kernel's grid follows)
+      pl.grid_cap = (int)std::max<size_t>(1, std::min<size_t>((size_t)pl.grid_cap, (size_t)IREC_SLAB_BYTES_MAX / pl.ws_per_wg));
   }
   if (!pl.table) pl.K_tab = 0;
   return pl;
 }
+
+// (defined below) workgroups of the chunked encoder for a call: one per CU, not more than blocks nor than the plan's slabs
+static int chunk_grid(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks);
 
 // Workgroups of a persistent batch encoder (team / one-beam): one per CU, not more than blocks -- rounded up to a multiple of
 // 8 where that fits, so that hand-out slot u runs on XCD u mod 8 (irec_fast_common.h: xcd_static_row); the extra workgroups
@@ -649,6 +658,12 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
 static int batch_grid(int64_t n_blocks, int cap) {
   const int64_t g = std::min<int64_t>(n_blocks, cap), r = (g + 7) & ~(int64_t)7;
   return (int)(r <= cap ? r : g);
+}
+
+static int chunk_grid(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks) {
+  const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+  const int teams = std::max(1, irec::chunk_teams(p->n_beams, p->n_samples));
+  return batch_grid(n_blocks, std::min(n_cu, std::max(1, pl.grid_cap / teams)));
 }
 
 // Split encoder for calls of so few blocks that most CUs would idle (one image's residual block: 9 blocks): W workgroups
@@ -817,7 +832,7 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
       out->table_steps = pl.K_tab; out->n_tables = pl.n_tab; out->table_bytes = (int64_t)pl.tab_bytes;
     } else {
       std::snprintf(out->kernel, sizeof out->kernel, "encode_generic_kernel (margins)");
-      out->grid = (int32_t)std::min<int64_t>(n_blocks, 2 * n_cu);
+      out->grid = (int32_t)std::min<int64_t>(n_blocks, std::min(pl.grid_cap, 2 * n_cu));
       out->waves_per_wg = 4; out->teams_per_wg = 1;
       out->lds_bytes = (int32_t)irec::generic_lds_bytes();
     }
@@ -826,10 +841,9 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
     return IREC_OK;
   }
   if (pl.chunk) {
-    const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
     std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::chunk_kernel_name(B, S));
     std::snprintf(out->table_kernel, sizeof out->table_kernel, "prep_kernel (copy bits)");
-    out->grid = batch_grid(n_blocks, n_cu);
+    out->grid = chunk_grid(ctx, pl, p, n_blocks);
     out->waves_per_wg = irec::chunk_teams(B, S) * 4;
     out->teams_per_wg = irec::chunk_teams(B, S);
     out->lds_bytes = (int32_t)irec::chunk_lds_for(B, S);
@@ -1041,14 +1055,13 @@ irec_status irec_beam_encode_ex(irec_context *ctx, const irec_params *p, int64_t
       A2.deferred_pass = 1; A2.coop_W = 1;
       A2.counter = (unsigned int *)workspace + 2;
       for (int q = 0; q < 4; ++q) { A2.tab[q] = nullptr; A2.tab_dim[q] = -1; }
-      if (out_margin) HIP_TRY(irec::launch_encode_generic(A2, (int)std::min<int64_t>(n_blocks, 2 * (ctx->n_cu > 0 ? ctx->n_cu : 256)), st));
+      if (out_margin) HIP_TRY(irec::launch_encode_generic(A2, (int)std::min<int64_t>(n_blocks, std::min(pl.grid_cap, 2 * (ctx->n_cu > 0 ? ctx->n_cu : 256))), st));
       else if (pl.team_only || pl.chunk) HIP_TRY(irec::launch_encode_generic(A2, (int)std::min<int64_t>(n_blocks, pl.fast_grid_cap), st));
       else HIP_TRY(irec::launch_encode_fast(A2, false, (int)std::min<int64_t>(n_blocks, pl.fast_grid_cap), st));
       return IREC_OK;
     };
-    if (pl.chunk) {   // one workgroup per CU, two teams, a block of any dim count per team
-      HIP_TRY(irec::launch_encode_chunk(A, batch_grid(n_blocks, ctx->n_cu > 0 ? ctx->n_cu : 256), st));
-      if (irec_status s2 = deferred_pass()) return s2;
+    if (pl.chunk) {   // one workgroup per CU, a block of any dim count per team; steps beyond the table window are drawn in the kernel: no second pass
+      HIP_TRY(irec::launch_encode_chunk(A, chunk_grid(ctx, pl, p, n_blocks), st));
     } else if (pl.team && pl.lone) { // one workgroup per CU, a block per wave
       HIP_TRY(irec::launch_encode_lone(A, batch_grid(n_blocks, ctx->n_cu > 0 ? ctx->n_cu : 256), st));
       if (irec_status s2 = deferred_pass()) return s2;
@@ -1134,7 +1147,7 @@ irec_status irec_beam_encode_ex(irec_context *ctx, const irec_params *p, int64_t
   } else if (pl.fast) {
     HIP_TRY(irec::launch_encode_fast(A, false, grid, st));
   } else {
-    if (out_margin) grid = (int)std::min<int64_t>(n_blocks, 2 * (ctx->n_cu > 0 ? ctx->n_cu : 256));
+    if (out_margin) grid = (int)std::min<int64_t>(n_blocks, std::min(pl.grid_cap, 2 * (ctx->n_cu > 0 ? ctx->n_cu : 256)));
     HIP_TRY(irec::launch_encode_generic(A, grid, st));
   }
 #ifdef IREC_HOST_STAMPS

@@ -116,7 +116,7 @@ hipError_t launch_alpha_choice(int64_t seed, int32_t S, int32_t D, int32_t K_tab
 hipError_t launch_alpha_choice_all(int64_t seed, int32_t S, int32_t K_tab, const uint16_t *dlog4r, int n, const int32_t *dims,
                                    uint16_t *const *tabs, const uint32_t *const *keeps, hipStream_t st);
 // blocks of more than 1024 dims: a team walks the block in chunks of 1024 over the team encoder's tables (irec_team.hip, encode_chunk_kernel)
-bool chunk_applies(int B, int S, int max_dim);          // B <= 60, 1024 < max_dim <= 65536, a step's partials and running scores fit the LDS next to the tables
+bool chunk_applies(int B, int S, int max_dim);          // B <= 60, max_dim > 1024, a step's partials and running scores fit the LDS next to the tables
 int chunk_teams(int B, int S);                           // teams (= scratch slabs) per workgroup of the build that serves the call: 2, 1, or 0 = none
 size_t chunk_lds_for(int B, int S);
 size_t chunk_ws_for(int B, int dpad, int max_K);         // scratch slab of one team

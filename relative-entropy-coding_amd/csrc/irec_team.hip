@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 //  beams; one team (beam passes of 10 / 16) for 30 / 32 beam slots, whose partials take the LDS of two.
 //  Slab of a team: stats [3][Dpad] | cvar [2][Dpad] (by step parity) | sa [Dpad] | beams [2][NB][Dpad] | bp [max_K][NB].
 // ======================================================================================================
-constexpr int CHUNK_MAX_DIM = 65536;
+constexpr int CHUNK_MAX_DIM = 1 << 22;   // (= the bound of irec_beam_encode's max_block_dim; the host caps the scratch slabs of huge blocks)
 __host__ __device__ inline size_t chunk_ws_bytes(int NB, int dpad, int max_K) {
   return (size_t)(6 + 2 * NB) * dpad * 4 + ((((size_t)(max_K > 0 ? max_K : 1) * NB * 4) + 255) & ~(size_t)255);
 }
@@ -1100,7 +1100,8 @@ __host__ __device__ inline size_t chunk_lds_total(int NB, int NBP, int S, int te
 // NB beam slots; NBP beams per scoring PASS (the G of NBP beams is what a wave holds in registers: NB = 30 scores a chunk in three passes
 // of 10 beams, NB = 32 in two of 16 -- the chunk's step constants are formed once, its rows are re-read per pass); TEAMS per workgroup.
 // Round 5: the steady-state scoring is the team encoder's software pipeline (the look-ups of the next dim slot in flight under the
-// current slot's fma, accumulators in register pairs, reduce_scatter_20 where 20 values are reduced together); B <= 32; D <= 65536;
+// current slot's fma, accumulators in register pairs, reduce_scatter_20 where 20 values are reduced together); any D; steps beyond the
+// proposal tables draw their rows in the kernel (plain scoring form), so no block of a chunked call is left to a second pass;
 // the partials are those of ONE pass (combined into the running scores pass by pass), so three teams of 10-beam passes -- 12 waves
 // per CU at 168 VGPRs, the register budget G of 10 beams fits without a spill -- find room next to the table copies; up to 60 beam slots
 // (passes of 10, two teams: 32 < B <= 60 of blocks beyond 1024 dims no longer falls to the generic kernel).
@@ -1232,10 +1233,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
     tsync();
     const int K = misc[1];
     if (K > A.max_K || K > A.K_limit) continue;
-    if (K > A.K_tab) { // beyond the table window: the second pass (generic kernel) codes it
-      if (tid == 0) atomicAdd(A.defer_count, 1u);
-      continue;
-    }
+    // (steps beyond the table window -- K grows with the dims: 2 200 partitions for a 301 056-dim block -- draw their rows in the kernel, below)
     if (K == 0) { // nothing to code: sample = p.loc
       for (int c = 0; c < NC; ++c) {
         const int d0 = (c << 10) + g * 256 + lane * 4;
@@ -1249,7 +1247,20 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
     int cur = 0, Bcur = 1;
     uint32_t bv_cur = 0u;                                            // lane j: 4 * dlog(hash(path of beam j))
     for (int t = 0; t < K; ++t) {
-      const uint16_t *tab_tu = tab + (size_t)t * S * Dp;             // this step's rows
+      const bool fused = t >= A.K_tab;                               // beyond the proposal tables: the rows are drawn here
+      const uint16_t *tab_tu = tab + (size_t)(fused ? 0 : t) * S * Dp; // this step's rows (fused: never read)
+      const StepSeed ss = make_step_seed(A.seed + t);
+      // Row of sample s_ for the quad at dim q0 (a multiple of 4) of a step beyond the tables: the int32 draw of get_pseudo_random_sample
+      // itself (beam_search_coder.py:38-43) mapped to discrete logs, copy bit 0 -- the table's format, random banks (8.9 instead of
+      // 13.7 look-ups/clk/CU, and a Philox block per quad and sample on the VALU: the regime of blocks no window can hold).
+      auto fused_row = [&](int s_, uint32_t q0) {
+        uint32_t rm1[4];
+        draw_rm1_x4(ss, (uint64_t)s_ * (uint64_t)D + (uint64_t)q0, rm1);   // ((s_ * D + q0) & 3 is wave-uniform: q0 % 4 == 0)
+        uint32_t a_[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_[i] = (uint32_t)dlog_s[rm1[i]] >> 2;
+        return make_uint2(a_[0] | (a_[1] << 16), a_[2] | (a_[3] << 16));
+      };
       const float rho = A.rho[K - 1 - t];
       const int N = S * Bcur;
       // ---------------- scoring, chunk by chunk (beam_search_coder.py:67-84) ----------------
@@ -1316,7 +1327,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
             uint32_t bet[NBP];
 #pragma unroll
             for (int b = 0; b < NBP; ++b) bet[b] = (uint32_t)__builtin_amdgcn_readlane((int)bv_cur, bp0 + b < Bcur ? bp0 + b : 0);
-            if (nlive == NBP && Bcur > 1) {
+            if (nlive == NBP && Bcur > 1 && !fused) {
               // ---- steady state, software pipelined by dim slot (as encode_team_kernel's scoring loop): the NBP look-ups of the NEXT slot are
               // issued before the current slot's values are consumed; values in register pairs (v_pk_fma_f32); rows two sample-chunks ahead
               typedef float f2 __attribute__((ext_vector_type(2)));
@@ -1397,7 +1408,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
 #pragma unroll
               for (int cc = 0; cc < SPC; ++cc) {
                 alp_next[cc] = make_uint2(0u, 0u);
-                if (cc < S) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)cc * Dp);
+                if (cc < S) alp_next[cc] = fused ? fused_row(cc, tab_lo) : *reinterpret_cast<const uint2 *>(tab_t + (size_t)cc * Dp);
               }
               for (int ch = 0; ch < nchunks; ++ch) {
                 float acc[rsn_room(RW)];
@@ -1408,7 +1419,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
                 for (int cc = 0; cc < SPC; ++cc) {
                   alp[cc] = alp_next[cc];
                   const int sn = (ch + 1) * SPC + cc;
-                  if (sn < S) alp_next[cc] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sn * Dp);
+                  if (sn < S) alp_next[cc] = fused ? fused_row(sn, tab_lo) : *reinterpret_cast<const uint2 *>(tab_t + (size_t)sn * Dp);
                 }
 #pragma unroll
                 for (int cc = 0; cc < SPC; ++cc) {
@@ -1499,7 +1510,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
               const int32_t sp_ = __builtin_amdgcn_readlane(v_sp, j);
               const int32_t bp_ = __builtin_amdgcn_readlane(v_bp, j);
               bet_old[u] = (uint32_t)__builtin_amdgcn_readlane((int)v_bo, j);
-              apv[u] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sp_ * Dp);
+              apv[u] = fused ? fused_row(sp_, tab_lo) : *reinterpret_cast<const uint2 *>(tab_t + (size_t)sp_ * Dp);
               if (t) obv4[u] = *reinterpret_cast<const float4 *>(bold + (size_t)bp_ * Dpad);
             }
           }

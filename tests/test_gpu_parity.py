@@ -336,8 +336,9 @@ def test_blocks_beyond_1024_dims_take_the_chunked_encoder(engine, oracle, n, bs,
 
 
 def test_chunked_encoder_second_pass_and_batches(engine, oracle):
-    """Blocks whose K exceeds the proposal-table window are left by the chunked encoder and coded by the generic kernel in
-    the call's second pass; K = 0 blocks return p.loc; a batch of more blocks than resident teams pulls from the counters."""
+    """Steps beyond the proposal-table window: the chunked encoder draws their rows in the kernel (round 5: Philox + discrete log per
+    quad and sample, copy bit 0 -- the generic kernel's second pass took such blocks until then); K = 0 blocks return p.loc; a batch
+    of more blocks than resident teams pulls from the counters."""
     n, bs, S, B = 4096, 2048, 36, 20
     n_t = 300                                              # 600 blocks > 512 resident teams
     stats = [oracle.synthetic_latent(8200 + i, n) for i in range(n_t)]
@@ -345,7 +346,7 @@ def test_chunked_encoder_second_pass_and_batches(engine, oracle):
     ql[5] = pl[5]; qs[5] = ps[5]                           # posterior == prior: KL = 0, K = 0
     lay = engine.layout(n_t, n, bs, 42)
     full = engine.params(3.0, S, B)
-    short = engine.params(3.0, S, B, table_steps=8)        # K ~ 15 per 2048-dim block: everything takes the second pass
+    short = engine.params(3.0, S, B, table_steps=8)        # K ~ 15 per 2048-dim block: every block codes its last steps from the draw itself
     K, idx, sample = engine.encode_blocks(full, lay, ql, qs, pl, ps, 42, 64)
     K2, idx2, sample2 = engine.encode_blocks(short, lay, ql, qs, pl, ps, 42, 64)
     Kh = K.cpu().numpy()
@@ -363,6 +364,31 @@ def test_chunked_encoder_second_pass_and_batches(engine, oracle):
         ridx, rs = oracle.encode_tensor(mq, sq, mp, sp, 42, 3.0, S, B, block_size=bs)
         assert [ih[lay.natural[i * bpt + j], :Kh[lay.natural[i * bpt + j]]].tolist() for j in range(bpt)] == ridx, i
         assert np.array_equal(sample[i].cpu().numpy(), rs), i
+
+
+def test_blocks_of_any_size_stay_off_the_generic_kernel(engine, oracle):
+    """Round 5: `Coder.__init__(block_size=None)` on a tensor of any size (coder.py:29-36,415-419) -- a block of 70 000 dims (beyond round
+    4's 16 384 and this round's first 65 536), posteriors close to the prior so that the oracle finishes: the chunked encoder, its scratch
+    slabs capped by IREC_SLAB_BYTES_MAX, a table window far shorter than K so that most steps draw their rows in the kernel; and the same
+    for 30 beams (passes of 10)."""
+    import irec
+    rng = np.random.default_rng(77)
+    for n, B, eps1, delta in ((70000, 20, 1.2, 0.02), (40000, 30, 1.0, 0.035), (301056, 20, 1.2, 0.01)):   # (the last: Kodak level 1 as ONE block)
+        S = oracle.n_samples(3.0, eps1)
+        mp = rng.normal(0, 1, n).astype(np.float32); sp = np.exp(rng.normal(0, 0.25, n)).astype(np.float32)
+        mq = (mp + sp * rng.normal(0, delta, n)).astype(np.float32); sq = (sp * np.exp(-np.abs(rng.normal(0, 0.005, n)))).astype(np.float32)
+        ridx, rs = oracle.encode_block(mq, sq, mp, sp, 11, 3.0, S, B)
+        assert 4 <= len(ridx) <= 12, len(ridx)
+        lay = engine.layout(1, n, None, 11)
+        params = engine.params(3.0, S, B, table_steps=2)
+        plan = engine.plan(params, lay, 32)
+        assert plan["kernel"].startswith("encode_chunk_kernel<%d," % (20 if B == 20 else 30)) and plan["table_steps"] == 2, plan
+        assert plan["workspace_bytes"] < 20 * 2 ** 30
+        q = tuple(torch.from_numpy(a[None]).cuda().contiguous() for a in (mq, sq, mp, sp))
+        K, idx, sample = engine.encode_blocks(params, lay, *q, 11, 32)
+        assert int(K.cpu()[0]) == len(ridx) and idx.cpu().numpy()[0, :len(ridx)].tolist() == ridx
+        assert np.array_equal(sample.cpu().numpy()[0], rs)
+        assert torch.equal(engine.decode_blocks(params, lay, q[2], q[3], 11, K, idx), sample)
 
 
 def test_wide_beam_uses_generic_path(engine, oracle):
