@@ -368,11 +368,23 @@ def secondary_config(eng, device, name, omega, eps1, beams, n_tensors, n_dims, r
                 assert ih[row, :Kh[row]].tolist() == ridx[i][j], f"{name}: parity, tensor {i} block {j}"
             assert np.array_equal(sh[i], rsamp[i]), f"{name}: parity, tensor {i} sample"
         checked = c
+    # how close this configuration's selections are (irec_beam_encode_ex on the same batch, outside the timing; same outputs asserted)
+    margins = None
+    if n_tensors >= 64:
+        K2, idx2, samp2, mg = eng.encode_blocks_margins(params, lay, *q, SEED, max_K)
+        torch.cuda.synchronize(device)
+        assert torch.equal(K2, out[0]) and torch.equal(samp2, out[2]), f"{name}: margins call differs from the timed call"
+        m = mg.cpu().numpy().astype(np.float64)
+        small = np.minimum(m[:, 0], m[:, 2])
+        margins = {"kernel": eng.plan(params, lay, max_K, margins=True)["kernel"], "blocks": int(m.shape[0]),
+                   "blocks_closer_than_1e-5": float((small < 1e-5).mean()), "blocks_closer_than_6.5e-5": float((small < 6.5e-5).mean()),
+                   "exact_ties": int((small == 0).sum()), "median_closest_comparison": float(np.median(small[np.isfinite(small)]))}
+        del K2, idx2, samp2, mg
     res = {"name": name, "reference": ref_line, "omega": omega, "extra_samples": eps1, "n_beams": beams, "n_samples": S,
            "tensors_per_call": n_tensors, "dims_per_tensor": n_dims, "block_size": block_size, "blocks_per_call": int(lay.n_blocks), "kernel": plan["kernel"],
            "grid": plan["grid"], "teams_sharing_a_row": plan["split"], "ms_per_call": ms, "ms_per_call_tables_kept": ms_keep,
            "tensors_per_s": n_tensors / (ms * 1e-3),
-           "lookups_per_clk_per_cu": lookups, "mean_K": float(Kh.mean()), "oracle_checked_tensors": checked}
+           "lookups_per_clk_per_cu": lookups, "mean_K": float(Kh.mean()), "oracle_checked_tensors": checked, "margins": margins}
     log(f"secondary {name}: {plan['kernel']} {ms:.3f} ms/call ({ms_keep:.3f} with the tables kept), {res['tensors_per_s']:.0f} tensors/s, {lookups:.2f} look-ups/clk/CU, "
         f"oracle-checked {checked}")
     del q, out
