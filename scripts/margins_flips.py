@@ -40,7 +40,11 @@ def main():
     ap.add_argument("--chunk", type=int, default=224)
     ap.add_argument("--first-image", type=int, default=100000)
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "margins_flips.json"))
+    ap.add_argument("--beams", type=int, default=B, help="n_beams (default: the headline's 20)")
+    ap.add_argument("--omega", type=float, default=OMEGA)
+    ap.add_argument("--eps1", type=float, default=EPS1, help="1 + extra_samples exponent (default 1.2: S = 36 at Omega = 3)")
     args = ap.parse_args()
+    globals().update(B=args.beams, OMEGA=args.omega, EPS1=args.eps1)
     S = O.n_samples(OMEGA, EPS1)
     gaps, tops, flips, kdiff, lit_small = [], [], [], [], []
     t0 = time.time()
