@@ -1,3 +1,5 @@
+"""Diagnostic (round 5): the chunked encoder on 3072 / 6144 one-block latents of 8192 dims per call, as listed and longest first --
+how much of a call is its tail (a block holds its team for 40 ms).  Usage: python scripts/chunk_tail.py"""
 import os, sys, time
 import numpy as np, torch
 ROOT = "/root/repo" if os.path.isdir("/root/repo/relative-entropy-coding_amd") else os.getcwd()
