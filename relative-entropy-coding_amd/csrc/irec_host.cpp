@@ -526,7 +526,10 @@ struct Plan {
   int tab_dim[4];
   size_t tab_off[4]; // byte offsets of the proposal tables inside the workspace (after the 256-byte counter block)
   size_t tab_bytes;  // total
+  int gang_blocks;   // chunk plans: blocks of one call that gangs of teams may code (0: no gang build for the shape), and
+  size_t gang_stride, gang_bytes;   // the exchange of one block / of all, behind the slabs
 };
+size_t plan_ws_bytes(const Plan &pl) { return irec::WS_HEAD_BYTES + pl.tab_bytes + (size_t)pl.grid_cap * pl.ws_per_wg + pl.gang_bytes; }
 
 // steps of proposal tables the byte bounds allow at `per_step` bytes per step: what IREC_TABLE_BYTES_MAX holds, but not fewer
 // than IREC_TABLE_STEPS_FLOOR while those stay within IREC_TABLE_BYTES_HARD
@@ -558,6 +561,7 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
             irec::fast_lds_for(B, S, false) <= irec::FAST_LDS_LIMIT && (int64_t)S * B < (1 << 24);
   pl.grid_cap = 2 * n_cu; // measured residency: 2 workgroups per CU for every encoder
   pl.table = false; pl.team = false; pl.lone = false; pl.chunk = false; pl.n_tab = 0; pl.tab_bytes = 0;
+  pl.gang_blocks = 0; pl.gang_stride = 0; pl.gang_bytes = 0;
   // table window: the tables cover the first K_tab partitions; blocks with more go to the fused-Philox second pass
   const int want = p->table_steps > 0 ? p->table_steps : IREC_TABLE_STEPS_DEFAULT;
   pl.K_tab = std::max(1, std::min(std::min(want, IREC_TABLE_STEPS_MAX), max_K > 0 ? max_K : 1));
@@ -630,6 +634,12 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
       const int teams = irec::chunk_teams(B, S);
       const size_t fit = (size_t)IREC_SLAB_BYTES_MAX / pl.ws_per_wg;
       pl.grid_cap = (int)std::max<size_t>((size_t)teams, std::min<size_t>((size_t)teams * n_cu, fit / teams * teams));
+      // gangs (calls of fewer blocks than team slots, gang_width below): the exchange of up to GANG_MAX_BLOCKS blocks behind the slabs
+      if (const int gnb = irec::chunk_gang_nb(B, S); gnb && !(p->flags & (IREC_FLAG_NO_SPLIT | IREC_FLAG_MARGINS))) {
+        pl.gang_stride = irec::gang_xch_bytes(gnb, S, pl.dpad);
+        pl.gang_blocks = (int)std::min<size_t>((size_t)irec::GANG_MAX_BLOCKS, irec::GANG_XCH_BYTES_MAX / pl.gang_stride);
+        pl.gang_bytes = (size_t)pl.gang_blocks * pl.gang_stride;
+      }
     } else {
       pl.one_grid_cap = pl.grid_cap; pl.fast_grid_cap = 0;
       pl.ws_per_wg = generic_ws;
@@ -664,6 +674,32 @@ static int chunk_grid(const irec_context *ctx, const Plan &pl, const irec_params
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
   const int teams = std::max(1, irec::chunk_teams(p->n_beams, p->n_samples));
   return batch_grid(n_blocks, std::min(n_cu, std::max(1, pl.grid_cap / teams)));
+}
+// Gangs of the chunked encoder (irec_team.hip, "Gangs"): a call of fewer blocks than team slots -- block_size = None on one image's
+// latents -- has G teams code each block together, a chunk of 1024 dims (or several) per member.  All n_blocks * G teams must be resident
+// at once (one static hand-out slot each; they wait for each other twice per step).  Returns G (0: every block on one team) and the
+// grid that puts the members on CUs of their own as far as the CUs go.
+int gang_width(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks, int32_t max_block_dim, int *grid, int *chunk_owners) {
+  if (!pl.chunk || pl.gang_blocks < 1 || n_blocks < 1 || n_blocks > pl.gang_blocks || (p->flags & (IREC_FLAG_NO_SPLIT | IREC_FLAG_MARGINS))) return 0;
+  const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+  const int teams = std::max(1, irec::chunk_teams(p->n_beams, p->n_samples));
+  const int wgs = std::min(n_cu, std::max(1, pl.grid_cap / teams));
+  const int64_t slots = (int64_t)wgs * teams;
+  const int64_t chunks = ((int64_t)max_block_dim + 1023) >> 10;
+  const int64_t GC = std::min(chunks, slots / n_blocks);               // chunk owners per block
+  if (GC < 1) return 0;
+  // ... x sample stripes per chunk: the sample-chunks of a step (two samples each) shared between SP teams -- while there are CUs without a
+  // member: a stripe repeats its chunk's statistics, step constants and update, which costs more than it saves where members share a CU
+  // (r05s/gang_stripes.log: 24 blocks of 8192 dims 6.1 ms with 192 members, 8.9 ms with 576)
+  const int want = (p->flags & IREC_FLAG_SPLIT_MASK) >> IREC_FLAG_SPLIT_SHIFT;
+  int64_t SP = std::min<int64_t>(wgs / (n_blocks * GC), want >= 1 ? want : IREC_GANG_STRIPES);
+  SP = std::max<int64_t>(1, std::min<int64_t>(SP, (p->n_samples + 1) / 2));
+  const int64_t G = GC * SP;
+  if (G < 2) return 0;
+  const int64_t n_slots = n_blocks * G;
+  if (grid) *grid = (int)std::min<int64_t>(wgs, n_slots);   // slot u = team u / grid of workgroup u % grid: one member per CU first
+  if (chunk_owners) *chunk_owners = (int)GC;
+  return (int)G;
 }
 
 // Split encoder for calls of so few blocks that most CUs would idle (one image's residual block: 9 blocks): W workgroups
@@ -802,7 +838,7 @@ extern "C" {
 size_t irec_encode_workspace_bytes(const irec_context *ctx, const irec_params *p, int32_t max_dim, int32_t max_K) {
   if (!ctx || check_params(p) != IREC_OK || max_dim < 1 || max_K < 0) return 0;
   const Plan pl = make_plan(ctx, p, max_dim, max_K);
-  return irec::WS_HEAD_BYTES + pl.tab_bytes + (size_t)pl.grid_cap * pl.ws_per_wg;
+  return plan_ws_bytes(pl);
 }
 
 irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int64_t n_blocks, int32_t max_block_dim,
@@ -837,13 +873,18 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
       out->lds_bytes = (int32_t)irec::generic_lds_bytes();
     }
     out->n_cu = ctx->n_cu; out->clock_mhz = ctx->clock_mhz;
-    out->workspace_bytes = (int64_t)(irec::WS_HEAD_BYTES + pl.tab_bytes + (size_t)pl.grid_cap * pl.ws_per_wg);
+    out->workspace_bytes = (int64_t)plan_ws_bytes(pl);
     return IREC_OK;
   }
   if (pl.chunk) {
     std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::chunk_kernel_name(B, S));
     std::snprintf(out->table_kernel, sizeof out->table_kernel, "prep_kernel (copy bits)");
     out->grid = chunk_grid(ctx, pl, p, n_blocks);
+    {
+      int ggrid = 0;
+      out->split = gang_width(ctx, pl, p, n_blocks, max_block_dim, &ggrid, nullptr);   // teams that code each block together
+      if (out->split >= 2) { out->grid = ggrid; std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::chunk_kernel_name(B, S, true)); }
+    }
     out->waves_per_wg = irec::chunk_teams(B, S) * 4;
     out->teams_per_wg = irec::chunk_teams(B, S);
     out->lds_bytes = (int32_t)irec::chunk_lds_for(B, S);
@@ -897,7 +938,7 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
   out->n_cu = ctx->n_cu;
   out->clock_mhz = ctx->clock_mhz;
   out->table_bytes = (int64_t)pl.tab_bytes;
-  out->workspace_bytes = (int64_t)(irec::WS_HEAD_BYTES + pl.tab_bytes + (size_t)pl.grid_cap * pl.ws_per_wg);
+  out->workspace_bytes = (int64_t)plan_ws_bytes(pl);
   return IREC_OK;
 }
 
@@ -952,7 +993,7 @@ irec_status irec_beam_encode_ex(irec_context *ctx, const irec_params *p, int64_t
   if (max_K > 0 && !out_indices) return fail(IREC_E_INVALID, "irec_beam_encode: null out_indices");
   if (max_block_dim < 1 || max_block_dim > (1 << 22)) return fail(IREC_E_INVALID, "irec_beam_encode: max_block_dim %d out of range", max_block_dim);
   Plan pl = make_plan(ctx, p, max_block_dim, max_K);
-  const size_t need = irec::WS_HEAD_BYTES + pl.tab_bytes + (size_t)pl.grid_cap * pl.ws_per_wg;
+  const size_t need = plan_ws_bytes(pl);
   if (!workspace || workspace_bytes < need)
     return fail(IREC_E_WORKSPACE, "irec_beam_encode: workspace %zu bytes < required %zu", workspace_bytes, need);
   // top-B margins: a margin build of the team encoder where one serves the call's shape (whatever the call's size), else the generic
@@ -1007,6 +1048,7 @@ irec_status irec_beam_encode_ex(irec_context *ctx, const irec_params *p, int64_t
   int share_grid = 0;
   const int share_W = (pl.table && pl.team) ? team_share_width(ctx, pl, p, n_blocks, pl.shape, &share_first, &share_grid) : 0;
   if (share_W >= 2) split_blocks = (int)(n_blocks - share_first);
+  if (pl.chunk && gang_width(ctx, pl, p, n_blocks, max_block_dim, nullptr, nullptr) >= 2) split_blocks = (int)n_blocks;   // (their granules' first words: the gangs' arrival counters)
   // Cost-ordered hand-out (team encoder, calls of more rows than workgroups whose slots the static round deals completely --
   // one to TEAMS rows per CU): the preparation kernel also writes K * dims of every row, and the teams take their rows by cost rank
   // (irec_team.hip, "Cost-ordered hand-out").  IREC_FLAG_LISTED_ORDER: rows as listed (A/B runs).
@@ -1061,7 +1103,14 @@ irec_status irec_beam_encode_ex(irec_context *ctx, const irec_params *p, int64_t
       return IREC_OK;
     };
     if (pl.chunk) {   // one workgroup per CU, a block of any dim count per team; steps beyond the table window are drawn in the kernel: no second pass
-      HIP_TRY(irec::launch_encode_chunk(A, chunk_grid(ctx, pl, p, n_blocks), st));
+      int cgrid = chunk_grid(ctx, pl, p, n_blocks), ggrid = 0, gchunks = 0;
+      if (const int G = gang_width(ctx, pl, p, n_blocks, max_block_dim, &ggrid, &gchunks)) {
+        A.coop_W = G; A.gang_chunks = gchunks; cgrid = ggrid;
+        A.gang_xch = (char *)workspace + irec::WS_HEAD_BYTES + pl.tab_bytes + (size_t)pl.grid_cap * pl.ws_per_wg;
+        A.gang_stride = pl.gang_stride;
+        A.coop_test_orphan = (p->flags & IREC_FLAG_TEST_SPLIT_ORPHAN) ? 1 : 0;
+      }
+      HIP_TRY(irec::launch_encode_chunk(A, cgrid, st));
     } else if (pl.team && pl.lone) { // one workgroup per CU, a block per wave
       HIP_TRY(irec::launch_encode_lone(A, batch_grid(n_blocks, ctx->n_cu > 0 ? ctx->n_cu : 256), st));
       if (irec_status s2 = deferred_pass()) return s2;

@@ -55,6 +55,12 @@ struct EncArgs {
   // head of the workspace (nullptr: no table books, e.g. irec_block_kl): every encode kernel's first workgroup commits the table
   // stamps the call's preparation kernel left pending (commit_table_stamps, irec_fast_common.h)
   uint32_t *ws_head;
+  // Gangs of the chunked encoder (irec_team.hip, round 5): calls of so few blocks of more than 1024 dims that most CUs would idle --
+  // block_size = None on one image's latents.  coop_W teams code a block together, each the chunks c = member (mod coop_W) of it; per step
+  // they hand the group sums of their chunks over through gang_xch (gang_stride bytes per block: gang_xch_bytes) behind an arrival
+  // counter (first word of the block's granules in coop_xch), and every canonical sum is formed from all of its group sums in group order.
+  char *gang_xch; size_t gang_stride;
+  int32_t gang_chunks;        // the coop_W members of a gang = gang_chunks chunk owners x coop_W / gang_chunks sample stripes
   int32_t coop_beams;         // 1: the workgroups of a block share its beams (slots w, w + coop_W) instead of its samples
   int32_t coop_test_orphan;   // IREC_FLAG_TEST_SPLIT_ORPHAN: partners leave at once (exercises the give-up exit)
   // top-B margins (irec_beam_encode_ex, IREC_FLAG_MARGINS): [n_blocks][4] floats, see "top-B margins" in irec_fast_common.h; nullptr in
@@ -120,7 +126,8 @@ bool chunk_applies(int B, int S, int max_dim);          // B <= 60, max_dim > 10
 int chunk_teams(int B, int S);                           // teams (= scratch slabs) per workgroup of the build that serves the call: 2, 1, or 0 = none
 size_t chunk_lds_for(int B, int S);
 size_t chunk_ws_for(int B, int dpad, int max_K);         // scratch slab of one team
-const char *chunk_kernel_name(int B, int S);
+const char *chunk_kernel_name(int B, int S, bool gang = false);
+int chunk_gang_nb(int B, int S);                         // beam slots of the gang build that serves the call, 0 = none
 hipError_t launch_encode_chunk(const EncArgs &A, int grid, hipStream_t st);
 // one-beam calls: one wave per block over the team encoder's tables (irec_lone.hip)
 bool lone_applies(int B, int shape_override);           // n_beams == 1 and no diagnostic shape pinned (IREC_FLAG_SHAPE_TEAM pins the team encoder)
@@ -173,6 +180,18 @@ constexpr int COOP_SPLIT_MAX_BLOCKS = 64;                  // the split encoder 
 #endif
 constexpr bool IREC_COOP_GRANULES_ON = IREC_COOP_GRANULES != 0;
 constexpr size_t WS_XCH_BYTES = (size_t)2 * COOP_MAX_BLOCKS * COOP_KEYS * 8;   // key exchange of the split encoder, double buffered: {key, tag} granules
+// gang exchange of one block: group sums of the candidates [S * nb][NGm] and of the C_b terms [nb][NGm] (float), of the KL [NGm] (double),
+// the step's sort keys [S * nb]; NGm = 4 * chunks of the call's largest block (dpad: its dims rounded up to 256)
+__host__ __device__ inline size_t gang_xch_bytes(int nb, int S, int dpad) {
+  const size_t NGm = (size_t)4 * (((size_t)dpad + 1023) >> 10), NC_ = (size_t)S * nb;
+  return (4 * NGm * (NC_ + nb) + 8 * NGm + 4 * NC_ + 255) & ~(size_t)255;
+}
+#ifndef IREC_GANG_STRIPES
+#define IREC_GANG_STRIPES 8   // sample stripes per chunk of a gang, at most (r05s/gang_stripes.log: one block of 8192 dims 5.2 / 3.5 / 2.9 / 2.5 / 2.3 ms with
+                              // 1 / 2 / 4 / 6 / 9; IREC_FLAG_SPLIT_* bits: a call's own cap)
+#endif
+constexpr int GANG_MAX_BLOCKS = COOP_MAX_BLOCKS;                 // blocks of a call coded by gangs (their arrival counters: the head's exchange granules)
+constexpr size_t GANG_XCH_BYTES_MAX = (size_t)1 << 30;          // ... and no more of them than this much exchange holds
 constexpr int COST_MAX_ROWS = 1024;                              // rows of a call whose hand-out is cost-ordered (EncArgs::row_cost)
 constexpr size_t WS_COST_BYTES = (size_t)COST_MAX_ROWS * 4;
 constexpr size_t WS_HEAD_BYTES = WS_COUNTER_BYTES + WS_XCH_BYTES + WS_COST_BYTES;   // (the row costs lie behind the exchange granules)

@@ -1087,6 +1087,16 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 //  only shared state is the team's LDS (partials, running scores / keys, selection).  Two teams per CU at 256 VGPRs for up to 20
 //  beams; one team (beam passes of 10 / 16) for 30 / 32 beam slots, whose partials take the LDS of two.
 //  Slab of a team: stats [3][Dpad] | cvar [2][Dpad] (by step parity) | sa [Dpad] | beams [2][NB][Dpad] | bp [max_K][NB].
+//
+//  Gangs (GANG builds, round 5): a call of FEWER blocks than team slots -- block_size = None on one image's latents: one block of 8192
+//  dims would keep one team of one CU busy for 40 ms while 255 CUs idle.  G = A.coop_W teams, each on a CU of its own where the grid allows,
+//  code a block together: member m owns the chunks m, m + G, ... (statistics, scoring, update: nothing of a chunk ever leaves its
+//  member but its group sums).  Per step: every member writes the group sums of its chunks to the block's exchange in HBM; gang barrier;
+//  member m forms the canonical sums -- all group sums of a candidate in increasing group order: the same float32 chain the
+//  one-team form adds chunk by chunk -- of the candidates m, m + G, ..., and publishes their sort keys; gang barrier; every member reads
+//  all keys and runs the same selection.  The bits are the one-team form's (and the generic kernel's); the K of the block comes the same
+//  way from the group sums of its KL.  Members wait for each other: all n_blocks * G teams must be resident (one static hand-out slot
+//  each), a member that waits 100 ms for partners that are not poisons the block's counter and the block is reported not coded (-2).
 // ======================================================================================================
 constexpr int CHUNK_MAX_DIM = 1 << 22;   // (= the bound of irec_beam_encode's max_block_dim; the host caps the scratch slabs of huge blocks)
 __host__ __device__ inline size_t chunk_ws_bytes(int NB, int dpad, int max_K) {
@@ -1105,7 +1115,7 @@ __host__ __device__ inline size_t chunk_lds_total(int NB, int NBP, int S, int te
 // the partials are those of ONE pass (combined into the running scores pass by pass), so three teams of 10-beam passes -- 12 waves
 // per CU at 168 VGPRs, the register budget G of 10 beams fits without a spill -- find room next to the table copies; up to 60 beam slots
 // (passes of 10, two teams: 32 < B <= 60 of blocks beyond 1024 dims no longer falls to the generic kernel).
-template <int NB, int NBP, int TEAMS>
+template <int NB, int NBP, int TEAMS, bool GANG = false>
 __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArgs A) {
   using TeamLds = TeamLdsT<NB>;
   constexpr int TEAM_MB = team_mb(NB);
@@ -1162,11 +1172,23 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
   const int64_t n_static = (int64_t)TEAMS * (int64_t)gridDim.x < A.n_blocks ? (int64_t)TEAMS * (int64_t)gridDim.x : A.n_blocks;
   bool first_block = true;
   int steal = 0;
+  // GANG: the G = A.coop_W teams in hand-out slots [blk * G, blk * G + G) code block blk together -- member gm owns the chunks gm, gm + G, ...
+  // of it (see "gangs" above the kernel); a team takes its one slot of the static round and leaves
+  // The G members are GC chunk owners x SP sample stripes: member gm owns the chunks gc = gm % GC, gc + GC, ... and scores the samples of
+  // sample-chunk sp = gm / GC, sp + SP, ... of them (statistics, step constants, G and the update of a chunk are repeated by its SP stripes,
+  // each in its own slab; the group sums of a candidate still come from ONE member each).
+  const int G = GANG ? A.coop_W : 1;
+  const int GC = GANG ? A.gang_chunks : 1, SP = GANG ? G / GC : 1;
+  uint32_t gang_epoch = 0u;
   for (;;) {
     tsync();
     if (tid == 0) {
       int64_t r;
-      if (first_block) {
+      if constexpr (GANG) {
+        const int64_t slot = (int64_t)team * (int64_t)gridDim.x + (int64_t)blockIdx.x;
+        r = first_block && slot < A.n_blocks * (int64_t)G ? slot / G : A.n_blocks;
+        misc[2] = (int32_t)(slot % G);
+      } else if (first_block) {
         r = (int64_t)team * (int64_t)gridDim.x + (int64_t)blockIdx.x;
         r = r < n_static ? xcd_static_row(r, n_static, (int)gridDim.x) : A.n_blocks;
       } else r = xcd_pull_row(A, n_static, A.n_blocks, steal);
@@ -1176,6 +1198,9 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
     tsync();
     const int64_t blk = misc[0];
     if (blk >= A.n_blocks) break; // every wave of the team reaches this
+    const int gm = GANG ? misc[2] : 0;
+    const int gc = gm % GC, sp = gm / GC;
+    if (GANG && A.coop_test_orphan && gm != 0) break;   // IREC_FLAG_TEST_SPLIT_ORPHAN: member 0 waits alone, gives up, reports -2
     const int D = A.block_dim[blk];
     const int64_t base = A.block_base[blk];
     const int32_t pos = A.block_pos[blk];
@@ -1190,9 +1215,89 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
     const int Dp = (D + 3) & ~3;            // row stride of the proposal table
     const int NC = (D + 1023) >> 10;        // chunks of 1024 dims
     auto groups_of = [&](int c) { const int left = D - (c << 10); return left >= 1024 ? 4 : (left + 255) >> 8; };
+    // ---- gang exchange of this block (GANG only; layout: gang_xch_bytes, irec_kernels.h) ----
+    const int NGt = (D + 255) >> 8;                                // dim groups of the block: the terms of every canonical sum, in order
+    const int NGm = 4 * ((Dpad + 1023) >> 10);                     // row stride of the exchange (groups of the call's largest block)
+    const int NCAND = S * NB;
+    float *gx_part = nullptr, *gx_cpart = nullptr;
+    unsigned long long *gx_kl = nullptr;
+    uint32_t *gx_keys = nullptr;
+    unsigned int *gang_ctr = nullptr;
+    if constexpr (GANG) {
+      char *xb = A.gang_xch + (size_t)blk * A.gang_stride;
+      gx_part = reinterpret_cast<float *>(xb);                     // [S * NB][NGm]: group sums of every candidate, candidate-major
+      gx_cpart = gx_part + (size_t)NCAND * NGm;                    // [NB][NGm]: group sums of the C_b terms
+      gx_kl = reinterpret_cast<unsigned long long *>(gx_cpart + (size_t)NB * NGm);   // [NGm] doubles: group sums of the KL
+      gx_keys = reinterpret_cast<uint32_t *>(gx_kl + NGm);         // [S * NB] sort keys of the step
+      gang_ctr = reinterpret_cast<unsigned int *>(A.coop_xch) + (size_t)blk * (COOP_KEYS * 2);   // first word of the block's exchange granules in the
+                                                                                             // workspace head: zeroed by the call's preparation kernel
+    }
+    // Barrier of the gang: a monotonic arrival counter in HBM.  Everything handed over travels as agent-scope (sc1) stores that have
+    // drained before the arrival (the team barrier's release fence waits for vmcnt) and is read back by agent-scope loads.  A member
+    // that has waited COOP_GIVE_UP_TICKS for partners that are not resident POISONS the counter (bit 31, by compare-and-swap against an
+    // incomplete count, so that either every member passes a barrier or none does) and the block is reported as not coded (out_K = -2).
+    auto gsync = [&]() -> bool {
+      gang_epoch += (uint32_t)G;
+      tsync();
+      if (tid == 0) {
+        int32_t bad = 0;
+        __hip_atomic_fetch_add(gang_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (uint32_t turn = 1;; ++turn) {
+          const uint32_t v = __hip_atomic_load(gang_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (v >> 31) { bad = 1; break; }
+          if ((int32_t)(v - gang_epoch) >= 0) break;
+          __builtin_amdgcn_s_sleep(2);
+          if ((turn & 63u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > COOP_GIVE_UP_TICKS) {
+            uint32_t expect = v;
+            if (__hip_atomic_compare_exchange_strong(gang_ctr, &expect, v | 0x80000000u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+              __hip_atomic_store(A.coop_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              bad = 1; break;
+            }
+          }
+        }
+        misc[6] = bad;
+      }
+      tsync();
+      return misc[6] == 0;
+    };
+    auto ld_f32 = [](const float *p_) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(p_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
+    auto st_f32x2 = [](float *p_, float a_, float b_) {   // (8-byte aligned)
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(p_), (unsigned long long)__float_as_uint(a_) | ((unsigned long long)__float_as_uint(b_) << 32),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // Canonical sums of `nrows` exchange rows (NGt terms each, increasing group order), staged through the partial buffer: all threads
+    // fetch a range of groups of up to NT rows, one thread per row adds the range onto its running value in order.
+    // src(i): the row's base; sink(i, v): what to do with its sum.
+    auto gang_reduce = [&](int nrows, auto src, auto sink) {
+      float *stage = part_s;
+      const int CAP = 4 * S * NBP;
+      const int TI = NT < CAP ? NT : CAP;
+      for (int r0 = 0; r0 < nrows; r0 += TI) {
+        const int nr = nrows - r0 < TI ? nrows - r0 : TI;
+        int GR = CAP / nr;
+        if (GR > NGt) GR = NGt;
+        float v = 0.f;
+        for (int g0 = 0; g0 < NGt; g0 += GR) {
+          const int ng = NGt - g0 < GR ? NGt - g0 : GR;
+          for (int e = tid; e < nr * ng; e += NT) { const int i = e / ng, gi = e - i * ng; stage[e] = ld_f32(src(r0 + i) + g0 + gi); }
+          tsync();
+          if (tid < nr) {
+            const float *p_ = stage + tid * ng;
+            int gi = 0;
+            if (g0 == 0) { v = p_[0]; gi = 1; }
+            for (; gi < ng; ++gi) v = v + p_[gi];
+          }
+          tsync();
+        }
+        if (tid < nr) sink(r0 + tid, v);
+      }
+      tsync();
+    };
+    bool gang_lost = false;
 
     // ---- statistics (split == gather through perm) and the block's KL, groups in increasing order ----
-    for (int c = 0; c < NC; ++c) {
+    for (int c = gc; c < NC; c += GC) {
       const int ngc = groups_of(c);
       const int d0 = (c << 10) + g * 256 + lane * 4;
       double klacc = 0.0;
@@ -1214,6 +1319,10 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
         *reinterpret_cast<float4 *>(cvar_g + d0) = make_float4(0.f, 0.f, 0.f, 0.f);
       }
       const double gs = wave_tree_sum(klacc);
+      if constexpr (GANG) {
+        if (g < ngc && lane == 0 && sp == 0) __hip_atomic_store(gx_kl + c * 4 + g, (unsigned long long)__double_as_longlong(gs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        continue;
+      }
       if (g < ngc && lane == 0) gpart[g] = gs;
       tsync();
       if (tid == 0) {
@@ -1223,10 +1332,28 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
       }
       tsync();
     }
+    if constexpr (GANG) {   // the group sums of every member, added in group order by every member
+      if (!gsync()) { if (tid == 0) A.out_K[blk] = -2; continue; }
+      double *stage = reinterpret_cast<double *>(part_s);
+      const int CAPD = 2 * S * NBP;
+      double tot = 0.0;
+      for (int g0 = 0; g0 < NGt; g0 += CAPD) {
+        const int ng = NGt - g0 < CAPD ? NGt - g0 : CAPD;
+        for (int e = tid; e < ng; e += NT) stage[e] = __longlong_as_double((long long)__hip_atomic_load(gx_kl + g0 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        tsync();
+        if (tid == 0) {
+          int gi = 0;
+          if (g0 == 0) { tot = stage[0]; gi = 1; }
+          for (; gi < ng; ++gi) tot = tot + stage[gi];
+        }
+        tsync();
+      }
+      if (tid == 0) *kl_tot = tot;
+    }
     if (tid == 0) {
       const int32_t K = num_aux((float)*kl_tot, A.omega);
       misc[1] = K;
-      A.out_K[blk] = K;
+      if (gm == 0) A.out_K[blk] = K;
       hsum[0] = 0;
       beta4[0] = 0u; // hash of the empty path is 1 = g^0
     }
@@ -1235,7 +1362,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
     if (K > A.max_K || K > A.K_limit) continue;
     // (steps beyond the table window -- K grows with the dims: 2 200 partitions for a 301 056-dim block -- draw their rows in the kernel, below)
     if (K == 0) { // nothing to code: sample = p.loc
-      for (int c = 0; c < NC; ++c) {
+      for (int c = gc; sp == 0 && c < NC; c += GC) {
         const int d0 = (c << 10) + g * 256 + lane * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1264,7 +1391,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
       const float rho = A.rho[K - 1 - t];
       const int N = S * Bcur;
       // ---------------- scoring, chunk by chunk (beam_search_coder.py:67-84) ----------------
-      for (int c = 0; c < NC; ++c) {
+      for (int c = gc; c < NC; c += GC) {
         const int ngc = groups_of(c);
         const int d0 = (c << 10) + g * 256 + lane * 4;
         const bool mine = g < ngc;                                    // (wave-uniform) this dim group exists in the chunk
@@ -1340,7 +1467,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
               };
               uint2 ap_cur[SPC], ap_nxt[SPC];
 #pragma unroll
-              for (int cc = 0; cc < SPC; ++cc) { ap_cur[cc] = row(cc); ap_nxt[cc] = row(SPC + cc); }
+              for (int cc = 0; cc < SPC; ++cc) { ap_cur[cc] = row(sp * SPC + cc); ap_nxt[cc] = row((sp + SP) * SPC + cc); }
 #define CHUNK_AL(CC, I) ((((I) & 2) ? (((I) & 1) ? (ap_cur[CC].y >> 16) : (ap_cur[CC].y & 0xFFFFu)) : (((I) & 1) ? (ap_cur[CC].x >> 16) : (ap_cur[CC].x & 0xFFFFu))) << 2)
 #define CHUNK_ISSUE(Z, AD) do { _Pragma("unroll") for (int k = 0; k < NP; ++k) { Z[k].x = lds_abs_f32((AD) + bet[2 * k]); Z[k].y = lds_abs_f32((AD) + bet[2 * k + 1]); } \
                                 __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -1354,7 +1481,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
                                 __builtin_amdgcn_sched_barrier(0); } while (0)
               f2 zz[2][NP];
               CHUNK_ISSUE(zz[0], CHUNK_AL(0, 0));
-              for (int ch = 0; ch < n_sch; ++ch) {
+              for (int ch = sp; ch < n_sch; ch += SP) {          // (my stripe of the sample-chunks; SP = 1 but in gangs)
                 f2 acc2[SPC][NP];
 #pragma unroll
                 for (int cc = 0; cc < SPC; ++cc)
@@ -1362,7 +1489,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
                   for (int k = 0; k < NP; ++k) acc2[cc][k] = (f2){0.f, 0.f};
                 uint2 ap_new[SPC];
 #pragma unroll
-                for (int cc = 0; cc < SPC; ++cc) ap_new[cc] = row((ch + 2) * SPC + cc);
+                for (int cc = 0; cc < SPC; ++cc) ap_new[cc] = row((ch + 2 * SP) * SPC + cc);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                   if (q + 1 < NQ) CHUNK_ISSUE(zz[(q + 1) & 1], CHUNK_AL((q + 1) >> 2, (q + 1) & 3));
@@ -1408,9 +1535,10 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
 #pragma unroll
               for (int cc = 0; cc < SPC; ++cc) {
                 alp_next[cc] = make_uint2(0u, 0u);
-                if (cc < S) alp_next[cc] = fused ? fused_row(cc, tab_lo) : *reinterpret_cast<const uint2 *>(tab_t + (size_t)cc * Dp);
+                const int s0 = sp * SPC + cc;
+                if (s0 < S) alp_next[cc] = fused ? fused_row(s0, tab_lo) : *reinterpret_cast<const uint2 *>(tab_t + (size_t)s0 * Dp);
               }
-              for (int ch = 0; ch < nchunks; ++ch) {
+              for (int ch = sp; ch < nchunks; ch += SP) {
                 float acc[rsn_room(RW)];
 #pragma unroll
                 for (int p_ = 0; p_ < rsn_room(RW); ++p_) acc[p_] = 0.f;
@@ -1418,7 +1546,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
 #pragma unroll
                 for (int cc = 0; cc < SPC; ++cc) {
                   alp[cc] = alp_next[cc];
-                  const int sn = (ch + 1) * SPC + cc;
+                  const int sn = (ch + SP) * SPC + cc;
                   if (sn < S) alp_next[cc] = fused ? fused_row(sn, tab_lo) : *reinterpret_cast<const uint2 *>(tab_t + (size_t)sn * Dp);
                 }
 #pragma unroll
@@ -1446,6 +1574,27 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
             }
           }
           tsync();
+          if constexpr (GANG) {   // the pass's group sums of this chunk: to the gang's exchange, four groups of a candidate side by side
+            for (int f = tid; f < S * nlive; f += NT) {
+              const int s_ = f / nlive, bl = f - s_ * nlive;
+              if ((s_ / SPC) % SP != sp) continue;                     // (another stripe's sample)
+              float *row = gx_part + (size_t)(s_ * Bcur + bp0 + bl) * NGm + c * 4;
+              float v4[4];
+#pragma unroll
+              for (int gg = 0; gg < 4; ++gg) v4[gg] = gg < ngc ? part_s[((size_t)gg * S + s_) * NBP + bl] : 0.f;
+              st_f32x2(row, v4[0], v4[1]); st_f32x2(row + 2, v4[2], v4[3]);
+            }
+            if (tid < nlive && sp == 0) {
+              const int b = bp0 + tid;
+              float *row = gx_cpart + (size_t)b * NGm + c * 4;
+              float v4[4];
+#pragma unroll
+              for (int gg = 0; gg < 4; ++gg) v4[gg] = gg < ngc ? cpart_s[gg * TEAM_MB + b] : 0.f;
+              st_f32x2(row, v4[0], v4[1]); st_f32x2(row + 2, v4[2], v4[3]);
+            }
+            tsync();   // partials free for the next pass / chunk
+            continue;
+          }
           // the pass's group sums of this chunk onto the running scores / C_b of its beams, increasing group order
           for (int f = tid; f < S * nlive; f += NT) {
             const int s_ = f / nlive, bl = f - s_ * nlive;
@@ -1465,9 +1614,28 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
           tsync();   // partials free for the next pass / chunk; running sums and C_b published
         }
       }
-      for (int f = tid; f < N; f += NT) {
-        const int s_ = f / Bcur, b = f - s_ * Bcur;
-        key_s[f] = score_key(run_s[f] + Cb_s[b]);
+      if constexpr (GANG) {
+        // every group sum of the step is out: C_b of every beam by every member, the scores of the candidates gm, gm + G, ... by member gm
+        // (the terms of each in increasing group order: the canonical sums), their sort keys to the exchange, all keys back
+        if (!gsync()) { gang_lost = true; break; }
+        const int n_mine = gm < N ? (N - gm + G - 1) / G : 0;
+        const bool cb_all = n_mine >= Bcur;                       // (else: only the C_b of my candidates' beams)
+        const int n_cb = cb_all ? Bcur : n_mine;
+        auto cb_of = [&](int i) { return cb_all ? i : (gm + i * G) % Bcur; };
+        gang_reduce(n_cb + n_mine,
+                    [&](int i) { return i < n_cb ? gx_cpart + (size_t)cb_of(i) * NGm : gx_part + (size_t)(gm + (i - n_cb) * G) * NGm; },
+                    [&](int i, float v) { if (i < n_cb) Cb_s[cb_of(i)] = v; else run_s[i - n_cb] = v; });
+        for (int i = tid; i < n_mine; i += NT) {
+          const int f = gm + i * G;
+          __hip_atomic_store(gx_keys + f, score_key(run_s[i] + Cb_s[f % Bcur]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!gsync()) { gang_lost = true; break; }
+        for (int f = tid; f < N; f += NT) key_s[f] = __hip_atomic_load(gx_keys + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        for (int f = tid; f < N; f += NT) {
+          const int s_ = f / Bcur, b = f - s_ * Bcur;
+          key_s[f] = score_key(run_s[f] + Cb_s[b]);
+        }
       }
       const int Bnew = B < N ? B : N;
       // top-B (beam_search_coder.py:85-89); the selection's first barrier orders the key writes
@@ -1487,7 +1655,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
       const int Bupd = last ? 1 : Bnew;     // beams[0] is all that leaves the block (:118-122)
       const int32_t v_sp = sel_s[lane < Bnew ? lane : 0], v_bp = sel_b[lane < Bnew ? lane : 0];
       const uint32_t v_bo = sm->sel_bo[lane < Bnew ? lane : 0];
-      for (int c = 0; c < NC; ++c) {
+      for (int c = gc; c < NC; c += GC) {
         const int d0 = (c << 10) + g * 256 + lane * 4;
         if (g >= groups_of(c)) continue;     // wave-uniform
         const uint32_t tab_lo = (uint32_t)(d0 < Dp ? d0 : Dp - 4);
@@ -1529,7 +1697,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
               if (last) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                  if (d0 + i < D) { // beams[0] + coding_dist.loc, :122
+                  if (d0 + i < D && sp == 0) { // beams[0] + coding_dist.loc, :122
                     const int64_t ixo = src_index(A, base, pos, d0 + i);
                     A.out_sample[ixo] = nb[i] + A.p_loc[ixo];
                   }
@@ -1547,7 +1715,11 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
     }
     // ---- index path of beam 0 (beam_search_coder.py:118-121) ----
     tsync();
-    if (tid == 0) {
+    if (gang_lost) {                           // partners not resident: the block is not coded (the caller codes the call again, IREC_FLAG_NO_SPLIT)
+      if (tid == 0) A.out_K[blk] = -2;
+      continue;
+    }
+    if (tid == 0 && gm == 0) {
       int j = 0;
       for (int t = K - 1; t >= 0; --t) {
         const int32_t v = __builtin_nontemporal_load(&bp[(size_t)t * NB + j]);
@@ -1946,24 +2118,38 @@ bool chunk_applies(int B, int S, int max_dim) {
 }
 size_t chunk_lds_for(int B, int S) { const ChunkShape c = chunk_shape(B, S); return chunk_lds_total(c.nb, c.nbp, S, c.teams); }
 size_t chunk_ws_for(int B, int dpad, int max_K) { return chunk_ws_bytes(chunk_nb(B) ? chunk_nb(B) : 60, dpad, max_K); }
-const char *chunk_kernel_name(int B, int S) {
-  static thread_local char buf[48];
+const char *chunk_kernel_name(int B, int S, bool gang) {
+  static thread_local char buf[56];
   const ChunkShape c = chunk_shape(B, S);
-  snprintf(buf, sizeof buf, "encode_chunk_kernel<%d,%d,%d>", c.nb, c.nbp, c.teams);
+  snprintf(buf, sizeof buf, gang ? "encode_chunk_kernel<%d,%d,%d,gang>" : "encode_chunk_kernel<%d,%d,%d>", c.nb, c.nbp, c.teams);
   return buf;
 }
-template <int NB, int NBP, int TEAMS>
+// gang builds (A.coop_W > 1): the three-team shapes of passes of ten beams -- B <= 30 at the sample counts whose LDS fits three teams
+int chunk_gang_nb(int B, int S) {
+  const ChunkShape c = chunk_shape(B, S);
+  return (c.teams == 3 && c.nbp == 10 && c.nb <= 30) ? c.nb : 0;
+}
+template <int NB, int NBP, int TEAMS, bool GANG = false>
 static hipError_t launch_chunk_t(const EncArgs &A, int grid, hipStream_t st) {
   const size_t lds = chunk_lds_total(NB, NBP, A.S, TEAMS);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_chunk_kernel<NB, NBP, TEAMS>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_chunk_kernel<NB, NBP, TEAMS, GANG>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((encode_chunk_kernel<NB, NBP, TEAMS>), dim3(grid), dim3(TEAMS * TEAM_NT), lds, st, A);
+  hipLaunchKernelGGL((encode_chunk_kernel<NB, NBP, TEAMS, GANG>), dim3(grid), dim3(TEAMS * TEAM_NT), lds, st, A);
   return hipGetLastError();
 }
 hipError_t launch_encode_chunk(const EncArgs &A, int grid, hipStream_t st) {
   if (!chunk_applies(A.B, A.S, A.max_dim_pad)) return hipErrorInvalidValue;
   const ChunkShape c = chunk_shape(A.B, A.S);
+  if (A.coop_W > 1) {
+    if (!A.gang_xch || A.n_blocks > GANG_MAX_BLOCKS || A.n_blocks * (int64_t)A.coop_W > (int64_t)grid * c.teams) return hipErrorInvalidValue;
+    switch (chunk_gang_nb(A.B, A.S)) {
+      case 10: return launch_chunk_t<10, 10, 3, true>(A, grid, st);
+      case 20: return launch_chunk_t<20, 10, 3, true>(A, grid, st);
+      case 30: return launch_chunk_t<30, 10, 3, true>(A, grid, st);
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (c.nb * 1000 + c.nbp * 10 + c.teams) {
     case 10103: return launch_chunk_t<10, 10, 3>(A, grid, st);
     case 10102: return launch_chunk_t<10, 10, 2>(A, grid, st);

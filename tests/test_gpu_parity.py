@@ -311,12 +311,17 @@ def test_blocks_beyond_1024_dims_take_the_chunked_encoder(engine, oracle, n, bs,
     want = ("encode_chunk_kernel<10,10,3>" if B <= 10 else "encode_chunk_kernel<20,10,3>" if B <= 20 else
             "encode_chunk_kernel<30,10,3>" if B <= 30 else "encode_chunk_kernel<32,16,2>" if B <= 32 else
             "encode_chunk_kernel<%d,10,2>" % (-(-B // 10) * 10))
-    assert plan["kernel"] == want, plan["kernel"]
+    import irec
+    assert plan["kernel"].replace(",gang>", ">") == want, plan["kernel"]   # (calls this small are coded by gangs of teams where a gang build exists)
     assert plan["table_kernel"] == "prep_kernel (copy bits)" and plan["lds_bytes"] <= 160 * 1024
     K, idx, sample = engine.encode_blocks(params, lay, ql, qs, pl, ps, 42, max_K)
     Kh, ih = K.cpu().numpy(), idx.cpu().numpy()
     assert Kh.min() >= 0 and Kh.max() <= max_K, (int(Kh.min()), int(Kh.max()))
-    import irec
+    if plan["split"] >= 2:                                      # ... and every block on ONE team gives the same bits
+        alone = engine.params(omega, S, B, irec._lib.IREC_FLAG_NO_SPLIT, table_steps=max_K)
+        assert engine.plan(alone, lay, max_K)["kernel"] == want
+        K1, idx1, sample1 = engine.encode_blocks(alone, lay, ql, qs, pl, ps, 42, max_K)
+        assert torch.equal(K, K1) and torch.equal(sample, sample1) and all(np.array_equal(ih[r, :Kh[r]], idx1.cpu().numpy()[r, :Kh[r]]) for r in range(lay.n_blocks))
     gen = engine.params(omega, S, B, irec._lib.IREC_FLAG_FORCE_GENERIC)
     K2, idx2, sample2 = engine.encode_blocks(gen, lay, ql, qs, pl, ps, 42, max_K)
     assert torch.equal(K, K2) and torch.equal(sample, sample2)
@@ -389,6 +394,62 @@ def test_blocks_of_any_size_stay_off_the_generic_kernel(engine, oracle):
         assert int(K.cpu()[0]) == len(ridx) and idx.cpu().numpy()[0, :len(ridx)].tolist() == ridx
         assert np.array_equal(sample.cpu().numpy()[0], rs)
         assert torch.equal(engine.decode_blocks(params, lay, q[2], q[3], 11, K, idx), sample)
+
+
+@pytest.mark.parametrize("n,bs,B,eps1,n_t", [(8192, None, 20, 1.2, 1), (8192, None, 10, 1.2, 3), (8192, 3000, 20, 1.2, 2), (5000, None, 30, 1.0, 2),
+                                              (8192, 2048, 20, 1.2, 1), (20000, None, 20, 1.2, 1)])
+def test_gangs_of_teams_code_the_blocks_of_a_small_call(engine, oracle, n, bs, B, eps1, n_t):
+    """Round 5: the reference's default `block_size=None` on ONE image's latents is one block of 8192 dims -- on one team of one CU
+    40 ms, 255 CUs idle.  A call of fewer blocks than team slots is coded by GANGS (irec_team.hip): G teams per block, a chunk of 1024
+    dims (or several) each, group sums exchanged through HBM and added in group order.  Same bits as the one-team form (NO_SPLIT) and as
+    the oracle; ragged blocks (two table dims), beam passes (B = 30), members with several chunks (20 000 dims on ... teams)."""
+    import irec
+    S = oracle.n_samples(3.0, eps1)
+    stats = [oracle.synthetic_latent(9300 + i, n) for i in range(n_t)]
+    q = tuple(torch.from_numpy(np.stack([st[k] for st in stats])).cuda().contiguous() for k in range(4))
+    lay = engine.layout(n_t, n, bs, 42)
+    params = engine.params(3.0, S, B)
+    alone = engine.params(3.0, S, B, irec._lib.IREC_FLAG_NO_SPLIT)
+    plan = engine.plan(params, lay, 256)
+    assert plan["kernel"].endswith(",gang>") and plan["split"] >= 2, plan
+    assert plan["grid"] * plan["teams_per_wg"] >= lay.n_blocks * plan["split"], plan      # every member in the static round
+    assert not engine.plan(alone, lay, 256)["kernel"].endswith(",gang>")
+    K, idx, sample = engine.encode_blocks(params, lay, *q, 42, 256)
+    K1, idx1, sample1 = engine.encode_blocks(alone, lay, *q, 42, 256)
+    Kh = K.cpu().numpy()
+    assert Kh.min() >= 1 and torch.equal(K, K1) and torch.equal(sample, sample1)
+    ih, ih1 = idx.cpu().numpy(), idx1.cpu().numpy()
+    for r in range(lay.n_blocks):
+        assert np.array_equal(ih[r, :Kh[r]], ih1[r, :Kh[r]]), r
+    assert torch.equal(engine.decode_blocks(params, lay, q[2], q[3], 42, K, idx), sample)
+    bpt = lay.blocks_per_tensor
+    ridx, rs = oracle.encode_tensor(*stats[n_t - 1], 42, 3.0, S, B, block_size=bs)
+    got = [ih[lay.natural[(n_t - 1) * bpt + j], :Kh[lay.natural[(n_t - 1) * bpt + j]]].tolist() for j in range(bpt)]
+    assert (got[0] == ridx) if bs is None else (got == ridx)
+    assert np.array_equal(sample[n_t - 1].cpu().numpy(), rs)
+
+
+def test_a_gang_whose_partners_are_not_resident_gives_up(engine, oracle):
+    """IREC_FLAG_TEST_SPLIT_ORPHAN: every member but the first leaves at once; member 0 waits its 100 ms, poisons the block's arrival counter
+    and reports the block as not coded (-2); BeamSearchCoder codes the call again on one team (the back-off of test_recovery_from_a_give_up)."""
+    import irec
+    stats = oracle.synthetic_latent(9400, 4096)
+    q = tuple(torch.as_tensor(a[None], device="cuda") for a in stats)
+    lay = engine.layout(1, 4096, None, 42)
+    orphan = engine.params(3.0, 36, 20, irec._lib.IREC_FLAG_TEST_SPLIT_ORPHAN)
+    assert engine.plan(orphan, lay, 64)["split"] >= 4                              # (4 chunk owners x sample stripes)
+    t0 = time.perf_counter()
+    K, _, _ = engine.encode_blocks(orphan, lay, *q, 42, 64)
+    assert int(K.cpu()[0]) == -2 and 0.09 < time.perf_counter() - t0 < 1.0
+    ridx, rs = oracle.encode_tensor(*stats, 42, 3.0, 36, 20, block_size=None)
+    c = irec.BeamSearchCoder(kl_per_partition=3., n_beams=20, extra_samples=1.2, block_size=None)
+    c._test_split_orphan = True
+    idx, sample = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42)
+    assert [int(v) for v in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
+    assert (c._split_strikes, c._split_pause) == (1, 0)
+    c._test_split_orphan = False
+    idx, sample = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42)     # shared again, whole: count reset
+    assert [int(v) for v in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs) and c._split_strikes == 0
 
 
 def test_wide_beam_uses_generic_path(engine, oracle):
