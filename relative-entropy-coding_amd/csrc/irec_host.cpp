@@ -635,7 +635,7 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
       const size_t fit = (size_t)IREC_SLAB_BYTES_MAX / pl.ws_per_wg;
       pl.grid_cap = (int)std::max<size_t>((size_t)teams, std::min<size_t>((size_t)teams * n_cu, fit / teams * teams));
       // gangs (calls of fewer blocks than team slots, gang_width below): the exchange of up to GANG_MAX_BLOCKS blocks behind the slabs
-      if (const int gnb = irec::chunk_gang_nb(B, S); gnb && !(p->flags & (IREC_FLAG_NO_SPLIT | IREC_FLAG_MARGINS))) {
+      if (const int gnb = irec::chunk_gang_nb(B, S); gnb && irec::chunk_gang_teams(B, S) > 0 && !(p->flags & (IREC_FLAG_NO_SPLIT | IREC_FLAG_MARGINS))) {
         pl.gang_stride = irec::gang_xch_bytes(gnb, S, pl.dpad);
         pl.gang_blocks = (int)std::min<size_t>((size_t)irec::GANG_MAX_BLOCKS, irec::GANG_XCH_BYTES_MAX / pl.gang_stride);
         pl.gang_bytes = (size_t)pl.gang_blocks * pl.gang_stride;
@@ -682,7 +682,8 @@ static int chunk_grid(const irec_context *ctx, const Plan &pl, const irec_params
 int gang_width(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks, int32_t max_block_dim, int *grid, int *chunk_owners) {
   if (!pl.chunk || pl.gang_blocks < 1 || n_blocks < 1 || n_blocks > pl.gang_blocks || (p->flags & (IREC_FLAG_NO_SPLIT | IREC_FLAG_MARGINS))) return 0;
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
-  const int teams = std::max(1, irec::chunk_teams(p->n_beams, p->n_samples));
+  const int teams = irec::chunk_gang_teams(p->n_beams, p->n_samples);   // (of the gang build: three, or one for the shapes without a three-team build)
+  if (teams < 1) return 0;
   const int wgs = std::min(n_cu, std::max(1, pl.grid_cap / teams));
   const int64_t slots = (int64_t)wgs * teams;
   const int64_t chunks = ((int64_t)max_block_dim + 1023) >> 10;
@@ -883,11 +884,16 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
     {
       int ggrid = 0;
       out->split = gang_width(ctx, pl, p, n_blocks, max_block_dim, &ggrid, nullptr);   // teams that code each block together
-      if (out->split >= 2) { out->grid = ggrid; std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::chunk_kernel_name(B, S, true)); }
+      if (out->split >= 2) out->grid = ggrid;
     }
     out->waves_per_wg = irec::chunk_teams(B, S) * 4;
     out->teams_per_wg = irec::chunk_teams(B, S);
     out->lds_bytes = (int32_t)irec::chunk_lds_for(B, S);
+    if (out->split >= 2) {
+      std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::chunk_gang_kernel_name(B, S));
+      out->teams_per_wg = irec::chunk_gang_teams(B, S); out->waves_per_wg = out->teams_per_wg * 4;
+      out->lds_bytes = (int32_t)irec::chunk_gang_lds_for(B, S);
+    }
   } else if (team && pl.lone) {
     const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
     std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::lone_kernel_name());

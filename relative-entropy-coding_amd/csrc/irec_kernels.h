@@ -126,8 +126,13 @@ bool chunk_applies(int B, int S, int max_dim);          // B <= 60, max_dim > 10
 int chunk_teams(int B, int S);                           // teams (= scratch slabs) per workgroup of the build that serves the call: 2, 1, or 0 = none
 size_t chunk_lds_for(int B, int S);
 size_t chunk_ws_for(int B, int dpad, int max_K);         // scratch slab of one team
-const char *chunk_kernel_name(int B, int S, bool gang = false);
-int chunk_gang_nb(int B, int S);                         // beam slots of the gang build that serves the call, 0 = none
+const char *chunk_kernel_name(int B, int S);
+// gang builds of the chunked encoder (irec_team_gang.hip): teams per workgroup (0 = none), beam slots, LDS, name
+int chunk_gang_teams(int B, int S);
+int chunk_gang_nb(int B, int S);
+size_t chunk_gang_lds_for(int B, int S);
+const char *chunk_gang_kernel_name(int B, int S);
+hipError_t launch_encode_chunk_gang(const EncArgs &A, int grid, hipStream_t st);
 hipError_t launch_encode_chunk(const EncArgs &A, int grid, hipStream_t st);
 // one-beam calls: one wave per block over the team encoder's tables (irec_lone.hip)
 bool lone_applies(int B, int shape_override);           // n_beams == 1 and no diagnostic shape pinned (IREC_FLAG_SHAPE_TEAM pins the team encoder)

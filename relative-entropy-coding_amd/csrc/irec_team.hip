@@ -61,6 +61,9 @@
 #ifndef IREC_STEP0_WIDE
 #define IREC_STEP0_WIDE 1   // first step (one beam): RW samples per reduce-scatter instead of one (0: the beam-wise path, A/B builds)
 #endif
+#if defined(IREC_TEAM_MARGIN_TU) || defined(IREC_TEAM_GANG_TU)
+#define IREC_TEAM_AUX_TU 1   // (irec_team_margin.hip / irec_team_gang.hip: this file once more, for their builds only)
+#endif
 namespace irec {
 
 constexpr int TEAM_NW = 4;                       // waves per team
@@ -1730,6 +1733,8 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
   }
 }
 
+#endif   // IREC_TEAM_MARGIN_TU
+#ifndef IREC_TEAM_AUX_TU
 // ======================================================================================================
 //  proposal table with copy bits: tab[t][s][d] = dlog_g(r[s, d]) + 10006 * c   (uint16, row stride = D rounded up to 4)
 //
@@ -1931,10 +1936,11 @@ __global__ __launch_bounds__(256, IREC_CHOICE_WPE) void prep_kernel(PrepArgs P, 
   }
 }
 
-#endif   // IREC_TEAM_MARGIN_TU
+#endif   // IREC_TEAM_AUX_TU
 // ======================================================================================================
 //  launchers
 // ======================================================================================================
+#ifndef IREC_TEAM_GANG_TU
 // teams per workgroup / beam stripes per team.  Defaults: B <= 20: 3 x 1 where the LDS allows (else 2 x 1, or 1 x 2 with
 // sample passes); B <= 30: 1 x 3.  Diagnostic overrides for B <= 20 travel in irec_params.flags (IREC_FLAG_SHAPE_*, no
 // environment variable is read on the product path): cfg 1 = one team, 20 = exactly two teams (also where three would be
@@ -1991,7 +1997,7 @@ static TeamShape team_shape(int B, int S, int ovr) {
   if (B <= 60) return TeamShape{60, 1, 3, false};
   return TeamShape{0, 0, 0, false};
 }
-#ifndef IREC_TEAM_MARGIN_TU
+#ifndef IREC_TEAM_AUX_TU
 int team_count_for(int B, int S, int ovr) { return team_shape(B, S, ovr).teams; }
 int team_shareable(int B, int S, int ovr) {
   const TeamShape sh = team_shape(B, S, ovr);
@@ -2030,7 +2036,7 @@ size_t team_lds_for(int B, int S, int ovr) {
   return b <= FAST_LDS_LIMIT ? b : (size_t)-1;
 }
 
-#endif   // IREC_TEAM_MARGIN_TU
+#endif   // IREC_TEAM_AUX_TU
 
 template <int NB, int TEAMS, int BS, bool PASSES = false, bool ONE = false, bool SHARE = false, bool MARGIN = false>
 static hipError_t launch_team_t(const EncArgs &A, int grid, hipStream_t st) {
@@ -2097,6 +2103,10 @@ hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
   }
 }
 
+#endif   // IREC_TEAM_MARGIN_TU (else)
+#endif   // IREC_TEAM_GANG_TU
+
+#ifndef IREC_TEAM_MARGIN_TU
 // ---- chunked encoder (blocks of more than 1024 dims) ----
 // The build that serves B beams and S samples: beam slots, beams per scoring pass, teams per workgroup -- the first of the candidates
 // whose LDS fits next to the table copies (three teams only with passes of 10 beams: 168 VGPRs hold the G of ten, not of twenty).
@@ -2112,23 +2122,6 @@ static ChunkShape chunk_shape(int B, int S) {
     if (c.nb == nb && chunk_lds_total(c.nb, c.nbp, S, c.teams) <= FAST_LDS_LIMIT) return c;
   return ChunkShape{0, 0, 0};
 }
-int chunk_teams(int B, int S) { return chunk_shape(B, S).teams; }
-bool chunk_applies(int B, int S, int max_dim) {
-  return max_dim > FAST_MAX_DIM && max_dim <= CHUNK_MAX_DIM && chunk_shape(B, S).teams != 0;
-}
-size_t chunk_lds_for(int B, int S) { const ChunkShape c = chunk_shape(B, S); return chunk_lds_total(c.nb, c.nbp, S, c.teams); }
-size_t chunk_ws_for(int B, int dpad, int max_K) { return chunk_ws_bytes(chunk_nb(B) ? chunk_nb(B) : 60, dpad, max_K); }
-const char *chunk_kernel_name(int B, int S, bool gang) {
-  static thread_local char buf[56];
-  const ChunkShape c = chunk_shape(B, S);
-  snprintf(buf, sizeof buf, gang ? "encode_chunk_kernel<%d,%d,%d,gang>" : "encode_chunk_kernel<%d,%d,%d>", c.nb, c.nbp, c.teams);
-  return buf;
-}
-// gang builds (A.coop_W > 1): the three-team shapes of passes of ten beams -- B <= 30 at the sample counts whose LDS fits three teams
-int chunk_gang_nb(int B, int S) {
-  const ChunkShape c = chunk_shape(B, S);
-  return (c.teams == 3 && c.nbp == 10 && c.nb <= 30) ? c.nb : 0;
-}
 template <int NB, int NBP, int TEAMS, bool GANG = false>
 static hipError_t launch_chunk_t(const EncArgs &A, int grid, hipStream_t st) {
   const size_t lds = chunk_lds_total(NB, NBP, A.S, TEAMS);
@@ -2138,18 +2131,61 @@ static hipError_t launch_chunk_t(const EncArgs &A, int grid, hipStream_t st) {
   hipLaunchKernelGGL((encode_chunk_kernel<NB, NBP, TEAMS, GANG>), dim3(grid), dim3(TEAMS * TEAM_NT), lds, st, A);
   return hipGetLastError();
 }
+#ifdef IREC_TEAM_GANG_TU
+// Gang builds (A.coop_W > 1, irec_team_gang.hip): the three-team shape of passes of ten beams where its LDS fits (B <= 30), else the one-team
+// shape of the beam count -- a gang spreads its members over the CUs, so teams per workgroup only bound how many members a call may have.
+static ChunkShape chunk_gang_shape(int B, int S) {
+  const ChunkShape c = chunk_shape(B, S);
+  if (!c.teams) return c;
+  if (c.nb <= 30 && c.nbp == 10 && c.teams == 3) return c;
+  return ChunkShape{c.nb, c.nb == 32 ? 16 : 10, 1};            // (the last candidate of every beam count: fits where any does)
+}
+int chunk_gang_teams(int B, int S) { return chunk_gang_shape(B, S).teams; }
+int chunk_gang_nb(int B, int S) { return chunk_gang_shape(B, S).nb; }
+size_t chunk_gang_lds_for(int B, int S) { const ChunkShape c = chunk_gang_shape(B, S); return chunk_lds_total(c.nb, c.nbp, S, c.teams); }
+const char *chunk_gang_kernel_name(int B, int S) {
+  static thread_local char buf[56];
+  const ChunkShape c = chunk_gang_shape(B, S);
+  snprintf(buf, sizeof buf, "encode_chunk_kernel<%d,%d,%d,gang>", c.nb, c.nbp, c.teams);
+  return buf;
+}
+hipError_t launch_encode_chunk_gang(const EncArgs &A, int grid, hipStream_t st) {
+  const ChunkShape c = chunk_gang_shape(A.B, A.S);
+  if (!c.teams || A.max_dim_pad <= FAST_MAX_DIM || A.max_dim_pad > CHUNK_MAX_DIM) return hipErrorInvalidValue;
+  if (A.coop_W < 2 || A.gang_chunks < 1 || A.coop_W % A.gang_chunks != 0 || !A.gang_xch || A.n_blocks > GANG_MAX_BLOCKS ||
+      A.n_blocks * (int64_t)A.coop_W > (int64_t)grid * c.teams)
+    return hipErrorInvalidValue;
+  switch (c.nb * 1000 + c.nbp * 10 + c.teams) {
+    case 10103: return launch_chunk_t<10, 10, 3, true>(A, grid, st);
+    case 20103: return launch_chunk_t<20, 10, 3, true>(A, grid, st);
+    case 30103: return launch_chunk_t<30, 10, 3, true>(A, grid, st);
+    case 10101: return launch_chunk_t<10, 10, 1, true>(A, grid, st);
+    case 20101: return launch_chunk_t<20, 10, 1, true>(A, grid, st);
+    case 30101: return launch_chunk_t<30, 10, 1, true>(A, grid, st);
+    case 32161: return launch_chunk_t<32, 16, 1, true>(A, grid, st);
+    case 40101: return launch_chunk_t<40, 10, 1, true>(A, grid, st);
+    case 50101: return launch_chunk_t<50, 10, 1, true>(A, grid, st);
+    case 60101: return launch_chunk_t<60, 10, 1, true>(A, grid, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+#else
+int chunk_teams(int B, int S) { return chunk_shape(B, S).teams; }
+bool chunk_applies(int B, int S, int max_dim) {
+  return max_dim > FAST_MAX_DIM && max_dim <= CHUNK_MAX_DIM && chunk_shape(B, S).teams != 0;
+}
+size_t chunk_lds_for(int B, int S) { const ChunkShape c = chunk_shape(B, S); return chunk_lds_total(c.nb, c.nbp, S, c.teams); }
+size_t chunk_ws_for(int B, int dpad, int max_K) { return chunk_ws_bytes(chunk_nb(B) ? chunk_nb(B) : 60, dpad, max_K); }
+const char *chunk_kernel_name(int B, int S) {
+  static thread_local char buf[48];
+  const ChunkShape c = chunk_shape(B, S);
+  snprintf(buf, sizeof buf, "encode_chunk_kernel<%d,%d,%d>", c.nb, c.nbp, c.teams);
+  return buf;
+}
 hipError_t launch_encode_chunk(const EncArgs &A, int grid, hipStream_t st) {
   if (!chunk_applies(A.B, A.S, A.max_dim_pad)) return hipErrorInvalidValue;
+  if (A.coop_W > 1) return launch_encode_chunk_gang(A, grid, st);
   const ChunkShape c = chunk_shape(A.B, A.S);
-  if (A.coop_W > 1) {
-    if (!A.gang_xch || A.n_blocks > GANG_MAX_BLOCKS || A.n_blocks * (int64_t)A.coop_W > (int64_t)grid * c.teams) return hipErrorInvalidValue;
-    switch (chunk_gang_nb(A.B, A.S)) {
-      case 10: return launch_chunk_t<10, 10, 3, true>(A, grid, st);
-      case 20: return launch_chunk_t<20, 10, 3, true>(A, grid, st);
-      case 30: return launch_chunk_t<30, 10, 3, true>(A, grid, st);
-      default: return hipErrorInvalidValue;
-    }
-  }
   switch (c.nb * 1000 + c.nbp * 10 + c.teams) {
     case 10103: return launch_chunk_t<10, 10, 3>(A, grid, st);
     case 10102: return launch_chunk_t<10, 10, 2>(A, grid, st);
@@ -2171,7 +2207,10 @@ hipError_t launch_encode_chunk(const EncArgs &A, int grid, hipStream_t st) {
     default: return hipErrorInvalidValue;
   }
 }
+#endif   // IREC_TEAM_GANG_TU
+#endif   // IREC_TEAM_MARGIN_TU
 
+#ifndef IREC_TEAM_AUX_TU
 // workgroups that build the call's tables (kind 1: 8 half-waves per workgroup, at most 4096 workgroups, grid-stride; kind 2: per table
 // one workgroup per 1024 entries, at most 1024 per table, grid-stride inside the table); fills jobs->D / hw_end / n
 int64_t prep_table_wgs(int kind, int32_t S, int32_t K_tab, int n, const int32_t *dims, ChoiceJobs *jobs) {
@@ -2207,6 +2246,6 @@ hipError_t launch_alpha_choice(int64_t seed, int32_t S, int32_t D, int32_t K_tab
   return launch_alpha_choice_all(seed, S, K_tab, dlog4r, 1, &D, &tab, &keep, st);
 }
 
-#endif   // IREC_TEAM_MARGIN_TU
+#endif   // IREC_TEAM_AUX_TU
 
 } // namespace irec

@@ -21,7 +21,7 @@ for case in range(n_cases):
         B = int(rng.choice([1, 10, 11, 16, 20, 21, 30, 31, 32, 40, 50, 60])); omega = float(rng.choice([4.0, 5.0, 5.5, 6.0])); eps1 = float(rng.choice([1.0, 1.1, 1.2]))
         D = int(rng.choice([192, 777, 1000, 1024]))
     if os.environ.get("SOAK_LARGE"):   # round 4: blocks of more than 1024 dims (chunked encoder for B <= 20, generic beyond) and up to 256 beams
-        D = int(rng.choice([1025, 1279, 1500, 2048, 2049, 2500, 3000, 4096, int(rng.integers(1025, 4200))]))
+        D = int(rng.choice([1025, 1279, 1500, 2048, 2049, 2500, 3000, 4096, 6000, 9217, int(rng.integers(1025, 4200)), int(rng.integers(1025, 12000))]))
         B = int(rng.choice([1, 2, 7, 10, 11, 20, 20, 10, 21, 25, 30, 31, 32, 33, 41, 50, 60, 61, 100, 256])); omega = float(rng.choice([2.0, 3.0, 3.5, float(rng.uniform(1.0, 3.6))]))
         eps1 = float(rng.choice([1.0, 1.2]))
     S = int(np.exp(omega * eps1))
@@ -59,10 +59,12 @@ for case in range(n_cases):
     mq, sq, mp, sp = (np.stack([t4[k] for t4 in tens]) for k in range(4))
     q = torch.distributions.Normal(torch.from_numpy(mq).cuda(), torch.from_numpy(sq).cuda(), validate_args=False)
     p = torch.distributions.Normal(torch.from_numpy(mp).cuda(), torch.from_numpy(sp).cuda(), validate_args=False)
-    for variant in (("table", "generic") if os.environ.get("SOAK_LARGE") else ("table", "one_table", "fused", "generic")):
+    # (SOAK_LARGE, round 5: calls this small are coded by gangs of teams -- "alone" pins one team per block)
+    for variant in (("table", "alone", "generic") if os.environ.get("SOAK_LARGE") else ("table", "one_table", "fused", "generic")):
         c = irec.BeamSearchCoder(kl_per_partition=omega, n_beams=B, extra_samples=eps1)
         c.n_samples = S
-        c.force_generic = variant == "generic"; c.fused_philox = variant == "fused"; c.one_table = variant == "one_table"; c.team = variant == "table"
+        c.force_generic = variant == "generic"; c.fused_philox = variant == "fused"; c.one_table = variant == "one_table"; c.team = variant in ("table", "alone")
+        c.no_split = variant == "alone"
         idx, sample = c.encode(q, p, seed=seed, batched=True)
         sh = sample.cpu().numpy()
         ok = all([int(i) for i in idx[n]] == refs[n][0] and np.array_equal(sh[n], refs[n][1]) for n in range(len(tens)))
@@ -87,7 +89,7 @@ for case in range(n_cases):
     done += len(tens); stats["K"].append(K)
     if case % 100 == 99:   # a long run must keep writing: the GPU box takes minutes of silence for a hang
         print(f"[soak] case {case + 1}/{n_cases}: {done} blocks, {len(bad)} mismatches, {time.time() - t0:.0f} s", flush=True)
-print(f"soak: {done} random blocks x {2 if os.environ.get('SOAK_LARGE') else 4} variants in {time.time() - t0:.0f} s; K range {min(stats['K'])}..{max(stats['K'])}; "
+print(f"soak: {done} random blocks x {3 if os.environ.get('SOAK_LARGE') else 4} variants in {time.time() - t0:.0f} s; K range {min(stats['K'])}..{max(stats['K'])}; "
       f"{stats['evals'] / 1e9:.2f} G proposal evals checked; mismatches: {len(bad)}")
 for b in bad[:20]:
     print("MISMATCH case=%d variant=%s D=%d B=%d S=%d omega=%.3f K=%d style=%d seed=%d" % b)

@@ -312,7 +312,10 @@ def test_blocks_beyond_1024_dims_take_the_chunked_encoder(engine, oracle, n, bs,
             "encode_chunk_kernel<30,10,3>" if B <= 30 else "encode_chunk_kernel<32,16,2>" if B <= 32 else
             "encode_chunk_kernel<%d,10,2>" % (-(-B // 10) * 10))
     import irec
-    assert plan["kernel"].replace(",gang>", ">") == want, plan["kernel"]   # (calls this small are coded by gangs of teams where a gang build exists)
+    if plan["split"] >= 2:    # (calls this small are coded by gangs of teams: the three-team build, else the one-team build of the beam count)
+        assert plan["kernel"] == (want[:-1] + ",gang>" if want.endswith(",10,3>") else want[:-2] + "1,gang>"), plan["kernel"]
+    else:
+        assert plan["kernel"] == want, plan["kernel"]
     assert plan["table_kernel"] == "prep_kernel (copy bits)" and plan["lds_bytes"] <= 160 * 1024
     K, idx, sample = engine.encode_blocks(params, lay, ql, qs, pl, ps, 42, max_K)
     Kh, ih = K.cpu().numpy(), idx.cpu().numpy()
@@ -397,12 +400,16 @@ def test_blocks_of_any_size_stay_off_the_generic_kernel(engine, oracle):
 
 
 @pytest.mark.parametrize("n,bs,B,eps1,n_t", [(8192, None, 20, 1.2, 1), (8192, None, 10, 1.2, 3), (8192, 3000, 20, 1.2, 2), (5000, None, 30, 1.0, 2),
-                                              (8192, 2048, 20, 1.2, 1), (20000, None, 20, 1.2, 1)])
+                                              (8192, 2048, 20, 1.2, 1), (20000, None, 20, 1.2, 1),
+                                              # the one-team gang builds: beam counts / sample counts without a three-team build
+                                              (8192, None, 32, 1.2, 1), (3000, None, 50, 1.0, 2), (4096, None, 60, 1.2, 1), (3000, None, 10, 1.6, 1),
+                                              (5000, None, 30, 1.34, 1)])
 def test_gangs_of_teams_code_the_blocks_of_a_small_call(engine, oracle, n, bs, B, eps1, n_t):
     """Round 5: the reference's default `block_size=None` on ONE image's latents is one block of 8192 dims -- on one team of one CU
     40 ms, 255 CUs idle.  A call of fewer blocks than team slots is coded by GANGS (irec_team.hip): G teams per block, a chunk of 1024
     dims (or several) each, group sums exchanged through HBM and added in group order.  Same bits as the one-team form (NO_SPLIT) and as
-    the oracle; ragged blocks (two table dims), beam passes (B = 30), members with several chunks (20 000 dims on ... teams)."""
+    the oracle; ragged blocks (two table dims), beam passes (B = 30), sample stripes (one block: 8 chunk owners x 8 stripes).
+    Gang builds: three teams per workgroup for B <= 30 where the LDS holds them, else one team (B = 32 ... 60, S = 122, B = 30 at S = 56)."""
     import irec
     S = oracle.n_samples(3.0, eps1)
     stats = [oracle.synthetic_latent(9300 + i, n) for i in range(n_t)]
@@ -427,6 +434,41 @@ def test_gangs_of_teams_code_the_blocks_of_a_small_call(engine, oracle, n, bs, B
     got = [ih[lay.natural[(n_t - 1) * bpt + j], :Kh[lay.natural[(n_t - 1) * bpt + j]]].tolist() for j in range(bpt)]
     assert (got[0] == ridx) if bs is None else (got == ridx)
     assert np.array_equal(sample[n_t - 1].cpu().numpy(), rs)
+
+
+def test_gangs_whose_members_own_several_chunks_and_share_cus(engine, oracle):
+    """More blocks x chunks than team slots: 200 blocks of 5 chunks on 768 slots -- three chunk owners per block (two chunks, two, one), three
+    members per CU, no stripes; a stripe cap in the flags changes nothing there (stripes only where CUs are idle).  Against the one-team form
+    on every block, against the oracle on two.  Then 12 of the blocks: 60 chunk owners, four stripes each on 256 CUs."""
+    import irec
+    n, n_t, S, B = 5000, 200, 36, 20
+    stats = [oracle.synthetic_latent(9500 + i, n) for i in range(n_t)]
+    q = tuple(torch.from_numpy(np.stack([st[k] for st in stats])).cuda().contiguous() for k in range(4))
+    lay = engine.layout(n_t, n, None, 42)
+    alone = engine.params(3.0, S, B, irec._lib.IREC_FLAG_NO_SPLIT)
+    K1, idx1, sample1 = engine.encode_blocks(alone, lay, *q, 42, 64)
+    Kh, ih1 = K1.cpu().numpy(), idx1.cpu().numpy()
+    for flags in (0, 2 << 12):
+        params = engine.params(3.0, S, B, flags)
+        plan = engine.plan(params, lay, 64)
+        assert plan["kernel"] == "encode_chunk_kernel<20,10,3,gang>" and plan["split"] == 3 and plan["grid"] == plan["n_cu"], plan
+        K, idx, sample = engine.encode_blocks(params, lay, *q, 42, 64)
+        assert torch.equal(K, K1) and torch.equal(sample, sample1)
+        ih = idx.cpu().numpy()
+        assert all(np.array_equal(ih[r, :Kh[r]], ih1[r, :Kh[r]]) for r in range(lay.n_blocks))
+    for i in (0, n_t - 1):
+        ridx, rs = oracle.encode_tensor(*stats[i], 42, 3.0, S, B, block_size=None)
+        assert ih1[lay.natural[i], :Kh[lay.natural[i]]].tolist() == ridx and np.array_equal(sample1[i].cpu().numpy(), rs)
+    lay12 = engine.layout(12, n, None, 42)
+    q12 = tuple(t[:12].contiguous() for t in q)
+    plan = engine.plan(engine.params(3.0, S, B), lay12, 64)
+    assert plan["split"] == 5 * (plan["n_cu"] // 60), plan
+    K, idx, sample = engine.encode_blocks(engine.params(3.0, S, B), lay12, *q12, 42, 64)
+    K12, i12 = K.cpu().numpy(), idx.cpu().numpy()
+    assert torch.equal(sample, sample1[:12])
+    for i in range(12):
+        r, r1 = lay12.natural[i], lay.natural[i]
+        assert K12[r] == Kh[r1] and np.array_equal(i12[r, :K12[r]], ih1[r1, :Kh[r1]]), i
 
 
 def test_a_gang_whose_partners_are_not_resident_gives_up(engine, oracle):
