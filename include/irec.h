@@ -71,7 +71,8 @@ typedef struct {
                                   /* Neither flag: the team encoder for calls of >= 64 blocks, the one-table encoder   */
                                   /* (cheaper per-call set-up) below; same outputs, bit for bit                        */
 #define IREC_FLAG_NO_SPLIT 16     /* no block is shared: neither the split encoder (several workgroups per block for calls of few     */
-                                  /* blocks) nor shared rows between teams (calls of one to 1.5 blocks per CU, B > 10)                */
+                                  /* blocks) nor shared rows between teams (calls of one to 1.5 blocks per CU, B > 10) nor gangs of   */
+                                  /* teams (calls of at most 384 blocks of more than 1024 dims: several teams per block)              */
 #define IREC_FLAG_TEST_SPLIT_ORPHAN 32 /* test hook: the partner workgroups of the split encoder leave at once, so workgroup 0  */
                                   /* of every block must take the give-up exit (100 ms) (out_K = -2) instead of hanging   */
 #define IREC_FLAG_TABLES_PRESENT 65536 /* stronger than REUSE_TABLES: the caller vouches that the PREVIOUS irec_beam_encode call on this  */
@@ -97,7 +98,8 @@ typedef struct {
                                   /* flag is part of the params because it sizes the workspace (irec_encode_workspace_bytes) and picks the kernels     */
                                   /* (irec_encode_plan): a margin build of the team encoder where one exists, the generic kernel otherwise; no block   */
                                   /* is shared between workgroups or teams.  Indices, K and samples are the plain call's, bit for bit.                 */
-#define IREC_FLAG_SPLIT_SHIFT 12  /* bits 12-15: workgroups per block of the split encoder, 0 = chosen by the library (diagnostics) */
+#define IREC_FLAG_SPLIT_SHIFT 12  /* bits 12-15: workgroups per block of the split encoder / sample stripes per chunk of a gang, at most; */
+                                  /* 0 = chosen by the library (diagnostics) */
 #define IREC_FLAG_SPLIT_MASK (0xF << IREC_FLAG_SPLIT_SHIFT)
 /* Diagnostic workgroup shapes of the team encoder for B <= 20 (bits 8-11 of flags; 0 = the default shape).  Same outputs. */
 #define IREC_FLAG_SHAPE_SHIFT 8
