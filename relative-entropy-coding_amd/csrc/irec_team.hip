@@ -58,6 +58,10 @@
 #ifndef IREC_BARRIER_SLEEP
 #define IREC_BARRIER_SLEEP 1   // s_sleep argument (x 64 clocks) between two polls of a team barrier's LDS counter (A/B r05l)
 #endif
+#ifndef IREC_GANG_ABLATE
+#define IREC_GANG_ABLATE 0   // diagnostics (make variant_gang): phases of a gang step removed -- 1 sample loops, 2 update, 4 reduction, 8 selection,
+                             // 32 gang barriers; the outputs are wrong, the time that remains is the point (scripts/gang_latency.py --ablate)
+#endif
 #ifndef IREC_STEP0_WIDE
 #define IREC_STEP0_WIDE 1   // first step (one beam): RW samples per reduce-scatter instead of one (0: the beam-wise path, A/B builds)
 #endif
@@ -1180,6 +1184,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
   // The G members are GC chunk owners x SP sample stripes: member gm owns the chunks gc = gm % GC, gc + GC, ... and scores the samples of
   // sample-chunk sp = gm / GC, sp + SP, ... of them (statistics, step constants, G and the update of a chunk are repeated by its SP stripes,
   // each in its own slab; the group sums of a candidate still come from ONE member each).
+  constexpr int ABL = GANG ? IREC_GANG_ABLATE : 0;
   const int G = GANG ? A.coop_W : 1;
   const int GC = GANG ? A.gang_chunks : 1, SP = GANG ? G / GC : 1;
   uint32_t gang_epoch = 0u;
@@ -1240,6 +1245,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
     // that has waited COOP_GIVE_UP_TICKS for partners that are not resident POISONS the counter (bit 31, by compare-and-swap against an
     // incomplete count, so that either every member passes a barrier or none does) and the block is reported as not coded (out_K = -2).
     auto gsync = [&]() -> bool {
+      if constexpr ((ABL & 32) != 0) { tsync(); return true; }
       gang_epoch += (uint32_t)G;
       tsync();
       if (tid == 0) {
@@ -1484,7 +1490,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
                                 __builtin_amdgcn_sched_barrier(0); } while (0)
               f2 zz[2][NP];
               CHUNK_ISSUE(zz[0], CHUNK_AL(0, 0));
-              for (int ch = sp; ch < n_sch; ch += SP) {          // (my stripe of the sample-chunks; SP = 1 but in gangs)
+              for (int ch = sp; ch < ((ABL & 1) ? 0 : n_sch); ch += SP) {          // (my stripe of the sample-chunks; SP = 1 but in gangs)
                 f2 acc2[SPC][NP];
 #pragma unroll
                 for (int cc = 0; cc < SPC; ++cc)
@@ -1541,7 +1547,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
                 const int s0 = sp * SPC + cc;
                 if (s0 < S) alp_next[cc] = fused ? fused_row(s0, tab_lo) : *reinterpret_cast<const uint2 *>(tab_t + (size_t)s0 * Dp);
               }
-              for (int ch = sp; ch < nchunks; ch += SP) {
+              for (int ch = sp; ch < ((ABL & 1) ? 0 : nchunks); ch += SP) {
                 float acc[rsn_room(RW)];
 #pragma unroll
                 for (int p_ = 0; p_ < rsn_room(RW); ++p_) acc[p_] = 0.f;
@@ -1625,6 +1631,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
         const bool cb_all = n_mine >= Bcur;                       // (else: only the C_b of my candidates' beams)
         const int n_cb = cb_all ? Bcur : n_mine;
         auto cb_of = [&](int i) { return cb_all ? i : (gm + i * G) % Bcur; };
+        if constexpr ((ABL & 4) == 0)
         gang_reduce(n_cb + n_mine,
                     [&](int i) { return i < n_cb ? gx_cpart + (size_t)cb_of(i) * NGm : gx_part + (size_t)(gm + (i - n_cb) * G) * NGm; },
                     [&](int i, float v) { if (i < n_cb) Cb_s[cb_of(i)] = v; else run_s[i - n_cb] = v; });
@@ -1642,6 +1649,12 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
       }
       const int Bnew = B < N ? B : N;
       // top-B (beam_search_coder.py:85-89); the selection's first barrier orders the key writes
+      if constexpr ((ABL & 8) != 0) {
+        tsync();
+        if (tid < Bnew) { sel_s[tid] = tid % S; sel_b[tid] = tid % Bcur; sm->sel_bo[tid] = beta4[cur * TEAM_MB + tid % Bcur];
+                          hsum[(cur ^ 1) * TEAM_MB + tid] = 0; bp[(size_t)t * NB + tid] = ((tid % S) << 6) | (tid % Bcur); }
+        tsync();
+      } else
       select_topB_sync<NT>(key_s, N, Bnew, Bcur, sm, tid, tsync, nullptr, [&](int j, int32_t sp_, int32_t bp_, uint32_t) {
         const int32_t nh = (int32_t)((uint32_t)hsum[cur * TEAM_MB + bp_] + (uint32_t)sp_ * (uint32_t)(69 + t));
         hsum[(cur ^ 1) * TEAM_MB + j] = nh;
@@ -1655,7 +1668,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
         const int32_t nh = hsum[(cur ^ 1) * TEAM_MB + (lane < Bnew ? lane : 0)];
         bv_new = dlog_s[hash_from_sum(nh) - 1u];
       }
-      const int Bupd = last ? 1 : Bnew;     // beams[0] is all that leaves the block (:118-122)
+      const int Bupd = last ? 1 : ((ABL & 2) ? 0 : Bnew);     // beams[0] is all that leaves the block (:118-122)
       const int32_t v_sp = sel_s[lane < Bnew ? lane : 0], v_bp = sel_b[lane < Bnew ? lane : 0];
       const uint32_t v_bo = sm->sel_bo[lane < Bnew ? lane : 0];
       for (int c = gc; c < NC; c += GC) {

@@ -1,6 +1,6 @@
 """Diagnostic: latency of calls of FEW blocks of more than 1024 dims -- the reference's default block_size=None on one image's latents --
 coded by gangs of teams (irec_team.hip, "Gangs") against every block on one team (IREC_FLAG_NO_SPLIT).
-Usage: python scripts/gang_latency.py [--huge]   (--huge: also ONE block of 301 056 dims, Kodak level 1 whole: ~2 200 partitions)"""
+Usage: python scripts/gang_latency.py [--huge] [--stripes] | python scripts/with_lib.py gang_ablN scripts/gang_latency.py --ablate   (--huge: also ONE block of 301 056 dims, Kodak level 1 whole: ~2 200 partitions)"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,18 +27,24 @@ def run(label, n_t, n, bs, B, S, max_K, reps, flags=0, table_steps=0):
             K, idx, s = eng.encode_blocks(params, lay, *q, bench.SEED, max_K)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
         Kh = K.cpu().numpy().astype(np.int64); dims = lay.block_dim.cpu().numpy().astype(np.int64)
-        assert Kh.min() >= 0, Kh
+        assert Kh.min() >= 0 or "--ablate" in sys.argv, Kh
         evals = float((S * dims * (1 + np.maximum(Kh - 1, 0) * B) * (Kh > 0)).sum())
         out[name] = (K, idx, s)
         print(f"{label:34s} {name:8s} {plan['kernel']:34s} grid {plan['grid']:3d} x{plan['teams_per_wg']} split {plan['split']:3d}: {dt * 1e3:10.3f} ms, "
               f"max K {int(Kh.max()):4d}, {evals / dt / (plan['n_cu'] * plan['clock_mhz'] * 1e6):6.3f} look-ups/clk/CU (chip), "
               f"{dt / max(1, int(Kh.max())) * 1e6:7.1f} us/step", flush=True)
+    if "--ablate" in sys.argv:      # (a diagnostic build with phases removed: wrong outputs, only the time counts)
+        return
     a, b = out["gang"], out["one team"]
     Kh = a[0].cpu().numpy(); ia, ib = a[1].cpu().numpy(), b[1].cpu().numpy()
     assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and all(np.array_equal(ia[r, :Kh[r]], ib[r, :Kh[r]]) for r in range(len(Kh))), \
         "gang and one-team bits differ"
 
 
+if "--ablate" in sys.argv:
+    run("1 x 8192 dims, B=20 (None)", 1, 8192, None, 20, 36, 128, 5)
+    run("24 x 8192 dims (one image, None)", 24, 8192, None, 20, 36, 128, 3)
+    sys.exit(0)
 for st in (1, 2, 3, 4, 6, 9) if "--stripes" in sys.argv else ():
     run("1 x 8192 dims, B=20, stripes<=%d" % st, 1, 8192, None, 20, 36, 128, 5, flags=st << 12)
     run("24 x 8192 dims, B=20, stripes<=%d" % st, 24, 8192, None, 20, 36, 128, 3, flags=st << 12)
