@@ -41,6 +41,29 @@ def run(label, n_t, n, bs, B, S, max_K, reps, flags=0, table_steps=0):
         "gang and one-team bits differ"
 
 
+if "--api" in sys.argv:      # what a caller of the Python mirror sees: BeamSearchCoder(block_size=None).encode / decode of ONE latent, host work included
+    from torch.distributions import Normal
+    for B in (20, 10):
+        q = bench.synthetic_batch(1, eng.device, 0)
+        for shared in (True, False):
+            c = irec.BeamSearchCoder(kl_per_partition=3., n_beams=B, extra_samples=1.2, block_size=None)
+            c.no_split = not shared
+            qd, pd = Normal(q[0], q[1], validate_args=False), Normal(q[2], q[3], validate_args=False)
+            for _ in range(3):
+                idx, sample = c.encode(qd, pd, seed=42)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(10):
+                idx, sample = c.encode(qd, pd, seed=42)
+            torch.cuda.synchronize(); te = (time.perf_counter() - t0) / 10
+            out = c.decode(pd, idx, seed=42)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(10):
+                out = c.decode(pd, idx, seed=42)
+            torch.cuda.synchronize(); td = (time.perf_counter() - t0) / 10
+            assert torch.equal(out, sample)
+            print(f"BeamSearchCoder(block_size=None, n_beams={B}) on one 8192-dim latent, {'gangs' if shared else 'no_split'}: encode {te * 1e3:.3f} ms, "
+                  f"decode {td * 1e3:.3f} ms, K = {len(idx)}", flush=True)
+    sys.exit(0)
 if "--ablate" in sys.argv:
     run("1 x 8192 dims, B=20 (None)", 1, 8192, None, 20, 36, 128, 5)
     run("24 x 8192 dims (one image, None)", 24, 8192, None, 20, 36, 128, 3)
