@@ -471,6 +471,43 @@ def test_gangs_whose_members_own_several_chunks_and_share_cus(engine, oracle):
         assert K12[r] == Kh[r1] and np.array_equal(i12[r, :K12[r]], ih1[r1, :Kh[r1]]), i
 
 
+def test_two_gang_calls_in_flight_on_two_streams(engine, oracle):
+    """Two calls of 24 one-block latents each (192 members each, one per CU) issued from two threads on two streams: 384 workgroups do not
+    fit 256 CUs, so the later call's members wait for the earlier call's to leave -- 5 ms, far from the 100 ms give-up -- or, if a call does
+    give up, BeamSearchCoder codes it again on one team per block.  Either way: no hang, the oracle's bits on both streams, every repetition."""
+    import threading
+    import irec
+    n_t, n, S, B = 24, 8192, 36, 20
+    stats = [[oracle.synthetic_latent(9600 + 100 * w + i, n) for i in range(n_t)] for w in range(2)]
+    qs = [tuple(torch.from_numpy(np.stack([st[k] for st in stats[w]])).cuda().contiguous() for k in range(4)) for w in range(2)]
+    refs = [oracle.encode_tensor(*stats[w][n_t - 1], 42, 3.0, S, B, block_size=None) for w in range(2)]
+    torch.cuda.synchronize()
+    results, errors = [[], []], []
+
+    def work(w):
+        try:
+            c = irec.BeamSearchCoder(kl_per_partition=3., n_beams=B, extra_samples=1.2, block_size=None)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for rep in range(4):
+                    idx, sample = c.encode(_normal(qs[w][0], qs[w][1]), _normal(qs[w][2], qs[w][3]), seed=42, batched=True)
+                    results[w].append((idx[n_t - 1], sample[n_t - 1].cpu().numpy(), c._split_strikes))
+        except Exception as e:                      # noqa: BLE001 (reported below, in the main thread)
+            errors.append((w, repr(e)))
+    th = [threading.Thread(target=work, args=(w,)) for w in range(2)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in th), "a gang call hangs"
+    assert not errors, errors
+    assert time.perf_counter() - t0 < 60
+    for w in range(2):
+        assert len(results[w]) == 4
+        for idx, sample, _ in results[w]:
+            assert [int(v) for v in idx] == refs[w][0] and np.array_equal(sample, refs[w][1]), w
+
+
 def test_a_gang_whose_partners_are_not_resident_gives_up(engine, oracle):
     """IREC_FLAG_TEST_SPLIT_ORPHAN: every member but the first leaves at once; member 0 waits its 100 ms, poisons the block's arrival counter
     and reports the block as not coded (-2); BeamSearchCoder codes the call again on one team (the back-off of test_recovery_from_a_give_up)."""
