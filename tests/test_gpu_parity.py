@@ -471,6 +471,26 @@ def test_gangs_whose_members_own_several_chunks_and_share_cus(engine, oracle):
         assert K12[r] == Kh[r1] and np.array_equal(i12[r, :K12[r]], ih1[r1, :Kh[r1]]), i
 
 
+def test_gang_blocks_with_nothing_to_code_and_too_small_an_index_buffer(engine, oracle):
+    """A gang whose block has KL = 0 (posterior == prior: K = 0, sample = p.loc, written by the chunk owners' first stripes) next to ordinary
+    blocks; and max_K below the blocks' K: every member leaves the block uncoded with out_K = K (what BeamSearchCoder raises its hint from)."""
+    n, n_t, S, B = 5000, 3, 36, 20
+    stats = [oracle.synthetic_latent(9700 + i, n) for i in range(n_t)]
+    ql, qs, pl, ps = (torch.from_numpy(np.stack([st[k] for st in stats])).cuda().contiguous() for k in range(4))
+    ql[1] = pl[1]; qs[1] = ps[1]
+    lay = engine.layout(n_t, n, None, 42)
+    params = engine.params(3.0, S, B)
+    assert engine.plan(params, lay, 64)["kernel"].endswith(",gang>")
+    K, idx, sample = engine.encode_blocks(params, lay, ql, qs, pl, ps, 42, 64)
+    Kh, ih = K.cpu().numpy(), idx.cpu().numpy()
+    assert Kh[lay.natural[1]] == 0 and torch.equal(sample[1], pl[1])
+    for i in (0, 2):
+        ridx, rs = oracle.encode_tensor(*stats[i], 42, 3.0, S, B, block_size=None)
+        assert ih[lay.natural[i], :Kh[lay.natural[i]]].tolist() == ridx and np.array_equal(sample[i].cpu().numpy(), rs)
+    K8, _, _ = engine.encode_blocks(params, lay, ql, qs, pl, ps, 42, 8)        # K ~ 38 > 8
+    assert np.array_equal(K8.cpu().numpy(), Kh)
+
+
 def test_two_gang_calls_in_flight_on_two_streams(engine, oracle):
     """Two calls of 24 one-block latents each (192 members each, one per CU) issued from two threads on two streams: 384 workgroups do not
     fit 256 CUs, so the later call's members wait for the earlier call's to leave -- 5 ms, far from the 100 ms give-up -- or, if a call does
