@@ -681,6 +681,7 @@ static int chunk_grid(const irec_context *ctx, const Plan &pl, const irec_params
 // grid that puts the members on CUs of their own as far as the CUs go.
 int gang_width(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks, int32_t max_block_dim, int *grid, int *chunk_owners) {
   if (!pl.chunk || pl.gang_blocks < 1 || n_blocks < 1 || n_blocks > pl.gang_blocks || (p->flags & (IREC_FLAG_NO_SPLIT | IREC_FLAG_MARGINS))) return 0;
+  if (!irec::IREC_COOP_GRANULES_ON) return 0;   // (the gangs' arrival counters are exchange granules: zeroed by the preparation kernel only in that form)
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
   const int teams = irec::chunk_gang_teams(p->n_beams, p->n_samples);   // (of the gang build: three, or one for the shapes without a three-team build)
   if (teams < 1) return 0;

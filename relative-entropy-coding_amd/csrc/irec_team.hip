@@ -1097,8 +1097,10 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 //
 //  Gangs (GANG builds, round 5): a call of FEWER blocks than team slots -- block_size = None on one image's latents: one block of 8192
 //  dims would keep one team of one CU busy for 40 ms while 255 CUs idle.  G = A.coop_W teams, each on a CU of its own where the grid allows,
-//  code a block together: member m owns the chunks m, m + G, ... (statistics, scoring, update: nothing of a chunk ever leaves its
-//  member but its group sums).  Per step: every member writes the group sums of its chunks to the block's exchange in HBM; gang barrier;
+//  code a block together: G = GC chunk owners x SP sample stripes; member m owns the chunks m % GC, + GC, ... (statistics, step constants,
+//  update: nothing of a chunk ever leaves its member but its group sums; the SP stripes of a chunk repeat that work, each in its own slab)
+//  and scores the sample-chunks m / GC, + SP, ... of them.  Per step: every member writes the group sums of its chunks and samples to the
+//  block's exchange in HBM; gang barrier;
 //  member m forms the canonical sums -- all group sums of a candidate in increasing group order: the same float32 chain the
 //  one-team form adds chunk by chunk -- of the candidates m, m + G, ..., and publishes their sort keys; gang barrier; every member reads
 //  all keys and runs the same selection.  The bits are the one-team form's (and the generic kernel's); the K of the block comes the same
