@@ -1243,12 +1243,16 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
                                                                                              // workspace head: zeroed by the call's preparation kernel
     }
     // Barrier of the gang: a monotonic arrival counter in HBM.  Everything handed over travels as agent-scope (sc1) stores that have
-    // drained before the arrival (the team barrier's release fence waits for vmcnt) and is read back by agent-scope loads.  A member
+    // drained before the arrival (s_waitcnt vmcnt(0) in every wave, then the team barrier, then one arrival) and is read back by agent-scope loads.  A member
     // that has waited COOP_GIVE_UP_TICKS for partners that are not resident POISONS the counter (bit 31, by compare-and-swap against an
     // incomplete count, so that either every member passes a barrier or none does) and the block is reported as not coded (out_K = -2).
     auto gsync = [&]() -> bool {
       if constexpr ((ABL & 32) != 0) { tsync(); return true; }
       gang_epoch += (uint32_t)G;
+      // every wave drains its stores before the team barrier: the release fence in there is workgroup-scoped and need not wait for
+      // vector-memory stores to be acknowledged (the waves of a workgroup share their L1), but the partners of the gang sit on other CUs
+      // and must find the sums in place once the arrival below is visible
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       tsync();
       if (tid == 0) {
         int32_t bad = 0;

@@ -471,6 +471,20 @@ def test_gangs_whose_members_own_several_chunks_and_share_cus(engine, oracle):
         assert K12[r] == Kh[r1] and np.array_equal(i12[r, :K12[r]], ih1[r1, :Kh[r1]]), i
 
 
+def test_gang_calls_under_contention_match_the_one_team_form(engine, monkeypatch):
+    """scripts/soak_gangs_threads.py in small: three threads issue gang calls of random shapes back to back on their own streams, so the
+    members of a gang run late and out of step with each other.  Round 5 found its one gang bug here (11 of 360 calls differed): the sums a
+    member hands over must have DRAINED (s_waitcnt vmcnt(0) in every wave) before its arrival is counted -- the team barrier's
+    workgroup-scoped release fence does not wait for vector-memory stores.  Every call against the same call on one team per block."""
+    import runpy
+    monkeypatch.setenv("SOAK_THREADS", "3")
+    monkeypatch.setenv("SOAK_CALLS", "120")
+    monkeypatch.setenv("SOAK_SEED", "3")
+    with pytest.raises(SystemExit) as e:
+        runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "soak_gangs_threads.py"), run_name="__main__")
+    assert e.value.code == 0
+
+
 def test_gang_blocks_with_nothing_to_code_and_too_small_an_index_buffer(engine, oracle):
     """A gang whose block has KL = 0 (posterior == prior: K = 0, sample = p.loc, written by the chunk owners' first stripes) next to ordinary
     blocks; and max_K below the blocks' K: every member leaves the block uncoded with out_K = K (what BeamSearchCoder raises its hint from)."""
