@@ -485,6 +485,36 @@ def test_gang_calls_under_contention_match_the_one_team_form(engine, monkeypatch
     assert e.value.code == 0
 
 
+def test_gang_calls_inside_a_replayed_graph(engine, oracle):
+    """A gang call is plain stream work (its arrival counters are zeroed by the call's own preparation kernel), so a captured sequence of
+    such calls -- irec.models.GraphedCompress with block_size=None -- stays correct on every replay."""
+    stats = [oracle.synthetic_latent(9800 + i, 4096) for i in range(2)]
+    t = [torch.from_numpy(np.stack([st[k] for st in stats])).cuda().contiguous() for k in range(4)]
+    refs = [oracle.encode_tensor(*stats[i], 42, 3.0, 36, 20, block_size=None) for i in range(2)]
+    c = _coder(3.0, 20, 1.2, block_size=None, variant="auto")
+    c.encode_tensors_device(*t, 42, None, max_K=64).to_lists()             # (warm: the partition hint and the stream's scratch)
+    lay = engine.layout(2, 4096, None, 42)
+    assert engine.plan(c._params(), lay, 64)["kernel"].endswith(",gang>")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        c.encode_tensors_device(*t, 42, None, max_K=64)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        p1 = c.encode_tensors_device(*t, 42, None, max_K=64)
+        p2 = c.encode_tensors_device(*t, 42, None, max_K=64)
+    for rep in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        for p in (p1, p2):
+            lists = p.to_lists()
+            for i in range(2):
+                got = lists[i][0] if isinstance(lists[i][0], (list, tuple)) else lists[i]
+                assert [int(v) for v in got] == refs[i][0] and np.array_equal(p.sample[i].cpu().numpy(), refs[i][1]), (rep, i)
+
+
 def test_gang_blocks_with_nothing_to_code_and_too_small_an_index_buffer(engine, oracle):
     """A gang whose block has KL = 0 (posterior == prior: K = 0, sample = p.loc, written by the chunk owners' first stripes) next to ordinary
     blocks; and max_K below the blocks' K: every member leaves the block uncoded with out_K = K (what BeamSearchCoder raises its hint from)."""
