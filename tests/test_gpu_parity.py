@@ -485,6 +485,41 @@ def test_gang_calls_under_contention_match_the_one_team_form(engine, monkeypatch
     assert e.value.code == 0
 
 
+def test_a_gang_really_short_of_cus_gives_up_and_is_coded_again(engine, oracle):
+    """No test hook: another stream holds 200 CUs for seconds (200 blocks of 65 536 dims, one team each) while ONE block of 16 384 dims asks
+    for a gang of 128 teams, one per CU.  The members that find a CU wait 100 ms, poison the block's counter and leave; the rest start when
+    CUs come free, see the poison and leave; BeamSearchCoder codes the call again on one team -- the bits of the one-team form.
+    (Many SMALL gangs next to such a hog need no give-up: gangs drain in workgroup order, test_two_gang_calls_in_flight_on_two_streams.)"""
+    import irec
+    n, S, B = 16384, 36, 20
+    st = oracle.synthetic_latent(9900, n)
+    q = tuple(torch.from_numpy(a[None]).cuda().contiguous() for a in st)
+    lay = engine.layout(1, n, None, 42)
+    assert engine.plan(engine.params(3.0, S, B), lay, 256)["split"] == 128
+    K1, idx1, sample1 = engine.encode_blocks(engine.params(3.0, S, B, irec._lib.IREC_FLAG_NO_SPLIT), lay, *q, 42, 256)
+    k1 = int(K1.cpu()[0]); want = idx1.cpu().numpy()[0, :k1].tolist()
+    big = oracle.synthetic_latent(9950, 65536)
+    qb = tuple(torch.from_numpy(np.stack([a] * 200)).cuda().contiguous() for a in big)
+    layb = engine.layout(200, 65536, None, 7)
+    hog = engine.params(3.0, S, B, irec._lib.IREC_FLAG_NO_SPLIT)
+    assert engine.plan(hog, layb, 1024)["grid"] == 200
+    c = irec.BeamSearchCoder(kl_per_partition=3., n_beams=B, extra_samples=1.2, block_size=None)
+    c._max_K_hint = 256
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        Kb, _, _ = engine.encode_blocks(hog, layb, *qb, 7, 1024)            # ~2.6 s on 200 CUs
+    time.sleep(0.2)                                                          # (the long call is running)
+    t0 = time.perf_counter()
+    idx, sample = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42)
+    t_gang = time.perf_counter() - t0
+    print(f"[gang short of CUs] give-ups {c._split_strikes}, {t_gang:.2f} s until the call was coded")
+    assert [int(v) for v in idx] == want and torch.equal(sample, sample1)
+    assert c._split_strikes == 1 and t_gang > 0.1                            # it did give up, and was coded again without sharing
+    torch.cuda.synchronize()
+    assert int(Kb.cpu().min()) > 100                                         # the long call coded its blocks meanwhile
+
+
 def test_gang_calls_inside_a_replayed_graph(engine, oracle):
     """A gang call is plain stream work (its arrival counters are zeroed by the call's own preparation kernel), so a captured sequence of
     such calls -- irec.models.GraphedCompress with block_size=None -- stays correct on every replay."""
