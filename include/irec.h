@@ -133,7 +133,9 @@ typedef struct {
   int32_t table_steps;     /* partitions the proposal tables cover (0 = no tables)                              */
   int32_t n_tables;
   int32_t split;           /* workgroups that share one block (split encoder of calls of < 64 blocks), or teams that share each */
-                           /* row beyond one per CU (team encoder, calls of one to 1.5 blocks per CU); 0 = nothing is shared   */
+                           /* row beyond one per CU (team encoder, calls of one to 1.5 blocks per CU), or the teams of a gang  */
+                           /* (chunked encoder, calls of <= 384 blocks of more than 1024 dims: chunk owners x sample stripes,  */
+                           /* kernel "...,gang>"); 0 = nothing is shared                                                       */
   int32_t n_cu;            /* compute units of the context's device                                             */
   int32_t clock_mhz;       /* its maximum engine clock                                                          */
   int32_t split_beams;     /* split encoder: 1 = the workgroups of a block share its beams (each owns <= 2 beam slots,  */
