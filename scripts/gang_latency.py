@@ -10,7 +10,9 @@ from irec import _lib
 eng = irec.get_engine()
 
 
-def run(label, n_t, n, bs, B, S, max_K, reps, flags=0, table_steps=0):
+def run(label, n_t, n, bs, B, S, max_K, reps, flags=0, table_steps=None):
+    table_steps = max_K if table_steps is None else table_steps   # (a window over every partition, as BeamSearchCoder sizes it from the K it has seen;
+                                                                  #  the library bounds the bytes: steps beyond the window draw their rows in the kernel)
     q = bench.synthetic_batch(n_t, eng.device, 0) if n == bench.N_DIMS else None
     if q is None:
         from oracle import oracle as O
