@@ -16,11 +16,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "relative-entropy-coding_amd")]
 
 
-def build_model(device, blocks=24):
+def build_model(device, blocks=24, block_size=1000):
     from irec.models import BidirectionalResNetVAE
     torch.manual_seed(0)
     m = BidirectionalResNetVAE(num_res_blocks=blocks, sampler="beam_search",
-                               sampler_args={"n_beams": 20, "extra_samples": 1.2}, coder_args={"block_size": 1000},
+                               sampler_args={"n_beams": 20, "extra_samples": 1.2}, coder_args={"block_size": block_size},
                                deterministic_filters=160, stochastic_filters=32, kl_per_partition=3.)
     with torch.no_grad():   # keep posteriors near priors so that K ~ 6..10 per 1000-dim block, as on trained models' latents
         for b in m.residual_blocks:
