@@ -614,7 +614,7 @@ def run_rank(args):
             # (one 8192-dim block holds a team for ~40 ms: four blocks per team slot of the three-team build, 768 slots)
             secondary_config(eng, device, "block_size = None (one 8192-dim block per latent), 3072 latents", OMEGA, EPS1, BEAMS, 3072, N_DIMS, 3, 2, big, block_size=None, max_K=128),
             # (round 5: calls of few such blocks are coded by gangs of teams -- chunk owners x sample stripes over the CUs)
-            secondary_config(eng, device, "block_size = None, ONE latent per call (1 block of 8192 dims: a gang of 64 teams)", OMEGA, EPS1, BEAMS, 1, N_DIMS, 10, 1, big, block_size=None, max_K=128),
+            secondary_config(eng, device, "block_size = None, ONE latent per call (1 block of 8192 dims: a gang of 72 teams)", OMEGA, EPS1, BEAMS, 1, N_DIMS, 10, 1, big, block_size=None, max_K=128),
             secondary_config(eng, device, "block_size = None, one image's 24 latents per call (24 blocks: gangs of 8 teams)", OMEGA, EPS1, BEAMS, 24, N_DIMS, 5, 1, big, block_size=None, max_K=128)]
         result["secondary"]["skewed_K"] = skewed_K_leg(eng, device, 8192, 5, 16)
         result["secondary"]["margins"] = margins_leg(eng, device, params, lay, q, out, S, max_K)

@@ -694,8 +694,13 @@ int gang_width(const irec_context *ctx, const Plan &pl, const irec_params *p, in
   // member: a stripe repeats its chunk's statistics, step constants and update, which costs more than it saves where members share a CU
   // (r05s/gang_stripes.log: 24 blocks of 8192 dims 6.1 ms with 192 members, 8.9 ms with 576)
   const int want = (p->flags & IREC_FLAG_SPLIT_MASK) >> IREC_FLAG_SPLIT_SHIFT;
+  // A stripe takes whole sample-chunks (two samples; one in the 16-beam passes of the 32-slot build), so the step is as long as the
+  // stripe with the most of them: of the stripe counts the cap allows, the FEWEST that reach the shortest step (S = 36: 18 sample-chunks,
+  // cap 9 -> 9 stripes of 2; cap 8 -> 6 stripes of 3, not 8 of 3 or 2)
+  const int64_t n_sch = irec::chunk_gang_nb(p->n_beams, p->n_samples) == 32 ? p->n_samples : (p->n_samples + 1) / 2;
   int64_t SP = std::min<int64_t>(wgs / (n_blocks * GC), want >= 1 ? want : IREC_GANG_STRIPES);
-  SP = std::max<int64_t>(1, std::min<int64_t>(SP, (p->n_samples + 1) / 2));
+  SP = std::max<int64_t>(1, std::min<int64_t>(SP, n_sch));
+  SP = (n_sch + (n_sch + SP - 1) / SP - 1) / ((n_sch + SP - 1) / SP);
   const int64_t G = GC * SP;
   if (G < 2) return 0;
   const int64_t n_slots = n_blocks * G;

@@ -192,8 +192,8 @@ __host__ __device__ inline size_t gang_xch_bytes(int nb, int S, int dpad) {
   return (4 * NGm * (NC_ + nb) + 8 * NGm + 4 * NC_ + 255) & ~(size_t)255;
 }
 #ifndef IREC_GANG_STRIPES
-#define IREC_GANG_STRIPES 8   // sample stripes per chunk of a gang, at most (r05s/gang_stripes.log: one block of 8192 dims 5.2 / 3.5 / 2.9 / 2.5 / 2.3 ms with
-                              // 1 / 2 / 4 / 6 / 9; IREC_FLAG_SPLIT_* bits: a call's own cap)
+#define IREC_GANG_STRIPES 9   // sample stripes per chunk of a gang, at most (r05s/gang_stripes.log: one block of 8192 dims 5.2 / 3.5 / 2.9 / 2.5 / 2.3 ms with
+                              // 1 / 2 / 4 / 6 / 9; flat from there to 15; IREC_FLAG_SPLIT_* bits: a call's own cap)
 #endif
 constexpr int GANG_MAX_BLOCKS = COOP_MAX_BLOCKS;                 // blocks of a call coded by gangs (their arrival counters: the head's exchange granules)
 constexpr size_t GANG_XCH_BYTES_MAX = (size_t)1 << 30;          // ... and no more of them than this much exchange holds

@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 //  Slab of a team: stats [3][Dpad] | cvar [2][Dpad] (by step parity) | sa [Dpad] | beams [2][NB][Dpad] | bp [max_K][NB].
 //
 //  Gangs (GANG builds, round 5): a call of FEWER blocks than team slots -- block_size = None on one image's latents: one block of 8192
-//  dims would keep one team of one CU busy for 40 ms while 255 CUs idle.  G = A.coop_W teams, each on a CU of its own where the grid allows,
+//  dims would keep one team of one CU busy for 21 ms while 255 CUs idle.  G = A.coop_W teams, each on a CU of its own where the grid allows,
 //  code a block together: G = GC chunk owners x SP sample stripes; member m owns the chunks m % GC, + GC, ... (statistics, step constants,
 //  update: nothing of a chunk ever leaves its member but its group sums; the SP stripes of a chunk repeat that work, each in its own slab)
 //  and scores the sample-chunks m / GC, + SP, ... of them.  Per step: every member writes the group sums of its chunks and samples to the

@@ -408,7 +408,7 @@ def test_gangs_of_teams_code_the_blocks_of_a_small_call(engine, oracle, n, bs, B
     """Round 5: the reference's default `block_size=None` on ONE image's latents is one block of 8192 dims -- on one team of one CU
     40 ms, 255 CUs idle.  A call of fewer blocks than team slots is coded by GANGS (irec_team.hip): G teams per block, a chunk of 1024
     dims (or several) each, group sums exchanged through HBM and added in group order.  Same bits as the one-team form (NO_SPLIT) and as
-    the oracle; ragged blocks (two table dims), beam passes (B = 30), sample stripes (one block: 8 chunk owners x 8 stripes).
+    the oracle; ragged blocks (two table dims), beam passes (B = 30), sample stripes (one block: 8 chunk owners x 9 stripes).
     Gang builds: three teams per workgroup for B <= 30 where the LDS holds them, else one team (B = 32 ... 60, S = 122, B = 30 at S = 56)."""
     import irec
     S = oracle.n_samples(3.0, eps1)
@@ -487,7 +487,7 @@ def test_gang_calls_under_contention_match_the_one_team_form(engine, monkeypatch
 
 def test_a_gang_really_short_of_cus_gives_up_and_is_coded_again(engine, oracle):
     """No test hook: another stream holds 200 CUs for seconds (200 blocks of 65 536 dims, one team each) while ONE block of 16 384 dims asks
-    for a gang of 128 teams, one per CU.  The members that find a CU wait 100 ms, poison the block's counter and leave; the rest start when
+    for a gang of 144 teams, one per CU.  The members that find a CU wait 100 ms, poison the block's counter and leave; the rest start when
     CUs come free, see the poison and leave; BeamSearchCoder codes the call again on one team -- the bits of the one-team form.
     (Many SMALL gangs next to such a hog need no give-up: gangs drain in workgroup order, test_two_gang_calls_in_flight_on_two_streams.)"""
     import irec
@@ -495,7 +495,7 @@ def test_a_gang_really_short_of_cus_gives_up_and_is_coded_again(engine, oracle):
     st = oracle.synthetic_latent(9900, n)
     q = tuple(torch.from_numpy(a[None]).cuda().contiguous() for a in st)
     lay = engine.layout(1, n, None, 42)
-    assert engine.plan(engine.params(3.0, S, B), lay, 256)["split"] == 128
+    assert engine.plan(engine.params(3.0, S, B), lay, 256)["split"] == 144                    # (16 chunk owners x 9 sample stripes)
     K1, idx1, sample1 = engine.encode_blocks(engine.params(3.0, S, B, irec._lib.IREC_FLAG_NO_SPLIT), lay, *q, 42, 256)
     k1 = int(K1.cpu()[0]); want = idx1.cpu().numpy()[0, :k1].tolist()
     big = oracle.synthetic_latent(9950, 65536)
