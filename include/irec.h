@@ -98,6 +98,8 @@ typedef struct {
                                   /* flag is part of the params because it sizes the workspace (irec_encode_workspace_bytes) and picks the kernels     */
                                   /* (irec_encode_plan): a margin build of the team encoder where one exists, the generic kernel otherwise; no block   */
                                   /* is shared between workgroups or teams.  Indices, K and samples are the plain call's, bit for bit.                 */
+#define IREC_FLAG_NO_TEN 1048576   /* diagnostics (A/B, tests): plain calls of at most ten beams and S * 10 <= 256 stay on encode_team_kernel<10,..> instead */
+                                  /* of encode_ten_kernel (irec_ten.hip).  Results do not depend on it.                                  */
 #define IREC_FLAG_SPLIT_SHIFT 12  /* bits 12-15: workgroups per block of the split encoder / sample stripes per chunk of a gang, at most; */
                                   /* 0 = chosen by the library (diagnostics) */
 #define IREC_FLAG_SPLIT_MASK (0xF << IREC_FLAG_SPLIT_SHIFT)

@@ -206,6 +206,13 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
   return v;
 }
 
+// v_writelane_b32: `value` (wave-uniform) into lane `lane_select` (wave-uniform) of `old`; the other lanes keep `old`.  This clang has no
+// builtin for it; the intrinsic is reached by its IR name.
+extern "C" __device__ int irec_llvm_writelane_i32(int, int, int) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ uint32_t writelane_u32(uint32_t value, int lane_select, uint32_t old) {
+  return (uint32_t)irec_llvm_writelane_i32((int)value, lane_select, (int)old);
+}
+
 // canonical 64-lane tree: pair lanes at distance 32,16,8,4,2,1 (all lanes end with the same bits).
 __device__ __forceinline__ float wave_tree_sum(float v) {
 #pragma unroll

@@ -586,7 +586,7 @@ Plan make_plan(const irec_context *ctx, const irec_params *p, int32_t max_dim, i
     if (!pl.table) { pl.n_tab = 0; pl.tab_bytes = 0; }
     pl.team = pl.table && !(p->flags & IREC_FLAG_ONE_TABLE) && irec::team_lds_for(B, S, pl.shape) != (size_t)-1;
     if (pl.team_only && !pl.team) { pl.table = false; pl.n_tab = 0; pl.tab_bytes = 0; }
-    if (pl.team) pl.grid_cap = irec::team_count_for(B, S, pl.shape) * n_cu; // one scratch slab per team
+    if (pl.team) pl.grid_cap = std::max(irec::team_count_for(B, S, pl.shape), (p->flags & IREC_FLAG_NO_TEN) ? 0 : irec::team_ten_teams(B, S, pl.shape)) * n_cu; // one scratch slab per team
     pl.lone = pl.team && irec::lone_applies(B, pl.shape);
   }
   if (!pl.table) pl.team_only = false;
@@ -792,6 +792,11 @@ int team_share_width(const irec_context *ctx, const Plan &pl, const irec_params 
   return (int)W;
 }
 
+// teams per workgroup of the kernel a team call of this shape runs: encode_ten_kernel's (irec_ten.hip) for plain calls of at most ten beams
+int call_teams(const irec_params *p, int shape, int share_W, bool margins) {
+  const int tt = (share_W >= 2 || margins || (p->flags & IREC_FLAG_NO_TEN)) ? 0 : irec::team_ten_teams(p->n_beams, p->n_samples, shape);
+  return tt ? tt : irec::team_count_for(p->n_beams, p->n_samples, shape);
+}
 // small calls (a single image's res-block: 9 blocks) are latency-bound: the one-table encoder's set-up (a 6 us proposal
 // table, 40 KB of LDS to fill) beats the team encoder's (38 us per table for the bank assignment, 120 KB); the scratch
 // sized for the team plan covers both
@@ -923,6 +928,12 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
     out->waves_per_wg = irec::team_waves_for(B, S, shape);
     out->teams_per_wg = n_teams;
     out->lds_bytes = (int32_t)irec::team_lds_for(B, S, shape);
+    if (const int tt = irec::team_ten_teams(B, S, shape); tt && out->split < 2 && !(p->flags & IREC_FLAG_NO_TEN)) {   // plain call of at most ten beams
+      std::snprintf(out->kernel, sizeof out->kernel, "encode_ten_kernel<%d>", tt);
+      out->lds_bytes = (int32_t)irec::ten_lds_for(tt);
+      out->teams_per_wg = tt; out->waves_per_wg = 4 * tt;
+      out->grid = batch_grid(n_blocks, std::min(pl.grid_cap / tt, n_cu));
+    }
   } else if (pl.fast) {
     std::snprintf(out->kernel, sizeof out->kernel, "%s", irec::fast_kernel_name(B, S, pl.table));
     if (pl.table) std::snprintf(out->table_kernel, sizeof out->table_kernel, "prep_kernel (plain rows)");
@@ -1032,7 +1043,7 @@ irec_status irec_beam_encode_ex(irec_context *ctx, const irec_params *p, int64_t
   A.defer_count = (unsigned int *)workspace + 1;
   if (mshape >= 0) pl.shape = mshape;
   else if (pl.team) pl.shape = shape_for_call(ctx, pl, p, n_blocks);
-  A.K_tab = pl.K_tab; A.deferred_pass = 0; A.shape_override = pl.shape;
+  A.K_tab = pl.K_tab; A.deferred_pass = 0; A.shape_override = pl.shape; A.no_ten = (p->flags & IREC_FLAG_NO_TEN) ? 1 : 0;
   A.coop_W = 1; A.coop_err = (unsigned int *)workspace + 3; A.coop_arrive = (unsigned int *)workspace + 64;
   A.coop_xch = (uint32_t *)((char *)workspace + irec::WS_COUNTER_BYTES);
   A.ws = (char *)workspace + irec::WS_HEAD_BYTES + pl.tab_bytes;
@@ -1142,7 +1153,7 @@ irec_status irec_beam_encode_ex(irec_context *ctx, const irec_params *p, int64_t
       }
 #endif
     } else if (pl.team) { // grid_cap counts teams (= scratch slabs): two per workgroup, one workgroup per CU
-      const int n_teams = irec::team_count_for(p->n_beams, p->n_samples, pl.shape);
+      const int n_teams = call_teams(p, pl.shape, share_W, out_margin != nullptr);
       // one workgroup per CU as soon as there is a block for it: team k of workgroup w starts on block k * grid + w
       int tgrid = batch_grid(n_blocks, std::min(pl.grid_cap / n_teams, ctx->n_cu > 0 ? ctx->n_cu : 256));
       if (share_W >= 2) {   // rows [share_first, n_blocks) are coded by share_W teams each; the static round deals every slot
@@ -1156,7 +1167,7 @@ irec_status irec_beam_encode_ex(irec_context *ctx, const irec_params *p, int64_t
 #else
       if (!ctx->d_dbg) { if (irec_status s2 = deferred_pass()) return s2; }
       if (ctx->d_dbg) { // diagnostic build (-DIREC_TEAM_STAMPS) only: per-wave phase cycles, wave 0 of a team vs the others
-        const int nwv = irec::team_waves_for(p->n_beams, p->n_samples, pl.shape);
+        const int nwv = n_teams != irec::team_count_for(p->n_beams, p->n_samples, pl.shape) ? 4 * n_teams : irec::team_waves_for(p->n_beams, p->n_samples, pl.shape);
         std::vector<unsigned long long> h((size_t)tgrid * nwv * 16);
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(h.data(), ctx->d_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));

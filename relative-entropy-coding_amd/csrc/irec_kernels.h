@@ -37,6 +37,7 @@ struct EncArgs {
   // the fused-Philox encoder with deferred_pass = 1, which codes exactly the blocks with K_tab < out_K[blk] <= max_K.
   int32_t K_tab; int32_t deferred_pass; unsigned int *defer_count;
   int32_t shape_override;   // team-encoder workgroup shape (diagnostics; 0 = default)
+  int32_t no_ten;           // IREC_FLAG_NO_TEN (diagnostics): plain calls of at most ten beams stay on encode_team_kernel<10,..>
   // Split encoder (small calls: fewer blocks than CUs).  coop_W > 1: workgroup blockIdx.x serves block blockIdx.x / coop_W
   // and scores the samples of stripe blockIdx.x % coop_W only; per step the coop_W workgroups of a block publish the sort keys
   // of their candidates in coop_xch [2][COOP_MAX_BLOCKS][COOP_KEYS] behind the arrival counter coop_arrive[block], read all of
@@ -121,6 +122,12 @@ hipError_t launch_alpha_choice(int64_t seed, int32_t S, int32_t D, int32_t K_tab
 // every proposal table of a call (one per distinct block dim, at most four) in ONE launch
 hipError_t launch_alpha_choice_all(int64_t seed, int32_t S, int32_t K_tab, const uint16_t *dlog4r, int n, const int32_t *dims,
                                    uint16_t *const *tabs, const uint32_t *const *keeps, hipStream_t st);
+// at most ten beams and S * 10 <= 256 candidates per step (the reference's default settings): one team barrier per step, the selection
+// in every wave's registers (irec_ten.hip); plain calls of encode_team_kernel<10,3|2,1>'s shapes take it
+bool ten_applies(int B, int S);
+size_t ten_lds_for(int teams);
+hipError_t launch_encode_ten(const EncArgs &A, int teams, int grid, hipStream_t st);
+int team_ten_teams(int B, int S, int shape_override);   // teams per workgroup of encode_ten_kernel when a plain call of this shape takes it, else 0
 // blocks of more than 1024 dims: a team walks the block in chunks of 1024 over the team encoder's tables (irec_team.hip, encode_chunk_kernel)
 bool chunk_applies(int B, int S, int max_dim);          // B <= 60, max_dim > 1024, a step's partials and running scores fit the LDS next to the tables
 int chunk_teams(int B, int S);                           // teams (= scratch slabs) per workgroup of the build that serves the call: 2, 1, or 0 = none

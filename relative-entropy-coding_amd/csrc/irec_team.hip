@@ -32,6 +32,7 @@
 #include "irec_device.h"
 #include "irec_kernels.h"
 #include "irec_fast_common.h"
+#include "irec_team_common.h"
 
 #ifndef IREC_UB3
 #define IREC_UB3 5   // beams per load batch of the update in the register-short builds
@@ -55,12 +56,15 @@
 #ifndef IREC_PRIO_ROTATE_SHIFT
 #define IREC_PRIO_ROTATE_SHIFT 2
 #endif
-#ifndef IREC_BARRIER_SLEEP
-#define IREC_BARRIER_SLEEP 1   // s_sleep argument (x 64 clocks) between two polls of a team barrier's LDS counter (A/B r05l)
-#endif
 #ifndef IREC_GANG_ABLATE
 #define IREC_GANG_ABLATE 0   // diagnostics (make variant_gang): phases of a gang step removed -- 1 sample loops, 2 update, 4 reduction, 8 selection,
                              // 32 gang barriers; the outputs are wrong, the time that remains is the point (scripts/gang_latency.py --ablate)
+#endif
+#ifndef IREC_TEN_TEAMS
+#define IREC_TEN_TEAMS 3       // teams per workgroup of encode_ten_kernel where encode_team_kernel<10,..> has three (3: A/B builds)
+#endif
+#ifndef IREC_PK_ADDR
+#define IREC_PK_ADDR 1          // scoring loop: look-up addresses of a beam pair by one v_pk_add_f32 (0: two v_add_u32; A/B builds)
 #endif
 #ifndef IREC_STEP0_WIDE
 #define IREC_STEP0_WIDE 1   // first step (one beam): RW samples per reduce-scatter instead of one (0: the beam-wise path, A/B builds)
@@ -70,8 +74,6 @@
 #endif
 namespace irec {
 
-constexpr int TEAM_NW = 4;                       // waves per team
-constexpr int TEAM_NT = TEAM_NW * 64;            // threads per team
 // beams a team serves at most (sizes its small LDS arrays): 32 for the builds of up to 32 beams -- the three-team 20-beam
 // build has no LDS to spare -- and 64 (with room for 512 selection survivors) for the 60-beam build
 __host__ __device__ constexpr int team_mb(int NB) { return NB <= 32 ? 32 : 64; }
@@ -79,9 +81,6 @@ template <int NB> using TeamLdsT = SmallLdsT<(NB <= 32 ? 32 : 64), (NB <= 32 ? 3
 __host__ __device__ inline size_t team_small_bytes(int NB) {
   return NB <= 32 ? ((sizeof(TeamLdsT<32>) + 15) & ~(size_t)15) : ((sizeof(TeamLdsT<64>) + 15) & ~(size_t)15);
 }
-constexpr uint32_t T3_FLOATS = 3u * IREC_PM1;    // three copies of lut2
-constexpr size_t T3_BYTES = ((size_t)T3_FLOATS * 4 + 15) & ~(size_t)15;
-
 // Sample passes.  The per-group partial scores of SP samples sit in LDS at a time ([4][SP][NB] f32); a step scores S in
 // ceil(S / SP) passes, each followed by the group combine into the sort keys ([S*NB] u32, all of them resident).  Every
 // BASELINE configuration with B <= 20 takes one pass; the 30-beam stress configuration (S = 148) takes four of 37.
@@ -124,26 +123,6 @@ __host__ __device__ inline size_t team_lds_one(int NB, int S, int SP, int teams,
 __host__ __device__ inline size_t team_lds_total(int NB, int S, int SP, int teams, bool passes = false, int ps = 0) {
   return T3_BYTES + (size_t)teams * team_lds_one(NB, S, SP, teams, passes, ps);
 }
-
-// Barrier of the 4 waves of one team: a monotonic LDS counter.  LDS operations of one wave execute in program order and
-// the LDS serves one instruction at a time, so a wave's earlier writes are in place before its add lands; the fences
-// order the global slab traffic (vmcnt) the way __syncthreads would.
-struct TeamBarrier {
-  uint32_t *cnt;
-  uint32_t epoch;
-  uint32_t n_waves;
-  __device__ __forceinline__ void operator()() {
-    epoch += n_waves;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    for (;;) {
-      const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-      if ((int32_t)(v - epoch) >= 0) break; // every wave of the team has arrived
-      __builtin_amdgcn_s_sleep(IREC_BARRIER_SLEEP);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  }
-};
 
 // Diagnostic build (-DIREC_TEAM_STAMPS, scripts/gpu_stamps.sh): per-wave cycle sums per phase, written once at exit.
 #ifdef IREC_TEAM_STAMPS
@@ -533,8 +512,21 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         constexpr int NQH = NQ * NH;                                // granules per chunk
         static_assert(NP % NH == 0 && NQH % 2 == 0, "granules must tile the slots and alternate buffers cleanly");
         f2 zz[2][HP];
+#if IREC_PK_ADDR
+        // round 6: the two addresses of a beam pair come out of ONE v_pk_add_f32 on their bit patterns -- byte addresses below 2^23 read as
+        // float32 are denormals, denormals are preserved (the arithmetic contract needs them), and the sum of two such numbers is exact and
+        // carries the integer sum in its bits: half the address instructions (irec_ten.hip has the same)
+        f2 betf[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) betf[k] = (f2){__uint_as_float(bet[2 * k]), __uint_as_float(bet[2 * k + 1])};
+#define IREC_ISSUE(Z, AD, K0) do { const float adf_ = __uint_as_float(AD); const f2 ad2_ = {adf_, adf_}; \
+                               _Pragma("unroll") for (int k = 0; k < HP; ++k) { const f2 a2_ = ad2_ + betf[(K0) + k]; \
+                                 Z[k].x = lds_abs_f32(__float_as_uint(a2_.x)); Z[k].y = lds_abs_f32(__float_as_uint(a2_.y)); } \
+                               __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
 #define IREC_ISSUE(Z, AD, K0) do { _Pragma("unroll") for (int k = 0; k < HP; ++k) { Z[k].x = lds_abs_f32((AD) + bet[2 * ((K0) + k)]); Z[k].y = lds_abs_f32((AD) + bet[2 * ((K0) + k) + 1]); } \
                                __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
 #define IREC_CONSUME(Z, I, ACC, K0) do { _Pragma("unroll") for (int k = 0; k < HP; ++k) asm volatile("" : "+v"(Z[k])); \
                                 f2 t2_[HP]; \
                                 _Pragma("unroll") for (int k = 0; k < HP; ++k) { \
@@ -2036,6 +2028,12 @@ size_t team_ws_bytes_for(int B, int S, int ovr, int max_K) {
   const TeamShape sh = team_shape(B, S, ovr);
   return sh.nb ? fast_ws_bytes(sh.nb, max_K) + team_ws_extra_for(B, S, ovr) : 0;
 }
+// teams per workgroup of encode_ten_kernel (irec_ten.hip) when a plain call of this shape takes it, else 0
+int team_ten_teams(int B, int S, int ovr) {
+  const TeamShape sh = team_shape(B, S, ovr);
+  if (!(sh.nb == 10 && sh.bs == 1 && !sh.passes && !sh.one && (sh.teams == 2 || sh.teams == 3) && ten_applies(B, S))) return 0;
+  return sh.teams == 3 ? IREC_TEN_TEAMS : 2;   // (r06f: four teams at 128 VGPRs hold the scoring loop without a spill and LOSE 12 %: 4096 latents 8.6 -> 9.7 ms)
+}
 const char *team_kernel_name(int B, int S, int ovr) {
   static thread_local char buf[64];
   const TeamShape sh = team_shape(B, S, ovr);
@@ -2103,6 +2101,7 @@ hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
       default: return hipErrorInvalidValue;
     }
   }
+  if ((key == 1031 || key == 1021) && !A.no_ten && ten_applies(A.B, A.S)) return launch_encode_ten(A, team_ten_teams(A.B, A.S, A.shape_override), grid, st);   // (irec_ten.hip)
   switch (key) {
     case 101031: return launch_team_t<10, 3, 1, false, true>(A, grid, st);
     case 111031: return launch_team_t<10, 3, 1, true, true>(A, grid, st);

@@ -12,8 +12,8 @@ echo "# kernel | VGPRs | AGPRs | SGPRs | scratch B/lane | static LDS B | scratch
 echo "# (round 5, last column: the loop of 80 ds_read_b32 and 0 scratch operations is the software-pipelined steady state that every full step of a 20-beam build"
 echo "#  runs -- 20 beams x 4 dim slots per sample; the loops listed before it are the beam-by-beam fall-back of partly filled stripes and the first step's"
 echo "#  wide path: the headline build's 588 B/lane of scratch are outside the steady state)"
-for f in irec_team irec_team_margin irec_lone irec_kernels irec_decode; do
-  extra=""; [ $f = irec_team -o $f = irec_team_margin -o $f = irec_kernels ] && extra="-mllvm -sink-insts-to-avoid-spills=true"
+for f in irec_team irec_team_margin irec_ten irec_lone irec_kernels irec_decode; do
+  extra=""; [ $f = irec_team -o $f = irec_team_margin -o $f = irec_ten -o $f = irec_kernels ] && extra="-mllvm -sink-insts-to-avoid-spills=true"
   hipcc $FLAGS $extra "$ROOT/relative-entropy-coding_amd/csrc/$f.hip" -o "$TMP/$f.s" 2>/dev/null
   python3 - "$TMP/$f.s" <<'PY'
 import re, subprocess, sys

@@ -13,6 +13,7 @@ flags = {"table": 8, "auto": 0, "one_table": 4, "fused": 2, "generic": 1}[varian
 flags |= irec._lib.IREC_FLAG_SHAPE[os.environ.get("SHAPE", "default")]   # team-encoder workgroup shape (diagnostics)
 flags |= int(os.environ.get("SPLIT_W", "0")) << 12                         # split-encoder width (diagnostics)
 if os.environ.get("NO_SPLIT"): flags |= 16
+if os.environ.get("NO_TEN"): flags |= irec._lib.IREC_FLAG_NO_TEN            # at most ten beams: encode_team_kernel<10,..> instead of encode_ten_kernel
 if os.environ.get("SHARE_ALL"): flags |= 131072                                 # team encoder: share every row of the call between teams
 if os.environ.get("SPLIT_SAMPLES"): flags |= 128                                      # split encoder: samples, not beams
 max_K = int(os.environ.get("MAXK", "32"))

@@ -766,7 +766,7 @@ def test_block_hand_out_codes_every_block_once(engine, oracle, B, n_tensors):
     S = oracle.n_samples(2.0, 1.0)
     lay = engine.layout(n_tensors, n, bs, 42)
     plan = engine.plan(c._params(), lay, 32)
-    assert plan["kernel"].startswith("encode_lone_kernel" if B == 1 else "encode_team_kernel"), plan
+    assert plan["kernel"].startswith("encode_lone_kernel" if B == 1 else ("encode_ten_kernel", "encode_team_kernel")), plan
     assert lay.n_blocks == 8 * n_tensors and plan["grid"] % 8 == 0
     idx, sample = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)
     for i in range(n_tensors):
@@ -880,7 +880,7 @@ def test_reference_sweep_grid(engine, oracle, omega, B):
             assert np.array_equal(sample.cpu().numpy()[0], rs), (omega, eps1, S, B, flags, plan["kernel"])
             if flags and B <= 60:
                 lone = B == 1 and not (flags & _lib.IREC_FLAG_SHAPE["team"])
-                assert plan["kernel"].startswith("encode_lone_kernel" if lone else "encode_team_kernel"), plan
+                assert plan["kernel"].startswith("encode_lone_kernel" if lone else ("encode_ten_kernel", "encode_team_kernel")), plan
             assert torch.equal(engine.decode_blocks(params, lay, pl, ps, 42, K, idx), sample)
 
 
@@ -1384,7 +1384,12 @@ def test_plan_names_the_kernels_that_run(engine, oracle):
     assert engine.plan(p, big, 32)["table_kernel"] == "prep_kernel (copy bits)"
     assert engine.plan(p, small, 32)["kernel"].startswith("encode_fast_kernel<20,")       # < 64 blocks: one-table set-up
     assert engine.plan(engine.params(3.0, S, 20, irec._lib.IREC_FLAG_FUSED_PHILOX), big, 32)["table_kernel"] == ""
-    assert engine.plan(engine.params(3.0, 20, 10), big, 32)["kernel"] == "encode_team_kernel<10,3,1>"
+    # round 6: the reference's default settings (at most ten beams, S * 10 <= 256) run encode_ten_kernel; the
+    # team encoder's ten-beam builds keep more samples, shared rows, margins -- and plain calls under IREC_FLAG_NO_TEN
+    ten = engine.plan(engine.params(3.0, 20, 10), big, 32)
+    assert ten["kernel"] == "encode_ten_kernel<3>" and ten["teams_per_wg"] == 3 and ten["waves_per_wg"] == 12 and ten["lds_bytes"] <= 160 * 1024
+    assert engine.plan(engine.params(3.0, 20, 10, irec._lib.IREC_FLAG_NO_TEN), big, 32)["kernel"] == "encode_team_kernel<10,3,1>"
+    assert engine.plan(engine.params(3.3, 27, 10), big, 32)["kernel"] == "encode_team_kernel<10,3,1>"      # 270 candidates per step
     assert engine.plan(engine.params(5.0, 148, 30), big, 32)["kernel"] == "encode_team_kernel<30,1,3>"
     assert engine.plan(engine.params(3.0, S, 40), big, 32)["kernel"] == "encode_team_kernel<60,1,3>"     # round 3: 32 < B <= 60
     assert engine.plan(engine.params(3.0, S, 40), small, 32)["kernel"] == "encode_team_kernel<60,1,3>"   # (no one-table encoder there)
