@@ -225,4 +225,27 @@ __device__ __forceinline__ double wave_tree_sum(double v) {
   return v;
 }
 
+// The same trees on the VALU (DPP / permlane swaps) instead of ds_bpermute: same partner at every stage (lane ^ 32, 16, 8, 4, 2, 1), same
+// additions, same bits -- and no LDS round trip per stage (round 6: six dependent trips through an LDS queue full of look-ups)
+__device__ __forceinline__ float wave_tree_sum_valu(float v) {
+  v = v + __uint_as_float(xor_lane_u32<32>(__float_as_uint(v)));
+  v = v + __uint_as_float(xor_lane_u32<16>(__float_as_uint(v)));
+  v = v + __uint_as_float(xor_lane_u32<8>(__float_as_uint(v)));
+  v = v + __uint_as_float(xor_lane_u32<4>(__float_as_uint(v)));
+  v = v + __uint_as_float(xor_lane_u32<2>(__float_as_uint(v)));
+  v = v + __uint_as_float(xor_lane_u32<1>(__float_as_uint(v)));
+  return v;
+}
+template <int DIST>
+__device__ __forceinline__ double xor_lane_f64(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const uint32_t lo = xor_lane_u32<DIST>((uint32_t)b), hi = xor_lane_u32<DIST>((uint32_t)(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_tree_sum_valu(double v) {
+  v = v + xor_lane_f64<32>(v); v = v + xor_lane_f64<16>(v); v = v + xor_lane_f64<8>(v);
+  v = v + xor_lane_f64<4>(v); v = v + xor_lane_f64<2>(v); v = v + xor_lane_f64<1>(v);
+  return v;
+}
+
 } // namespace irec

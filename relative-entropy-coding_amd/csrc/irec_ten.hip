@@ -38,6 +38,12 @@
 #ifndef IREC_TEN_SELECT_FAST
 #define IREC_TEN_SELECT_FAST 1     // the selection in straight-line vector code with ds_permute compaction (0: scalar loops over ballot masks)
 #endif
+#ifndef IREC_TEN_PREPULL
+#define IREC_TEN_PREPULL 0         // 1: the next hand-out slot is pulled during a block's last step (r06p: 1.5 % SLOWER than pulling at the loop top)
+#endif
+#ifndef IREC_TEN_TREE_VALU
+#define IREC_TEN_TREE_VALU 1       // KL / C_b lane trees on DPP and permlane swaps (0: ds_bpermute)
+#endif
 #ifndef IREC_TEN_INPLACE
 #define IREC_TEN_INPLACE 1      // beams updated in place where one wave owns a dim group (0: always double buffered; A/B builds)
 #endif
@@ -141,7 +147,8 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
   { const uint32_t o = xor_lane_u32<32>(v); v = o < v ? o : v; }
   return v;
 }
-__device__ __forceinline__ uint32_t ten_select_fast(const uint32_t (&k)[4], int N, int Bnew, int lane) {
+template <class Mid>
+__device__ __forceinline__ uint32_t ten_select_fast(const uint32_t (&k)[4], int N, int Bnew, int lane, Mid &&mid) {
   uint32_t M = k[0] > k[1] ? k[0] : k[1];
   { const uint32_t m2 = k[2] > k[3] ? k[2] : k[3]; M = M > m2 ? M : m2; }
   { const uint32_t o = dpp_u32<0xB1, 0xF>(M, M); M = M > o ? M : o; }      // quad_perm [1,0,3,2]
@@ -172,6 +179,7 @@ __device__ __forceinline__ uint32_t ten_select_fast(const uint32_t (&k)[4], int 
     cf |= (uint32_t)__builtin_amdgcn_ds_permute(dst, 64 * q + lane);
   }
   ck = (uint32_t)lane < C ? ck : 0u;                             // (lane 63 caught what the non-survivors sent)
+  mid();                                                         // (diagnostic builds: a phase stamp)
   uint32_t rank = 0u, eq = 0u;
   for (uint32_t l = 0; l < C; ++l) {                             // (wave-uniform trip count)
     const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)ck, (int)l);
@@ -229,6 +237,8 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
 #endif
   bool first_block = true;
   int steal = 0;
+  int64_t pre_slot = -1;                     // (thread 0 of a team) the next hand-out slot, pulled one step early: its atomic's round trip
+                                             // to the L2 then lies under a step's serial phase instead of in front of a block's prologue
   for (;;) {
     tsync();
     if (tid == 0) {
@@ -236,12 +246,14 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
       if (first_block) {
         r = (int64_t)team * (int64_t)gridDim.x + (int64_t)blockIdx.x;
         r = r < n_static ? xcd_static_row(r, n_static, (int)gridDim.x) : n_slots;
-      } else r = xcd_pull_row(A, n_static, n_slots, steal);
+      } else if (pre_slot >= 0) r = pre_slot;       // pulled during the previous block's last step (below)
+      else r = xcd_pull_row(A, n_static, n_slots, steal);
+      pre_slot = -1;
       misc[0] = (int32_t)r;
     }
     first_block = false;
     tsync();
-    const int64_t blk = misc[0];
+    const int64_t blk = __builtin_amdgcn_readfirstlane(misc[0]);   // (wave-uniform: the block's descriptors come by scalar loads)
     TSTAMP(0);
     if (blk >= n_slots) break; // every wave of the team reaches this; the other teams drain on their own
     const int D = A.block_dim[blk];
@@ -287,19 +299,17 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
       }
     }
     {
-      const double gs = wave_tree_sum(klacc);
+      const double gs = IREC_TEN_TREE_VALU ? wave_tree_sum_valu(klacc) : wave_tree_sum(klacc);
       if (sw == 0 && active && lane == 0) sm->gpart[g] = gs;
       tsync();
-      if (tid == 0) {
-        double tot = sm->gpart[0];
-        for (int gg = 1; gg < NG; ++gg) tot = tot + sm->gpart[gg];
-        const int32_t K = num_aux((float)tot, A.omega);
-        misc[1] = K;
-        A.out_K[blk] = K;
-      }
-      tsync();
     }
-    const int K = misc[1];
+    int K;
+    {                                            // every wave forms K itself: no second barrier
+      double tot = sm->gpart[0];
+      for (int gg = 1; gg < NG; ++gg) tot = tot + sm->gpart[gg];
+      K = __builtin_amdgcn_readfirstlane(num_aux((float)tot, A.omega));
+      if (tid == 0) A.out_K[blk] = K;
+    }
     if (K > A.max_K || K > A.K_limit) continue;
     if (K > A.K_tab) { // beyond the table window: the fused-Philox pass codes it
       if (tid == 0) atomicAdd(A.defer_count, 1u);
@@ -355,7 +365,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
         G2[0][i].x = beam_G(0.f, m[i], cA[i], cBv[i], sa[i]);
         cacc = beam_C_term(cacc, 0.f, m[i], cA[i], cBv[i]);
       }
-      const float cg = wave_tree_sum(cacc);
+      const float cg = IREC_TEN_TREE_VALU ? wave_tree_sum_valu(cacc) : wave_tree_sum(cacc);
       if (active && sw == 0 && lane == 0) sm->cpart[0][0][g] = cg;
       // (visibility of the C_b partials: the barrier after scoring)
     }
@@ -375,7 +385,6 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
       // my quad inside a row; lanes past the padded row end read the row's LAST quad (irec_team.hip: same addresses as the last
       // real lane of their 32-lane group, no extra bank conflict)
       const uint32_t tab_lo = (uint32_t)(d0 < Dp ? d0 : Dp - 4);
-      const uint16_t *tab_t = tab_tu + tab_lo;
       uint32_t bet[NB];
 #pragma unroll
       for (int b = 0; b < NB; ++b) bet[b] = (uint32_t)__builtin_amdgcn_readlane((int)bv_cur, b < Bcur ? b : 0);   // dead slots: beam 0's (phantoms)
@@ -501,6 +510,9 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
       TSTAMP(3);
       const int Bnew = B < N ? B : N;
       const bool last = (t == K - 1);
+#if IREC_TEN_PREPULL
+      if (last && tid == 0) pre_slot = xcd_pull_row(A, n_static, n_slots, steal);   // the next block's slot, a serial phase early
+#endif
       uint32_t bv_new = 0u;
       int32_t hs_new = 0;
       if (active) {
@@ -536,7 +548,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
         const uint32_t sel = (uint32_t)lane + (key[0] & 1u);
 #else
 #if IREC_TEN_SELECT_FAST
-        const uint32_t sel = ten_select_fast(key, N, Bnew, lane);   // lane r < Bnew: flat index of rank r
+        const uint32_t sel = ten_select_fast(key, N, Bnew, lane, [&]() { TSTAMP(7); });   // lane r < Bnew: flat index of rank r
 #else
         const uint32_t sel = ten_select(key, N, Bnew, lane);        // lane r < Bnew: flat index of rank r
 #endif
@@ -547,11 +559,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
           const uint32_t fl = lane < Bnew ? sel : 0u;
           v_sp = (int32_t)((fl * inv) >> 16);                       // best_ind_aux  (:89)
           v_bp = (int32_t)fl - v_sp * Bcur;                         // best_ind_beam (:88)
-          int32_t hp = 0;
-          for (int b = 0; b < Bcur; ++b) {                          // the parent's hash sum: lane b's
-            const int32_t v = __builtin_amdgcn_readlane(hs_cur, b);
-            hp = v_bp == b ? v : hp;
-          }
+          const int32_t hp = __builtin_amdgcn_ds_bpermute(v_bp << 2, hs_cur);   // the parent's hash sum: lane b's (LDS crossbar, no bank)
           hs_new = (int32_t)((uint32_t)hp + (uint32_t)v_sp * (uint32_t)(69 + t));   // (:33-35, int32 wrap-around)
           if (wave == 0 && lane < Bnew) bp[(size_t)t * NB + lane] = (v_sp << 6) | v_bp;
         }
@@ -559,10 +567,13 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
         // ---------------- gather the surviving beams (beam_search_coder.py:92-93), prepare the next step ----------------
         // new beams' table offsets: lane j looks up dlog(hash(path_j)) -- a global load, consumed at the end of the update
         bv_new = dlog_s[hash_from_sum(lane < Bnew ? hs_new : 0) - 1u];
-        const float sa_t[4] = {sa[0], sa[1], sa[2], sa[3]};   // this step's sample scale
+        const f2t sa_t2[2] = {{sa[0], sa[1]}, {sa[2], sa[3]}};   // this step's sample scale (dims in pairs: the update runs on v_pk_*_f32)
         const int nxt = inplace ? cur : (cur ^ 1);
-        const float *bold = beams_g + ((size_t)cur * NB) * FAST_MAX_DIM + d0;
-        float *bnew = beams_g + ((size_t)nxt * NB) * FAST_MAX_DIM + d0;
+        // addresses: a wave-uniform base (scalar arithmetic on the selected sample / parent) plus my quad's byte offset
+        const char *rows_u = reinterpret_cast<const char *>(tab_tu);
+        const uint32_t row_lane = tab_lo * 2u, beam_lane = (uint32_t)d0 * 4u;
+        const char *bold_u = reinterpret_cast<const char *>(beams_g + ((size_t)cur * NB) * FAST_MAX_DIM);
+        char *bnew_u = reinterpret_cast<char *>(beams_g + ((size_t)nxt * NB) * FAST_MAX_DIM);
         // the last step keeps ONE beam: beams[0] is all that leaves the block (beam_search_coder.py:118-122)
         const int Bupd = last ? 1 : Bnew;
         // ---- every global read of the update back to back: proposal rows, parents ----
@@ -575,11 +586,11 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
           obv4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
           bet_old[j] = 0u;
           if (j < Bupd) { // wave-uniform
-            const int32_t sp_ = __builtin_amdgcn_readlane(v_sp, j);
-            const int32_t bp_ = __builtin_amdgcn_readlane(v_bp, j);
-            bet_old[j] = (uint32_t)__builtin_amdgcn_readlane((int)bv_cur, bp_);
-            apv[j] = *reinterpret_cast<const uint2 *>(tab_t + (size_t)sp_ * Dp);
-            if (t) obv4[j] = *reinterpret_cast<const float4 *>(bold + (size_t)bp_ * FAST_MAX_DIM);
+            const uint32_t sp_ = (uint32_t)__builtin_amdgcn_readlane(v_sp, j);
+            const uint32_t bp_ = (uint32_t)__builtin_amdgcn_readlane(v_bp, j);
+            bet_old[j] = (uint32_t)__builtin_amdgcn_readlane((int)bv_cur, (int)bp_);
+            apv[j] = *reinterpret_cast<const uint2 *>(rows_u + (size_t)(sp_ * (uint32_t)Dp * 2u) + row_lane);
+            if (t) obv4[j] = *reinterpret_cast<const float4 *>(bold_u + (size_t)(bp_ * (uint32_t)(FAST_MAX_DIM * 4)) + beam_lane);
           }
         }
         float m[4], cA[4], cBv[4];
@@ -594,6 +605,8 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
         if (!last) step_consts(t + 1, m, cA, cBv); // next step's constants, under the loads' latency
 #endif
         TSTAMP(9);
+        const f2t m2[2] = {{m[0], m[1]}, {m[2], m[3]}}, A2[2] = {{cA[0], cA[1]}, {cA[2], cA[3]}}, Bv2[2] = {{cBv[0], cBv[1]}, {cBv[2], cBv[3]}};
+        const f2t AA2[2] = {A2[0] + A2[0], A2[1] + A2[1]};          // (beam_G: A + A)
         float cacc[rsn_room(NB)];
 #pragma unroll
         for (int j = 0; j < rsn_room(NB); ++j) cacc[j] = 0.f;
@@ -605,46 +618,55 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
         constexpr int YB = 5;
 #pragma unroll
         for (int j0 = 0; j0 < NB; j0 += YB) {
-          float zy[YB][4];
+          f2t zy[YB][2];
 #pragma unroll
           for (int v = 0; v < YB; ++v) {
             const int j = j0 + v;
             const uint32_t al[4] = {(apv[j].x & 0xFFFFu) << 2, (apv[j].x >> 16) << 2, (apv[j].y & 0xFFFFu) << 2, (apv[j].y >> 16) << 2};
             const f2t bo2 = {__uint_as_float(bet_old[j]), __uint_as_float(bet_old[j])};
 #pragma unroll
-            for (int i = 0; i < 4; i += 2) {                          // entry 0 for beams that do not exist
-              const f2t a2 = (f2t){__uint_as_float(al[i]), __uint_as_float(al[i + 1])} + bo2;
-              zy[v][i] = lds_abs_f32(__float_as_uint(a2.x)); zy[v][i + 1] = lds_abs_f32(__float_as_uint(a2.y));
+            for (int h = 0; h < 2; ++h) {                             // entry 0 for beams that do not exist
+              const f2t a2 = (f2t){__uint_as_float(al[2 * h]), __uint_as_float(al[2 * h + 1])} + bo2;
+              zy[v][h] = (f2t){lds_abs_f32(__float_as_uint(a2.x)), lds_abs_f32(__float_as_uint(a2.y))};
             }
           }
 #pragma unroll
           for (int v = 0; v < YB; ++v) {
             const int j = j0 + v;
             if (j < Bupd) { // wave-uniform
-              const float obv[4] = {obv4[j].x, obv4[j].y, obv4[j].z, obv4[j].w};
-              float nb[4];
+              const f2t obv[2] = {{obv4[j].x, obv4[j].y}, {obv4[j].z, obv4[j].w}};
+              f2t nb[2];
 #pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                const float y = sa_t[i] * zy[v][i];                         // dist.quantile(.), :48-49
-                nb[i] = obv[i] + y;                                         // combined_samples[best_ind_aux, best_ind_beam], :81,92-93
+              for (int h = 0; h < 2; ++h) {
+                const f2t y = sa_t2[h] * zy[v][h];                          // dist.quantile(.), :48-49
+                nb[h] = obv[h] + y;                                         // combined_samples[best_ind_aux, best_ind_beam], :81,92-93
               }
               if (last) {
                 if (sw == 0) {                                              // (j == 0: Bupd == 1)
+                  const float nbs[4] = {nb[0].x, nb[0].y, nb[1].x, nb[1].y};
 #pragma unroll
                   for (int i = 0; i < 4; ++i)
                     if (valid[i]) { // beams[0] + coding_dist.loc, :122
                       const int64_t ixo = src_index(A, base, pos, d0 + i);
-                      A.out_sample[ixo] = nb[i] + A.p_loc[ixo];
+                      A.out_sample[ixo] = nbs[i] + A.p_loc[ixo];
                     }
                 }
               } else {
-                if (sw == 0) *reinterpret_cast<float4 *>(bnew + (size_t)j * FAST_MAX_DIM) = make_float4(nb[0], nb[1], nb[2], nb[3]);
+                if (sw == 0) *reinterpret_cast<float4 *>(bnew_u + (size_t)(j * FAST_MAX_DIM * 4) + beam_lane) = make_float4(nb[0].x, nb[0].y, nb[1].x, nb[1].y);
+                // beam_G / beam_C_term (irec_device.h) on dim pairs: p = beam - m; G = fma(A + A, p, Bv) * sa; C += fma(fma(A, p, Bv), p, .) in dim order
+                f2t u2[2], t2[2], p2[2];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                  const float gv = beam_G(nb[i], m[i], cA[i], cBv[i], sa[i]);
-                  if (j & 1) G2[j >> 1][i].y = gv; else G2[j >> 1][i].x = gv;
-                  cacc[j] = beam_C_term(cacc[j], nb[i], m[i], cA[i], cBv[i]);
+                for (int h = 0; h < 2; ++h) {
+                  p2[h] = nb[h] - m2[h];
+                  t2[h] = __builtin_elementwise_fma(AA2[h], p2[h], Bv2[h]);
+                  u2[h] = __builtin_elementwise_fma(A2[h], p2[h], Bv2[h]);
                 }
+                const float gv[4] = {t2[0].x * sa[0], t2[0].y * sa[1], t2[1].x * sa[2], t2[1].y * sa[3]};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { if (j & 1) G2[j >> 1][i].y = gv[i]; else G2[j >> 1][i].x = gv[i]; }
+                float ca = cacc[j];
+                ca = fmaf(u2[0].x, p2[0].x, ca); ca = fmaf(u2[0].y, p2[0].y, ca); ca = fmaf(u2[1].x, p2[1].x, ca); ca = fmaf(u2[1].y, p2[1].y, ca);
+                cacc[j] = ca;
               }
             }
           }

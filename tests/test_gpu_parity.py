@@ -1491,7 +1491,8 @@ def test_one_to_two_blocks_per_cu_take_the_two_team_shape(engine, oracle, B, eps
     c = _coder(3.0, B, eps1, block_size=1000)
     lay = engine.layout(n_latents, 8192, 1000, 42)
     plan = engine.plan(c._params(), lay, 32)
-    assert plan["n_cu"] < lay.n_blocks <= 2 * plan["n_cu"] and plan["kernel"] == f"encode_team_kernel<{B},2,1>", plan
+    # (round 6: plain calls of at most ten beams and S * 10 <= 256 run the two-team build of encode_ten_kernel)
+    assert plan["n_cu"] < lay.n_blocks <= 2 * plan["n_cu"] and plan["kernel"] == (f"encode_team_kernel<{B},2,1>" if B > 10 else "encode_ten_kernel<2>"), plan
     assert plan["teams_per_wg"] == 2 and plan["grid"] == plan["n_cu"]
     idx, sample = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42, batched=True)
     for i in (0, 17, 37):
