@@ -35,6 +35,7 @@ for p in (ROOT, PKG):
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 LDS_HW_LOOKUPS = 32.0     # ds_read_b32: 128 B/clk/CU = 32 four-byte look-ups per clock per CU (MI355X_MICROARCH.md §LDS)
+LDS_STREAM_LOOKUPS = 13.68   # the same mixture with the kernel's own instruction stream (profiles/r05b/bank_limits.log)
 LDS_2CHOICE_LOOKUPS = 13.70  # measured ceiling of random look-ups with the 2-choice bank assignment at the 12 waves per CU
                              # the default kernel runs (profiles/r01j/gather_rates.log; 13.4 at 8 waves, 14.0 at 16; round 5, with the
                              # kernel's own instruction stream: 13.68, profiles/r05b/bank_limits.log -- DESIGN.md §4 "The gather ceiling")
@@ -42,8 +43,8 @@ TENSOR_SHAPE = (16, 16, 32)
 N_DIMS = 8192
 BLOCK_SIZE = 1000
 OMEGA, EPS1, BEAMS, SEED = 3.0, 1.2, 20, 42
-KERNEL_SOURCES = ("irec_team.hip", "irec_lone.hip", "irec_kernels.hip", "irec_fast_common.h", "irec_device.h", "irec_kernels.h",
-                  "irec_host.cpp")
+KERNEL_SOURCES = ("irec_team.hip", "irec_ten.hip", "irec_lone.hip", "irec_kernels.hip", "irec_fast_common.h", "irec_team_common.h",
+                  "irec_device.h", "irec_kernels.h", "irec_host.cpp")
 
 
 def kernel_source_hash():
@@ -522,6 +523,7 @@ def run_rank(args):
     # MI355X_MICROARCH.md prescribes) counts only if it was taken on THESE kernel sources
     src_hash = kernel_source_hash()
     traffic, traffic_note = None, "no profiles/traffic.json"
+    pmc = {"lds_conflict_frac": None, "lds_busy": None, "valu_busy": None}   # (PMC passes of the same sources, or null)
     tj = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tj):
         tr = json.load(open(tj))
@@ -531,6 +533,7 @@ def run_rank(args):
         if tr.get("source_sha16") == src_hash and norm(tr.get("kernel", "")) == norm(plan["kernel"]):
             traffic = tr["hbm_bytes_per_latent"] * L
             traffic_note = tr.get("source", "")
+            pmc = {k: tr.get(k) for k in ("lds_conflict_frac", "lds_busy", "valu_busy")}
         else:
             traffic_note = (f"profiles/traffic.json is for sources {tr.get('source_sha16')} / {tr.get('kernel')}; "
                             f"this build is {src_hash} / {plan['kernel']}: not reported")
@@ -565,7 +568,17 @@ def run_rank(args):
                      "unit": "GB/s", "frac": algo_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_note": traffic_note, "kernel": plan["kernel"], "table_kernel": plan["table_kernel"],
                      "grid": plan["grid"], "waves_per_wg": plan["waves_per_wg"], "lds_bytes": plan["lds_bytes"],
-                     "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes, "source_sha16": src_hash},
+                     "kernel_ms": kernel_ms, "algorithmic_bytes": algo_bytes, "source_sha16": src_hash,
+                     # "report all three fractions" -- the contractual one above is a property of the algorithm
+                     # (~2e3 op/B); what BINDS the kernel is the LDS gather pipe (look-ups per clock per CU at the device's maximum clock)
+                     "binding": {"pipe": "lds_gather", "unit": "look-ups/clk/CU", "achieved": lookups,
+                                 "hw_peak": LDS_HW_LOOKUPS, "frac_hw": lookups / LDS_HW_LOOKUPS,
+                                 "microbench_peak": LDS_STREAM_LOOKUPS, "frac_microbench": lookups / LDS_STREAM_LOOKUPS,
+                                 "lds_conflict_frac": pmc["lds_conflict_frac"], "lds_busy": pmc["lds_busy"], "valu_busy": pmc["valu_busy"],
+                                 "note": "microbench_peak: the kernel's own address mixture and instruction stream at 12 waves per CU "
+                                         "(scripts/microbench/bank_limits.hip, profiles/r05b); PMC fractions from profiles/traffic.json "
+                                         "when it was taken on these sources, else null"},
+                     "configs": []},
         "secondary": {"proposal_evals_per_s": evals / (kernel_ms * 1e-3), "n_cu": n_cu, "clock_ghz": clk_ghz,
                       "lookups_per_clk_per_cu": lookups,
                       # hardware rate of the instruction the look-ups use (conflict-free ds_read_b32)
@@ -616,6 +629,10 @@ def run_rank(args):
             # (round 5: calls of few such blocks are coded by gangs of teams -- chunk owners x sample stripes over the CUs)
             secondary_config(eng, device, "block_size = None, ONE latent per call (1 block of 8192 dims: a gang of 72 teams)", OMEGA, EPS1, BEAMS, 1, N_DIMS, 10, 1, big, block_size=None, max_K=128),
             secondary_config(eng, device, "block_size = None, one image's 24 latents per call (24 blocks: gangs of 8 teams)", OMEGA, EPS1, BEAMS, 24, N_DIMS, 5, 1, big, block_size=None, max_K=128)]
+        # the driver keeps `roofline`: the other BASELINE configurations and the mid-size calls, compactly (full entries: secondary.*)
+        result["roofline"]["configs"] = [{"name": c["name"], "kernel": c["kernel"], "ms_per_call": c["ms_per_call"],
+                                          "lookups_per_clk_per_cu": c["lookups_per_clk_per_cu"], "tensors_per_s": c["tensors_per_s"]}
+                                         for c in sec + result["secondary"]["midsize"]]
         result["secondary"]["skewed_K"] = skewed_K_leg(eng, device, 8192, 5, 16)
         result["secondary"]["margins"] = margins_leg(eng, device, params, lay, q, out, S, max_K)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

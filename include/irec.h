@@ -65,22 +65,13 @@ typedef struct {
 } irec_params;
 
 #define IREC_FLAG_FORCE_GENERIC 1 /* use the generic (any D, any B) kernel even where the fast kernels apply   */
-#define IREC_FLAG_FUSED_PHILOX 2  /* keep the Philox draw fused in the block kernel even when table_dims is set */
-#define IREC_FLAG_ONE_TABLE 4     /* with table_dims: always the one-table-copy encoder (one workgroup per block)      */
-#define IREC_FLAG_TEAM 8          /* with table_dims: always the teams-per-CU encoder over three table copies.         */
-                                  /* Neither flag: the team encoder for calls of >= 64 blocks, the one-table encoder   */
-                                  /* (cheaper per-call set-up) below; same outputs, bit for bit                        */
 #define IREC_FLAG_NO_SPLIT 16     /* no block is shared: neither the split encoder (several workgroups per block for calls of few     */
                                   /* blocks) nor shared rows between teams (calls of one to 1.5 blocks per CU, B > 10) nor gangs of   */
                                   /* teams (calls of at most 384 blocks of more than 1024 dims: several teams per block)              */
-#define IREC_FLAG_TEST_SPLIT_ORPHAN 32 /* test hook: the partner workgroups of the split encoder leave at once, so workgroup 0  */
-                                  /* of every block must take the give-up exit (100 ms) (out_K = -2) instead of hanging   */
 #define IREC_FLAG_TABLES_PRESENT 65536 /* stronger than REUSE_TABLES: the caller vouches that the PREVIOUS irec_beam_encode call on this  */
                                   /* workspace and stream was this call's twin (same seed, S, table_dims, table window, table kind --  */
                                   /* e.g. the next residual block of the same image) and that nothing has run on the workspace since:   */
                                   /* the table kernels are not even launched (two launches fewer per call of a latency-bound pass).     */
-#define IREC_FLAG_SPLIT_SAMPLES 128 /* split encoder: share a block's samples among its workgroups (the r02b form: every workgroup */
-                                  /* repeats the whole beam update) instead of its beams (default where <= 2 beams per workgroup)  */
 #define IREC_FLAG_REUSE_TABLES 64 /* the caller vouches for the workspace: its first 512 bytes were zero when it was allocated  */
                                   /* and nothing but irec_beam_encode has written to it since.  Every call stamps the key of  */
                                   /* each proposal table it builds (seed, S, D, table window, table kind, offset) into the    */
@@ -88,31 +79,11 @@ typedef struct {
                                   /* stamp -- checked on the device, so also inside a replayed HIP graph -- keeps the table   */
                                   /* instead of rebuilding it (the 24 residual blocks of an image share seed, S and dims:     */
                                   /* beam_search_coder.py:38-43, resnet_vae.py:822-824).  Same outputs, bit for bit.          */
-#define IREC_FLAG_SHARE_ALL 131072 /* team encoder, calls that leave team slots idle: share EVERY row of the call between teams instead of only */
-                                  /* the rows beyond one per CU (diagnostics, r04j: slower than the default at every size; same outputs)     */
-#define IREC_FLAG_LISTED_ORDER 262144 /* team encoder, calls of one to a few rows per CU: deal the rows to the CUs in the order listed.    */
-                                  /* Default: by cost -- the call's preparation kernel also computes K * dims of every row and a CU's first   */
-                                  /* team takes a cheap row, its other teams (and the teams that share a row) the costliest ones, so   */
-                                  /* that the longest rows do not meet on one CU.  Results do not depend on it (diagnostics, A/B).     */
 #define IREC_FLAG_MARGINS 524288   /* the call reports its top-B margins: irec_beam_encode_ex with out_margin (and only that entry point) takes it.  The    */
                                   /* flag is part of the params because it sizes the workspace (irec_encode_workspace_bytes) and picks the kernels     */
                                   /* (irec_encode_plan): a margin build of the team encoder where one exists, the generic kernel otherwise; no block   */
                                   /* is shared between workgroups or teams.  Indices, K and samples are the plain call's, bit for bit.                 */
-#define IREC_FLAG_NO_TEN 1048576   /* diagnostics (A/B, tests): plain calls of at most ten beams and S * 10 <= 256 stay on encode_team_kernel<10,..> instead */
-                                  /* of encode_ten_kernel (irec_ten.hip).  Results do not depend on it.                                  */
-#define IREC_FLAG_SPLIT_SHIFT 12  /* bits 12-15: workgroups per block of the split encoder / sample stripes per chunk of a gang, at most; */
-                                  /* 0 = chosen by the library (diagnostics) */
-#define IREC_FLAG_SPLIT_MASK (0xF << IREC_FLAG_SPLIT_SHIFT)
-/* Diagnostic workgroup shapes of the team encoder for B <= 20 (bits 8-11 of flags; 0 = the default shape).  Same outputs. */
-#define IREC_FLAG_SHAPE_SHIFT 8
-#define IREC_FLAG_SHAPE_MASK (0xF << IREC_FLAG_SHAPE_SHIFT)
-#define IREC_FLAG_SHAPE_1 (1 << IREC_FLAG_SHAPE_SHIFT)   /* one 4-wave team per CU                                    */
-#define IREC_FLAG_SHAPE_2 (2 << IREC_FLAG_SHAPE_SHIFT)   /* exactly two teams (also where three are the default)      */
-#define IREC_FLAG_SHAPE_3 (3 << IREC_FLAG_SHAPE_SHIFT)   /* three 4-wave teams (168 VGPRs)                            */
-#define IREC_FLAG_SHAPE_2X2 (4 << IREC_FLAG_SHAPE_SHIFT) /* two 8-wave beam-striped teams (128 VGPRs)                 */
-#define IREC_FLAG_SHAPE_1X2 (5 << IREC_FLAG_SHAPE_SHIFT) /* one 8-wave beam-striped team (the default of 64..n_CU blocks) */
-#define IREC_FLAG_SHAPE_TEAM (6 << IREC_FLAG_SHAPE_SHIFT) /* the team encoder's default shape also for one-beam calls (which the one-wave-per-block encoder takes otherwise) */
-
+/* (diagnostic flag bits -- pinned kernel shapes, A/B switches, test hooks -- and the unit-test entry points: csrc/irec_internal.h) */
 #define IREC_TABLE_STEPS_DEFAULT 32
 #define IREC_TABLE_STEPS_MAX 4096
 #define IREC_TABLE_BYTES_MAX (64u << 20)
@@ -184,13 +155,6 @@ irec_status irec_importance_decode(const float *p_loc, const float *p_scale, int
                                    float *out_sample);
 /* n_samples of the call above (float32 arithmetic as in importance_sampling.py:50), or -1 if it does not fit int32. */
 int64_t irec_importance_n_samples(double coding_bits);
-/* out[e] = element e of tf.random.normal([count]) after tf.random.set_seed(seed) -- the stream behind
- * tfd.Normal.sample.  Host memory; test hook. */
-irec_status irec_tf_random_normal(int64_t seed, int64_t count, float *out);
-/* out[e] = element e of tf.random.stateless_normal([count], seed=[seed0, seed1]) -- the draw inside
- * stateless_gumbel_sample (rec/coding/utils.py:9-12).  Host memory; test hook. */
-irec_status irec_tf_stateless_normal(int64_t seed0, int64_t seed1, int64_t count, float *out);
-
 /* out[e] = element e of tf.random.uniform([n], 1, 10007, seed=seed, dtype=int32) after tf.random.set_seed(seed)
  * -- beam_search_coder.py:38-43.  Host memory; test hook for the in-kernel Philox stream. */
 irec_status irec_philox_uniform_int(int64_t seed, int64_t n, int32_t *out);
@@ -234,6 +198,13 @@ void irec_destroy(irec_context *ctx);
 /* Bytes of device scratch irec_beam_encode needs for blocks of at most max_dim dims and max_K partitions. */
 size_t irec_encode_workspace_bytes(const irec_context *ctx, const irec_params *p, int32_t max_dim, int32_t max_K);
 
+/* The same for ONE call of n_blocks blocks (round 6).  Differs from the bound above only for blocks of more than 1024 dims (block_size = None,
+ * 2048, ...): their scratch slab is (6 + 2 B) x dims x 4 bytes per team -- 55 MB at 301 056 dims -- and the bound above reserves one per team slot
+ * of the device (at most IREC_SLAB_BYTES_MAX = 16 GB, plus up to IREC_TABLE_BYTES_BIG = 4 GB of proposal tables and 1 GB of gang exchange),
+ * whereas a call uses one per team it launches: n_blocks x (teams per gang).  irec_beam_encode takes either size, or any size in between (it launches
+ * no more teams than the workspace has slabs; same results). */
+size_t irec_encode_workspace_bytes_for(const irec_context *ctx, const irec_params *p, int64_t n_blocks, int32_t max_dim, int32_t max_K);
+
 /* The kernels, grid and scratch irec_beam_encode(ctx, p, n_blocks, ..., max_block_dim, ..., max_K, ...) launches.
  * Host only, no device work; bench.py reports the kernel it measured from this instead of a string literal. */
 irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int64_t n_blocks, int32_t max_block_dim,
@@ -258,7 +229,7 @@ irec_status irec_block_kl(irec_context *ctx, const irec_params *p, int64_t n_blo
  *                                   cooperating calls in flight): call again, or with IREC_FLAG_NO_SPLIT.
  *   out_indices [n_blocks, max_K]   idx[t], t < K: the sample index chosen at iteration t (rest untouched)
  *   out_sample  flat, same indexing as the inputs: beams[0] + p.loc, merged
- *   workspace   device scratch of at least irec_encode_workspace_bytes() bytes, 256-byte aligned
+ *   workspace   device scratch of at least irec_encode_workspace_bytes() -- or irec_encode_workspace_bytes_for(n_blocks) -- bytes, 256-byte aligned
  * All pointers except p are device pointers. */
 irec_status irec_beam_encode(irec_context *ctx, const irec_params *p, int64_t n_blocks, const int64_t *block_base,
                              const int32_t *block_pos, const int32_t *block_dim, int32_t max_block_dim,
@@ -367,56 +338,6 @@ int64_t irec_rec_encode_files(uint32_t seed, uint32_t block_size, uint32_t max_i
 irec_status irec_rec_decode_files(const uint8_t *bytes, const int64_t *offsets, int32_t n_images, int32_t n_res_blocks,
                                   int32_t blocks_per_res, int32_t max_K, uint32_t *headers, int32_t *K, int32_t *idx,
                                   int32_t n_threads);
-
-/* ---- hand-offs of the RVAE model shim (device pointers, asynchronous; rec/models/resnet_vae.py:372-497) -------------------------
- * What lies between the convolutions of BidirectionalResidualBlock.call on the compression path, one launch each instead of
- * ~10 elementwise PyTorch launches per residual block and pass.  Activations NCHW float32 contiguous; statistics / latent NHWC.
- * irec_shim_stats: out [n_stats][n][hw][stochastic] = prior loc, exp(prior log-scale) (:409-413) and, for n_stats = 4, posterior
- *   loc = generative + inference side, exp(posterior log-scale) (:148-154, :464-469) from y [n][channels_y][hw] (channels
- *   0 .. n_stats * stochastic) and the inference pass's heads infer_heads [n][channels_infer][hw] (channels 0 .. 2 * stochastic).
- * irec_shim_cat_elu: out [n][deterministic + stochastic][hw] = elu(concat(y[:, channel_offset : + deterministic], latent NHWC))
- *   (:479-488); stochastic = 0: the ELU of a channel slice (:398-400).
- * irec_shim_residual_elu: out = input + alpha * tensor (:492-496), out_elu = elu(out) (the next block's first op, :385);
- *   tensors [n][channels][hw].
- * bias_* (device, per channel; may be NULL): the bias of the convolution that produced the operand, added first -- the
- *   convolution is then called without one, which saves its separate bias-add launch. */
-irec_status irec_shim_stats(irec_context *ctx, const float *y, const float *infer_heads, float *out, int32_t n_stats, int32_t n,
-                            int32_t channels_y, int32_t channels_infer, int32_t stochastic, int32_t hw, const float *bias_y,
-                            const float *bias_infer, void *hip_stream);
-irec_status irec_shim_cat_elu(irec_context *ctx, const float *y, const float *latent, float *out, int32_t n, int32_t channels_y,
-                              int32_t channel_offset, int32_t deterministic, int32_t stochastic, int32_t hw, const float *bias_y,
-                              void *hip_stream);
-irec_status irec_shim_residual_elu(irec_context *ctx, const float *input, const float *tensor, float alpha, float *out, float *out_elu,
-                                   int32_t n, int32_t channels, int32_t hw, const float *bias_tensor, void *hip_stream);
-
-/* ---- test hooks (device pointers) ---------------------------------------------------------------------------- */
-/* r[s*D + d] of get_pseudo_random_sample's int32 draw, generated by the in-kernel Philox stream.  out: int32 [n]. */
-irec_status irec_device_uniform_int(irec_context *ctx, int64_t seed, int64_t n, int32_t *out, void *hip_stream);
-/* The decoder's short correctly-rounded square root against sqrtf on every float32 bit pattern it is allowed to see (all
- * but the non-zero values below 2^-96, which take sqrtf itself): out2[0] = mismatches, out2[1] = patterns compared.
- * out2: device uint64 [2]. */
-irec_status irec_test_decoder_sqrt(irec_context *ctx, uint64_t *out2, void *hip_stream);
-/* in: float [64 lanes][width]; out: float [128].  width in {64, 32}: out[lane] = sum over lanes of
- * in[.][lane*width/64] in the canonical 64-lane reduction tree of the score kernels.  width in {20, 10}
- * (the arbitrary-width reduce-scatter of the team encoder): out[lane] = such a total of column out[64 + lane] (a column
- * index as a float, or -1 if the lane ends up with an unused slot); every column is owned by two lanes. */
-irec_status irec_test_reduce_scatter(irec_context *ctx, const float *in, float *out, int32_t width, void *hip_stream);
-/* tf.argsort(scores, DESCENDING)[:n_select] split into (index // n_beams_cur, index % n_beams_cur) -- the top-B step of
- * beam_search_coder.py:85-89 in isolation.  scores: float [n]; scratch_keys: uint32 [n]; out_sel: int32 [n_select][2]. */
-irec_status irec_test_select(irec_context *ctx, const float *scores, int32_t n, int32_t n_select, int32_t n_beams_cur,
-                             uint32_t *scratch_keys, int32_t *out_sel, void *hip_stream);
-/* The same step in the form the one-table / split encoders and the two-team builds of the team encoder run since round 4 (threshold by
- * probing the lane counts, ranks by the key alone with a collision check for ties): same outputs. */
-irec_status irec_test_select_quick(irec_context *ctx, const float *scores, int32_t n, int32_t n_select, int32_t n_beams_cur,
-                                   uint32_t *scratch_keys, int32_t *out_sel, void *hip_stream);
-/* The per-call proposal table of the default encoder for blocks of `dim` dims: out_tab uint16 [n_steps][n_samples][dim
- * rounded up to 4] = dlog_g(r) + 10006 * c, r the int32 draw of beam_search_coder.py:38-43 at seed + t, c the copy bit
- * that spreads each 32-lane look-up group over the LDS banks. */
-irec_status irec_test_proposal_table(irec_context *ctx, int64_t seed, int32_t n_samples, int32_t dim, int32_t n_steps,
-                                     uint16_t *out_tab, void *hip_stream);
-/* device addresses of the context's constant tables (lut [10007], lut2 [10006], dlog4r [10006] u16, rho [65536]). */
-irec_status irec_device_tables(irec_context *ctx, const float **lut, const float **lut2, const uint16_t **dlog4r,
-                               const float **rho);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@
 #include <string>
 #include <vector>
 
-#include "irec.h"
+#include "irec_internal.h"   // include/irec.h (the boundary) + the diagnostic flags and test hooks this library also exports
 #include "irec_kernels.h"
 
 namespace {
@@ -853,6 +853,24 @@ size_t irec_encode_workspace_bytes(const irec_context *ctx, const irec_params *p
   return plan_ws_bytes(pl);
 }
 
+// Scratch of ONE call (round 6; review r05: irec_encode_workspace_bytes sizes a call of blocks beyond 1024 dims for the whole device -- a slab
+// per team slot, up to IREC_SLAB_BYTES_MAX = 16 GB at 55 MB per slab of 301 056 dims -- whatever the call's block count).  The chunked
+// encoder indexes the slabs of the workgroups it launches: their count is what this call needs.  Every other plan: irec_encode_workspace_bytes.
+size_t irec_encode_workspace_bytes_for(const irec_context *ctx, const irec_params *p, int64_t n_blocks, int32_t max_dim, int32_t max_K) {
+  if (!ctx || check_params(p) != IREC_OK || max_dim < 1 || max_K < 0 || n_blocks < 0) return 0;
+  irec_params pm = *p;
+  if (pm.flags & IREC_FLAG_MARGINS) pm.flags |= IREC_FLAG_NO_SPLIT;
+  Plan pl = make_plan(ctx, &pm, max_dim, max_K);
+  if (pl.chunk && !(pm.flags & IREC_FLAG_MARGINS) && n_blocks > 0) {
+    const int teams = std::max(1, irec::chunk_teams(pm.n_beams, pm.n_samples));
+    int grid = chunk_grid(ctx, pl, &pm, n_blocks), ggrid = 0;
+    int gteams = teams;
+    if (gang_width(ctx, pl, &pm, n_blocks, max_dim, &ggrid, nullptr) >= 2) { grid = ggrid; gteams = std::max(1, irec::chunk_gang_teams(pm.n_beams, pm.n_samples)); }
+    pl.grid_cap = std::min(pl.grid_cap, std::max(teams, grid * std::max(teams, gteams)));
+  }
+  return plan_ws_bytes(pl);
+}
+
 irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int64_t n_blocks, int32_t max_block_dim,
                              int32_t max_K, irec_plan_info *out) {
   if (!ctx || !out) return fail(IREC_E_INVALID, "irec_encode_plan: null argument");
@@ -1016,7 +1034,15 @@ irec_status irec_beam_encode_ex(irec_context *ctx, const irec_params *p, int64_t
   if (max_K > 0 && !out_indices) return fail(IREC_E_INVALID, "irec_beam_encode: null out_indices");
   if (max_block_dim < 1 || max_block_dim > (1 << 22)) return fail(IREC_E_INVALID, "irec_beam_encode: max_block_dim %d out of range", max_block_dim);
   Plan pl = make_plan(ctx, p, max_block_dim, max_K);
-  const size_t need = plan_ws_bytes(pl);
+  size_t need = plan_ws_bytes(pl);
+  if (workspace && workspace_bytes < need && pl.chunk && !out_margin) {
+    // blocks beyond 1024 dims: a workspace sized for THIS call (irec_encode_workspace_bytes_for) -- or any size in between -- holds fewer
+    // slabs than the device has team slots; the call then launches no more teams than it has slabs (smaller gangs, same results)
+    const int teams = std::max(std::max(1, irec::chunk_teams(p->n_beams, p->n_samples)), std::max(1, irec::chunk_gang_teams(p->n_beams, p->n_samples)));
+    const size_t fixed = irec::WS_HEAD_BYTES + pl.tab_bytes + pl.gang_bytes;
+    const size_t fit = workspace_bytes > fixed ? (workspace_bytes - fixed) / pl.ws_per_wg : 0;
+    if (fit >= (size_t)teams) { pl.grid_cap = (int)std::min<size_t>((size_t)pl.grid_cap, fit / teams * teams); need = plan_ws_bytes(pl); }
+  }
   if (!workspace || workspace_bytes < need)
     return fail(IREC_E_WORKSPACE, "irec_beam_encode: workspace %zu bytes < required %zu", workspace_bytes, need);
   // top-B margins: a margin build of the team encoder where one serves the call's shape (whatever the call's size), else the generic

@@ -218,6 +218,7 @@ class BeamSearchCoder(GaussianCoder):
 
     # ---- recovery from a give-up (round 5; until then one give-up set no_split for the life of the coder) -----------
     SPLIT_PAUSE_MAX = 64
+    SPLIT_STRIKES_FINAL = 8    # consecutive give-ups after which the coder never shares a block again (no_split = True)
 
     def _split_gave_up(self):
         """A cooperative call of this coder read back K = -2 (partners not resident within 100 ms).  Bounded back-off: the
@@ -227,6 +228,10 @@ class BeamSearchCoder(GaussianCoder):
         a recode, not every later small call a factor of two."""
         self._split_strikes = min(self._split_strikes + 1, 1 + self.SPLIT_PAUSE_MAX.bit_length())
         self._split_pause = min(1 << (self._split_strikes - 1), self.SPLIT_PAUSE_MAX)
+        if self._split_strikes >= self.SPLIT_STRIKES_FINAL:
+            # a PERMANENT co-tenant (another stream's gangs hold the CUs for good): every retry costs its 100 ms, a recode and -- under
+            # HIP-graph replay -- a re-capture; after this many give-ups in a row (127 calls of back-off in between) the coder stops sharing
+            self.no_split = True
 
     def _take_sharing_turn(self):
         """May the call about to be issued share blocks?  Consumes one call of a running pause."""
@@ -268,13 +273,19 @@ class BeamSearchCoder(GaussianCoder):
         if self.extrapolate_auxiliary_ratios:
             return get_engine(t.device if t.device.type == "cuda" else None)
         # fitted ratios (extrapolate_auxiliary_ratios=False, coder.py:203-231): a context of this coder's own carries them
-        if getattr(self, "_ratio_engine", None) is None:
-            self.get_auxiliary_ratio(0)
-            dev = t.device if t.device.type == "cuda" else (self.engine.device if self.engine is not None else
-                                                            torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None)
-            if dev is None:
-                raise _lib.IrecLibraryError("irec needs a HIP device (MI355X / gfx950); there is no CPU fallback")
-            self._ratio_engine = Engine(dev, lut=getattr(self.engine, "lut", None), aux_ratios=self.aux_variable_variance_ratios)
+        # The context is keyed on what it was built from -- the device and the ratio table's bytes: assigning
+        # aux_variable_variance_ratios directly (the analogue of the reference restoring its tf.Variables from a checkpoint) or
+        # coding a tensor that lives on another GPU builds a new one instead of coding on a stale table.
+        self.get_auxiliary_ratio(0)
+        dev = t.device if t.device.type == "cuda" else (self.engine.device if self.engine is not None else
+                                                        torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None)
+        if dev is None:
+            raise _lib.IrecLibraryError("irec needs a HIP device (MI355X / gfx950); there is no CPU fallback")
+        ratios = np.ascontiguousarray(np.asarray(self.aux_variable_variance_ratios, dtype=np.float32))
+        key = (str(torch.device(dev)), ratios.tobytes())
+        if getattr(self, "_ratio_engine", None) is None or getattr(self, "_ratio_engine_key", None) != key:
+            self._ratio_engine = Engine(dev, lut=getattr(self.engine, "lut", None), aux_ratios=ratios)
+            self._ratio_engine_key = key
         return self._ratio_engine
 
     def encode_tensors_device(self, q_loc, q_scale, p_loc, p_scale, seed, block_size, max_K=None, table_steps=None):
@@ -326,6 +337,10 @@ class BeamSearchCoder(GaussianCoder):
         if len(indices) != n_tensors or any(len(b) != bpt for b in indices):
             raise CodingError("indices do not match the block structure of coding_dist")
         max_K = max(1, max((len(ix) for b in indices for ix in b), default=1))
+        if not self.extrapolate_auxiliary_ratios:
+            # decode_block asks get_auxiliary_ratio(i) for i = len(indices) - 1 .. 0 (beam_search_coder.py:129-131): an index list longer
+            # than the fitted table raises the reference's error here -- the kernels would only mark such a row "not decodable" (p.loc)
+            self.get_auxiliary_ratio(max_K - 1)
         K = np.zeros(lay.n_blocks, dtype=np.int32)
         idx = np.zeros((lay.n_blocks, max_K), dtype=np.int32)
         for i in range(n_tensors):

@@ -180,10 +180,15 @@ class Engine:
             self._layouts[key] = lay
         return lay
 
-    def workspace(self, params, max_dim, max_K):
+    def workspace(self, params, max_dim, max_K, n_blocks=None):
         """Scratch of the CURRENT torch stream (the C ABI is re-entrant; the scratch is what two concurrent calls must
-        not share: block counter, proposal tables, beam slabs)."""
-        need = self.lib.irec_encode_workspace_bytes(self.ctx, ctypes.byref(params), int(max_dim), int(max_K))
+        not share: block counter, proposal tables, beam slabs).  Calls of blocks beyond 1024 dims are sized for their own
+        block count (irec_encode_workspace_bytes_for: one slab per team the call launches, not per team slot of the device --
+        16 GB at 301 056 dims); the buffer of a stream only grows."""
+        if n_blocks is not None and max_dim > 1024:
+            need = self.lib.irec_encode_workspace_bytes_for(self.ctx, ctypes.byref(params), int(n_blocks), int(max_dim), int(max_K))
+        else:
+            need = self.lib.irec_encode_workspace_bytes(self.ctx, ctypes.byref(params), int(max_dim), int(max_K))
         if need == 0:
             raise _lib.IrecLibraryError("irec_encode_workspace_bytes rejected the parameters: " +
                                         self.lib.irec_last_error().decode())
@@ -310,7 +315,7 @@ class Engine:
             sample = torch.empty_like(q_loc)
         else:
             out_K, out_idx, sample = out
-        ws, need = self.workspace(params, lay.max_dim, max_K)
+        ws, need = self.workspace(params, lay.max_dim, max_K, lay.n_blocks)
         session = getattr(self._tls, "session", None)
         if session is not None:
             # EVERY call inside a session moves the key on: one that does not carry REUSE_TABLES (another coder's settings, a

@@ -4,7 +4,7 @@
 #
 #   usage: scripts/gpu_ab.sh NAME [-DIREC_...=v ...]     one variant: built from DEFS if csrc/variants/NAME.so is missing
 #          VARIANTS="a b c" scripts/gpu_ab.sh            several prebuilt variants (make -C .../csrc variant NAME=a DEFS=...)
-#   env:   KIND=team|k|lone|dec   which translation unit the DEFS go to (Makefile targets variant, variant_k, variant_lone, variant_dec)
+#   env:   KIND=team|k|lone|dec|gang|ten   which translation unit the DEFS go to (Makefile targets variant, variant_k, variant_lone, variant_dec, variant_gang, variant_ten)
 #          LATENTS BEAMS OMEGA EPS1 MAXK SHAPE IREC_VARIANT ...   passed on to run_variant.py;  REPS (default 4), ROUNDS (default 2)
 #          STAMPS=1               run NAME = stamps (make stamps) once with IREC_STAMPS=1 instead of an A/B: phase shares
 #          TESTS="-k expr"        first run the GPU parity tests selected by expr against every variant (bit-exactness of an A/B build)
@@ -17,7 +17,7 @@ R=$PWD; C=$R/relative-entropy-coding_amd/csrc
 V=${VARIANTS:-${1:?variant name}}
 [ $# -ge 1 ] && shift
 if [ -z "${VARIANTS:-}" ] && [ ! -f $C/variants/$V.so ]; then
-  case ${KIND:-team} in team) T=variant;; k) T=variant_k;; lone) T=variant_lone;; dec) T=variant_dec;; esac
+  case ${KIND:-team} in team) T=variant;; k) T=variant_k;; lone) T=variant_lone;; dec) T=variant_dec;; gang) T=variant_gang;; ten) T=variant_ten;; *) echo "unknown KIND=$KIND"; exit 1;; esac
   if [ "$V" = stamps ]; then make -s -C $C stamps; else make -s -C $C $T NAME=$V DEFS="$*"; fi || exit 1
 fi
 run() { timeout -k 10 300 python scripts/with_lib.py $1 scripts/run_variant.py 2>&1 | grep -v amdgpu.ids | tail -${TAIL:-2}; }

@@ -28,5 +28,16 @@ out = {"source": f"{d}: pmc FETCH_SIZE / WRITE_SIZE summaries (rocprofv3 --pmc, 
        "WRITE_SIZE_KiB": write,
        "correction": "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024  (MI355X_MICROARCH.md: KiB units; FETCH_SIZE reads half of 16 B/lane streams on gfx950)",
        "hbm_bytes_per_launch": total, "hbm_bytes_per_latent": total / latents}
+# the binding pipes (same run's SQ pass, when it is there): share of LDS-active cycles that are bank conflicts; LDS array and VALU busy
+# (SQ_LDS_IDX_ACTIVE is per CU, SQ_ACTIVE_INST_VALU in quad-cycles per SIMD; GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+if "SQ_LDS_BANK_CONFLICT" in vals and vals.get("SQ_LDS_IDX_ACTIVE"):
+    out["lds_conflict_frac"] = vals["SQ_LDS_BANK_CONFLICT"] / vals["SQ_LDS_IDX_ACTIVE"]
+if "GRBM_GUI_ACTIVE" in vals and vals["GRBM_GUI_ACTIVE"] > 0:
+    cyc = vals["GRBM_GUI_ACTIVE"] / 8.0
+    n_cu = int(os.environ.get("N_CU", "256"))
+    if "SQ_LDS_IDX_ACTIVE" in vals:
+        out["lds_busy"] = vals["SQ_LDS_IDX_ACTIVE"] / (n_cu * cyc)
+    if "SQ_ACTIVE_INST_VALU" in vals:
+        out["valu_busy"] = 4.0 * vals["SQ_ACTIVE_INST_VALU"] / (4 * n_cu * cyc)
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

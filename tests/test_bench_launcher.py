@@ -94,6 +94,15 @@ def test_single_rank_line_is_self_describing():
     assert res["n_gpus"] == 1 and res["roofline"]["kernel"] == "encode_team_kernel<20,3,1>"
     assert res["roofline"]["bound"] == "hbm" and 0 < res["roofline"]["frac"] < 1
     assert res["secondary"]["lds_hw"]["peak"] == 32.0 and res["secondary"]["n_cu"] == 256
+    # round 6: the object the driver keeps says what binds the kernel, and carries the other configurations compactly
+    b = res["roofline"]["binding"]
+    assert b["pipe"] == "lds_gather" and b["hw_peak"] == 32.0 and b["microbench_peak"] == 13.68
+    assert {"achieved", "frac_hw", "frac_microbench", "lds_conflict_frac", "lds_busy", "valu_busy"} <= set(b)
+    assert abs(b["frac_hw"] - b["achieved"] / 32.0) < 1e-12 and 0 < b["frac_microbench"] < 1.2
+    cfg = res["roofline"]["configs"]
+    assert len(cfg) == 8 and all({"name", "kernel", "ms_per_call", "lookups_per_clk_per_cu"} <= set(c) for c in cfg)
+    assert any("configs[3] settings" in c["name"] and c["kernel"].startswith("encode_ten_kernel") for c in cfg)
+    assert sum("configs[4]" in c["name"] for c in cfg) == 2 and any("342 blocks" in c["name"] for c in cfg)
 
 
 @pytest.mark.gpu

@@ -1719,10 +1719,44 @@ def test_recovery_from_a_give_up(engine, oracle):
     assert time.perf_counter() - t0 < 0.08                                         # (no 100 ms wait in it)
     assert [int(v) for v in idx] == ridx and np.array_equal(sample.cpu().numpy()[0], rs)
     assert (c._split_strikes, c._split_pause) == (0, 0) and plan_split() >= 2
-    # the bound: the pause never exceeds SPLIT_PAUSE_MAX calls, and the caller's own knob is never touched
-    for _ in range(12):
+    # the bound: the pause never exceeds SPLIT_PAUSE_MAX calls; a PERMANENT co-tenant (round 5's advice: a 100 ms stall, a recode and a graph
+    # re-capture every 65th call for ever) ends the sharing for good after SPLIT_STRIKES_FINAL give-ups in a row
+    for _ in range(c.SPLIT_STRIKES_FINAL - 1):
         c._split_gave_up()
     assert c._split_pause == c.SPLIT_PAUSE_MAX == 64 and not c.no_split
+    c._split_gave_up()
+    assert c.no_split and plan_split() == 0
+
+
+def test_workspace_sized_for_the_call(engine, oracle):
+    """Round 5's advice: irec_encode_workspace_bytes sizes a call of blocks beyond 1024 dims for every team slot of the device.
+    irec_encode_workspace_bytes_for(n_blocks) sizes it for the teams the call launches; irec_beam_encode takes that, the device-wide
+    bound, and anything in between -- same K, indices and sample, the oracle's."""
+    import ctypes
+    from irec import _lib
+    stats = oracle.synthetic_latent(8800, 8192)
+    ql, qs, pl, ps = (torch.from_numpy(a[None]).cuda().contiguous() for a in stats)
+    lay = engine.layout(1, 8192, None, 42)
+    params = engine.with_table_dims(engine.params(3.0, 36, 20), lay)
+    full = engine.lib.irec_encode_workspace_bytes(engine.ctx, ctypes.byref(params), lay.max_dim, 64)
+    mine = engine.lib.irec_encode_workspace_bytes_for(engine.ctx, ctypes.byref(params), lay.n_blocks, lay.max_dim, 64)
+    assert 0 < mine < full
+    ridx, rs = oracle.encode_tensor(*stats, 42, 3.0, 36, 20, block_size=None)
+    out = []
+    for size in (mine, (mine + full) // 2 // 256 * 256, full):
+        ws = torch.zeros(size, dtype=torch.uint8, device="cuda")
+        K = torch.empty(1, dtype=torch.int32, device="cuda"); idx = torch.empty((1, 64), dtype=torch.int32, device="cuda"); sample = torch.empty_like(ql)
+        _lib.check(engine.lib.irec_beam_encode(engine.ctx, ctypes.byref(params), 1, lay.block_base.data_ptr(), lay.block_pos.data_ptr(), lay.block_dim.data_ptr(),
+                                               lay.max_dim, None, ql.data_ptr(), qs.data_ptr(), pl.data_ptr(), ps.data_ptr(), 42, 64, K.data_ptr(),
+                                               idx.data_ptr(), sample.data_ptr(), ws.data_ptr(), ws.numel(), engine._stream()), "irec_beam_encode")
+        torch.cuda.synchronize()
+        k = int(K[0])
+        assert idx[0, :k].tolist() == ridx[0] and np.array_equal(sample.cpu().numpy()[0], rs), size
+        out.append(k)
+    too_small = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")       # (not even the workspace head)
+    assert engine.lib.irec_beam_encode(engine.ctx, ctypes.byref(params), 1, lay.block_base.data_ptr(), lay.block_pos.data_ptr(), lay.block_dim.data_ptr(),
+                                       lay.max_dim, None, ql.data_ptr(), qs.data_ptr(), pl.data_ptr(), ps.data_ptr(), 42, 64, K.data_ptr(),
+                                       idx.data_ptr(), sample.data_ptr(), too_small.data_ptr(), too_small.numel(), engine._stream()) == -4   # IREC_E_WORKSPACE
 
 
 def test_infinite_kl_block_does_not_poison_the_partition_hint(engine, oracle):
@@ -1921,6 +1955,23 @@ def test_fitted_auxiliary_ratios_as_data(engine, oracle):
         oracle.set_aux_ratios(None)
     assert torch.equal(c.decode(p, idx, seed=42), sample)
     assert c._engine_for(q.loc).max_partitions == 12
+    # decoding an index list longer than the fitted table: the reference's error (beam_search_coder.py:129-131 asks for ratio len - 1), not a
+    # silent p.loc (round 5's advice)
+    too_long = [list(b) for b in idx]
+    too_long[0] = list(too_long[0]) + [0] * (13 - len(too_long[0]))
+    with pytest.raises(CodingError, match="Maximum possible number of partitions is 12"):
+        c.decode(p, too_long, seed=42)
+    # the table as an attribute (a checkpoint restore): the device context follows it
+    ratios2 = ratios.copy(); ratios2[1:] *= 0.97
+    c.aux_variable_variance_ratios = ratios2
+    idx2, sample2 = c.encode(q, p, seed=42)
+    oracle.set_aux_ratios(ratios2)
+    try:
+        ridx2, rs2 = oracle.encode_tensor(*stats, 42, 3.0, 36, 20, block_size=1000)
+    finally:
+        oracle.set_aux_ratios(None)
+    assert idx2 == ridx2 and np.array_equal(sample2.cpu().numpy()[0], rs2)
+    c.aux_variable_variance_ratios = ratios
     # a block whose KL asks for more partitions than the table has: the reference's error, nothing coded
     sharp = oracle.synthetic_latent(5151, 8192)
     sq = (sharp[1] * 0.25).astype(np.float32)                                # KL ~ 1.4 nats per dim more: K far beyond 12
