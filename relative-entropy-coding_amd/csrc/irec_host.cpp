@@ -709,6 +709,14 @@ int gang_width(const irec_context *ctx, const Plan &pl, const irec_params *p, in
   return (int)G;
 }
 
+// Calls of fewer blocks than this take the one-table / split encoders (cheaper set-up: a 6 us plain table and 40 KB of LDS to fill, against
+// the bank assignment and 120 KB); from here on the team encoder.  A QUARTER OF THE CUs -- 64 on the 256-CU device the crossover was measured
+// on (r02b, r03m) -- within what the split encoder's arrival counters hold (COOP_SPLIT_MAX_BLOCKS) and not below 8.
+int small_call_blocks(const irec_context *ctx) {
+  const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+  return std::max(8, std::min(irec::COOP_SPLIT_MAX_BLOCKS, n_cu / 4));
+}
+
 // Split encoder for calls of so few blocks that most CUs would idle (one image's residual block: 9 blocks): W workgroups
 // per block, each scoring a stripe of the samples (irec_kernels.hip).  All n_blocks * W workgroups must be resident at once
 // (they wait for each other every step), so the grid stays within HALF the CUs -- room for a second such call on another
@@ -754,7 +762,7 @@ int split_beam_width(const irec_params *p, int W) {
 // such a call uses one): 72 blocks 0.159 -> 0.134, 252 blocks 0.183 -> 0.168 -- also with two partners.
 bool share_all_auto(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks) {
   if (!pl.team || pl.lone || pl.team_only || pl.chunk || !pl.table || (p->flags & (IREC_FLAG_NO_SPLIT | IREC_FLAG_SHARE_ALL))) return false;
-  if ((p->flags & IREC_FLAG_SHAPE_MASK) != 0 || n_blocks < 64 || n_blocks > irec::COOP_MAX_BLOCKS) return false;
+  if ((p->flags & IREC_FLAG_SHAPE_MASK) != 0 || n_blocks < small_call_blocks(ctx) || n_blocks > irec::COOP_MAX_BLOCKS) return false;
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
   const int B = p->n_beams, S = p->n_samples;
   if (B > 20 || irec::team_shareable(B, S, 2) != 2 || irec::team_lds_for(B, S, 2) == (size_t)-1 ||
@@ -773,7 +781,7 @@ int team_share_width(const irec_context *ctx, const Plan &pl, const irec_params 
   const int64_t slots = (int64_t)teams * n_cu;
   int64_t W = 0, f = 0;
   if ((p->flags & IREC_FLAG_SHARE_ALL) || (shape == 2 && share_all_auto(ctx, pl, p, n_blocks))) {
-    if (n_blocks < 64 || n_blocks > irec::COOP_MAX_BLOCKS || 2 * n_blocks > slots) return 0;
+    if (n_blocks < small_call_blocks(ctx) || n_blocks > irec::COOP_MAX_BLOCKS || 2 * n_blocks > slots) return 0;
     W = slots / n_blocks;
   } else {
     if (p->n_beams <= 10 || n_blocks <= n_cu || n_blocks >= slots || n_blocks - n_cu > irec::COOP_MAX_BLOCKS) return 0;
@@ -800,8 +808,8 @@ int call_teams(const irec_params *p, int shape, int share_W, bool margins) {
 // small calls (a single image's res-block: 9 blocks) are latency-bound: the one-table encoder's set-up (a 6 us proposal
 // table, 40 KB of LDS to fill) beats the team encoder's (38 us per table for the bank assignment, 120 KB); the scratch
 // sized for the team plan covers both
-bool team_for_call(const Plan &pl, const irec_params *p, int64_t n_blocks) {
-  return pl.team && (pl.team_only || (p->flags & IREC_FLAG_TEAM) || n_blocks >= 64);
+bool team_for_call(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks) {
+  return pl.team && (pl.team_only || (p->flags & IREC_FLAG_TEAM) || n_blocks >= small_call_blocks(ctx));
 }
 // Workgroup shape of the team encoder for THIS call.  With at most one block per CU a lone 4-wave team is latency-bound
 // (one wave per SIMD, ~43 us per step at B = 20, S = 36): the 8-wave beam-striped team (two stripes of 10 beams: half the
@@ -813,7 +821,7 @@ int shape_for_call(const irec_context *ctx, const Plan &pl, const irec_params *p
   if ((p->flags & IREC_FLAG_SHARE_ALL) && !(p->flags & IREC_FLAG_NO_SPLIT) && pl.shape == 0 &&
       team_share_width(ctx, pl, p, n_blocks, 0, nullptr, nullptr) >= 2) return pl.shape;   // (diagnostics) every row shared between teams: the three-team shape
   if (share_all_auto(ctx, pl, p, n_blocks)) return 2;                             // every row shared between the teams of the two-team build
-  if (pl.shape != 0 || !pl.team || pl.lone || n_blocks < 64 || n_blocks > 2 * (int64_t)n_cu || B > 20) return pl.shape;   // (< 64 blocks: only calls
+  if (pl.shape != 0 || !pl.team || pl.lone || n_blocks < small_call_blocks(ctx) || n_blocks > 2 * (int64_t)n_cu || B > 20) return pl.shape;   // (< 64 blocks: only calls
                                                                          // that pin IREC_FLAG_TEAM get here, tests of the default shape among them)
   if (irec::team_count_for(B, S, 0) < 2) return pl.shape;                       // already one striped team
   if (n_blocks <= n_cu && B <= 10) return pl.shape;                             // (no 8-wave build for 10 beams)
@@ -841,6 +849,74 @@ int margin_team_shape(const irec_context *ctx, const Plan &pl, const irec_params
   if (irec::team_margin_build(p->n_beams, p->n_samples, shape)) return shape;
   if (irec::team_margin_build(p->n_beams, p->n_samples, pl.shape)) return pl.shape;
   return -1;
+}
+
+// What ONE call launches, in numbers: the grid, the teams (= scratch slabs) per workgroup, the cooperative width and what the kernels'
+// own checks rest on.  irec_beam_encode_ex takes its launch from here; irec_test_plan (csrc/irec_internal.h) returns it for any CU count,
+// so that the planner's invariants are tested host-only at 32 ... 304 CUs (round 5's review: every threshold had been measured on one
+// 256-CU box).  `pl` is the call's plan with pl.team / pl.shape already settled for the call.
+struct CallDetail {
+  int kind = 0;             // 1 chunk, 2 lone, 3 team, 4 one-table / split (fast, table), 5 fused fast, 6 generic
+  int grid = 0;             // workgroups of the block kernel
+  int teams = 1;            // teams (scratch slabs) per workgroup
+  int W = 0;                // cooperative width: teams per shared row / workgroups per block / members per gang; 0 = nothing is shared
+  int coop_beams = 0;       // split encoder: beams, not samples, are shared
+  int gang_chunks = 0;      // chunk owners of a gang
+  int64_t share_first = 0;  // team encoder: first shared row
+  int64_t n_slots = 0;      // hand-out slots of the call (whole rows + W per shared row)
+  int placed = 0;           // team encoder: rows dealt by cost (EncArgs::row_cost)
+  int split_blocks = 0;     // blocks whose exchange granules the preparation kernel zeroes
+};
+CallDetail call_detail(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks, int32_t max_block_dim, bool margins) {
+  CallDetail d;
+  const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+  d.n_slots = n_blocks;
+  if (pl.table && !pl.team && split_width(ctx, pl, p, n_blocks) >= 2) d.split_blocks = (int)n_blocks;   // (pl.team: of THIS call)
+  int share_grid = 0;
+  const int share_W = (pl.table && pl.team) ? team_share_width(ctx, pl, p, n_blocks, pl.shape, &d.share_first, &share_grid) : 0;
+  if (share_W >= 2) d.split_blocks = (int)(n_blocks - d.share_first);
+  if (pl.chunk && gang_width(ctx, pl, p, n_blocks, max_block_dim, nullptr, nullptr) >= 2) d.split_blocks = (int)n_blocks;   // (their granules' first words: the gangs' arrival counters)
+  if (pl.table && pl.chunk) {
+    d.kind = 1;
+    d.teams = std::max(1, irec::chunk_teams(p->n_beams, p->n_samples));
+    d.grid = chunk_grid(ctx, pl, p, n_blocks);
+    int ggrid = 0, gchunks = 0;
+    if (const int G = gang_width(ctx, pl, p, n_blocks, max_block_dim, &ggrid, &gchunks)) {
+      d.W = G; d.gang_chunks = gchunks; d.grid = ggrid; d.n_slots = n_blocks * G;
+      d.teams = std::max(1, irec::chunk_gang_teams(p->n_beams, p->n_samples));
+    }
+  } else if (pl.table && pl.team && pl.lone) {
+    d.kind = 2; d.grid = batch_grid(n_blocks, n_cu); d.teams = irec::lone_waves();
+  } else if (pl.table && pl.team) {
+    d.kind = 3;
+    d.teams = call_teams(p, pl.shape, share_W, margins);
+    // one workgroup per CU as soon as there is a block for it: team k of workgroup w starts on block k * grid + w
+    d.grid = batch_grid(n_blocks, std::min(pl.grid_cap / d.teams, n_cu));
+    if (share_W >= 2) {   // rows [share_first, n_blocks) are coded by share_W teams each; the static round deals every slot
+      d.W = share_W; d.grid = share_grid; d.n_slots = d.share_first + (n_blocks - d.share_first) * share_W;
+    }
+    // Cost-ordered hand-out (calls of more rows than workgroups whose slots the static round deals completely -- one to TEAMS rows per
+    // CU): the preparation kernel also writes K * dims of every row, and the teams take their rows by cost rank (irec_team.hip).
+    // (measured, profiles/archive/r04w: pays on the two-team build with 20-beam steps: 342 blocks 0.467 -> 0.449 ms; not with 10-beam
+    //  steps of half the length, nor on the three-team build)
+    if (!pl.lone && !pl.chunk && !(p->flags & IREC_FLAG_LISTED_ORDER) && n_blocks <= irec::COST_MAX_ROWS) {
+      const int n_teams = irec::team_count_for(p->n_beams, p->n_samples, pl.shape);
+      const int64_t tg = share_W >= 2 ? share_grid : batch_grid(n_blocks, std::min(pl.grid_cap / n_teams, n_cu));
+      if (n_blocks > tg && d.n_slots <= tg * n_teams && n_teams == 2 && p->n_beams > 10 && irec::team_placeable(p->n_beams, p->n_samples, pl.shape)) d.placed = 1;
+    }
+  } else if (pl.table) {
+    d.kind = 4;
+    d.grid = (int)std::min<int64_t>(n_blocks, pl.one_grid_cap);
+    int W = split_width(ctx, pl, p, n_blocks);
+    if (const int wb = split_beam_width(p, W)) { W = wb; d.coop_beams = 1; }
+    if (W >= 2) { d.W = W; d.grid = (int)(n_blocks * W); d.n_slots = n_blocks * W; }
+  } else if (pl.fast) {
+    d.kind = 5; d.grid = (int)std::min<int64_t>(n_blocks, pl.one_grid_cap);
+  } else {
+    d.kind = 6;
+    d.grid = margins ? (int)std::min<int64_t>(n_blocks, std::min(pl.grid_cap, 2 * n_cu)) : (int)std::min<int64_t>(n_blocks, pl.grid_cap);
+  }
+  return d;
 }
 
 } // namespace
@@ -879,7 +955,7 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
   irec_params pm = *p;
   if (pm.flags & IREC_FLAG_MARGINS) { pm.flags |= IREC_FLAG_NO_SPLIT; p = &pm; }
   const Plan pl = make_plan(ctx, p, max_block_dim, max_K);
-  const bool team = team_for_call(pl, p, n_blocks);
+  const bool team = team_for_call(ctx, pl, p, n_blocks);
   std::memset(out, 0, sizeof(*out));
   const int B = p->n_beams, S = p->n_samples;
   if (p->flags & IREC_FLAG_MARGINS) {   // irec_beam_encode_ex: a margin build of the team encoder, or the generic kernel
@@ -983,6 +1059,33 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
   return IREC_OK;
 }
 
+// Test hook (csrc/irec_internal.h): the plan and the launch numbers of a call on a device of `n_cu` compute units -- no device is touched.
+irec_status irec_test_plan(int32_t n_cu, int32_t clock_mhz, const irec_params *p, int64_t n_blocks, int32_t max_block_dim, int32_t max_K,
+                           irec_plan_info *info, irec_plan_detail *detail) {
+  if (!info || !detail || n_cu < 1) return fail(IREC_E_INVALID, "irec_test_plan: bad argument");
+  irec_context fake;
+  fake.n_cu = n_cu; fake.clock_mhz = clock_mhz;
+  if (irec_status st = irec_encode_plan(&fake, p, n_blocks, max_block_dim, max_K, info)) return st;
+  const bool margins = (p->flags & IREC_FLAG_MARGINS) != 0;
+  irec_params pm = *p;
+  if (margins) pm.flags |= IREC_FLAG_NO_SPLIT;
+  Plan pl = make_plan(&fake, &pm, max_block_dim, max_K);   // ... and then exactly what irec_beam_encode_ex does with it
+  const int mshape = margins ? margin_team_shape(&fake, pl, &pm, n_blocks) : -1;
+  if (margins && mshape < 0) { pl.table = false; pl.team = false; pl.lone = false; pl.chunk = false; pl.fast = false; pl.team_only = false; pl.n_tab = 0; pl.K_tab = 0; }
+  pl.team = mshape >= 0 ? true : team_for_call(&fake, pl, &pm, n_blocks);
+  if (mshape >= 0) pl.shape = mshape;
+  else if (pl.team) pl.shape = shape_for_call(&fake, pl, &pm, n_blocks);
+  const CallDetail cd = call_detail(&fake, pl, &pm, n_blocks, max_block_dim, margins);
+  std::memset(detail, 0, sizeof(*detail));
+  detail->kind = cd.kind; detail->grid = cd.grid; detail->teams_per_wg = cd.teams; detail->coop_width = cd.W; detail->coop_beams = cd.coop_beams;
+  detail->gang_chunks = cd.gang_chunks; detail->placed = cd.placed; detail->split_blocks = cd.split_blocks;
+  detail->share_first = cd.share_first; detail->n_slots = cd.n_slots;
+  detail->slabs_in_workspace = pl.grid_cap; detail->slab_bytes = (int64_t)pl.ws_per_wg;
+  detail->fixed_bytes = (int64_t)(irec::WS_HEAD_BYTES + pl.tab_bytes + pl.gang_bytes);
+  detail->exchange_rows = irec::COOP_MAX_BLOCKS; detail->exchange_keys = irec::COOP_KEYS;
+  return IREC_OK;
+}
+
 irec_status irec_block_kl(irec_context *ctx, const irec_params *p, int64_t n_blocks, const int64_t *block_base,
                           const int32_t *block_pos, const int32_t *block_dim, const int32_t *perm, const float *q_loc,
                           const float *q_scale, const float *p_loc, const float *p_scale, float *out_kl, int32_t *out_K,
@@ -1049,7 +1152,7 @@ irec_status irec_beam_encode_ex(irec_context *ctx, const irec_params *p, int64_t
   // kernel, which draws in the kernel: no tables
   const int mshape = out_margin ? margin_team_shape(ctx, pl, p, n_blocks) : -1;
   if (out_margin && mshape < 0) { pl.table = false; pl.team = false; pl.lone = false; pl.chunk = false; pl.fast = false; pl.team_only = false; pl.n_tab = 0; pl.K_tab = 0; }
-  pl.team = mshape >= 0 ? true : team_for_call(pl, p, n_blocks);
+  pl.team = mshape >= 0 ? true : team_for_call(ctx, pl, p, n_blocks);
   if (((uintptr_t)workspace & 255) != 0) return fail(IREC_E_WORKSPACE, "irec_beam_encode: workspace must be 256-byte aligned");
   IREC_ON_DEVICE(ctx->device);
   hipStream_t st = (hipStream_t)hip_stream;
@@ -1091,25 +1194,10 @@ irec_status irec_beam_encode_ex(irec_context *ctx, const irec_params *p, int64_t
       w[7] = ~(w[1] ^ w[2] ^ w[3] ^ w[4] ^ w[5] ^ w[6]);
     }
   stamps.reuse = (p->flags & IREC_FLAG_REUSE_TABLES) ? 1 : 0;
-  int split_blocks = 0;   // a split call: the preparation kernel also zeroes the exchange granules of its blocks
-  if (pl.table && !pl.team && split_width(ctx, pl, p, n_blocks) >= 2) split_blocks = (int)n_blocks;   // (pl.team: of THIS call, above)
-  int64_t share_first = 0;
-  int share_grid = 0;
-  const int share_W = (pl.table && pl.team) ? team_share_width(ctx, pl, p, n_blocks, pl.shape, &share_first, &share_grid) : 0;
-  if (share_W >= 2) split_blocks = (int)(n_blocks - share_first);
-  if (pl.chunk && gang_width(ctx, pl, p, n_blocks, max_block_dim, nullptr, nullptr) >= 2) split_blocks = (int)n_blocks;   // (their granules' first words: the gangs' arrival counters)
-  // Cost-ordered hand-out (team encoder, calls of more rows than workgroups whose slots the static round deals completely --
-  // one to TEAMS rows per CU): the preparation kernel also writes K * dims of every row, and the teams take their rows by cost rank
-  // (irec_team.hip, "Cost-ordered hand-out").  IREC_FLAG_LISTED_ORDER: rows as listed (A/B runs).
-  if (pl.table && pl.team && !pl.lone && !pl.chunk && !(p->flags & IREC_FLAG_LISTED_ORDER) && n_blocks <= irec::COST_MAX_ROWS) {
-    const int n_teams = irec::team_count_for(p->n_beams, p->n_samples, pl.shape);
-    const int64_t tg = share_W >= 2 ? share_grid : batch_grid(n_blocks, std::min(pl.grid_cap / n_teams, ctx->n_cu > 0 ? ctx->n_cu : 256));
-    const int64_t slots = share_W >= 2 ? share_first + (n_blocks - share_first) * share_W : n_blocks;
-    // (measured, profiles/archive/r04w: the pre-pass -- a random gather of the call's statistics, +8 us on the preparation kernel -- and the ranking
-    //  pay for themselves on the two-team build with 20-beam steps: 342 blocks 0.467 -> 0.449 ms, 405 blocks 0.538 -> 0.507; not with
-    //  10-beam steps of half the length, nor on the three-team build)
-    if (n_blocks > tg && slots <= tg * n_teams && n_teams == 2 && p->n_beams > 10 && irec::team_placeable(p->n_beams, p->n_samples, pl.shape)) A.row_cost = (const uint32_t *)((char *)workspace + irec::WS_COUNTER_BYTES + irec::WS_XCH_BYTES);
-  }
+  // the call in numbers (grid, teams per workgroup, cooperative width, cost-ordered hand-out): call_detail, also behind irec_test_plan
+  const CallDetail cd = call_detail(ctx, pl, p, n_blocks, max_block_dim, out_margin != nullptr);
+  const int split_blocks = cd.split_blocks;   // a cooperative call: the preparation kernel also zeroes the exchange granules of its blocks
+  if (cd.placed) A.row_cost = (const uint32_t *)((char *)workspace + irec::WS_COUNTER_BYTES + irec::WS_XCH_BYTES);
   int grid = (int)std::min<int64_t>(n_blocks, pl.one_grid_cap);
   A.dbg = nullptr;
 #ifdef IREC_HOST_STAMPS
@@ -1152,16 +1240,16 @@ irec_status irec_beam_encode_ex(irec_context *ctx, const irec_params *p, int64_t
       return IREC_OK;
     };
     if (pl.chunk) {   // one workgroup per CU, a block of any dim count per team; steps beyond the table window are drawn in the kernel: no second pass
-      int cgrid = chunk_grid(ctx, pl, p, n_blocks), ggrid = 0, gchunks = 0;
-      if (const int G = gang_width(ctx, pl, p, n_blocks, max_block_dim, &ggrid, &gchunks)) {
-        A.coop_W = G; A.gang_chunks = gchunks; cgrid = ggrid;
+      const int cgrid = cd.grid;
+      if (cd.W >= 2) {
+        A.coop_W = cd.W; A.gang_chunks = cd.gang_chunks;
         A.gang_xch = (char *)workspace + irec::WS_HEAD_BYTES + pl.tab_bytes + (size_t)pl.grid_cap * pl.ws_per_wg;
         A.gang_stride = pl.gang_stride;
         A.coop_test_orphan = (p->flags & IREC_FLAG_TEST_SPLIT_ORPHAN) ? 1 : 0;
       }
       HIP_TRY(irec::launch_encode_chunk(A, cgrid, st));
     } else if (pl.team && pl.lone) { // one workgroup per CU, a block per wave
-      HIP_TRY(irec::launch_encode_lone(A, batch_grid(n_blocks, ctx->n_cu > 0 ? ctx->n_cu : 256), st));
+      HIP_TRY(irec::launch_encode_lone(A, cd.grid, st));
       if (irec_status s2 = deferred_pass()) return s2;
 #ifdef IREC_HOST_STAMPS
       if (ctx->d_dbg) {   // diagnostic build (-DIREC_LONE_STAMPS): per-wave phase cycles of the one-beam encoder
@@ -1179,11 +1267,10 @@ irec_status irec_beam_encode_ex(irec_context *ctx, const irec_params *p, int64_t
       }
 #endif
     } else if (pl.team) { // grid_cap counts teams (= scratch slabs): two per workgroup, one workgroup per CU
-      const int n_teams = call_teams(p, pl.shape, share_W, out_margin != nullptr);
-      // one workgroup per CU as soon as there is a block for it: team k of workgroup w starts on block k * grid + w
-      int tgrid = batch_grid(n_blocks, std::min(pl.grid_cap / n_teams, ctx->n_cu > 0 ? ctx->n_cu : 256));
-      if (share_W >= 2) {   // rows [share_first, n_blocks) are coded by share_W teams each; the static round deals every slot
-        A.coop_W = share_W; A.tsplit_first = share_first; tgrid = share_grid;
+      const int n_teams = cd.teams;
+      const int tgrid = cd.grid;
+      if (cd.W >= 2) {   // rows [share_first, n_blocks) are coded by W teams each; the static round deals every slot
+        A.coop_W = cd.W; A.tsplit_first = cd.share_first;
         A.coop_test_orphan = (p->flags & IREC_FLAG_TEST_SPLIT_ORPHAN) ? 1 : 0;
       }
       if (out_margin) HIP_TRY(irec::launch_encode_team_margin(A, tgrid, st));
@@ -1230,14 +1317,14 @@ irec_status irec_beam_encode_ex(irec_context *ctx, const irec_params *p, int64_t
       }
 #endif
     } else {
-      int W = split_width(ctx, pl, p, n_blocks);
-      if (const int wb = split_beam_width(p, W)) { W = wb; A.coop_beams = 1; }
+      const int W = cd.W;
+      A.coop_beams = cd.coop_beams;
       if (W >= 2) {
         A.coop_W = W;
         A.coop_test_orphan = (p->flags & IREC_FLAG_TEST_SPLIT_ORPHAN) ? 1 : 0;
-        HIP_TRY(irec::launch_encode_fast(A, true, (int)(n_blocks * W), st));
+        HIP_TRY(irec::launch_encode_fast(A, true, cd.grid, st));
 #ifdef IREC_HOST_STAMPS
-        if (ctx->d_dbg) grid = (int)(n_blocks * W);   // (diagnostics below: the stamps of every workgroup)
+        if (ctx->d_dbg) grid = cd.grid;   // (diagnostics below: the stamps of every workgroup)
 #endif
       } else HIP_TRY(irec::launch_encode_fast(A, true, grid, st));
       if (irec_status s2 = deferred_pass()) return s2;

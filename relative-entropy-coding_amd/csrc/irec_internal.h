@@ -46,6 +46,22 @@ extern "C" {
 
 
 /* ---- test hooks (host memory) -------------------------------------------------------------------------------------------- */
+/* The launch of irec_beam_encode(p, n_blocks, max_block_dim, max_K) on a device of n_cu compute units, in numbers -- the same code the
+ * launch runs (irec_host.cpp: call_detail), no device touched: the planner's invariants are tested host-only at other CU counts than the
+ * one box everything was measured on (MI355X partition modes expose 32 / 64 / 128 CUs).
+ *   kind 1 chunked, 2 one-beam, 3 team (encode_team_kernel / encode_ten_kernel), 4 one-table / split, 5 fused-Philox fast, 6 generic */
+typedef struct {
+  int32_t kind, grid, teams_per_wg;   /* workgroups; teams (= scratch slabs) per workgroup: slab index < grid * teams_per_wg           */
+  int32_t coop_width;                 /* teams per shared row / workgroups per block / members per gang; 0 = nothing is shared        */
+  int32_t coop_beams, gang_chunks;    /* split encoder shares beams (not samples); chunk owners of a gang                              */
+  int32_t placed;                     /* team encoder: rows dealt by cost -- the kernel requires the static round to deal EVERY slot  */
+  int32_t split_blocks;               /* blocks whose exchange granules the preparation kernel zeroes                                 */
+  int64_t share_first, n_slots;       /* first shared row; hand-out slots (whole rows + coop_width per shared row / block)             */
+  int64_t slabs_in_workspace, slab_bytes, fixed_bytes;   /* what irec_encode_workspace_bytes sizes: fixed + slabs * slab_bytes        */
+  int32_t exchange_rows, exchange_keys;                  /* key exchange: shared blocks per call, sort keys per step, at most          */
+} irec_plan_detail;
+irec_status irec_test_plan(int32_t n_cu, int32_t clock_mhz, const irec_params *p, int64_t n_blocks, int32_t max_block_dim, int32_t max_K,
+                           irec_plan_info *info, irec_plan_detail *detail);
 /* out[e] = element e of tf.random.normal([count]) after tf.random.set_seed(seed) -- the stream behind
  * tfd.Normal.sample.  Host memory; test hook. */
 irec_status irec_tf_random_normal(int64_t seed, int64_t count, float *out);

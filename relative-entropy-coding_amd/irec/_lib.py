@@ -56,6 +56,17 @@ class IrecPlanInfo(ctypes.Structure):
                 for name, _ in self._fields_}
 
 
+class IrecPlanDetail(ctypes.Structure):
+    """irec_plan_detail of csrc/irec_internal.h (test hook irec_test_plan)."""
+    _fields_ = [("kind", ctypes.c_int32), ("grid", ctypes.c_int32), ("teams_per_wg", ctypes.c_int32), ("coop_width", ctypes.c_int32),
+                ("coop_beams", ctypes.c_int32), ("gang_chunks", ctypes.c_int32), ("placed", ctypes.c_int32), ("split_blocks", ctypes.c_int32),
+                ("share_first", ctypes.c_int64), ("n_slots", ctypes.c_int64), ("slabs_in_workspace", ctypes.c_int64),
+                ("slab_bytes", ctypes.c_int64), ("fixed_bytes", ctypes.c_int64), ("exchange_rows", ctypes.c_int32), ("exchange_keys", ctypes.c_int32)]
+
+    def as_dict(self):
+        return {name: int(getattr(self, name)) for name, _ in self._fields_}
+
+
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
 _i32 = ctypes.c_int32
@@ -83,6 +94,7 @@ SIGNATURES = {
     "irec_destroy": (None, [_vp]),
     "irec_encode_workspace_bytes": (ctypes.c_size_t, [_vp, _PP, _i32, _i32]),
     "irec_encode_workspace_bytes_for": (ctypes.c_size_t, [_vp, _PP, _i64, _i32, _i32]),
+    "irec_test_plan": (ctypes.c_int, [_i32, _i32, _PP, _i64, _i32, _i32, _vp, _vp]),
     "irec_encode_plan": (ctypes.c_int, [_vp, _PP, _i64, _i32, _i32, ctypes.POINTER(IrecPlanInfo)]),
     "irec_block_kl": (ctypes.c_int, [_vp, _PP, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "irec_beam_encode": (ctypes.c_int, [_vp, _PP, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32,
