@@ -547,7 +547,8 @@ irec_status check_params(const irec_params *p) {
   if (p->n_samples < 1 || p->n_samples > (1 << 24)) return fail(IREC_E_INVALID, "n_samples %d out of range", p->n_samples);
   if (p->n_beams < 1 || p->n_beams > IREC_MAX_BEAMS) return fail(IREC_E_INVALID, "n_beams %d out of range [1,%d]", p->n_beams, IREC_MAX_BEAMS);
   if (p->table_steps < 0) return fail(IREC_E_INVALID, "table_steps %d < 0", p->table_steps);
-  if (((p->flags & IREC_FLAG_SHAPE_MASK) >> IREC_FLAG_SHAPE_SHIFT) > 6) return fail(IREC_E_INVALID, "unknown IREC_FLAG_SHAPE_* value");
+  { const int sh = (p->flags & IREC_FLAG_SHAPE_MASK) >> IREC_FLAG_SHAPE_SHIFT;
+    if (sh > 6 || sh == 1 || sh == 4) return fail(IREC_E_INVALID, "unknown IREC_FLAG_SHAPE_* value"); }   // (1 and 4: the one-team and 2 x 2 shapes, removed in round 6)
   return IREC_OK;
 }
 
@@ -737,7 +738,7 @@ int split_width(const irec_context *ctx, const Plan &pl, const irec_params *p, i
 // sample stripes -- possible when two slots per workgroup cover the B beams.  Returns the width to launch with (the
 // fewest workgroups that still own at most as many slots each: 10, not 12, for B = 20), 0 = stay with sample stripes.
 int split_beam_width(const irec_params *p, int W) {
-  if (W < 2 || (p->flags & IREC_FLAG_SPLIT_SAMPLES)) return 0;
+  if (W < 2) return 0;
   const int B = p->n_beams;
   if (W > B) W = B;
   if (W < 2) return 0;
@@ -752,8 +753,8 @@ int split_beam_width(const irec_params *p, int W) {
 // teams in the idle team slots of W CUs, which split its samples and exchange sort keys, so a CU carries one block and a fraction
 // instead of two -- the call is as long as its most loaded CU (r04i: 342 blocks 0.59 -> 0.555 ms, 297 blocks 0.575 -> 0.54 ms).
 // Not for B <= 10 (302 blocks of a Kodak level: 0.26 ms either way) and not beyond 1.5 blocks per CU (W = 1).
-// IREC_FLAG_SHARE_ALL (diagnostics): every row of a call of 64 .. 384 blocks is shared, W = slots / blocks -- slower than the
-// default at every size (r04j: 252 blocks 0.49 against 0.44 ms on the 8-wave team; the partners of a row wait for the slowest).
+// (Round 6: the diagnostic flag that shared EVERY row of any mid-size call on the three-team build -- slower than the default at every
+//  size, r04j -- is gone, and with it the builds only it reached.)
 // Returns W (0: no sharing) for the shape the call runs; *first = first shared row, *grid = workgroups the static round needs.
 // Calls of 64 blocks up to ~ a block per CU, no shape pinned: EVERY row is shared between the teams of the two-team build (shape 2)
 // instead of sitting alone on a CU's one team -- r04x/share_all_probe.log, max_K = 32, as issued: B = 20: 72 blocks 0.296 -> 0.245 ms,
@@ -761,7 +762,7 @@ int split_beam_width(const irec_params *p, int W) {
 // costs more than half a step's scoring saves: 180 blocks 0.332 -> 0.368); B = 10 (whose default build has three 4-wave teams of which
 // such a call uses one): 72 blocks 0.159 -> 0.134, 252 blocks 0.183 -> 0.168 -- also with two partners.
 bool share_all_auto(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks) {
-  if (!pl.team || pl.lone || pl.team_only || pl.chunk || !pl.table || (p->flags & (IREC_FLAG_NO_SPLIT | IREC_FLAG_SHARE_ALL))) return false;
+  if (!pl.team || pl.lone || pl.team_only || pl.chunk || !pl.table || (p->flags & IREC_FLAG_NO_SPLIT)) return false;
   if ((p->flags & IREC_FLAG_SHAPE_MASK) != 0 || n_blocks < small_call_blocks(ctx) || n_blocks > irec::COOP_MAX_BLOCKS) return false;
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
   const int B = p->n_beams, S = p->n_samples;
@@ -780,7 +781,7 @@ int team_share_width(const irec_context *ctx, const Plan &pl, const irec_params 
   const int64_t cap = std::min<int64_t>(8, p->n_samples);
   const int64_t slots = (int64_t)teams * n_cu;
   int64_t W = 0, f = 0;
-  if ((p->flags & IREC_FLAG_SHARE_ALL) || (shape == 2 && share_all_auto(ctx, pl, p, n_blocks))) {
+  if (shape == 2 && share_all_auto(ctx, pl, p, n_blocks)) {
     if (n_blocks < small_call_blocks(ctx) || n_blocks > irec::COOP_MAX_BLOCKS || 2 * n_blocks > slots) return 0;
     W = slots / n_blocks;
   } else {
@@ -818,8 +819,6 @@ bool team_for_call(const irec_context *ctx, const Plan &pl, const irec_params *p
 int shape_for_call(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks) {
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
   const int B = p->n_beams, S = p->n_samples;
-  if ((p->flags & IREC_FLAG_SHARE_ALL) && !(p->flags & IREC_FLAG_NO_SPLIT) && pl.shape == 0 &&
-      team_share_width(ctx, pl, p, n_blocks, 0, nullptr, nullptr) >= 2) return pl.shape;   // (diagnostics) every row shared between teams: the three-team shape
   if (share_all_auto(ctx, pl, p, n_blocks)) return 2;                             // every row shared between the teams of the two-team build
   if (pl.shape != 0 || !pl.team || pl.lone || n_blocks < small_call_blocks(ctx) || n_blocks > 2 * (int64_t)n_cu || B > 20) return pl.shape;   // (< 64 blocks: only calls
                                                                          // that pin IREC_FLAG_TEAM get here, tests of the default shape among them)

@@ -21,10 +21,6 @@ extern "C" {
                                   /* (cheaper per-call set-up) below; same outputs, bit for bit                        */
 #define IREC_FLAG_TEST_SPLIT_ORPHAN 32 /* test hook: the partner workgroups of the split encoder leave at once, so workgroup 0  */
                                   /* of every block must take the give-up exit (100 ms) (out_K = -2) instead of hanging   */
-#define IREC_FLAG_SPLIT_SAMPLES 128 /* split encoder: share a block's samples among its workgroups (the r02b form: every workgroup */
-                                  /* repeats the whole beam update) instead of its beams (default where <= 2 beams per workgroup)  */
-#define IREC_FLAG_SHARE_ALL 131072 /* team encoder, calls that leave team slots idle: share EVERY row of the call between teams instead of only */
-                                  /* the rows beyond one per CU (diagnostics, r04j: slower than the default at every size; same outputs)     */
 #define IREC_FLAG_LISTED_ORDER 262144 /* team encoder, calls of one to a few rows per CU: deal the rows to the CUs in the order listed.    */
                                   /* Default: by cost -- the call's preparation kernel also computes K * dims of every row and a CU's first   */
                                   /* team takes a cheap row, its other teams (and the teams that share a row) the costliest ones, so   */
@@ -34,13 +30,12 @@ extern "C" {
 #define IREC_FLAG_SPLIT_SHIFT 12  /* bits 12-15: workgroups per block of the split encoder / sample stripes per chunk of a gang, at most; */
                                   /* 0 = chosen by the library (diagnostics) */
 #define IREC_FLAG_SPLIT_MASK (0xF << IREC_FLAG_SPLIT_SHIFT)
-/* Diagnostic workgroup shapes of the team encoder for B <= 20 (bits 8-11 of flags; 0 = the default shape).  Same outputs. */
+/* Diagnostic workgroup shapes of the team encoder for B <= 20 (bits 8-11 of flags; 0 = the default shape).  Same outputs.
+ * (Values 1 and 4 -- one 4-wave team per CU, two 8-wave striped teams -- lost at every size and were removed in round 6 with their builds.) */
 #define IREC_FLAG_SHAPE_SHIFT 8
 #define IREC_FLAG_SHAPE_MASK (0xF << IREC_FLAG_SHAPE_SHIFT)
-#define IREC_FLAG_SHAPE_1 (1 << IREC_FLAG_SHAPE_SHIFT)   /* one 4-wave team per CU                                    */
 #define IREC_FLAG_SHAPE_2 (2 << IREC_FLAG_SHAPE_SHIFT)   /* exactly two teams (also where three are the default)      */
 #define IREC_FLAG_SHAPE_3 (3 << IREC_FLAG_SHAPE_SHIFT)   /* three 4-wave teams (168 VGPRs)                            */
-#define IREC_FLAG_SHAPE_2X2 (4 << IREC_FLAG_SHAPE_SHIFT) /* two 8-wave beam-striped teams (128 VGPRs)                 */
 #define IREC_FLAG_SHAPE_1X2 (5 << IREC_FLAG_SHAPE_SHIFT) /* one 8-wave beam-striped team (the default of 64..n_CU blocks) */
 #define IREC_FLAG_SHAPE_TEAM (6 << IREC_FLAG_SHAPE_SHIFT) /* the team encoder's default shape also for one-beam calls (which the one-wave-per-block encoder takes otherwise) */
 

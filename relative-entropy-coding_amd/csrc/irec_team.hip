@@ -60,9 +60,6 @@
 #define IREC_GANG_ABLATE 0   // diagnostics (make variant_gang): phases of a gang step removed -- 1 sample loops, 2 update, 4 reduction, 8 selection,
                              // 32 gang barriers; the outputs are wrong, the time that remains is the point (scripts/gang_latency.py --ablate)
 #endif
-#ifndef IREC_TEN_TEAMS
-#define IREC_TEN_TEAMS 3       // teams per workgroup of encode_ten_kernel where encode_team_kernel<10,..> has three (3: A/B builds)
-#endif
 #ifndef IREC_PK_ADDR
 #define IREC_PK_ADDR 1          // scoring loop: look-up addresses of a beam pair by one v_pk_add_f32 (0: two v_add_u32; A/B builds)
 #endif
@@ -1954,14 +1951,13 @@ __global__ __launch_bounds__(256, IREC_CHOICE_WPE) void prep_kernel(PrepArgs P, 
 #ifndef IREC_TEAM_GANG_TU
 // teams per workgroup / beam stripes per team.  Defaults: B <= 20: 3 x 1 where the LDS allows (else 2 x 1, or 1 x 2 with
 // sample passes); B <= 30: 1 x 3.  Diagnostic overrides for B <= 20 travel in irec_params.flags (IREC_FLAG_SHAPE_*, no
-// environment variable is read on the product path): cfg 1 = one team, 20 = exactly two teams (also where three would be
-// the default), 3 = three 4-wave teams (168 VGPRs), 22 = two 8-wave beam-striped teams (128 VGPRs).
+// environment variable is read on the product path): cfg 20 = exactly two teams (also where three would be the default),
+// 3 = three 4-wave teams (168 VGPRs), 12 = one 8-wave beam-striped team.  (Round 6: the one-team and the 2 x 2 shapes, which lost
+// at every size, are gone with their builds <20,1,1> and <20,2,2>.)
 static int team_cfg(int shape_override) {
   switch (shape_override) {
-    case 1: return 1;
     case 2: return 20;
     case 3: return 3;
-    case 4: return 22;
     case 5: return 12;
     default: return 2;
   }
@@ -1981,9 +1977,7 @@ static TeamShape team_shape(int B, int S, int ovr) {
     return TeamShape{10, 3, 1, true};   // more samples than one pass of two teams holds (S > 102): three teams, sample passes
   }
   if (B <= 20) {
-    if (cfg == 1) return TeamShape{20, 1, 1, false};
     if (cfg == 20) return TeamShape{20, 2, 1, false};
-    if (cfg == 22) return TeamShape{20, 2, 2, false};
     if (cfg == 12) return TeamShape{20, 1, 2, false};
     // three 4-wave teams (168 VGPRs: half-slot look-up pipeline, statistics / variance / scale parked in the slab, sort keys
     // over the partial scores) wherever their LDS fits next to the table copies -- S <= 38, the BASELINE workload: a third
@@ -2032,7 +2026,7 @@ size_t team_ws_bytes_for(int B, int S, int ovr, int max_K) {
 int team_ten_teams(int B, int S, int ovr) {
   const TeamShape sh = team_shape(B, S, ovr);
   if (!(sh.nb == 10 && sh.bs == 1 && !sh.passes && !sh.one && (sh.teams == 2 || sh.teams == 3) && ten_applies(B, S))) return 0;
-  return sh.teams == 3 ? IREC_TEN_TEAMS : 2;   // (r06f: four teams at 128 VGPRs hold the scoring loop without a spill and LOSE 12 %: 4096 latents 8.6 -> 9.7 ms)
+  return sh.teams;   // (r06f: FOUR teams at 128 VGPRs hold the scoring loop without a spill and LOSE 12 %: 4096 latents 8.6 -> 9.7 ms)
 }
 const char *team_kernel_name(int B, int S, int ovr) {
   static thread_local char buf[64];
@@ -2095,7 +2089,6 @@ hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
   if (A.coop_W > 1) {   // rows shared between teams (host: team_share_width -> team_shareable builds only)
     switch (key) {
       case 1021: return launch_team_t<10, 2, 1, false, false, true>(A, grid, st);
-      case 1031: return launch_team_t<10, 3, 1, false, false, true>(A, grid, st);
       case 2021: return launch_team_t<20, 2, 1, false, false, true>(A, grid, st);
       case 2031: return launch_team_t<20, 3, 1, false, false, true>(A, grid, st);
       default: return hipErrorInvalidValue;
@@ -2110,10 +2103,8 @@ hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
     case 5413: return launch_team_t<54, 1, 3>(A, grid, st);
     case 1021: return launch_team_t<10, 2, 1>(A, grid, st);
     case 1031: return launch_team_t<10, 3, 1>(A, grid, st);
-    case 2011: return launch_team_t<20, 1, 1>(A, grid, st);
     case 2021: return launch_team_t<20, 2, 1>(A, grid, st);
     case 2031: return launch_team_t<20, 3, 1>(A, grid, st);
-    case 2022: return launch_team_t<20, 2, 2>(A, grid, st);
     case 2012: return launch_team_t<20, 1, 2>(A, grid, st);
     case 3013: return launch_team_t<30, 1, 3>(A, grid, st);
     case 3212: return launch_team_t<32, 1, 2>(A, grid, st);
@@ -2131,7 +2122,9 @@ hipError_t launch_encode_team(const EncArgs &A, int grid, hipStream_t st) {
 struct ChunkShape { int nb, nbp, teams; };
 static int chunk_nb(int B) { return B <= 10 ? 10 : B <= 20 ? 20 : B <= 30 ? 30 : B <= 32 ? 32 : B <= 40 ? 40 : B <= 50 ? 50 : B <= 60 ? 60 : 0; }
 static ChunkShape chunk_shape(int B, int S) {
-  static const ChunkShape cand[] = {{10, 10, 3}, {10, 10, 2}, {10, 10, 1}, {20, 10, 3}, {20, 20, 2}, {20, 10, 1},
+  // (round 6: {20, 20, 2} -- passes of twenty beams on two teams -- could never be chosen: wherever its LDS fits (S <= 49), that of {20, 10, 3}
+  //  before it in the list does too (S <= 52); the planner enumeration of tests/test_kernel_coverage.py found it, the build is gone)
+  static const ChunkShape cand[] = {{10, 10, 3}, {10, 10, 2}, {10, 10, 1}, {20, 10, 3}, {20, 10, 1},
                                     {30, 10, 3}, {30, 10, 2}, {30, 10, 1}, {32, 16, 2}, {32, 16, 1},
                                     {40, 10, 2}, {40, 10, 1}, {50, 10, 2}, {50, 10, 1}, {60, 10, 2}, {60, 10, 1}};
   const int nb = chunk_nb(B);
@@ -2209,7 +2202,6 @@ hipError_t launch_encode_chunk(const EncArgs &A, int grid, hipStream_t st) {
     case 10102: return launch_chunk_t<10, 10, 2>(A, grid, st);
     case 10101: return launch_chunk_t<10, 10, 1>(A, grid, st);
     case 20103: return launch_chunk_t<20, 10, 3>(A, grid, st);
-    case 20202: return launch_chunk_t<20, 20, 2>(A, grid, st);
     case 20101: return launch_chunk_t<20, 10, 1>(A, grid, st);
     case 30103: return launch_chunk_t<30, 10, 3>(A, grid, st);
     case 30102: return launch_chunk_t<30, 10, 2>(A, grid, st);

@@ -726,7 +726,6 @@ hipError_t launch_encode_ten(const EncArgs &A, int teams, int grid, hipStream_t 
   switch (teams) {
     case 3: return launch_ten_t<3>(A, grid, st);
     case 2: return launch_ten_t<2>(A, grid, st);
-    case 4: return launch_ten_t<4>(A, grid, st);
     default: return hipErrorInvalidValue;
   }
 }

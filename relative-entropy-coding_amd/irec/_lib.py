@@ -18,15 +18,13 @@ IREC_FLAG_ONE_TABLE = 4
 IREC_FLAG_TEAM = 8
 IREC_FLAG_NO_SPLIT = 16
 IREC_FLAG_TEST_SPLIT_ORPHAN = 32   # test hook: the partner workgroups / teams of a shared block leave at once
-IREC_FLAG_SHARE_ALL = 131072        # team encoder: share every row of a mid-size call between teams (diagnostics)
 IREC_FLAG_LISTED_ORDER = 262144     # team encoder: deal the rows of a mid-size call as listed, not by cost (diagnostics)
 IREC_FLAG_MARGINS = 524288           # irec_beam_encode_ex: the call reports its top-B margins (out_margin)
 IREC_FLAG_NO_TEN = 1048576            # diagnostics: plain calls of at most ten beams stay on encode_team_kernel<10,..> (not encode_ten_kernel)
 IREC_FLAG_TABLES_PRESENT = 65536     # the previous call on this workspace / stream was this call's twin: no table launches
-IREC_FLAG_SPLIT_SAMPLES = 128      # split encoder: share samples (r02b form) instead of beams
 IREC_FLAG_REUSE_TABLES = 64        # keep a proposal table whose stamp in the workspace head matches the call's key
 IREC_FLAG_SHAPE_SHIFT = 8          # diagnostic workgroup shapes of the team encoder (include/irec.h)
-IREC_FLAG_SHAPE = {"default": 0, "1": 1 << 8, "2": 2 << 8, "3": 3 << 8, "2x2": 4 << 8, "1x2": 5 << 8, "team": 6 << 8}
+IREC_FLAG_SHAPE = {"default": 0, "2": 2 << 8, "3": 3 << 8, "1x2": 5 << 8, "team": 6 << 8}
 IREC_TABLE_STEPS_DEFAULT = 32
 IREC_TABLE_STEPS_MAX = 4096
 BIG_PRIME = 10007

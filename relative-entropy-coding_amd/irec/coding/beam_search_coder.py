@@ -184,7 +184,6 @@ class BeamSearchCoder(GaussianCoder):
         self.no_split = False        # the caller's knob: IREC_FLAG_NO_SPLIT on every call (no block is ever shared between workgroups / teams)
         self._split_strikes = 0      # consecutive give-ups of the cooperative encoders (SplitNotResident), see _split_gave_up
         self._split_pause = 0        # calls still to be issued without sharing
-        self.split_samples = False   # IREC_FLAG_SPLIT_SAMPLES: the split encoder shares a block's samples (r02b form), not its beams
         self._test_split_orphan = False  # test hook (IREC_FLAG_TEST_SPLIT_ORPHAN): the split encoder's partners leave at once
         self.team_shape = "default"  # diagnostics: IREC_FLAG_SHAPE_* workgroup shape of the team encoder
         self.reuse_tables = True     # IREC_FLAG_REUSE_TABLES: a call whose proposal tables are already in the stream's scratch
@@ -256,7 +255,7 @@ class BeamSearchCoder(GaussianCoder):
                 (_lib.IREC_FLAG_ONE_TABLE if self.one_table else 0) | \
                 (_lib.IREC_FLAG_TEAM if self.team else 0) | (0 if shared else _lib.IREC_FLAG_NO_SPLIT) | \
                 (_lib.IREC_FLAG_REUSE_TABLES if self.reuse_tables else 0) | \
-                (_lib.IREC_FLAG_SPLIT_SAMPLES if self.split_samples else 0) | _lib.IREC_FLAG_SHAPE[self.team_shape] | \
+                _lib.IREC_FLAG_SHAPE[self.team_shape] | \
                 (_lib.IREC_FLAG_TEST_SPLIT_ORPHAN if self._test_split_orphan and shared else 0)
         steps = int(table_steps) if table_steps else self.table_window()
         return Engine.params(self.kl_per_partition, self.n_samples, self.n_beams, flags, table_steps=steps)

@@ -38,7 +38,6 @@ def main():
                     m._level_1_posterior_log_scale_combiner):
             mod.weight.mul_(args.scale)
     sampler = irec.BeamSearchCoder(kl_per_partition=3., n_beams=10, extra_samples=1., block_size=1000)
-    sampler.split_samples = bool(os.environ.get("IREC_SPLIT_SAMPLES"))   # diagnostic: the split encoder's r02b form
     g = torch.Generator().manual_seed(11)
     out_dir = tempfile.mkdtemp(prefix="irec_cfg4_")
     rows = []

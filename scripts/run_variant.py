@@ -14,8 +14,6 @@ flags |= irec._lib.IREC_FLAG_SHAPE[os.environ.get("SHAPE", "default")]   # team-
 flags |= int(os.environ.get("SPLIT_W", "0")) << 12                         # split-encoder width (diagnostics)
 if os.environ.get("NO_SPLIT"): flags |= 16
 if os.environ.get("NO_TEN"): flags |= irec._lib.IREC_FLAG_NO_TEN            # at most ten beams: encode_team_kernel<10,..> instead of encode_ten_kernel
-if os.environ.get("SHARE_ALL"): flags |= 131072                                 # team encoder: share every row of the call between teams
-if os.environ.get("SPLIT_SAMPLES"): flags |= 128                                      # split encoder: samples, not beams
 max_K = int(os.environ.get("MAXK", "32"))
 params = eng.params(omega, S, B, flags, table_steps=int(os.environ.get("TABLE_STEPS", "0")))
 # SKEW=1: per-tensor log-normal scale on delta (bench.skewed_batch): K from 1 to 60 inside one call

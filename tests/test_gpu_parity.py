@@ -1050,7 +1050,10 @@ def test_decoder_tiny_variances_take_the_slow_sqrt(engine, oracle):
 @pytest.mark.parametrize("n_t,n,bs,omega,eps1,B", [(64, 8192, 1000, 3.0, 1.2, 20), (3, 8192, 1000, 3.0, 1.2, 20),
                                                    (2, 301056, 1000, 3.0, 1.0, 10), (5, 1234, 300, 2.0, 1.0, 1),
                                                    (4, 4099, 4099, 3.0, 1.5, 5), (3, 700, 7, 3.0, 1.0, 10),
-                                                   (1, 5000, 1000, 5.0, 1.2, 3), (2, 12288, 1000, 3.0, 1.0, 10)])
+                                                   (1, 5000, 1000, 5.0, 1.2, 3), (2, 12288, 1000, 3.0, 1.0, 10),
+                                                   # 4100 blocks >= 16 per CU: the legacy decoder's LDS-copy build decode_kernel<true> (round 6:
+                                                   # the kernel trace of the suite showed that nothing reached it)
+                                                   (4100, 64, 64, 3.0, 1.0, 5)])
 def test_decoder_variants_agree_with_the_oracle(engine, oracle, n_t, n, bs, omega, eps1, B):
     """Round 3 decoder (irec_decode.hip): one wave per 256 dims of a block, index path held in a lane vector, rows from the
     per-call proposal tables ("tables") or from the fused Philox draw ("fused"); the round-2 kernel ("legacy") serves calls
@@ -1436,7 +1439,7 @@ def test_two_streams_encode_concurrently(engine, oracle):
             assert np.array_equal(pa.sample[i].cpu().numpy(), rsa) and np.array_equal(pb.sample[i].cpu().numpy(), rsb)
 
 
-@pytest.mark.parametrize("shape", ["1", "2", "3", "2x2", "1x2"])
+@pytest.mark.parametrize("shape", ["2", "3", "1x2"])
 def test_diagnostic_team_shapes_are_bit_exact(engine, oracle, shape):
     q = [np.stack([oracle.synthetic_latent(20 + i, 8192)[j] for i in range(8)]) for j in range(4)]
     c = _coder(3.0, 20, 1.2, block_size=1000, variant="table")
@@ -1501,8 +1504,8 @@ def test_one_to_two_blocks_per_cu_take_the_two_team_shape(engine, oracle, B, eps
 
 
 @pytest.mark.parametrize("B,eps1,n_latents,shape,extra,want_W", [(20, 1.2, 38, "default", 0, 2), (20, 1.2, 38, "3", 0, 5), (20, 1.2, 29, "default", 0, 8),
-                                                                (13, 1.2, 45, "3", 0, 3), (10, 1.0, 34, "default", 131072, 2),
-                                                                (7, 1.0, 14, "default", 131072, 6), (20, 1.2, 38, "default", 131072, 2)])
+                                                                (13, 1.2, 45, "3", 0, 3), (10, 1.0, 28, "default", 0, 2),
+                                                                (7, 1.0, 14, "default", 0, 4), (20, 1.2, 14, "default", 0, 4)])
 def test_calls_of_one_to_two_blocks_per_cu_share_rows_between_teams(engine, oracle, B, eps1, n_latents, shape, extra, want_W):
     """Round 4: in a call of n_CU < blocks < teams * n_CU every CU gets ONE whole block; each row beyond that is coded by W teams
     in the idle team slots of W CUs, which split its samples, exchange their sort keys as tagged granules and then run the same
@@ -1515,7 +1518,7 @@ def test_calls_of_one_to_two_blocks_per_cu_share_rows_between_teams(engine, orac
     stats[-1][0], stats[-1][1] = stats[-1][2].copy(), stats[-1][3].copy()        # the last tensor (its rows are shared ones): KL = 0
     ql, qs, pl, ps = (torch.from_numpy(np.stack([s[k] for s in stats])).cuda().contiguous() for k in range(4))
     lay = engine.layout(n_latents, 8192, 1000, 42)
-    fl = irec._lib.IREC_FLAG_SHAPE[shape] | extra      # (extra = IREC_FLAG_SHARE_ALL: every row of the call shared, the diagnostic policy)
+    fl = irec._lib.IREC_FLAG_SHAPE[shape] | extra
     for steps in (0, 6):                               # tables over every partition / a window that the longer rows leave (second pass)
         share = engine.params(3.0, S, B, fl, table_steps=steps)
         whole = engine.params(3.0, S, B, fl | irec._lib.IREC_FLAG_NO_SPLIT, table_steps=steps)
@@ -1615,10 +1618,13 @@ def test_library_errors_are_coding_errors(engine):
 
 
 # ---- split encoder: several workgroups share one block of a small call -------------------------------------------------
-@pytest.mark.parametrize("n_tensors,n,bs,omega,eps1,B", [(1, 8192, 1000, 3.0, 1.2, 20), (1, 1000, None, 3.0, 1.2, 20),
-                                                         (3, 2048, 1000, 3.0, 1.0, 10), (1, 777, None, 2.0, 1.0, 7),
-                                                         (2, 4096, 1000, 3.0, 1.2, 11), (1, 64, None, 1.5, 1.0, 20)])
-@pytest.mark.parametrize("mode", ["beams", "samples"])
+@pytest.mark.parametrize("n_tensors,n,bs,omega,eps1,B,mode", [(1, 8192, 1000, 3.0, 1.2, 20, "beams"), (1, 1000, None, 3.0, 1.2, 20, "beams"),
+                                                              (3, 2048, 1000, 3.0, 1.0, 10, "beams"), (1, 777, None, 2.0, 1.0, 7, "beams"),
+                                                              (2, 4096, 1000, 3.0, 1.2, 11, "beams"), (1, 64, None, 1.5, 1.0, 20, "beams"),
+                                                              # 33 .. 63 blocks: two or three workgroups per block, more than two beam slots each -- the
+                                                              # sample-sharing form (round 6: the flag that forced it on the shapes above is gone)
+                                                              (5, 8192, 1000, 3.0, 1.2, 20, "samples"), (4, 8192, 1000, 3.0, 1.0, 10, "samples"),
+                                                              (40, 777, None, 2.0, 1.0, 7, "samples")])
 def test_split_encoder_small_calls(engine, oracle, n_tensors, n, bs, omega, eps1, B, mode):
     """Calls of few blocks run W workgroups per block (plan['split']) that share the block's beams (each owns at most two
     beam slots: scores every sample for them, forms only its own new beams; plan['split_beams']) or, in the r02b form, its
@@ -1627,10 +1633,9 @@ def test_split_encoder_small_calls(engine, oracle, n_tensors, n, bs, omega, eps1
     hand-offs (in beam mode: of beams read from another workgroup's stores)."""
     S = oracle.n_samples(omega, eps1)
     q = [np.stack([oracle.synthetic_latent(300 + i, n)[j] for i in range(n_tensors)]) for j in range(4)]
-    if n == 777:
+    if n == 777 and n_tensors == 1:
         q[1] = (q[1] * 0.3).astype(np.float32)            # sharper posterior: K in the hundreds
     c = _coder(omega, B, eps1, block_size=bs, variant="one_table")
-    c.split_samples = mode == "samples"
     lay = engine.layout(n_tensors, n, bs, 42)
     plan = engine.plan(c._params(), lay, 32)
     assert plan["split"] >= 2 and plan["grid"] == lay.n_blocks * plan["split"], plan
@@ -1651,7 +1656,7 @@ def test_split_encoder_small_calls(engine, oracle, n_tensors, n, bs, omega, eps1
         ridx, rs = oracle.encode_tensor(q[0][i], q[1][i], q[2][i], q[3][i], 42, omega, S, B, block_size=bs)
         got = idx[i] if bs is not None else idx[i]
         assert got == ridx and np.array_equal(sample[i].cpu().numpy(), rs), i
-    if n == 777:
+    if n == 777 and n_tensors == 1:
         assert len(idx[0]) > 100
 
 
@@ -1751,7 +1756,7 @@ def test_workspace_sized_for_the_call(engine, oracle):
                                                idx.data_ptr(), sample.data_ptr(), ws.data_ptr(), ws.numel(), engine._stream()), "irec_beam_encode")
         torch.cuda.synchronize()
         k = int(K[0])
-        assert idx[0, :k].tolist() == ridx[0] and np.array_equal(sample.cpu().numpy()[0], rs), size
+        assert idx[0, :k].tolist() == [int(v) for v in ridx] and np.array_equal(sample.cpu().numpy()[0], rs.reshape(-1)), size
         out.append(k)
     too_small = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda")       # (not even the workspace head)
     assert engine.lib.irec_beam_encode(engine.ctx, ctypes.byref(params), 1, lay.block_base.data_ptr(), lay.block_pos.data_ptr(), lay.block_dim.data_ptr(),
