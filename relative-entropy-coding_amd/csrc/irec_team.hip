@@ -1240,7 +1240,16 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
       gang_epoch += (uint32_t)G;
       // every wave drains its stores before the team barrier: the release fence in there is workgroup-scoped and need not wait for
       // vector-memory stores to be acknowledged (the waves of a workgroup share their L1), but the partners of the gang sit on other CUs
-      // and must find the sums in place once the arrival below is visible
+      // and must find the sums in place once the arrival below is visible.
+      // Why this is enough on gfx950, and why it is asm and not the memory model (round 6, scripts/microbench/litmus.hip, profiles/r06r/):
+      //   * everything handed over is written by agent-scope stores (global_store .. sc1: written through to the memory side that all XCDs
+      //     share) and read by agent-scope loads (global_load .. sc1: not served from a stale L1 / L2 line);
+      //   * vmcnt counts a store down when the memory side has ACKNOWLEDGED it, so after s_waitcnt vmcnt(0) the wave's data is where every
+      //     agent-scope load finds it; the team barrier then orders the four waves' drains before thread 0's arrival (LDS counter);
+      //   * the arrival itself is a relaxed agent-scope RMW on one word: whoever sees it, sees it after the acknowledgements.
+      //   The memory model says the same with an agent-scope release fence in every wave and an acquire fence behind the wait; that form
+      //   passes the litmus too (form 2m) and costs 3 x the hand-off (47 against 16 us for 16 KB under light load, 76 against 58 under
+      //   heavy): buffer_wbl2 + buffer_inv sc1 write back and invalidate the whole L2 for data that never was in it.
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       tsync();
       if (tid == 0) {

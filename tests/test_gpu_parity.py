@@ -485,6 +485,22 @@ def test_gang_calls_under_contention_match_the_one_team_form(engine, monkeypatch
     assert e.value.code == 0
 
 
+def test_split_encoder_and_shared_rows_under_contention_match_the_unshared_form(engine, monkeypatch):
+    """The same stress for the other two cooperative forms (round 5's review, Next #3c: only the gang form had a contention test): three
+    threads issue calls of blocks of at most 1024 dims back to back on their own streams -- calls of fewer than 64 blocks take the split
+    encoder (workgroups of a block exchange tagged 8-byte granules), calls of 64 blocks up to 1.5 per CU share rows between teams (the same
+    granules) -- so partners run late and out of step.  Every call against the same call with IREC_FLAG_NO_SPLIT; a call that gave up
+    (partners not resident) is counted, not compared."""
+    import runpy
+    monkeypatch.setenv("SOAK_THREADS", "3")
+    monkeypatch.setenv("SOAK_CALLS", "100")
+    monkeypatch.setenv("SOAK_SEED", "5")
+    monkeypatch.setenv("SOAK_MODE", "small")
+    with pytest.raises(SystemExit) as e:
+        runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "soak_gangs_threads.py"), run_name="__main__")
+    assert e.value.code == 0
+
+
 def test_a_gang_really_short_of_cus_gives_up_and_is_coded_again(engine, oracle):
     """No test hook: another stream holds 200 CUs for seconds (200 blocks of 65 536 dims, one team each) while ONE block of 16 384 dims asks
     for a gang of 144 teams, one per CU.  The members that find a CU wait 100 ms, poison the block's counter and leave; the rest start when
