@@ -44,6 +44,10 @@
 #ifndef IREC_TEN_TREE_VALU
 #define IREC_TEN_TREE_VALU 1       // KL / C_b lane trees on DPP and permlane swaps (0: ds_bpermute)
 #endif
+#ifndef IREC_TEN_WIDE
+#define IREC_TEN_WIDE 0            // 1: the two-team build runs 8-WAVE teams, a block's samples on two stripes (r06u: 128 VGPRs, 304 B of scratch in the
+                                   // serial phases, both stripes repeat selection and update: 302 blocks 0.21 -> 0.25 ms: not taken)
+#endif
 #ifndef IREC_TEN_INPLACE
 #define IREC_TEN_INPLACE 1      // beams updated in place where one wave owns a dim group (0: always double buffered; A/B builds)
 #endif
@@ -191,14 +195,18 @@ __device__ __forceinline__ uint32_t ten_select_fast(const uint32_t (&k)[4], int 
   return (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)cf);
 }
 
-template <int TEAMS>
-__global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs A) {
-  constexpr int NB = TEN_NB, NT = TEAM_NT, NP = NB / 2;
+// TEAMS teams per workgroup of NWT waves each: 3 x 4 for batches (a team per block, the other teams' scoring under its serial phases);
+// 2 x 8 for calls of at most two blocks per CU -- a block's samples on two stripes of four waves (sw = wave / NG, as blocks of fewer than four
+// dim groups have them on four waves): a lone chain's scoring, which one wave per SIMD runs at the latency of its own look-ups, halves;
+// every stripe repeats the update for its own registers (stripe 0 stores), the selection is every wave's anyway.
+template <int TEAMS, int NWT = TEAM_NW>
+__global__ __launch_bounds__(TEAMS * NWT * 64, 1) void encode_ten_kernel(EncArgs A) {
+  constexpr int NB = TEN_NB, NT = NWT * 64, NP = NB / 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int S = A.S, B = A.B;
   const int lane = threadIdx.x & 63;
   const int wave_wg = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // wave-uniform by construction
-  const int team = wave_wg / TEAM_NW, wave = wave_wg % TEAM_NW;
+  const int team = wave_wg / NWT, wave = wave_wg % NWT;
   const int tid = (int)threadIdx.x - team * NT;                                 // index inside the team
   TenLds *sm = reinterpret_cast<TenLds *>(smem + T3_BYTES + (size_t)team * TEN_LDS_ONE);
   int32_t *misc = sm->misc;
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
     if (tid == 0) sm->bar = 0u;
   }
   __syncthreads(); // the only workgroup-wide barrier: from here on the teams never wait for each other
-  TeamBarrier tsync{&sm->bar, 0u, (uint32_t)TEAM_NW};
+  TeamBarrier tsync{&sm->bar, 0u, (uint32_t)NWT};
 
   // scratch slab of the team (fast_ws_bytes(10, max_K)): bp int32 [max_K][10] | ... | stats [3][1024] | beams [2][10][1024]
   char *slab = A.ws + ((size_t)blockIdx.x * TEAMS + team) * A.ws_per_wg;
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
     }
     const int Dp = (D + 3) & ~3;            // row stride of the proposal table
     const int NG = (D + 255) >> 8;          // 1..4 dim groups
-    const int NSW = TEAM_NW / NG;           // sample stripes
+    const int NSW = NWT / NG;               // sample stripes
     const bool active = wave < NG * NSW;
     const int g = wave % NG, sw = wave / NG;
     const int d0 = g * 256 + lane * 4;
@@ -701,10 +709,10 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
   }
 #ifdef IREC_TEAM_STAMPS
   if (A.dbg && lane == 0)
-    for (int k = 0; k < 12; ++k) A.dbg[((size_t)blockIdx.x * (TEAMS * 4) + wave_wg) * 16 + k] = st_acc[k];
+    for (int k = 0; k < 12; ++k) A.dbg[((size_t)blockIdx.x * (TEAMS * NWT) + wave_wg) * 16 + k] = st_acc[k];
   if (A.dbg && lane == 0) {
-    A.dbg[((size_t)blockIdx.x * (TEAMS * 4) + wave_wg) * 16 + 12] = __builtin_amdgcn_s_memtime() - st_t0;
-    A.dbg[((size_t)blockIdx.x * (TEAMS * 4) + wave_wg) * 16 + 13] = __builtin_amdgcn_s_memrealtime() - st_r0;
+    A.dbg[((size_t)blockIdx.x * (TEAMS * NWT) + wave_wg) * 16 + 12] = __builtin_amdgcn_s_memtime() - st_t0;
+    A.dbg[((size_t)blockIdx.x * (TEAMS * NWT) + wave_wg) * 16 + 13] = __builtin_amdgcn_s_memrealtime() - st_r0;
   }
 #endif
 #undef TSTAMP
@@ -713,21 +721,27 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
 // ---- launcher ----
 bool ten_applies(int B, int S) { return B >= 2 && B <= TEN_NB && S >= 1 && (int64_t)S * TEN_NB <= TEN_MAXC; }
 size_t ten_lds_for(int teams) { return ten_lds_total(teams); }
-template <int TEAMS>
+template <int TEAMS, int NWT = TEAM_NW>
 static hipError_t launch_ten_t(const EncArgs &A, int grid, hipStream_t st) {
   const size_t lds = ten_lds_total(TEAMS);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_ten_kernel<TEAMS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_ten_kernel<TEAMS, NWT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((encode_ten_kernel<TEAMS>), dim3(grid), dim3(TEAMS * TEAM_NT), lds, st, A);
+  hipLaunchKernelGGL((encode_ten_kernel<TEAMS, NWT>), dim3(grid), dim3(TEAMS * NWT * 64), lds, st, A);
   return hipGetLastError();
 }
+// teams = 3: the batch build (three 4-wave teams); teams = 2: two 8-wave teams (calls of at most two blocks per CU)
 hipError_t launch_encode_ten(const EncArgs &A, int teams, int grid, hipStream_t st) {
   if (!ten_applies(A.B, A.S) || A.coop_W > 1 || A.out_margin != nullptr) return hipErrorInvalidValue;
   switch (teams) {
     case 3: return launch_ten_t<3>(A, grid, st);
-    case 2: return launch_ten_t<2>(A, grid, st);
+#if IREC_TEN_WIDE
+    case 2: return launch_ten_t<2, 8>(A, grid, st);
+#else
+    case 2: return launch_ten_t<2, 4>(A, grid, st);
+#endif
     default: return hipErrorInvalidValue;
   }
 }
+int ten_waves_per_team(int teams) { return (teams == 2 && IREC_TEN_WIDE) ? 8 : 4; }
 
 } // namespace irec
