@@ -4,7 +4,7 @@
 # written under gpurun_out/$TAG/ as it goes (no output held back behind a pipe).
 set -u
 export TMPDIR=/tmp
-TAG=${TAG:-r05d}
+TAG=${TAG:-r06v}
 STAGES=${STAGES:-ab}    # a: GPU suite, smoke;  b: PMC passes -> traffic.json, bench line, kernel trace of the same command;  g: sweep grid, decoder bench;  c: end-to-end shim
 O=gpurun_out/$TAG
 mkdir -p $O
@@ -12,10 +12,14 @@ if [[ $STAGES == *a* ]]; then
 echo "== pytest -m gpu"; timeout -k 10 1500 python -m pytest tests -q -m gpu > $O/pytest_gpu.full.log 2>&1; grep -v amdgpu.ids $O/pytest_gpu.full.log | tail -8 > $O/pytest_gpu.log; cat $O/pytest_gpu.log
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 fi
+if [[ $STAGES == *t* ]]; then   # the reference's default settings (configs[3]: B = 10, S = 20) on encode_ten_kernel: PMC passes of one 1024-latent call
+  LATENTS=1024 BEAMS=10 EPS1=1.0 MAXK=32 IREC_VARIANT=auto TAG=${TAG}_ten KERNEL=encode_ten scripts/gpu_pmc_variant.sh > /dev/null 2>&1
+  mkdir -p $O/pmc_ten; cp gpurun_out/pmc_${TAG}_ten/*.summary $O/pmc_ten/ 2>/dev/null; cat $O/pmc_ten/*.summary | cut -c1-160
+fi
 if [[ $STAGES == *b* ]]; then
 L=8192
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
-           "GRBM_GUI_ACTIVE FETCH_SIZE" "WRITE_SIZE GRBM_COUNT"; do
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_WAIT_INST_LDS" "GRBM_GUI_ACTIVE FETCH_SIZE" "WRITE_SIZE GRBM_COUNT"; do
   name=$(echo $set | tr ' ' '_' | cut -c1-40)
   echo "== pmc $name"
   timeout -k 10 900 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_$name -- python3 bench.py --steps 2 --warmup 1 --latents $L --no-cpu-baseline --no-secondary > $O/pmc_$name.log 2>&1
