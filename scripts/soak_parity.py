@@ -24,10 +24,13 @@ for case in range(n_cases):
         D = int(rng.choice([1025, 1279, 1500, 2048, 2049, 2500, 3000, 4096, 6000, 9217, int(rng.integers(1025, 4200)), int(rng.integers(1025, 12000))]))
         B = int(rng.choice([1, 2, 7, 10, 11, 20, 20, 10, 21, 25, 30, 31, 32, 33, 41, 50, 60, 61, 100, 256])); omega = float(rng.choice([2.0, 3.0, 3.5, float(rng.uniform(1.0, 3.6))]))
         eps1 = float(rng.choice([1.0, 1.2]))
+    if os.environ.get("SOAK_TEN"):   # round 6: the ten-beam encoder (irec_ten.hip): 2 <= B <= 10, S * 10 <= 256, every block size up to 1024, extreme statistics
+        B = int(rng.integers(2, 11)); omega = float(rng.choice([0.5, 1.0, 2.0, 3.0, 3.2, float(rng.uniform(0.1, 3.2))])); eps1 = 1.0
+        D = int(rng.choice([1, 2, 3, 4, 5, 63, 64, 65, 192, 255, 256, 257, 511, 512, 513, 767, 768, 769, 777, 1000, 1023, 1024, int(rng.integers(1, 1025))]))
     S = int(np.exp(omega * eps1))
     if S * B * D > (1.3e7 if (os.environ.get("SOAK_BIG") or os.environ.get("SOAK_LARGE")) else 6e6):          # keep the oracle fast
         continue
-    NT = int(rng.choice([1, 2, 3, 5, 8]))   # tensors per call (= blocks per call: both teams of a CU get work)
+    NT = int(rng.choice([1, 2, 3, 5, 8] + ([16, 40, 300] if os.environ.get("SOAK_TEN") else [])))   # tensors per call (= blocks per call: both teams of a CU get work)
     def draw():
         style = rng.integers(0, 5)
         mp = rng.normal(0, 1, D); lsp = rng.normal(0, 0.5, D); sp = np.exp(lsp)
