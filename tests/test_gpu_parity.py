@@ -485,6 +485,19 @@ def test_gang_calls_under_contention_match_the_one_team_form(engine, monkeypatch
     assert e.value.code == 0
 
 
+def test_ten_beam_encoder_random_shapes_against_the_oracle(engine, monkeypatch):
+    """scripts/soak_parity.py SOAK_TEN=1 in small (round 6): random blocks of 1 .. 1024 dims, 2 .. 10 beams, S * 10 <= 256, 1 .. 300 blocks per
+    call, benign to extreme statistics, K up to 300 (beyond the table window: the second pass), every encoder variant against the oracle --
+    the team variant runs encode_ten_kernel.  The long run: profiles/r06w/soak_ten.log (31 709 blocks, 0 mismatches)."""
+    import runpy
+    monkeypatch.setenv("SOAK_TEN", "1")
+    monkeypatch.setenv("SOAK_CASES", "70")
+    monkeypatch.setenv("SOAK_SEED", "23")
+    with pytest.raises(SystemExit) as e:
+        runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "soak_parity.py"), run_name="__main__")
+    assert e.value.code == 0
+
+
 def test_split_encoder_and_shared_rows_under_contention_match_the_unshared_form(engine, monkeypatch):
     """The same stress for the other two cooperative forms (round 5's review, Next #3c: only the gang form had a contention test): three
     threads issue calls of blocks of at most 1024 dims back to back on their own streams -- calls of fewer than 64 blocks take the split
