@@ -770,6 +770,9 @@ bool share_all_auto(const irec_context *ctx, const Plan &pl, const irec_params *
       irec::team_ws_extra_for(B, S, 2) > irec::team_ws_extra_for(B, S, 0) || irec::team_count_for(B, S, 0) < 2)
     return false;
   const int64_t W = std::min<int64_t>(std::min<int64_t>(8, S), 2LL * n_cu / n_blocks);
+  // (round 6: calls the ten-beam encoder serves stay whole -- a lone 10 x 20 chain on encode_ten_kernel is as fast as or faster than the same
+  //  row shared by partners on the team encoder: 126 / 180 / 252 blocks 0.17 / 0.18 / 0.18 ms against 0.18 / 0.19 / 0.20, 72 blocks level)
+  if (B <= 10 && !(p->flags & IREC_FLAG_NO_TEN) && irec::ten_applies(B, S)) return false;
   return B > 10 ? W >= 3 : (W >= 2 && n_blocks <= n_cu);
 }
 int team_share_width(const irec_context *ctx, const Plan &pl, const irec_params *p, int64_t n_blocks, int shape, int64_t *first, int *grid) {

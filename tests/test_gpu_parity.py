@@ -1485,12 +1485,16 @@ def test_mid_size_calls_take_the_eight_wave_team(engine, oracle, B, n_latents, w
     (irec_encode_plan: the two-team kernel, split = W); otherwise, 10 < B <= 20, the call runs ONE 8-wave beam-striped team per CU.
     A larger call of the same coder takes a multi-team shape without sharing; the oracle's outputs every way."""
     q = [np.stack([oracle.synthetic_latent(300 + i, 8192)[j] for i in range(n_latents)]) for j in range(4)]
-    eps1 = 1.2 if B > 10 else 1.0
+    eps1 = 1.2      # (S = 36.  Round 6: with S * 10 <= 256 -- the reference's default S = 20 -- a call of at most ten beams stays whole on
+                    #  encode_ten_kernel, whose lone chain is as fast as the shared rows of the team encoder: asserted below)
     S = oracle.n_samples(3.0, eps1)
     c = _coder(3.0, B, eps1, block_size=1000)
     lay = engine.layout(n_latents, 8192, 1000, 42)
     plan = engine.plan(c._params(), lay, 32)
     assert 64 <= lay.n_blocks <= plan["n_cu"], plan
+    if B <= 10:
+        ten = engine.plan(_coder(3.0, B, 1.0, block_size=1000)._params(), lay, 32)
+        assert ten["kernel"] == "encode_ten_kernel<3>" and ten["split"] == 0, ten
     if want_W:
         nb = 10 if B <= 10 else 20
         assert plan["kernel"] == f"encode_team_kernel<{nb},2,1>" and plan["teams_per_wg"] == 2 and plan["split"] == want_W, plan
@@ -1533,8 +1537,8 @@ def test_one_to_two_blocks_per_cu_take_the_two_team_shape(engine, oracle, B, eps
 
 
 @pytest.mark.parametrize("B,eps1,n_latents,shape,extra,want_W", [(20, 1.2, 38, "default", 0, 2), (20, 1.2, 38, "3", 0, 5), (20, 1.2, 29, "default", 0, 8),
-                                                                (13, 1.2, 45, "3", 0, 3), (10, 1.0, 28, "default", 0, 2),
-                                                                (7, 1.0, 14, "default", 0, 4), (20, 1.2, 14, "default", 0, 4)])
+                                                                (13, 1.2, 45, "3", 0, 3), (10, 1.2, 28, "default", 0, 2),
+                                                                (7, 1.2, 14, "default", 0, 4), (20, 1.2, 14, "default", 0, 4)])
 def test_calls_of_one_to_two_blocks_per_cu_share_rows_between_teams(engine, oracle, B, eps1, n_latents, shape, extra, want_W):
     """Round 4: in a call of n_CU < blocks < teams * n_CU every CU gets ONE whole block; each row beyond that is coded by W teams
     in the idle team slots of W CUs, which split its samples, exchange their sort keys as tagged granules and then run the same
