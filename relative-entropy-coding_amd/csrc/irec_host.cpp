@@ -1025,11 +1025,9 @@ irec_status irec_encode_plan(const irec_context *ctx, const irec_params *p, int6
     out->teams_per_wg = n_teams;
     out->lds_bytes = (int32_t)irec::team_lds_for(B, S, shape);
     if (const int tt = irec::team_ten_teams(B, S, shape); tt && out->split < 2 && !(p->flags & IREC_FLAG_NO_TEN)) {   // plain call of at most ten beams
-      const int nwt = irec::ten_waves_per_team(tt);
-      if (nwt == 4) std::snprintf(out->kernel, sizeof out->kernel, "encode_ten_kernel<%d>", tt);
-      else std::snprintf(out->kernel, sizeof out->kernel, "encode_ten_kernel<%d,%d>", tt, nwt);
+      std::snprintf(out->kernel, sizeof out->kernel, "encode_ten_kernel<%d>", tt);
       out->lds_bytes = (int32_t)irec::ten_lds_for(tt);
-      out->teams_per_wg = tt; out->waves_per_wg = nwt * tt;
+      out->teams_per_wg = tt; out->waves_per_wg = 4 * tt;
       out->grid = batch_grid(n_blocks, std::min(pl.grid_cap / tt, n_cu));
     }
   } else if (pl.fast) {
@@ -1271,8 +1269,10 @@ irec_status irec_beam_encode_ex(irec_context *ctx, const irec_params *p, int64_t
       }
 #endif
     } else if (pl.team) { // grid_cap counts teams (= scratch slabs): two per workgroup, one workgroup per CU
-      const int n_teams = cd.teams;
       const int tgrid = cd.grid;
+#ifdef IREC_HOST_STAMPS
+      const int n_teams = cd.teams;
+#endif
       if (cd.W >= 2) {   // rows [share_first, n_blocks) are coded by W teams each; the static round deals every slot
         A.coop_W = cd.W; A.tsplit_first = cd.share_first;
         A.coop_test_orphan = (p->flags & IREC_FLAG_TEST_SPLIT_ORPHAN) ? 1 : 0;
@@ -1285,7 +1285,7 @@ irec_status irec_beam_encode_ex(irec_context *ctx, const irec_params *p, int64_t
       if (!ctx->d_dbg) { if (irec_status s2 = deferred_pass()) return s2; }
       if (ctx->d_dbg) { // diagnostic build (-DIREC_TEAM_STAMPS) only: per-wave phase cycles, wave 0 of a team vs the others
         const bool ten_call = !cd.W && !out_margin && !(p->flags & IREC_FLAG_NO_TEN) && irec::team_ten_teams(p->n_beams, p->n_samples, pl.shape) != 0;
-        const int nwv = ten_call ? irec::ten_waves_per_team(n_teams) * n_teams : irec::team_waves_for(p->n_beams, p->n_samples, pl.shape);
+        const int nwv = ten_call ? 4 * n_teams : irec::team_waves_for(p->n_beams, p->n_samples, pl.shape);
         std::vector<unsigned long long> h((size_t)tgrid * nwv * 16);
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(h.data(), ctx->d_dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));

@@ -127,7 +127,6 @@ hipError_t launch_alpha_choice_all(int64_t seed, int32_t S, int32_t K_tab, const
 bool ten_applies(int B, int S);
 size_t ten_lds_for(int teams);
 hipError_t launch_encode_ten(const EncArgs &A, int teams, int grid, hipStream_t st);
-int ten_waves_per_team(int teams);                       // 4, or 8 for the two-team build
 int team_ten_teams(int B, int S, int shape_override);   // teams per workgroup of encode_ten_kernel when a plain call of this shape takes it, else 0
 // blocks of more than 1024 dims: a team walks the block in chunks of 1024 over the team encoder's tables (irec_team.hip, encode_chunk_kernel)
 bool chunk_applies(int B, int S, int max_dim);          // B <= 60, max_dim > 1024, a step's partials and running scores fit the LDS next to the tables

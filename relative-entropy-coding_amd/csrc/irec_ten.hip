@@ -32,25 +32,6 @@
 #define IREC_TEN_ABLATE 0       // diagnostics (make variant_ten): phases replaced by stubs -- 1 selection, 2 step constants, 4 update arithmetic, 8 keys,
                                 // 16 scoring; the outputs are wrong, the time that remains is the point
 #endif
-#ifndef IREC_TEN_CONSTS_SERIAL
-#define IREC_TEN_CONSTS_SERIAL 1   // 1: the step constants one dim at a time (irec_team.hip's form); 0: the four division chains of a lane interleave
-#endif
-#ifndef IREC_TEN_SELECT_FAST
-#define IREC_TEN_SELECT_FAST 1     // the selection in straight-line vector code with ds_permute compaction (0: scalar loops over ballot masks)
-#endif
-#ifndef IREC_TEN_PREPULL
-#define IREC_TEN_PREPULL 0         // 1: the next hand-out slot is pulled during a block's last step (r06p: 1.5 % SLOWER than pulling at the loop top)
-#endif
-#ifndef IREC_TEN_TREE_VALU
-#define IREC_TEN_TREE_VALU 1       // KL / C_b lane trees on DPP and permlane swaps (0: ds_bpermute)
-#endif
-#ifndef IREC_TEN_WIDE
-#define IREC_TEN_WIDE 0            // 1: the two-team build runs 8-WAVE teams, a block's samples on two stripes (r06u: 128 VGPRs, 304 B of scratch in the
-                                   // serial phases, both stripes repeat selection and update: 302 blocks 0.21 -> 0.25 ms: not taken)
-#endif
-#ifndef IREC_TEN_INPLACE
-#define IREC_TEN_INPLACE 1      // beams updated in place where one wave owns a dim group (0: always double buffered; A/B builds)
-#endif
 namespace irec {
 
 constexpr int TEN_NB = 10;
@@ -195,13 +176,13 @@ __device__ __forceinline__ uint32_t ten_select_fast(const uint32_t (&k)[4], int 
   return (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)cf);
 }
 
-// TEAMS teams per workgroup of NWT waves each: 3 x 4 for batches (a team per block, the other teams' scoring under its serial phases);
-// 2 x 8 for calls of at most two blocks per CU -- a block's samples on two stripes of four waves (sw = wave / NG, as blocks of fewer than four
-// dim groups have them on four waves): a lone chain's scoring, which one wave per SIMD runs at the latency of its own look-ups, halves;
-// every stripe repeats the update for its own registers (stripe 0 stores), the selection is every wave's anyway.
-template <int TEAMS, int NWT = TEAM_NW>
-__global__ __launch_bounds__(TEAMS * NWT * 64, 1) void encode_ten_kernel(EncArgs A) {
-  constexpr int NB = TEN_NB, NT = NWT * 64, NP = NB / 2;
+// TEAMS 4-wave teams per workgroup: three for batches (a team per block, the other teams' scoring under its serial phases), two at the full
+// register budget for calls of at most two blocks per CU.  (Measured and dropped, r06a: FOUR teams at 128 VGPRs -- no spill in the scoring
+// loop -- lose 12 %; two 8-WAVE teams for calls of at most two blocks per CU -- a block's samples on two stripes -- lose 20 % at 302 blocks:
+// 128 VGPRs, 304 B of scratch in the serial phases, both stripes repeat selection and update.)
+template <int TEAMS>
+__global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs A) {
+  constexpr int NB = TEN_NB, NT = TEAM_NT, NWT = TEAM_NW, NP = NB / 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int S = A.S, B = A.B;
   const int lane = threadIdx.x & 63;
@@ -245,8 +226,6 @@ __global__ __launch_bounds__(TEAMS * NWT * 64, 1) void encode_ten_kernel(EncArgs
 #endif
   bool first_block = true;
   int steal = 0;
-  int64_t pre_slot = -1;                     // (thread 0 of a team) the next hand-out slot, pulled one step early: its atomic's round trip
-                                             // to the L2 then lies under a step's serial phase instead of in front of a block's prologue
   for (;;) {
     tsync();
     if (tid == 0) {
@@ -254,9 +233,7 @@ __global__ __launch_bounds__(TEAMS * NWT * 64, 1) void encode_ten_kernel(EncArgs
       if (first_block) {
         r = (int64_t)team * (int64_t)gridDim.x + (int64_t)blockIdx.x;
         r = r < n_static ? xcd_static_row(r, n_static, (int)gridDim.x) : n_slots;
-      } else if (pre_slot >= 0) r = pre_slot;       // pulled during the previous block's last step (below)
-      else r = xcd_pull_row(A, n_static, n_slots, steal);
-      pre_slot = -1;
+      } else r = xcd_pull_row(A, n_static, n_slots, steal);   // (pulling the slot during the previous block's last step: 1.5 % slower, r06p)
       misc[0] = (int32_t)r;
     }
     first_block = false;
@@ -281,7 +258,7 @@ __global__ __launch_bounds__(TEAMS * NWT * 64, 1) void encode_ten_kernel(EncArgs
     const bool active = wave < NG * NSW;
     const int g = wave % NG, sw = wave / NG;
     const int d0 = g * 256 + lane * 4;
-    const bool inplace = IREC_TEN_INPLACE != 0 && NSW == 1;   // one wave per dim group: nobody else reads the beams it overwrites
+    const bool inplace = NSW == 1;          // one wave per dim group: nobody else reads the beams it overwrites
 
     // ---- my 4 dims (split == gather through perm) and the block's KL ----
     float c[4];
@@ -307,7 +284,7 @@ __global__ __launch_bounds__(TEAMS * NWT * 64, 1) void encode_ten_kernel(EncArgs
       }
     }
     {
-      const double gs = IREC_TEN_TREE_VALU ? wave_tree_sum_valu(klacc) : wave_tree_sum(klacc);
+      const double gs = wave_tree_sum_valu(klacc);   // (the lane tree on DPP / permlane swaps: +1.5 % against six ds_bpermute trips, r06p)
       if (sw == 0 && active && lane == 0) sm->gpart[g] = gs;
       tsync();
     }
@@ -354,9 +331,8 @@ __global__ __launch_bounds__(TEAMS * NWT * 64, 1) void encode_ten_kernel(EncArgs
         sa[i] = valid[i] ? sc.sa : 0.f; cH[i] = valid[i] ? sc.H : 0.f;
         m[i] = valid[i] ? sc.m : 0.f; cA[i] = valid[i] ? sc.A : 0.f; cBv[i] = valid[i] ? sc.Bv : 0.f;
         c[i] = c[i] + sc.a; // cumulative_auxiliary_variance += auxiliary_var (:109)
-#if IREC_TEN_CONSTS_SERIAL
-        __builtin_amdgcn_sched_barrier(0); // one dim at a time: the division sequences are register hungry
-#endif
+        __builtin_amdgcn_sched_barrier(0); // one dim at a time: the division sequences are register hungry (letting the four chains
+                                           // interleave changes nothing: r06i -- the phase is bound by VALU issue, not by the chain)
       }
     };
     // ---- prologue: step 0 has one (all-zero) beam ----
@@ -373,7 +349,7 @@ __global__ __launch_bounds__(TEAMS * NWT * 64, 1) void encode_ten_kernel(EncArgs
         G2[0][i].x = beam_G(0.f, m[i], cA[i], cBv[i], sa[i]);
         cacc = beam_C_term(cacc, 0.f, m[i], cA[i], cBv[i]);
       }
-      const float cg = IREC_TEN_TREE_VALU ? wave_tree_sum_valu(cacc) : wave_tree_sum(cacc);
+      const float cg = wave_tree_sum_valu(cacc);
       if (active && sw == 0 && lane == 0) sm->cpart[0][0][g] = cg;
       // (visibility of the C_b partials: the barrier after scoring)
     }
@@ -518,9 +494,6 @@ __global__ __launch_bounds__(TEAMS * NWT * 64, 1) void encode_ten_kernel(EncArgs
       TSTAMP(3);
       const int Bnew = B < N ? B : N;
       const bool last = (t == K - 1);
-#if IREC_TEN_PREPULL
-      if (last && tid == 0) pre_slot = xcd_pull_row(A, n_static, n_slots, steal);   // the next block's slot, a serial phase early
-#endif
       uint32_t bv_new = 0u;
       int32_t hs_new = 0;
       if (active) {
@@ -555,11 +528,7 @@ __global__ __launch_bounds__(TEAMS * NWT * 64, 1) void encode_ten_kernel(EncArgs
 #if (IREC_TEN_ABLATE & 1)
         const uint32_t sel = (uint32_t)lane + (key[0] & 1u);
 #else
-#if IREC_TEN_SELECT_FAST
         const uint32_t sel = ten_select_fast(key, N, Bnew, lane, [&]() { TSTAMP(7); });   // lane r < Bnew: flat index of rank r
-#else
-        const uint32_t sel = ten_select(key, N, Bnew, lane);        // lane r < Bnew: flat index of rank r
-#endif
 #endif
         int32_t v_sp, v_bp;
         {
@@ -721,27 +690,21 @@ __global__ __launch_bounds__(TEAMS * NWT * 64, 1) void encode_ten_kernel(EncArgs
 // ---- launcher ----
 bool ten_applies(int B, int S) { return B >= 2 && B <= TEN_NB && S >= 1 && (int64_t)S * TEN_NB <= TEN_MAXC; }
 size_t ten_lds_for(int teams) { return ten_lds_total(teams); }
-template <int TEAMS, int NWT = TEAM_NW>
+template <int TEAMS>
 static hipError_t launch_ten_t(const EncArgs &A, int grid, hipStream_t st) {
   const size_t lds = ten_lds_total(TEAMS);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_ten_kernel<TEAMS, NWT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(encode_ten_kernel<TEAMS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((encode_ten_kernel<TEAMS, NWT>), dim3(grid), dim3(TEAMS * NWT * 64), lds, st, A);
+  hipLaunchKernelGGL((encode_ten_kernel<TEAMS>), dim3(grid), dim3(TEAMS * TEAM_NT), lds, st, A);
   return hipGetLastError();
 }
-// teams = 3: the batch build (three 4-wave teams); teams = 2: two 8-wave teams (calls of at most two blocks per CU)
 hipError_t launch_encode_ten(const EncArgs &A, int teams, int grid, hipStream_t st) {
   if (!ten_applies(A.B, A.S) || A.coop_W > 1 || A.out_margin != nullptr) return hipErrorInvalidValue;
   switch (teams) {
     case 3: return launch_ten_t<3>(A, grid, st);
-#if IREC_TEN_WIDE
-    case 2: return launch_ten_t<2, 8>(A, grid, st);
-#else
-    case 2: return launch_ten_t<2, 4>(A, grid, st);
-#endif
+    case 2: return launch_ten_t<2>(A, grid, st);
     default: return hipErrorInvalidValue;
   }
 }
-int ten_waves_per_team(int teams) { return (teams == 2 && IREC_TEN_WIDE) ? 8 : 4; }
 
 } // namespace irec

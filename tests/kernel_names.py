@@ -45,9 +45,9 @@ def canonical(plan_kernel, split=0):
         return "encode_generic_kernel"
     if k == "encode_lone_kernel":
         return k
-    m = re.match(r"encode_ten_kernel<(\d+)(?:,(\d+))?>$", k)
+    m = re.match(r"encode_ten_kernel<(\d+)>$", k)
     if m:
-        return f"encode_ten_kernel<{m.group(1)},{m.group(2) or 4}>"
+        return f"encode_ten_kernel<{m.group(1)}>"
     m = re.match(r"encode_team_kernel<(\d+),(\d+),(\d+)((?:,\w+)*)>$", k)
     if m:
         tags = set(t for t in m.group(4).split(",") if t)

@@ -532,21 +532,30 @@ def test_a_gang_really_short_of_cus_gives_up_and_is_coded_again(engine, oracle):
     layb = engine.layout(200, 65536, None, 7)
     hog = engine.params(3.0, S, B, irec._lib.IREC_FLAG_NO_SPLIT)
     assert engine.plan(hog, layb, 1024)["grid"] == 200
-    c = irec.BeamSearchCoder(kl_per_partition=3., n_beams=B, extra_samples=1.2, block_size=None)
-    c._max_K_hint = 256
-    torch.cuda.synchronize()
-    side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        Kb, _, _ = engine.encode_blocks(hog, layb, *qb, 7, 1024)            # ~2.6 s on 200 CUs
-    time.sleep(0.2)                                                          # (the long call is running)
-    t0 = time.perf_counter()
-    idx, sample = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42)
-    t_gang = time.perf_counter() - t0
-    print(f"[gang short of CUs] give-ups {c._split_strikes}, {t_gang:.2f} s until the call was coded")
-    assert [int(v) for v in idx] == want and torch.equal(sample, sample1)
-    assert c._split_strikes == 1 and t_gang > 0.1                            # it did give up, and was coded again without sharing
-    torch.cuda.synchronize()
-    assert int(Kb.cpu().min()) > 100                                         # the long call coded its blocks meanwhile
+    # (HIP multiplexes its streams onto a few hardware queues: a side stream that lands on the queue of the current stream runs the two calls
+    #  one after the other -- no shortage of CUs, nothing to give up, 2.6 s until the call is coded.  Which queue a new stream gets depends on
+    #  how many the process has made before, i.e. on the tests that ran earlier: up to four side streams are tried.)
+    gave_up = False
+    for attempt in range(4):
+        c = irec.BeamSearchCoder(kl_per_partition=3., n_beams=B, extra_samples=1.2, block_size=None)
+        c._max_K_hint = 256
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            Kb, _, _ = engine.encode_blocks(hog, layb, *qb, 7, 1024)            # ~2.6 s on 200 CUs
+        time.sleep(0.2)                                                          # (the long call is running)
+        t0 = time.perf_counter()
+        idx, sample = c.encode(_normal(q[0], q[1]), _normal(q[2], q[3]), seed=42)
+        t_gang = time.perf_counter() - t0
+        print(f"[gang short of CUs] attempt {attempt}: give-ups {c._split_strikes}, {t_gang:.2f} s until the call was coded")
+        assert [int(v) for v in idx] == want and torch.equal(sample, sample1)
+        torch.cuda.synchronize()
+        assert int(Kb.cpu().min()) > 100                                         # the long call coded its blocks meanwhile
+        if c._split_strikes == 1 and t_gang > 0.1:                               # it did give up, and was coded again without sharing
+            gave_up = True
+            break
+        assert c._split_strikes == 0 and t_gang > 1.0, (c._split_strikes, t_gang)   # (else: the two calls never met on the device)
+    assert gave_up
 
 
 def test_gang_calls_inside_a_replayed_graph(engine, oracle):
