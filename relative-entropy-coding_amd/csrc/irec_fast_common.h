@@ -7,15 +7,6 @@
 #include "irec_device.h"
 #include "irec_kernels.h"
 
-#ifndef IREC_QUICK_SELECT
-#define IREC_QUICK_SELECT 1   // the round-4 form of the top-B selection where it pays (0: the form of rounds 1-3 everywhere; A/B builds)
-#endif
-#ifndef IREC_RANK_KEY32
-#define IREC_RANK_KEY32 1   // rank the survivors by the key alone first (0: always by (key, ~flat); A/B builds)
-#endif
-#ifndef IREC_SELECT_ASSUME
-#define IREC_SELECT_ASSUME 1   // tell the compiler N <= 1024 where the host guarantees it (0: A/B builds)
-#endif
 namespace irec {
 
 // ======================================================================================================
@@ -195,7 +186,7 @@ __device__ __forceinline__ bool rank_survivors(SM *sm, uint32_t C, int Bnew, int
   volatile unsigned long long *slot = sm->cand;   // (another lane may own the slot: no store-to-load forwarding)
   if (tid < (int)C) slot[rank] = (unsigned long long)tid;
   const bool lost = tid < (int)C && slot[rank] != (unsigned long long)tid;
-  if (!IREC_RANK_KEY32 || __ballot(lost)) { // wave-uniform
+  if (__ballot(lost)) { // wave-uniform
     rank = 0u;
 #pragma unroll
     for (int l0 = 0; l0 < 64; l0 += 8) {
@@ -232,24 +223,15 @@ __device__ __forceinline__ bool rank_survivors(SM *sm, uint32_t C, int Bnew, int
 //   * later blocks: one counter per XCD, value c of XCD x -> row first + 64 (c / 8) + 8 x + c mod 8; an XCD whose share has
 //     run out takes from the next one's (rows of a counter only grow, so "past the end" is final; this is also what codes
 //     the shares of XCDs that have no workgroup of the launch).  The counters lie 256 bytes apart.
-#ifndef IREC_XCD_HANDOUT
-#define IREC_XCD_HANDOUT 1
-#endif
 __device__ __forceinline__ int64_t xcd_static_row(int64_t u, int64_t n_static, int grid) {
-#if IREC_XCD_HANDOUT
   const int64_t m = u & ~(int64_t)63;
   if ((grid & 7) != 0 || m + 64 > n_static) return u;
   const int v = (int)(u & 63);
   return m + ((v & 7) << 3) + (v >> 3);
-#else
-  (void)n_static; (void)grid;
-  return u;
-#endif
 }
 // One lane calls this.  `steal` (0 at kernel start, kept by the caller) counts the XCD shares this caller found exhausted.
 // Returns n when nothing is left.
 __device__ __forceinline__ int64_t xcd_pull_row(const EncArgs &A, int64_t first, int64_t n, int &steal) {
-#if IREC_XCD_HANDOUT
   if (first >= n) return n;                       // the static round dealt every row: no counter is touched
   const uint32_t span = (uint32_t)(n - first);    // (n < 2^31: irec_beam_encode)
   for (; steal < 8; ++steal) {
@@ -260,16 +242,9 @@ __device__ __forceinline__ int64_t xcd_pull_row(const EncArgs &A, int64_t first,
     if (c < share) return first + (int64_t)(c >> 3) * 64 + (int64_t)(8u * x + (c & 7u));
   }
   return n;
-#else
-  (void)steal;
-  const int64_t row = first + (int64_t)atomicAdd(A.counter, 1u);
-  return row < n ? row : n;
-#endif
 }
 
-#ifndef IREC_SELECT_PAR_MIN
-#define IREC_SELECT_PAR_MIN 4096   // candidates per step from which every wave takes part in the streamed selection (0x7FFFFFFF: never)
-#endif
+constexpr int SELECT_PAR_MIN = 4096;   // candidates per step from which every wave takes part in the streamed selection
 // QUICK (round 4, scripts/microbench/select_rates.hip): the threshold by probing the lane counts and the ranks by constant-lane
 // broadcasts -- 6.6 k -> 5.0 k cycles per selection at 720 candidates.  The encoders whose calls are bound by a lone chain's serial
 // phases take it (one-table / split encoder, the two-team builds: 9 blocks 0.137 -> 0.131 ms); the three-team 168-VGPR builds keep the
@@ -281,7 +256,7 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
   int32_t *sel_s = sm->sel_s, *sel_b = sm->sel_b;
   unsigned long long t0 = dbg ? stamp_now() : 0ull;
   // (streamed selection by every wave, below: its lane-maxima array lies over cand[], which is idle until the compaction)
-  const bool par = NWV > 1 && N > IREC_SELECT_PAR_MIN;
+  const bool par = NWV > 1 && N > SELECT_PAR_MIN;
   uint32_t *lane_max = reinterpret_cast<uint32_t *>(sm->cand);
   if (par) { if (tid < 64) lane_max[tid] = 0u; if (tid == 0) sm->misc[4] = 0; }
   sync(); // keys written by all waves
@@ -323,7 +298,7 @@ __device__ __forceinline__ void select_topB_sync(uint32_t *key, int N, int Bnew,
     done = sm->misc[7] != 0;
   }
   else if (par) {
-    // N beyond IREC_SELECT_PAR_MIN (B = 30 / 50 with hundreds of samples; the keys may lie in the L2-resident slab): EVERY
+    // N beyond SELECT_PAR_MIN (B = 30 / 50 with hundreds of samples; the keys may lie in the L2-resident slab): EVERY
     // wave streams a share of the keys -- one wave alone is bound by the latency of its ~N / 256 dependent 16-byte reads per
     // pass (r03g stamps: 5-9 % of a step at B = 50).  Same three stages: (1) lane maxima of a share, merged over the waves
     // by LDS max (virtual lane l = the keys the lanes l of all waves read: 64 disjoint sets, so the Bnew-th largest of their
@@ -677,80 +652,54 @@ __device__ __forceinline__ int rsn_owner(int lane) {
 //    an add -- 8 instructions instead of ~22.  Inline assembly: the compiler's DPP combiner only folds full-mask moves.
 //    The s_nop in front of each group covers the "VALU write -> DPP read: 2 wait states" hazard, which the hazard
 //    recogniser cannot see inside an asm statement; no instruction of a group reads a register another one of it wrote.
-#ifndef IREC_RS20
-#define IREC_RS20 7   // bit 0: pair arithmetic at distance 32 / 16; bit 1: bank-masked DPP adds at distance 8 / 4; bit 2: DPP adds
-                      // at distance 2 / 1; 0: reduce_scatter_n<20>
-#endif
 typedef float rs_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float reduce_scatter_20(rs_f2 (&a)[10], int lane) {
-  float w[6];
-  if constexpr ((IREC_RS20 & 1) != 0) {
+  float w[5];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      float px = a[k].x, py = a[k].y, qx = a[k + 5].x, qy = a[k + 5].y;
-      swap32(px, qx); swap32(py, qy);
-      a[k] = (rs_f2){px, py} + (rs_f2){qx, qy};
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      float px = a[k].x, py = a[k].y, qx = a[k + 2].x, qy = a[k + 2].y;
-      swap16(px, qx); swap16(py, qy);
-      a[k] = (rs_f2){px, py} + (rs_f2){qx, qy};
-    }
-    float tx = a[4].x, ty = a[4].y;
-    swap16(tx, ty);
-    w[0] = a[0].x; w[1] = a[0].y; w[2] = a[1].x; w[3] = a[1].y; w[4] = tx + ty;
-  } else {
-    float v[20];
-#pragma unroll
-    for (int k = 0; k < 10; ++k) { v[2 * k] = a[k].x; v[2 * k + 1] = a[k].y; }
-    rsn_stage<32, 20>(v, lane);
-    rsn_stage<16, 10>(v, lane);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) w[k] = v[k];
+  for (int k = 0; k < 5; ++k) {
+    float px = a[k].x, py = a[k].y, qx = a[k + 5].x, qy = a[k + 5].y;
+    swap32(px, qx); swap32(py, qy);
+    a[k] = (rs_f2){px, py} + (rs_f2){qx, qy};
   }
-  if constexpr ((IREC_RS20 & 2) != 0) {
-    float r0, r1, r2, q0, q1;
-    // distance 8: 5 -> 3 values; pairs (w0, w3), (w1, w4), (w2, -)
-    asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %1, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %2, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %1, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc"
-        : "=&v"(r0), "=&v"(r1), "=&v"(r2) : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]));
-    // distance 4: 3 -> 2 values; pairs (r0, r2), (r1, -)
-    asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %1, %3, %3 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa"
-        : "=&v"(q0), "=&v"(q1) : "v"(r0), "v"(r1), "v"(r2));
-    w[0] = q0; w[1] = q1;
-  } else {
-    rsn_stage<8, 5>(w, lane);
-    rsn_stage<4, 3>(w, lane);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    float px = a[k].x, py = a[k].y, qx = a[k + 2].x, qy = a[k + 2].y;
+    swap16(px, qx); swap16(py, qy);
+    a[k] = (rs_f2){px, py} + (rs_f2){qx, qy};
   }
-  if constexpr ((IREC_RS20 & 4) != 0) {
-    // distance 2: both candidates add their partner's copy (a quad permutation has no per-lane mask), one select picks the
-    // value the lane keeps; distance 1: the closing all-reduce
-    float s0, s1, tot;
-    asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %1, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-        : "=&v"(s0), "=&v"(s1) : "v"(w[0]), "v"(w[1]));
-    const float kept = (lane & 2) ? s1 : s0;
-    asm("s_nop 1\n\t"
-        "v_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
-        : "=&v"(tot) : "v"(kept));
-    return tot;
-  }
-  rsn_stage<2, 2>(w, lane);
-  rsn_stage<1, 1>(w, lane);
-  return w[0];
+  float tx = a[4].x, ty = a[4].y;
+  swap16(tx, ty);
+  w[0] = a[0].x; w[1] = a[0].y; w[2] = a[1].x; w[3] = a[1].y; w[4] = tx + ty;
+  float r0, r1, r2, q0, q1;
+  // distance 8: 5 -> 3 values; pairs (w0, w3), (w1, w4), (w2, -)
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %1, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %2, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %1, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2) : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]));
+  // distance 4: 3 -> 2 values; pairs (r0, r2), (r1, -)
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %1, %3, %3 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %4, %4 row_shr:4 row_mask:0xf bank_mask:0xa"
+      : "=&v"(q0), "=&v"(q1) : "v"(r0), "v"(r1), "v"(r2));
+  // distance 2: both candidates add their partner's copy (a quad permutation has no per-lane mask), one select picks the
+  // value the lane keeps; distance 1: the closing all-reduce
+  float s0, s1, tot;
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+      : "=&v"(s0), "=&v"(s1) : "v"(q0), "v"(q1));
+  const float kept = (lane & 2) ? s1 : s0;
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+      : "=&v"(tot) : "v"(kept));
+  return tot;
 }
 // index (0..19) of the value whose total reduce_scatter_20 leaves in this lane, or -1 (unused slot)
 __device__ __forceinline__ int rs20_owner(int lane) {
-  if constexpr ((IREC_RS20 & 1) == 0) return rsn_owner<20>(lane);
   int o5 = 0, cnt = 5, n = 5;                      // distances 8, 4, 2, 1 over the five values a lane quarter keeps
 #pragma unroll
   for (int dist = 8; dist >= 1; dist >>= 1) {

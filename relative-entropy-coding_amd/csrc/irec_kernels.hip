@@ -959,8 +959,8 @@ __global__ __launch_bounds__(NW * 64, 2) void encode_fast_kernel(EncArgs A) {
         sub_stamp(14);
 #endif
       }
-      if constexpr (SPLIT != 0 && IREC_QUICK_SELECT && IREC_SELECT_ASSUME) __builtin_assume(Ng <= 1024);   // (host, split_width(): S * NB <= 1024 -- the selection's other paths fold away)
-      select_topB<NT, IREC_QUICK_SELECT != 0>(key_s, Ng, Bnew, Bcur, sm, A.dbg ? A.dbg + (size_t)blockIdx.x * 16 : nullptr); // first barrier inside orders key_s writes
+      if constexpr (SPLIT != 0) __builtin_assume(Ng <= 1024);   // (host, split_width(): S * NB <= 1024 -- the selection's other paths fold away)
+      select_topB<NT, true>(key_s, Ng, Bnew, Bcur, sm, A.dbg ? A.dbg + (size_t)blockIdx.x * 16 : nullptr); // first barrier inside orders key_s writes
       IREC_STAMP(2);
       // ---------------- new hashes / back-pointers (beam_search_coder.py:94-95) ----------------
       // (the discrete log of the new hash is a load from the global table when the proposals come from tables: it is issued

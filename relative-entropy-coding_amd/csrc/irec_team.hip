@@ -34,37 +34,12 @@
 #include "irec_fast_common.h"
 #include "irec_team_common.h"
 
-#ifndef IREC_UB3
-#define IREC_UB3 5   // beams per load batch of the update in the register-short builds
-#endif
-#ifndef IREC_ROW_EARLY
-#define IREC_ROW_EARLY 1    // 1: the scoring loop fetches the rows of the chunk after next at the chunk's start instead of its end
-#endif
-#ifndef IREC_LAST_ONE
-#define IREC_LAST_ONE 1     // last step: only beam 0 is gathered and formed (0: all B, A/B builds; 2: also leaves the batch
-                            // loop early -- r02i: that form makes the allocator spill G inside the scoring loop, 48 -> 76 ms)
-#endif
-#ifndef IREC_WIDE_V2
-#define IREC_WIDE_V2 1      // one-beam steps: rows prefetched a half batch ahead, two samples per v_pk_fma_f32 (0: round-2 form; 2: also the 168-VGPR builds)
-#endif
-#ifndef IREC_PHANTOM
-#define IREC_PHANTOM 1      // stripes at least half alive score their dead beams as phantoms in the pipelined loop (0: beam-by-beam path)
-#endif
-#ifndef IREC_PRIO_ROTATE
-#define IREC_PRIO_ROTATE 1        // beam-striped one-team builds: the stripe the SIMD arbiter favours rotates every 2^SHIFT chunks (0: off)
-#endif
-#ifndef IREC_PRIO_ROTATE_SHIFT
-#define IREC_PRIO_ROTATE_SHIFT 2
-#endif
 #ifndef IREC_GANG_ABLATE
 #define IREC_GANG_ABLATE 0   // diagnostics (make variant_gang): phases of a gang step removed -- 1 sample loops, 2 update, 4 reduction, 8 selection,
                              // 32 gang barriers; the outputs are wrong, the time that remains is the point (scripts/gang_latency.py --ablate)
 #endif
 #ifndef IREC_PK_ADDR
 #define IREC_PK_ADDR 1          // scoring loop: look-up addresses of a beam pair by one v_pk_add_f32 (0: two v_add_u32; A/B builds)
-#endif
-#ifndef IREC_STEP0_WIDE
-#define IREC_STEP0_WIDE 1   // first step (one beam): RW samples per reduce-scatter instead of one (0: the beam-wise path, A/B builds)
 #endif
 #if defined(IREC_TEAM_MARGIN_TU) || defined(IREC_TEAM_GANG_TU)
 #define IREC_TEAM_AUX_TU 1   // (irec_team_margin.hip / irec_team_gang.hip: this file once more, for their builds only)
@@ -476,7 +451,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
       // Steady state: every beam of my stripe alive -- or at least half of them (B = 50 on the 60-beam build: the third stripe
       // holds beams 40..49): the dead ones are scored as PHANTOM beams (G = 0, the address of beam 0: finite values that no
       // candidate ever reads) rather than sending the whole stripe down the beam-by-beam path below.
-      if (active && Bcur > 1 && (nlive == NBW || (IREC_PHANTOM != 0 && 2 * nlive >= NBW))) {
+      if (active && Bcur > 1 && (nlive == NBW || 2 * nlive >= NBW)) {
         // Steady state, software pipelined by dim slot: the NBW gathers of the NEXT slot (of this sample, of the chunk's
         // next sample, or of the next chunk's first sample) are issued before the current slot's values are consumed, so
         // the wave always has look-ups in flight -- also under the fma chain and the reduce-scatter.  A wave can have at
@@ -541,11 +516,11 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         }
         IREC_ISSUE(zz[0], IREC_AL(0, 0), 0);
         for (int ch = 0; ch < n_chunks; ++ch) {
-          if constexpr (BS >= 2 && IREC_PRIO_ROTATE != 0) {
+          if constexpr (BS >= 2) {
             // One team, BS waves per SIMD (the stripes' waves of one dim group share a SIMD): the SIMD's arbiter favours its
             // oldest wave, which then reaches the pass's barrier a third of the pass early and leaves the SIMD to two waves,
             // then one (r03g stamps: 20-28 % of every wave's time is that wait).  The favoured stripe rotates instead.
-            if ((((ch >> IREC_PRIO_ROTATE_SHIFT) + bs) % BS) == 0) __builtin_amdgcn_s_setprio(1);
+            if ((((ch >> 2) + bs) % BS) == 0) __builtin_amdgcn_s_setprio(1);   // (every four chunks)
             else __builtin_amdgcn_s_setprio(0);
           }
           f2 acc2[SPC][NP];
@@ -553,11 +528,9 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           for (int cc = 0; cc < SPC; ++cc)
 #pragma unroll
             for (int k = 0; k < NP; ++k) acc2[cc][k] = (f2){0.f, 0.f};
-#if IREC_ROW_EARLY
           uint2 ap_new[SPC];                                        // rows of the chunk after next: a whole chunk of lead
 #pragma unroll
           for (int cc = 0; cc < SPC; ++cc) ap_new[cc] = row((ch + 2) * SPC + cc);
-#endif
 #pragma unroll
           for (int qh = 0; qh < NQH; ++qh) {
             constexpr int dummy_ = 0; (void)dummy_;
@@ -568,18 +541,14 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
             } else {
               // next chunk's rows
 #pragma unroll
-#if IREC_ROW_EARLY
               for (int cc = 0; cc < SPC; ++cc) { ap_cur[cc] = ap_nxt[cc]; ap_nxt[cc] = ap_new[cc]; }
-#else
-              for (int cc = 0; cc < SPC; ++cc) { ap_cur[cc] = ap_nxt[cc]; ap_nxt[cc] = row((ch + 2) * SPC + cc); }
-#endif
               IREC_ISSUE(zz[0], IREC_AL(0, 0), 0);
             }
             IREC_CONSUME(zz[qh & 1], q & 3, acc2[q >> 2], h * HP);
           }
           float tot;
           int own;                                                  // value of the chunk whose total this lane ends up with
-          if constexpr (RW == 20 && IREC_RS20 != 0) {               // the accumulator pairs go in as they are
+          if constexpr (RW == 20) {               // the accumulator pairs go in as they are
             rs_f2 a20[10];
 #pragma unroll
             for (int cc = 0; cc < SPC; ++cc)
@@ -600,20 +569,20 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           const int m = ch * SPC + cc;                              // my m-th sample
           if (own >= 0 && (lane & 1) == 0 && m < n_mine && b < nlive) part_s[((size_t)g * SP + m * NSWe + swe) * PS + b_lo + b] = tot;
         }
-        if constexpr (BS >= 2 && IREC_PRIO_ROTATE != 0) __builtin_amdgcn_s_setprio(0);
+        if constexpr (BS >= 2) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int k = 0; k < HP; ++k) asm volatile("" : "+v"(zz[0][k])); // drain the look-ups issued past the last sample
 #undef IREC_ISSUE
 #undef IREC_CONSUME
 #undef IREC_AL
-      } else if (IREC_STEP0_WIDE && active && Bcur == 1 && bs == 0) {
+      } else if (active && Bcur == 1 && bs == 0) {
         // First step (beam_search_coder.py:97-106): ONE beam, so a sample is a single candidate.  Scored beam-wise it would
         // pay a whole reduce-scatter (86 instructions) for 4 look-ups; here RW SAMPLES share one -- a sample sits where a
         // beam sits in the steady state, every total still comes out of the same lane chain and lane tree.  36 samples: two
         // rounds instead of 36 (r02i: step 0 cost half a full step's instructions for a twentieth of its look-ups).
         const int n_mine = Sp > swe ? (Sp - swe + NSWe - 1) / NSWe : 0; // my samples of the pass: s_base + swe, + NSWe, ...
         const uint32_t bet0 = bet[0];
-        if constexpr (IREC_WIDE_V2 != 0 && (ONE || IREC_WIDE_V2 >= 2)) {
+        if constexpr (ONE) {   // (the one-beam builds: every step comes here)
         // two half batches of rows (even sizes: samples go through the fma in pairs), 20 registers as the steady state's
         constexpr int HA = ((RW / 2) + 1) & ~1, HBb = RW - HA;
         static_assert(RW % 2 == 0 && HBb >= 2 && HBb % 2 == 0, "half batches of sample pairs");
@@ -665,7 +634,7 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
           half(apB, &acc2[HA / 2]);
           float tot;
           int own;
-          if constexpr (RW == 20 && IREC_RS20 != 0) {
+          if constexpr (RW == 20) {
             rs_f2 a20[10];
 #pragma unroll
             for (int k = 0; k < 10; ++k) a20[k] = acc2[k];
@@ -875,8 +844,8 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
 #else
       // top-B (beam_search_coder.py:85-89); the thread that records new beam j also extends its hash / back-pointer
       // (:94-95) and notes its parent's table offset, so one barrier publishes everything the update needs
-      constexpr bool QUICK_SEL = IREC_QUICK_SELECT && TEAMS <= 2 && !MULTI_PASS;   // (fast_common.h, select_topB_sync: not the 168-VGPR builds)
-      if constexpr (QUICK_SEL && IREC_SELECT_ASSUME) __builtin_assume(N <= 1024);   // (host: one pass holds S * NB <= CMAX = 1024 candidates -- the
+      constexpr bool QUICK_SEL = TEAMS <= 2 && !MULTI_PASS;   // (fast_common.h, select_topB_sync: not the 168-VGPR builds)
+      if constexpr (QUICK_SEL) __builtin_assume(N <= 1024);   // (host: one pass holds S * NB <= CMAX = 1024 candidates -- the
                                                                 //  selection's other paths fold away: -500 cycles per step, scripts/microbench/select_rates.hip)
       select_topB_sync<NT, QUICK_SEL>(key_s, N, Bnew, Bcur, sm, tid, tsync, nullptr, [&](int j, int32_t sp_, int32_t bp_, uint32_t key_) {
         const int32_t nh = (int32_t)((uint32_t)hsum[cur * TEAM_MB + bp_] + (uint32_t)sp_ * (uint32_t)(69 + t));
@@ -920,16 +889,15 @@ __global__ __launch_bounds__(TEAMS * BS * TEAM_NT, 1) void encode_team_kernel(En
         float cacc[rsn_room(NBW)];
 #pragma unroll
         for (int j = 0; j < rsn_room(NBW); ++j) cacc[j] = 0.f;
-        constexpr int UB = (TEAMS >= 3 || BS >= 2) ? IREC_UB3 : NBW;              // beams per load batch: all at once (G's registers are free) unless registers are short
+        constexpr int UB = (TEAMS >= 3 || BS >= 2) ? 5 : NBW;              // beams per load batch: all at once (G's registers are free) unless registers are short
         // the last step keeps ONE beam: beams[0] is all that leaves the block (beam_search_coder.py:118-122), so the parents,
         // rows and look-ups of the other new beams are not fetched at all
-        const int Bupd = (IREC_LAST_ONE && last) ? 1 : Bnew;
+        const int Bupd = last ? 1 : Bnew;
         // lane j fetches the selection of new beam j and the offset of its parent: two LDS round trips for all beams
         const int32_t v_sp = sel_s[lane < Bnew ? lane : 0], v_bp = sel_b[lane < Bnew ? lane : 0];
         const uint32_t v_bo = sm->sel_bo[lane < Bnew ? lane : 0];
 #pragma unroll
         for (int j0 = 0; j0 < NBW; j0 += UB) {
-          if (IREC_LAST_ONE >= 2 && last && j0 > 0) break;   // (wave-uniform) only beam 0 is formed in the last step
           // ---- issue the batch's global reads (proposal rows, old beams) back to back ----
           uint2 apv[UB];
           float4 obv4[UB];
@@ -1515,7 +1483,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_chunk_kernel(EncArg
                 }
                 float tot;
                 int own;
-                if constexpr (RW == 20 && IREC_RS20 != 0) {
+                if constexpr (RW == 20) {
                   rs_f2 a20[10];
 #pragma unroll
                   for (int cc = 0; cc < SPC; ++cc)
