@@ -10,13 +10,14 @@
 // gather pipe idles.  Here a step has ONE team barrier:
 //   * partials leave the scoring loop as part[candidate][dim group] (one 16-byte read per candidate), double buffered by step parity;
 //   * behind the barrier EVERY wave forms all sort keys (four candidates per lane) and runs the SAME top-B selection in its own
-//     registers -- lane maxima per quad, their B-th largest as threshold, ranks of the survivors by scalar loops over ballot masks
-//     (v_readlane / v_writelane: nothing of it touches the LDS, whose queue the other teams' gathers fill) -- so no wave waits for a
-//     selecting wave and nothing is broadcast: the four waves of a team sit on four SIMDs, the redundancy costs issue slots the
-//     look-up-bound scoring waves of the other teams do not need;
-//   * hash sums and table offsets of the beams live in lanes (lane j = beam j), parents are fetched by v_readlane;
+//     registers -- quad maxima, their B-th largest as threshold, the dozen survivors compacted to one per lane through the LDS crossbar
+//     (ds_permute_b32: no bank is touched), ranked against their broadcasts, sent to the lane of their rank (ten_select_fast) -- so no
+//     wave waits for a selecting wave and nothing is broadcast: the four waves of a team sit on four SIMDs;
+//   * hash sums and table offsets of the beams live in lanes (lane j = beam j), parents are fetched by v_readlane / ds_bpermute;
 //   * all ten parents of a dim quad are loaded before the first new beam is stored, so blocks of more than 512 dims (one wave per
-//     dim group) update their beams IN PLACE: half the slab footprint in the L2.
+//     dim group) update their beams IN PLACE: half the slab footprint in the L2; the update's arithmetic runs on dim pairs (v_pk_*_f32);
+//   * look-up addresses of a beam pair by one v_pk_add_f32 on their bit patterns (see the scoring loop).
+// What bounds it: VALU issue and the LDS gather pipe together, both 68-69 % busy; time follows the VALU work of a step.
 // Serves 2 <= B <= 10, S * 10 <= 256, D <= 1024, plain calls (no shared rows, no margins: those stay on encode_team_kernel<10,..>).
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -41,7 +42,7 @@ struct TenLds {
   float part[2][TEN_MAXC][4];                    // by step parity: group partials of candidate (sample * 10 + beam)
   float cpart[2][16][4];                         // by step parity: group partials of C_b
   double gpart[4];                               // KL group sums of the block in hand
-  int32_t misc[8];                               // [0] hand-out slot, [1] K
+  int32_t misc[8];                               // [0] hand-out slot
   uint32_t bar;                                  // the team barrier's counter
   uint32_t pad[3];
 };
