@@ -164,9 +164,9 @@ struct TableStamps { uint32_t w[4][WS_STAMP_WORDS]; int32_t reuse; };   // all-z
 //                       match under IREC_FLAG_REUSE_TABLES), leave the key PENDING; a slot whose stamp differs is overwritten with the
 //                       key's complement -- never equal to the key, whatever mixture of old and new words a table workgroup reads,
 //   [1, 1 + n_granule)  zero the exchange granules of the call's shared blocks,
-//   [.., + n_cost)      write the cost key (K * dims) << 10 | row of one row each (EncArgs::row_cost),
-//   the rest            build the proposal tables of the slots whose stamp does not match (every table workgroup makes that
-//                       comparison itself: read-only, and a mismatch stays a mismatch while workgroup 0 overwrites the stamp).
+//   [.., + n_table_wgs) build the proposal tables of the slots whose stamp does not match (every table workgroup makes that
+//                       comparison itself: read-only, and a mismatch stays a mismatch while workgroup 0 overwrites the stamp),
+//   the rest (n_cost)   write the cost key (K * dims) << 10 | row of one row each (EncArgs::row_cost).
 // The first workgroup of the encode kernel that follows copies the pending key over the stamp (commit_table_stamps): a table is
 // stamped only once it has been built.
 struct ChoiceJobs { int32_t D[4]; uint16_t *tab[4]; const uint32_t *keep[4]; int64_t hw_end[4]; int32_t n; };

@@ -1827,6 +1827,41 @@ __global__ __launch_bounds__(256, IREC_CHOICE_WPE) void alpha_choice_kernel(int6
   choice_table_rows(seed, S, K_tab, dlog4r, jobs, 0u, (int64_t)blockIdx.x, (int64_t)gridDim.x);
 }
 
+// cost key of one row by one 256-thread workgroup: the row's KL summed in any order -- it places the row, it does not code it.
+// (Two halves: all gathers of the call's statistics -- four dims per thread -- are issued before the first is used.)
+struct CostRow { float v[4][4]; bool ok[4]; bool okD; int D; };
+__device__ __forceinline__ void cost_row_issue(const EncArgs &A, int64_t blk, int t, CostRow &c) {
+  c.D = A.block_dim[blk];
+  const int64_t base = A.block_base[blk];
+  const int32_t pos = A.block_pos[blk];
+  c.okD = c.D >= 1 && c.D <= FAST_MAX_DIM;
+  int64_t ix[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int d = t + 256 * i; c.ok[i] = c.okD && d < c.D; ix[i] = c.ok[i] ? src_index(A, base, pos, d) : 0; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    c.v[i][0] = c.v[i][1] = c.v[i][2] = c.v[i][3] = 1.f;
+    if (c.ok[i]) { c.v[i][0] = A.q_loc[ix[i]]; c.v[i][1] = A.q_scale[ix[i]]; c.v[i][2] = A.p_loc[ix[i]]; c.v[i][3] = A.p_scale[ix[i]]; }
+  }
+}
+__device__ __forceinline__ void cost_row_finish(const PrepArgs &P, const EncArgs &A, int64_t blk, int t, const CostRow &c) {
+  __shared__ double part[4];
+  double acc = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (c.ok[i]) acc = acc + kl_dim(c.v[i][0], c.v[i][1], c.v[i][2], c.v[i][3]);
+  const double ws = wave_tree_sum(acc);
+  if ((t & 63) == 0) part[t >> 6] = ws;
+  __syncthreads();
+  if (t == 0) {
+    const double tot = ((part[0] + part[1]) + part[2]) + part[3];
+    int32_t K = c.okD ? num_aux((float)tot, A.omega) : 0;
+    K = K < 0 ? 0 : (K > (1 << 20) ? (1 << 20) : K);
+    const uint32_t cst = (uint32_t)K * (uint32_t)(c.okD ? c.D : 0);
+    P.cost[blk] = ((cst < (1u << 22) ? cst : (1u << 22) - 1u) << 10) | (uint32_t)blk;   // distinct keys: ties go to the lower row
+  }
+}
+
 // ======================================================================================================
 //  the call's preparation kernel (irec_kernels.h, "The call's preparation kernel"): books, exchange granules, row costs, tables
 // ======================================================================================================
@@ -1867,57 +1902,36 @@ __global__ __launch_bounds__(256, IREC_CHOICE_WPE) void prep_kernel(PrepArgs P, 
     return;
   }
   wg -= P.n_granule;
-  if (wg < P.n_cost) { // ---- cost key of row `wg`: its KL summed in any order -- it places the row, it does not code it
-    __shared__ double part[4];
-    const int64_t blk = wg;
-    const int D = A.block_dim[blk];
-    const int64_t base = A.block_base[blk];
-    const int32_t pos = A.block_pos[blk];
-    const bool okD = D >= 1 && D <= FAST_MAX_DIM;
-    double acc = 0.0;
-    if (okD) {   // (four dims per thread, all loads of a level in flight together)
-      int64_t ix[4];
-      bool ok[4];
+  if (wg < P.n_table_wgs) {
+    // ---- proposal tables: which slots are in place?  (read-only; see irec_kernels.h for why the race with workgroup 0 is benign)
+    uint32_t skip = 0u;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const int d = t + 256 * i; ok[i] = d < D; ix[i] = ok[i] ? src_index(A, base, pos, d) : 0; }
-      float v[4][4];
+    for (int q = 0; q < 4; ++q) {
+      bool same = P.ts.reuse != 0 && P.ts.w[q][0] != 0u;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (ok[i]) { v[i][0] = A.q_loc[ix[i]]; v[i][1] = A.q_scale[ix[i]]; v[i][2] = A.p_loc[ix[i]]; v[i][3] = A.p_scale[ix[i]]; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (ok[i]) acc = acc + kl_dim(v[i][0], v[i][1], v[i][2], v[i][3]);
+      for (int k = 0; k < WS_STAMP_WORDS; ++k) same = same && __builtin_nontemporal_load(p + WS_STAMP_WORD + q * WS_STAMP_WORDS + k) == P.ts.w[q][k];
+      skip |= same ? (1u << q) : 0u;
     }
-    const double ws = wave_tree_sum(acc);
-    if ((t & 63) == 0) part[t >> 6] = ws;
-    __syncthreads();
-    if (t == 0) {
-      const double tot = ((part[0] + part[1]) + part[2]) + part[3];
-      int32_t K = okD ? num_aux((float)tot, A.omega) : 0;
-      K = K < 0 ? 0 : (K > (1 << 20) ? (1 << 20) : K);
-      const uint32_t c = (uint32_t)K * (uint32_t)(okD ? D : 0);
-      P.cost[blk] = ((c < (1u << 22) ? c : (1u << 22) - 1u) << 10) | (uint32_t)blk;   // distinct keys: ties go to the lower row
+    if (P.table_kind == 1) choice_table_rows(P.seed, P.S, P.K_tab, P.dlog4r, P.jobs, skip, (int64_t)wg, (int64_t)P.n_table_wgs);
+    else if (P.table_kind == 2) {
+      // plain rows: the workgroups are dealt to the tables in proportion to their rows (jobs.hw_end counts 1024-entry units)
+      int q = 0;
+      while (q + 1 < P.jobs.n && (int64_t)wg >= P.jobs.hw_end[q]) ++q;
+      const int64_t first = q ? P.jobs.hw_end[q - 1] : 0;
+      if (!((skip >> q) & 1u)) plain_table_rows(P.seed, P.S, P.jobs.D[q], P.K_tab, P.dlog4r, P.jobs.tab[q], (int64_t)wg - first, P.jobs.hw_end[q] - first);
     }
     return;
   }
-  wg -= P.n_cost;
-  // ---- proposal tables: which slots are in place?  (read-only; see irec_kernels.h for why the race with workgroup 0 is benign)
-  uint32_t skip = 0u;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    bool same = P.ts.reuse != 0 && P.ts.w[q][0] != 0u;
-#pragma unroll
-    for (int k = 0; k < WS_STAMP_WORDS; ++k) same = same && __builtin_nontemporal_load(p + WS_STAMP_WORD + q * WS_STAMP_WORDS + k) == P.ts.w[q][k];
-    skip |= same ? (1u << q) : 0u;
-  }
-  if (P.table_kind == 1) choice_table_rows(P.seed, P.S, P.K_tab, P.dlog4r, P.jobs, skip, (int64_t)wg, (int64_t)P.n_table_wgs);
-  else if (P.table_kind == 2) {
-    // plain rows: the workgroups are dealt to the tables in proportion to their rows (jobs.hw_end counts 1024-entry units)
-    int q = 0;
-    while (q + 1 < P.jobs.n && (int64_t)wg >= P.jobs.hw_end[q]) ++q;
-    if ((skip >> q) & 1u) return;
-    const int64_t first = q ? P.jobs.hw_end[q - 1] : 0;
-    plain_table_rows(P.seed, P.S, P.jobs.D[q], P.K_tab, P.dlog4r, P.jobs.tab[q], (int64_t)wg - first, P.jobs.hw_end[q] - first);
+  wg -= P.n_table_wgs;
+  // ---- cost key of row `wg`, a workgroup each, BEHIND the table workgroups.  The key is three dependent gathers away (descriptors ->
+  // permutation -> statistics: 13 us on their own, profiles/r06zz/placement_ab.log) and that chain, not the workgroup count, is what it
+  // costs: the launch is 17 us instead of 13 wherever the cost workgroups stand; in front of the tables they held those back as well
+  // (18.5 us at 302 rows, 29 at 512).  Also measured: the row riding on table workgroup `wg` with its gathers issued first (25 us: they
+  // did not overlap with the table work), a wave per row and four rows per workgroup (30 us).
+  if (wg < P.n_cost) {
+    CostRow cr;
+    cost_row_issue(A, wg, t, cr);
+    cost_row_finish(P, A, wg, t, cr);
   }
 }
 
@@ -2215,7 +2229,7 @@ int64_t prep_table_wgs(int kind, int32_t S, int32_t K_tab, int n, const int32_t 
   return end;
 }
 hipError_t launch_prep(const PrepArgs &P, const EncArgs &A, hipStream_t st) {
-  const int64_t grid = 1 + (int64_t)P.n_granule + P.n_cost + P.n_table_wgs;
+  const int64_t grid = 1 + (int64_t)P.n_granule + P.n_table_wgs + P.n_cost;
   hipLaunchKernelGGL(prep_kernel, dim3((unsigned)grid), dim3(256), 0, st, P, A);
   return hipGetLastError();
 }

@@ -198,7 +198,38 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
 
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap(); // see lds_abs_f32
   commit_table_stamps(A);
+  // Cost-ordered hand-out of a call of one to two rows per CU (two-team build; A.row_cost: distinct keys (K * dims) << 10 | row from the
+  // call's preparation kernel, set by the host only when the static round deals every row).  A CU that holds two rows steps each of them
+  // a fifth slower than a CU that holds one (257 blocks take 17 us longer than 256, profiles/r06zz/blocks_sweep.log), and the call is as long
+  // as its slowest CU: the n - grid workgroups with two busy teams get the 2 (n - grid) CHEAPEST rows, cheapest paired with the costliest
+  // of them, every other workgroup one of the rest.  Every workgroup ranks the rows itself, once, in the LDS the table copies are about
+  // to fill (one row per thread, n compares each): no second kernel, no grid-wide wait.
+  const bool placed = TEAMS == 2 && A.row_cost != nullptr && A.n_blocks > (int64_t)gridDim.x && A.n_blocks <= (int64_t)TEAMS * (int64_t)gridDim.x;
+  int32_t placed_row = -1;
+  if (placed) {
+    uint32_t *cs = reinterpret_cast<uint32_t *>(smem);
+    const int n = (int)A.n_blocks, n2 = n - (int)gridDim.x, w = (int)blockIdx.x;   // n2 workgroups hold two rows
+    for (int k = (int)threadIdx.x; k < n; k += TEAMS * NT) cs[k] = A.row_cost[k];
+    if ((int)threadIdx.x < TEAMS) cs[n + (int)threadIdx.x] = 0xFFFFFFFFu;
+    const int want0 = w < n2 ? w : 2 * n2 + (w - n2);       // ascending cost rank of team 0's row
+    const int want1 = w < n2 ? 2 * n2 - 1 - w : -1;         // ... of team 1's
+    __syncthreads();
+    for (int i = (int)threadIdx.x; i < n; i += TEAMS * NT) {
+      const uint32_t ci = cs[i];
+      int rk = 0;
+#pragma unroll 8
+      for (int j = 0; j < n; ++j) rk += cs[j] < ci ? 1 : 0;
+      if (rk == want0) cs[n] = (uint32_t)i;
+      if (rk == want1) cs[n + 1] = (uint32_t)i;
+    }
+    __syncthreads();
+    placed_row = (int32_t)cs[n + team];
+    __syncthreads();   // (the table copies overwrite the keys)
+  }
   {
+    // (measured and dropped, r06p8: the first block's gather chain -- descriptors -> permutation -> statistics -- walked once here, under the
+    //  table loads, so that the prologue finds the lines close by: 302 blocks 185 -> 194 us.  The chain is bound by the vector L1's one line
+    //  per clock -- 5 000 random lines per block --, not by where the lines are: walking it twice costs twice.)
     float *l3 = reinterpret_cast<float *>(smem);
     for (int k = (int)threadIdx.x; k < (int)IREC_PM1; k += TEAMS * NT) {
       const float v = A.lut2[k];
@@ -233,8 +264,9 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
       int64_t r;
       if (first_block) {
         r = (int64_t)team * (int64_t)gridDim.x + (int64_t)blockIdx.x;
-        r = r < n_static ? xcd_static_row(r, n_static, (int)gridDim.x) : n_slots;
-      } else r = xcd_pull_row(A, n_static, n_slots, steal);   // (pulling the slot during the previous block's last step: 1.5 % slower, r06p)
+        if (placed && r < n_static && (placed_row < 0 || placed_row >= (int32_t)n_slots)) __builtin_trap();   // (the cost keys are distinct: their ranks are a permutation of the rows)
+        r = r < n_static ? (placed ? (int64_t)placed_row : xcd_static_row(r, n_static, (int)gridDim.x)) : n_slots;
+      } else r = placed ? n_slots : xcd_pull_row(A, n_static, n_slots, steal);   // (pulling the slot during the previous block's last step: 1.5 % slower, r06p)
       misc[0] = (int32_t)r;
     }
     first_block = false;

@@ -4,7 +4,7 @@
 # written under gpurun_out/$TAG/ as it goes (no output held back behind a pipe).
 set -u
 export TMPDIR=/tmp
-TAG=${TAG:-r06v}
+TAG=${TAG:-r06end}
 STAGES=${STAGES:-ab}    # a: GPU suite, smoke;  b: PMC passes -> traffic.json, bench line, kernel trace of the same command;  g: sweep grid, decoder bench;  c: end-to-end shim
 O=gpurun_out/$TAG
 mkdir -p $O

@@ -9,8 +9,10 @@ eng = irec.get_engine()
 dev = eng.device
 case = os.environ.get("CASE", "kodak1")
 omega, eps1, B, nt, nd = {"kodak1": (3.0, 1.0, 10, 1, 301056), "share342": (3.0, 1.2, 20, 38, 8192), "nine": (3.0, 1.2, 20, 1, 8192)}[case]
+nd = int(os.environ.get("DIMS", nd))
 S = int(np.exp(omega * eps1)); max_K = 32
 flags = irec._lib.IREC_FLAG_REUSE_TABLES if os.environ.get("KEEP") else 0
+if os.environ.get("LISTED"): flags |= irec._lib.IREC_FLAG_LISTED_ORDER   # rows dealt as listed, not by cost
 params = eng.params(omega, S, B, flags)
 q = bench.synthetic_batch(nt, dev, 77, nd)
 lay = eng.layout(nt, nd, bench.BLOCK_SIZE, bench.SEED)

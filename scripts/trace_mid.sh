@@ -1,21 +1,14 @@
+#!/bin/bash
+# kernel trace of a mid-size call issued back to back (scripts/host_overhead.py): average duration of the preparation kernel and of the
+# block kernel.  LIB = main | a build under csrc/variants/; CASE / DIMS / LISTED / KEEP as host_overhead.py takes them; OUT = directory under gpurun_out/.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rm -rf gpurun_out/r06t2; mkdir -p gpurun_out/r06t2
-LATENTS=34 BEAMS=10 EPS1=1.0 IREC_VARIANT=auto REPS=40 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r06t2/trace -- python3 scripts/run_variant.py > gpurun_out/r06t2/run.log 2>&1
-f=$(find gpurun_out/r06t2/trace -name "*kernel_trace.csv" | head -1)
+O=gpurun_out/${OUT:-trace_mid}; rm -rf $O/trace; mkdir -p $O
+REPS=${REPS:-60} timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 scripts/with_lib.py ${LIB:-main} scripts/host_overhead.py > $O/run.log 2>&1
+f=$(find $O/trace -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
-rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-ks = [(r["Kernel_Name"][:60], int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if "irec" in r["Kernel_Name"]]
-# last 20 calls: prep + encode pairs
-import statistics
-prep = [k for k in ks if "prep_kernel" in k[0]][-20:]
-enc = [k for k in ks if "encode_" in k[0]][-20:]
-print("prep us", statistics.mean((e - s) / 1e3 for _, s, e in prep))
-print("encode us", statistics.mean((e - s) / 1e3 for _, s, e in enc), enc[0][0])
-print("gap prep end -> encode start us", statistics.mean((en[1] - pr[2]) / 1e3 for pr, en in zip(prep, enc)))
-print("span prep start -> encode end us", statistics.mean((en[2] - pr[1]) / 1e3 for pr, en in zip(prep, enc)))
-others = set(k[0] for k in ks)
-print(others)
+for r in csv.DictReader(open(sys.argv[1])):
+    if "irec" in r["Name"]: print(f'{r["Name"][:70]:70s} calls {r["Calls"]:>5s} avg {float(r["AverageNs"]) / 1e3:8.2f} us  min {float(r["MinNs"]) / 1e3:8.2f}')
 PY
-tail -3 gpurun_out/r06t2/run.log
+grep "back to back" $O/run.log | tail -1
+rm -rf $O/trace
