@@ -1923,11 +1923,11 @@ __global__ __launch_bounds__(256, IREC_CHOICE_WPE) void prep_kernel(PrepArgs P, 
     return;
   }
   wg -= P.n_table_wgs;
-  // ---- cost key of row `wg`, a workgroup each, BEHIND the table workgroups.  The key is three dependent gathers away (descriptors ->
-  // permutation -> statistics: 13 us on their own, profiles/r06zz/placement_ab.log) and that chain, not the workgroup count, is what it
-  // costs: the launch is 17 us instead of 13 wherever the cost workgroups stand; in front of the tables they held those back as well
-  // (18.5 us at 302 rows, 29 at 512).  Also measured: the row riding on table workgroup `wg` with its gathers issued first (25 us: they
-  // did not overlap with the table work), a wave per row and four rows per workgroup (30 us).
+  // ---- cost key of row `wg`, a workgroup each, BEHIND the table workgroups (profiles/r06end/).  The key is three dependent gathers away
+  // (descriptors -> permutation -> statistics, 5 000 random lines per row through the vector L1) and costs the launch 4 us (17 against 13)
+  // here; in front of the tables, as in round 4, the cost workgroups held those back as well (18.5 us at 302 rows, 29 at 512:
+  // prep_cost_first.log).  Also measured: the row riding on table workgroup `wg` with its gathers issued first (25 us: they did not overlap
+  // with the table work, prep_cost_riding.log); a wave per row, four rows per workgroup (30 us, prep_cost_wave_per_row.log).
   if (wg < P.n_cost) {
     CostRow cr;
     cost_row_issue(A, wg, t, cr);

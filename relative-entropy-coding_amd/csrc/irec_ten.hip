@@ -180,7 +180,12 @@ __device__ __forceinline__ uint32_t ten_select_fast(const uint32_t (&k)[4], int 
 // TEAMS 4-wave teams per workgroup: three for batches (a team per block, the other teams' scoring under its serial phases), two at the full
 // register budget for calls of at most two blocks per CU.  (Measured and dropped, r06a: FOUR teams at 128 VGPRs -- no spill in the scoring
 // loop -- lose 12 %; two 8-WAVE teams for calls of at most two blocks per CU -- a block's samples on two stripes -- lose 20 % at 302 blocks:
-// 128 VGPRs, 304 B of scratch in the serial phases, both stripes repeat selection and update.)
+// 128 VGPRs, 304 B of scratch in the serial phases, both stripes repeat selection and update.  A CU that holds two blocks steps each of
+// them 1.15 times slower in cycles at a clock 4 % lower (35.0 k -> 40.4 k cycles per block-step, all of it in the scoring loop: 18.3 k ->
+// 23.2 k, profiles/r06end/stamps_lone_vs_doubled.log); letting the two teams enter their scoring loops only by turns -- a gate of two LDS
+// counters, so that one team gathers under the other's serial phases -- made it 4 % worse still (302 blocks 185 -> 192 us,
+// score_gate_ab.log): the scoring team also loses VALU issue slots to the other team's serial phases, the two floors of section "What bounds
+// it" again.  What helps is which rows the two-row CUs get: the cost-ordered hand-out below.)
 template <int TEAMS>
 __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs A) {
   constexpr int NB = TEN_NB, NT = TEAM_NT, NWT = TEAM_NW, NP = NB / 2;
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
   commit_table_stamps(A);
   // Cost-ordered hand-out of a call of one to two rows per CU (two-team build; A.row_cost: distinct keys (K * dims) << 10 | row from the
   // call's preparation kernel, set by the host only when the static round deals every row).  A CU that holds two rows steps each of them
-  // a fifth slower than a CU that holds one (257 blocks take 17 us longer than 256, profiles/r06zz/blocks_sweep.log), and the call is as long
+  // a fifth slower than a CU that holds one (257 blocks take 17 us longer than 256, profiles/r06end/blocks_sweep.log), and the call is as long
   // as its slowest CU: the n - grid workgroups with two busy teams get the 2 (n - grid) CHEAPEST rows, cheapest paired with the costliest
   // of them, every other workgroup one of the rest.  Every workgroup ranks the rows itself, once, in the LDS the table copies are about
   // to fill (one row per thread, n compares each): no second kernel, no grid-wide wait.
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
     __syncthreads();   // (the table copies overwrite the keys)
   }
   {
-    // (measured and dropped, r06p8: the first block's gather chain -- descriptors -> permutation -> statistics -- walked once here, under the
+    // (measured and dropped, profiles/r06end/prefetch_first_block.log: the first block's gather chain -- descriptors -> permutation -> statistics -- walked once here, under the
     //  table loads, so that the prologue finds the lines close by: 302 blocks 185 -> 194 us.  The chain is bound by the vector L1's one line
     //  per clock -- 5 000 random lines per block --, not by where the lines are: walking it twice costs twice.)
     float *l3 = reinterpret_cast<float *>(smem);
