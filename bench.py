@@ -328,6 +328,17 @@ def secondary_config(eng, device, name, omega, eps1, beams, n_tensors, n_dims, r
     for _ in range(2):
         eng.encode_blocks(params, lay, *q, SEED, max_K, out=out)
     torch.cuda.synchronize(device)
+    # calls of a fraction of a millisecond: twenty of them are over before the clocks have settled after the host-side check of the
+    # configuration before (round 6: 302 blocks read 0.195 ms in a burst of 20, 0.185 ms from the 30th call on, profiles/r06end/).  Such calls
+    # are issued for 20 ms before the timed ones, and at least 20 ms of them are timed.
+    t_est = time.perf_counter()
+    eng.encode_blocks(params, lay, *q, SEED, max_K, out=out)
+    torch.cuda.synchronize(device)
+    t_est = max(time.perf_counter() - t_est, 1e-5)
+    n_settle = int(min(400, max(0, np.ceil(0.02 / t_est))))
+    reps = int(min(400, max(reps, np.ceil(0.02 / t_est))))
+    for _ in range(n_settle):
+        eng.encode_blocks(params, lay, *q, SEED, max_K, out=out)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
     ev[0].record()
     for r in range(reps):
