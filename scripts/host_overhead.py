@@ -1,5 +1,5 @@
 """Host side of a mid-size call: how long the CPU takes to issue one irec_beam_encode (Python mirror -> ctypes -> planning -> two launches)
-against what the GPU takes to run it; diagnostics only.  CASE = kodak1 | share342 | nine."""
+against what the GPU takes to run it; diagnostics only.  CASE = kodak1 | share342 | nine | one20 (one tensor at the headline settings); DIMS overrides its size."""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,7 +8,7 @@ import bench, irec
 eng = irec.get_engine()
 dev = eng.device
 case = os.environ.get("CASE", "kodak1")
-omega, eps1, B, nt, nd = {"kodak1": (3.0, 1.0, 10, 1, 301056), "share342": (3.0, 1.2, 20, 38, 8192), "nine": (3.0, 1.2, 20, 1, 8192)}[case]
+omega, eps1, B, nt, nd = {"kodak1": (3.0, 1.0, 10, 1, 301056), "share342": (3.0, 1.2, 20, 38, 8192), "nine": (3.0, 1.2, 20, 1, 8192), "one20": (3.0, 1.2, 20, 1, 301056)}[case]
 nd = int(os.environ.get("DIMS", nd))
 S = int(np.exp(omega * eps1)); max_K = 32
 flags = irec._lib.IREC_FLAG_REUSE_TABLES if os.environ.get("KEEP") else 0
