@@ -900,14 +900,10 @@ CallDetail call_detail(const irec_context *ctx, const Plan &pl, const irec_param
     // Cost-ordered hand-out (calls of more rows than workgroups whose slots the static round deals completely -- one to TEAMS rows per
     // CU): the preparation kernel also writes K * dims of every row, and the teams take their rows by cost rank (irec_team.hip).
     // (measured, profiles/archive/r04w: pays on the two-team build with 20-beam steps: 342 blocks 0.467 -> 0.449 ms; not with 10-beam
-    //  steps of half the length, nor on the three-team build)
-    //  Round 6, encode_ten_kernel<2> (plain calls of at most ten beams): the other way round -- the workgroups with two busy teams get the
-    //  CHEAPEST rows (irec_ten.hip): Kodak level 1 (302 blocks), block kernel 176 -> 167 us; 257 blocks 161 -> 145 us (profiles/r06end/placement_ab.log).
-    const bool ten_call = share_W < 2 && !margins && !(p->flags & IREC_FLAG_NO_TEN) && irec::team_ten_teams(p->n_beams, p->n_samples, pl.shape) != 0;
-    if (ten_call) {
-      if (!(p->flags & IREC_FLAG_LISTED_ORDER) && n_blocks <= irec::COST_MAX_ROWS && d.teams == 2 && n_blocks > d.grid && n_blocks <= (int64_t)d.grid + d.grid / 2)   // (beyond 1.5 rows per CU most CUs hold two rows: nothing to gain: 400 / 512 blocks, r06end)
-        d.placed = 1;
-    } else if (!pl.lone && !pl.chunk && !(p->flags & IREC_FLAG_LISTED_ORDER) && n_blocks <= irec::COST_MAX_ROWS) {
+    //  steps of half the length, nor on the three-team build.
+    //  Round 6: encode_ten_kernel<2> with its two-row workgroups on the cheapest rows gains 5 us of 190 on one tensor of 302 blocks and loses
+    //  1.5 - 11 us on calls of many tensors, whose layout lists the small blocks last anyway: not taken, profiles/r06end/.)
+    if (!pl.lone && !pl.chunk && !(p->flags & IREC_FLAG_LISTED_ORDER) && n_blocks <= irec::COST_MAX_ROWS) {
       const int n_teams = irec::team_count_for(p->n_beams, p->n_samples, pl.shape);
       const int64_t tg = share_W >= 2 ? share_grid : batch_grid(n_blocks, std::min(pl.grid_cap / n_teams, n_cu));
       if (n_blocks > tg && d.n_slots <= tg * n_teams && n_teams == 2 && p->n_beams > 10 && irec::team_placeable(p->n_beams, p->n_samples, pl.shape)) d.placed = 1;

@@ -185,7 +185,7 @@ __device__ __forceinline__ uint32_t ten_select_fast(const uint32_t (&k)[4], int 
 // 23.2 k, profiles/r06end/stamps_lone_vs_doubled.log); letting the two teams enter their scoring loops only by turns -- a gate of two LDS
 // counters, so that one team gathers under the other's serial phases -- made it 4 % worse still (302 blocks 185 -> 192 us,
 // score_gate_ab.log): the scoring team also loses VALU issue slots to the other team's serial phases, the two floors of section "What bounds
-// it" again.  What helps is which rows the two-row CUs get: the cost-ordered hand-out below.)
+// it" again.)
 template <int TEAMS>
 __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs A) {
   constexpr int NB = TEN_NB, NT = TEAM_NT, NWT = TEAM_NW, NP = NB / 2;
@@ -203,34 +203,11 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
 
   if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem != 0u) __builtin_trap(); // see lds_abs_f32
   commit_table_stamps(A);
-  // Cost-ordered hand-out of a call of one to two rows per CU (two-team build; A.row_cost: distinct keys (K * dims) << 10 | row from the
-  // call's preparation kernel, set by the host only when the static round deals every row).  A CU that holds two rows steps each of them
-  // a fifth slower than a CU that holds one (257 blocks take 17 us longer than 256, profiles/r06end/blocks_sweep.log), and the call is as long
-  // as its slowest CU: the n - grid workgroups with two busy teams get the 2 (n - grid) CHEAPEST rows, cheapest paired with the costliest
-  // of them, every other workgroup one of the rest.  Every workgroup ranks the rows itself, once, in the LDS the table copies are about
-  // to fill (one row per thread, n compares each): no second kernel, no grid-wide wait.
-  const bool placed = TEAMS == 2 && A.row_cost != nullptr && A.n_blocks > (int64_t)gridDim.x && A.n_blocks <= (int64_t)TEAMS * (int64_t)gridDim.x;
-  int32_t placed_row = -1;
-  if (placed) {
-    uint32_t *cs = reinterpret_cast<uint32_t *>(smem);
-    const int n = (int)A.n_blocks, n2 = n - (int)gridDim.x, w = (int)blockIdx.x;   // n2 workgroups hold two rows
-    for (int k = (int)threadIdx.x; k < n; k += TEAMS * NT) cs[k] = A.row_cost[k];
-    if ((int)threadIdx.x < TEAMS) cs[n + (int)threadIdx.x] = 0xFFFFFFFFu;
-    const int want0 = w < n2 ? w : 2 * n2 + (w - n2);       // ascending cost rank of team 0's row
-    const int want1 = w < n2 ? 2 * n2 - 1 - w : -1;         // ... of team 1's
-    __syncthreads();
-    for (int i = (int)threadIdx.x; i < n; i += TEAMS * NT) {
-      const uint32_t ci = cs[i];
-      int rk = 0;
-#pragma unroll 8
-      for (int j = 0; j < n; ++j) rk += cs[j] < ci ? 1 : 0;
-      if (rk == want0) cs[n] = (uint32_t)i;
-      if (rk == want1) cs[n + 1] = (uint32_t)i;
-    }
-    __syncthreads();
-    placed_row = (int32_t)cs[n + team];
-    __syncthreads();   // (the table copies overwrite the keys)
-  }
+  // (measured and not taken, profiles/r06end/: a call of one to 1.5 rows per CU dealt by cost as encode_team_kernel<20,2,1> deals its own --
+  //  here the workgroups that hold two rows get the cheapest.  One tensor of 302 blocks gains 5 us of 190, 257 blocks 12 us
+  //  (placement_ab.log); calls of many tensors LOSE 1.5 - 7 us, 11 us where K differs between tensors (placement_multi_tensor.log): their
+  //  layout lists the small residual blocks last, so the two-row workgroups hold those anyway, and the hand-out by XCD below keeps the
+  //  blocks of a tensor -- slices of the same cache lines -- on one L2; what is left is the price of the cost rows and of the ranking.)
   {
     // (measured and dropped, profiles/r06end/prefetch_first_block.log: the first block's gather chain -- descriptors -> permutation -> statistics -- walked once here, under the
     //  table loads, so that the prologue finds the lines close by: 302 blocks 185 -> 194 us.  The chain is bound by the vector L1's one line
@@ -269,9 +246,8 @@ __global__ __launch_bounds__(TEAMS * TEAM_NT, 1) void encode_ten_kernel(EncArgs 
       int64_t r;
       if (first_block) {
         r = (int64_t)team * (int64_t)gridDim.x + (int64_t)blockIdx.x;
-        if (placed && r < n_static && (placed_row < 0 || placed_row >= (int32_t)n_slots)) __builtin_trap();   // (the cost keys are distinct: their ranks are a permutation of the rows)
-        r = r < n_static ? (placed ? (int64_t)placed_row : xcd_static_row(r, n_static, (int)gridDim.x)) : n_slots;
-      } else r = placed ? n_slots : xcd_pull_row(A, n_static, n_slots, steal);   // (pulling the slot during the previous block's last step: 1.5 % slower, r06p)
+        r = r < n_static ? xcd_static_row(r, n_static, (int)gridDim.x) : n_slots;
+      } else r = xcd_pull_row(A, n_static, n_slots, steal);   // (pulling the slot during the previous block's last step: 1.5 % slower, r06p)
       misc[0] = (int32_t)r;
     }
     first_block = false;

@@ -1,5 +1,5 @@
 """Host side of a mid-size call: how long the CPU takes to issue one irec_beam_encode (Python mirror -> ctypes -> planning -> two launches)
-against what the GPU takes to run it; diagnostics only.  CASE = kodak1 | share342 | nine | one20 (one tensor at the headline settings); DIMS overrides its size."""
+against what the GPU takes to run it; diagnostics only.  CASE = kodak1 | share342 | nine | one20 (one tensor at the headline settings) | ten (34 latents at the reference's default settings); DIMS / TENSORS override the sizes."""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,13 +8,13 @@ import bench, irec
 eng = irec.get_engine()
 dev = eng.device
 case = os.environ.get("CASE", "kodak1")
-omega, eps1, B, nt, nd = {"kodak1": (3.0, 1.0, 10, 1, 301056), "share342": (3.0, 1.2, 20, 38, 8192), "nine": (3.0, 1.2, 20, 1, 8192), "one20": (3.0, 1.2, 20, 1, 301056)}[case]
-nd = int(os.environ.get("DIMS", nd))
+omega, eps1, B, nt, nd = {"kodak1": (3.0, 1.0, 10, 1, 301056), "share342": (3.0, 1.2, 20, 38, 8192), "nine": (3.0, 1.2, 20, 1, 8192), "one20": (3.0, 1.2, 20, 1, 301056), "ten": (3.0, 1.0, 10, 34, 8192)}[case]
+nd = int(os.environ.get("DIMS", nd)); nt = int(os.environ.get("TENSORS", nt))
 S = int(np.exp(omega * eps1)); max_K = 32
 flags = irec._lib.IREC_FLAG_REUSE_TABLES if os.environ.get("KEEP") else 0
 if os.environ.get("LISTED"): flags |= irec._lib.IREC_FLAG_LISTED_ORDER   # rows dealt as listed, not by cost
 params = eng.params(omega, S, B, flags)
-q = bench.synthetic_batch(nt, dev, 77, nd)
+q = bench.skewed_batch(nt, dev, 0, nd, sigma=float(os.environ["SKEW"])) if os.environ.get("SKEW") else bench.synthetic_batch(nt, dev, 77, nd)   # SKEW = sigma of a per-tensor log-normal scale on delta: K differs between tensors
 lay = eng.layout(nt, nd, bench.BLOCK_SIZE, bench.SEED)
 out = (torch.empty(lay.n_blocks, dtype=torch.int32, device=dev), torch.empty((lay.n_blocks, max_K), dtype=torch.int32, device=dev), torch.empty_like(q[0]))
 print("plan:", eng.plan(params, lay, max_K)["kernel"], flush=True)

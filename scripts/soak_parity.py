@@ -30,7 +30,7 @@ for case in range(n_cases):
     S = int(np.exp(omega * eps1))
     if S * B * D > (1.3e7 if (os.environ.get("SOAK_BIG") or os.environ.get("SOAK_LARGE")) else 6e6):          # keep the oracle fast
         continue
-    NT = int(rng.choice([1, 2, 3, 5, 8] + ([16, 40, 261, 300, 384] if os.environ.get("SOAK_TEN") else [])))   # tensors per call (= blocks per call: both teams of a CU get work; 257 .. 384 blocks: rows dealt by cost)
+    NT = int(rng.choice([1, 2, 3, 5, 8] + ([16, 40, 261, 300, 384] if os.environ.get("SOAK_TEN") else [])))   # tensors per call (= blocks per call: both teams of a CU get work)
     def draw():
         style = rng.integers(0, 5)
         mp = rng.normal(0, 1, D); lsp = rng.normal(0, 0.5, D); sp = np.exp(lsp)

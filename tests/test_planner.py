@@ -104,17 +104,14 @@ def test_thresholds_scale_with_the_cu_count():
     for n_cu in N_CU:
         info, d = _plan(n_cu, 20, 36, 1, 8192, (8192,), 128)
         assert info["kernel"].endswith(",gang>") and 8 <= d["coop_width"] <= min(72, n_cu * d["teams_per_wg"]), (n_cu, info, d)
-    # rows dealt by cost: the two-team builds at one to two rows per CU (20 beams: shared rows the costliest; at most ten beams on
-    # encode_ten_kernel<2>: the workgroups that hold two rows get the cheapest, up to 1.5 rows per CU -- round 6) -- wherever "a row per CU" lies
+    # rows dealt by cost: the two-team 20-beam build at one to two rows per CU -- wherever "a row per CU" lies; calls of at most ten beams
+    # deal their rows as listed (round 6: measured both ways, profiles/r06end/placement_multi_tensor.log)
     from irec import _lib
     for n_cu in N_CU:
-        for B, S in ((20, 36), (10, 20)):
-            at, d_at = _plan(n_cu, B, S, n_cu, 1000, (1000, 192), 32)
-            mid, d_mid = _plan(n_cu, B, S, n_cu + n_cu // 5, 1000, (1000, 192), 32)
-            far, d_far = _plan(n_cu, B, S, 2 * n_cu - 1, 1000, (1000, 192), 32)
-            listed, d_listed = _plan(n_cu, B, S, n_cu + n_cu // 5, 1000, (1000, 192), 32, _lib.IREC_FLAG_LISTED_ORDER)
-            assert not d_at["placed"] and d_mid["placed"] and not d_listed["placed"], (n_cu, B, d_at, d_mid, d_listed)
-            if B == 10:
-                assert mid["kernel"] == far["kernel"] == "encode_ten_kernel<2>" and not d_far["placed"], (n_cu, mid, far, d_far)
-                _, d_old = _plan(n_cu, B, S, n_cu + n_cu // 5, 1000, (1000, 192), 32, _lib.IREC_FLAG_NO_TEN)
-                assert not d_old["placed"], (n_cu, d_old)          # (encode_team_kernel<10,2,1> deals its rows as listed)
+        at, d_at = _plan(n_cu, 20, 36, n_cu, 1000, (1000, 192), 32)
+        mid, d_mid = _plan(n_cu, 20, 36, n_cu + n_cu // 5, 1000, (1000, 192), 32)
+        listed, d_listed = _plan(n_cu, 20, 36, n_cu + n_cu // 5, 1000, (1000, 192), 32, _lib.IREC_FLAG_LISTED_ORDER)
+        assert not d_at["placed"] and d_mid["placed"] and not d_listed["placed"], (n_cu, d_at, d_mid, d_listed)
+        for n_blocks in (n_cu + 1, n_cu + n_cu // 5, 2 * n_cu - 1):
+            ten, d_ten = _plan(n_cu, 10, 20, n_blocks, 1000, (1000, 192), 32)
+            assert ten["kernel"] == "encode_ten_kernel<2>" and not d_ten["placed"], (n_cu, n_blocks, ten, d_ten)
