@@ -403,6 +403,61 @@ def secondary_config(eng, device, name, omega, eps1, beams, n_tensors, n_dims, r
     return res
 
 
+class PowerSampler:
+    """Socket power of the busiest card over the timed region, from the amdgpu hwmon files (microwatts; no GPU call, no subprocess): both batch
+    kernels run the card at its power cap (profiles/r06end/power_probe.log), which is what the look-ups per NOMINAL clock and the
+    5 % between the pool's boxes are to be read against.  None where the files are not there."""
+
+    def __init__(self, period=0.25, pci=None):
+        """pci: "dddd:bb:dd" of the card to read (torch's device properties); without a match, the card that drew most"""
+        import glob
+        self.files = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") or
+                            glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))
+        if pci:
+            mine = [f for f in self.files if pci.lower() in os.path.realpath(f.split("/hwmon/")[0]).lower()]
+            self.files = mine or self.files
+        self.period, self.samples, self._stop, self._thread = period, [], None, None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip()) * 1e-6
+        except (OSError, ValueError):
+            return None
+
+    def start(self):
+        if not self.files:
+            return self
+        import threading
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.wait(self.period):
+                self.samples.append([self._read(f) for f in self.files])
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        """{"power_w": mean over the region of the card that drew most, "power_cap_w": that card's cap, "samples": n} or None"""
+        if self._thread is None:
+            return None
+        self._stop.set()
+        self._thread.join(timeout=2.0)
+        if not self.samples:
+            return None
+        means = []
+        for i in range(len(self.files)):
+            v = [row[i] for row in self.samples if row[i] is not None]
+            means.append(sum(v) / len(v) if v else -1.0)
+        i = int(np.argmax(means))
+        if means[i] <= 0:
+            return None
+        cap = self._read(self.files[i].rsplit("/", 1)[0] + "/power1_cap")
+        return {"power_w": means[i], "power_cap_w": cap, "samples": len(self.samples), "card": self.files[i].split("/")[4]}
+
+
 def run_rank_launch_only(args):
     """IREC_BENCH_LAUNCH_ONLY=1 (CPU test rigs, tests/test_bench_launcher.py): everything of the N-rank job except the GPU
     work -- rendezvous, the code-length exchange of irec/sharding.py over gloo on made-up K, max-over-ranks timing, the
@@ -503,6 +558,14 @@ def run_rank(args):
         exchange(out[0])
     barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    power = None
+    if world == 1 and rank == 0:
+        try:
+            pr = torch.cuda.get_device_properties(device)
+            pci = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+        except Exception:
+            pci = None
+        power = PowerSampler(pci=pci).start()
     t0 = time.perf_counter()
     for a, b in ev:
         a.record()
@@ -512,6 +575,7 @@ def run_rank(args):
     K = out[0]
     barrier()
     my_elapsed = time.perf_counter() - t0
+    power = power.stop() if power is not None else None
     elapsed = my_elapsed
     per_rank = [L * args.steps / my_elapsed]
     if dist is not None:
@@ -586,9 +650,12 @@ def run_rank(args):
                                  "hw_peak": LDS_HW_LOOKUPS, "frac_hw": lookups / LDS_HW_LOOKUPS,
                                  "microbench_peak": LDS_STREAM_LOOKUPS, "frac_microbench": lookups / LDS_STREAM_LOOKUPS,
                                  "lds_conflict_frac": pmc["lds_conflict_frac"], "lds_busy": pmc["lds_busy"], "valu_busy": pmc["valu_busy"],
+                                 "power_w": power["power_w"] if power else None, "power_cap_w": power["power_cap_w"] if power else None,
                                  "note": "microbench_peak: the kernel's own address mixture and instruction stream at 12 waves per CU "
                                          "(scripts/microbench/bank_limits.hip, profiles/r05b); PMC fractions from profiles/traffic.json "
-                                         "when it was taken on these sources, else null"},
+                                         "when it was taken on these sources, else null; power_w: socket power over the timed region "
+                                         "(amdgpu hwmon) -- the kernel runs the card at its cap, so 'achieved' per NOMINAL clock understates "
+                                         "the rate per delivered clock (DESIGN.md 4)"},
                      "configs": []},
         "secondary": {"proposal_evals_per_s": evals / (kernel_ms * 1e-3), "n_cu": n_cu, "clock_ghz": clk_ghz,
                       "lookups_per_clk_per_cu": lookups,

@@ -99,6 +99,8 @@ def test_single_rank_line_is_self_describing():
     assert b["pipe"] == "lds_gather" and b["hw_peak"] == 32.0 and b["microbench_peak"] == 13.68
     assert {"achieved", "frac_hw", "frac_microbench", "lds_conflict_frac", "lds_busy", "valu_busy"} <= set(b)
     assert abs(b["frac_hw"] - b["achieved"] / 32.0) < 1e-12 and 0 < b["frac_microbench"] < 1.2
+    # ... and what the card drew over the timed region against its cap (amdgpu hwmon; None where the files are missing)
+    assert {"power_w", "power_cap_w"} <= set(b) and (b["power_w"] is None or 100 < b["power_w"] < 2000)
     cfg = res["roofline"]["configs"]
     assert len(cfg) == 8 and all({"name", "kernel", "ms_per_call", "lookups_per_clk_per_cu"} <= set(c) for c in cfg)
     assert any("configs[3] settings" in c["name"] and c["kernel"].startswith("encode_ten_kernel") for c in cfg)
